@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py -- integrateCloud throughput on MI355X (BASELINE.json metric).
+
+One "step" = one integrateCloud pass of one synthetic 640x480 depth(+colour) frame over the whole
+voxel grid.  N=1 workload = BASELINE.json configs[3]: 2048^3 grid (8 m, voxel 2^-8 m),
+integrateColor=true, Scene A turntable frames.  Frames are resident in HBM before
+the timed region.  For N>1 (one process per GPU, torch.distributed/RCCL) the grid is Z-slab
+partitioned: weak scaling extends the grid along z by 2048 planes per GPU (default) -- every rank
+integrates its own 2048-plane slab after an RCCL broadcast of the frame from rank 0.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement), with `roofline` for the
+dominant kernel (k_integrate; HBM-bound) and `cpu_baseline` (the reference CPU path, timed on this
+host on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--res", type=int, default=2048, help="x/y resolution and planes per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--color", type=int, default=1)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--frames", type=int, default=0, help="distinct frames on the turntable (default steps+warmup)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sc, res3, size3, budget_s):
+    """Reference CPU path on this host, bounded sample.  Rank 0, N=1 only.  Uses oracle/_ref (the
+    reference's own sources compiled against the in-repo PCL/Eigen stand-ins, native adaptive octree
+    mode, OpenMP) when it was prebuilt; otherwise the dense C restatement on a Z-slab sample."""
+    from cpu_tsdf_amd import synth
+    cores = os.cpu_count() or 1
+    try:
+        from oracle import refbind
+        if refbind.available():
+            return refbind.time_integrate(sc, res3, size3, bool(args.color), budget_s, cores)
+    except ImportError:
+        pass
+    from cpu_tsdf_amd import capi
+    from oracle.oracle import OracleVolume
+    p = capi.default_params()
+    planes = max(8, min(res3[2], (64 * 2048 * 2048) // (res3[0] * res3[1])))
+    zb = (res3[2] - planes) // 2
+    # a slab-sized dense oracle: same x/y resolution, `planes` z planes re-centred on the slab
+    p.res[:] = (res3[0], res3[1], res3[2])
+    p.size[:] = size3
+    p.fx, p.fy, p.cx, p.cy = sc.fx, sc.fy, sc.cx, sc.cy
+    p.image_width, p.image_height = sc.width, sc.height
+    p.min_sensor_dist, p.max_sensor_dist = 0.0, 3 * max(size3)
+    p.integrate_color = args.color
+    ov = SlabOracle(p, zb, zb + planes)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        tr = synth.turntable_pose(n, 8, sc.size)
+        ov.integrate(sc.depth(tr), sc.bgra(n) if args.color else None, synth.cam_from_vol_f32(tr))
+        n += 1
+        if time.perf_counter() - t0 > budget_s / 2 or n >= 4:
+            break
+    dt = (time.perf_counter() - t0) / n
+    full = dt * res3[2] / planes
+    vox = res3[0] * res3[1] * res3[2]
+    return {"value": vox / full / 1e6, "unit": "Mvoxels/s", "frames_per_s": 1.0 / full, "cores": cores,
+            "kind": "port",
+            "sample": f"dense C restatement (OpenMP, {cores} threads), planes [{zb},{zb + planes}) of the "
+                      f"{res3[0]}x{res3[1]}x{res3[2]} grid, {n} frames, extrapolated x{res3[2] / planes:.0f}"}
+
+
+class SlabOracle:
+    """Dense oracle restricted to planes [zb, ze): arrays hold only the slab."""
+
+    def __init__(self, p, zb, ze):
+        from oracle import oracle as O
+        self.O = O
+        self.p = O.params_from(p)
+        self.zb, self.ze = zb, ze
+        nx, ny, _ = p.res
+        n = ze - zb
+        self.d = np.full((n, ny, nx), -1, np.float32)
+        self.w = np.zeros((n, ny, nx), np.float32)
+        self.rgb = np.zeros((n, ny, nx, 3), np.uint8) if p.integrate_color else None
+
+    def integrate(self, depth, bgra, T):
+        O = self.O
+        nx, ny, _ = self.p.res
+        off = self.zb * ny * nx
+        # the oracle indexes [z][y][x] from plane 0: hand it pointers shifted back by zb planes
+        fp = C.POINTER(C.c_float)
+        d = C.cast(self.d.ctypes.data - 4 * off, fp)
+        w = C.cast(self.w.ctypes.data - 4 * off, fp)
+        rgb = C.cast(self.rgb.ctypes.data - 3 * off, C.POINTER(C.c_uint8)) if self.rgb is not None else None
+        depth = np.ascontiguousarray(depth, np.float32)
+        col = np.ascontiguousarray(bgra, np.uint8) if bgra is not None else None
+        T = np.ascontiguousarray(T, np.float32)
+        return O.lib().oracle_integrate(C.byref(self.p), d, w, rgb, depth.ctypes.data_as(fp),
+                                        col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None,
+                                        T.ctypes.data_as(fp), self.zb, self.ze)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cpu_tsdf_amd import capi, synth
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    capi.load()  # raises if the HIP library is not built: there is no fallback
+
+    res = args.res
+    voxel = 2.0 ** -8
+    if args.scaling == "weak":
+        res3 = (res, res, res * world)
+        z_begin, z_end = rank * res, (rank + 1) * res
+    else:
+        res3 = (res, res, res)
+        per = res // world
+        z_begin, z_end = rank * per, (rank + 1) * per if rank < world - 1 else res
+    size3 = tuple(r * voxel for r in res3)
+    S = size3[0]
+    W, H = args.width, args.height
+    sc = synth.Scene(S, W, H)  # sphere + far-face box scaled to the x/y extent
+    if res3[2] != res3[0]:
+        sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
+
+    vol = TSDFVolumeOctree()
+    vol.setResolution(*res3)
+    vol.setGridSize(*size3)
+    vol.setImageSize(W, H)
+    vol.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    vol.setSensorDistanceBounds(0.0, 3.0 * max(size3))  # CLI default min 0 (integrate.cpp:333)
+    vol.setDepthTruncationLimits(0.03, 0.03)
+    vol.setIntegrateColor(bool(args.color))
+    vol.setZSlab(z_begin, z_end, 0, local_rank)
+    stream = torch.cuda.current_stream(dev)
+    vol.setStream(stream.cuda_stream)
+    vol.reset()
+
+    # ---- synthetic frames, resident in HBM before the timed region ---------------------------------
+    n_total = args.warmup + args.steps
+    n_distinct = args.frames or n_total
+    radius = 2.2 * max(size3) / S
+    poses = [synth.turntable_pose(i, n_distinct, S, radius_factor=radius) for i in range(n_total)]
+    T_all = [synth.cam_from_vol_f32(p) for p in poses]
+    depth_dev = torch.empty((n_total, H, W), dtype=torch.float32, device=dev)
+    bgra_dev = torch.empty((n_total, H, W, 4), dtype=torch.uint8, device=dev) if args.color else None
+    if rank == 0:
+        for i, p in enumerate(poses):
+            depth_dev[i].copy_(torch.from_numpy(sc.depth(p)))
+            if args.color:
+                bgra_dev[i].copy_(torch.from_numpy(sc.bgra(i)))
+    if world > 1:
+        recv_depth = torch.empty((H, W), dtype=torch.float32, device=dev)
+        recv_bgra = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if args.color else None
+    lib = capi.load()
+    h = vol._need()
+
+    def step(i, count=None):
+        if world > 1:
+            # the frame arrives on rank 0; RCCL broadcast over xGMI to every slab owner
+            src_d = depth_dev[i] if rank == 0 else recv_depth
+            dist.broadcast(src_d, src=0)
+            dptr = src_d.data_ptr()
+            cptr = None
+            if args.color:
+                src_c = bgra_dev[i] if rank == 0 else recv_bgra
+                dist.broadcast(src_c, src=0)
+                cptr = src_c.data_ptr()
+        else:
+            dptr = depth_dev[i].data_ptr()
+            cptr = bgra_dev[i].data_ptr() if args.color else None
+        rc = lib.tsdf_hip_integrate_device(h, C.c_void_p(dptr), C.c_void_p(cptr) if cptr else None,
+                                           capi.as_f32p(T_all[i]), count)
+        capi.check(rc, "integrate_device")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.warmup, n_total):
+        step(i)
+    ev1.record(stream)
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the kernel's stream
+
+    # observed voxels of the timed frames (state-independent: depends on pose + depth only), counted
+    # outside the timed region by re-running the same frames with the counter read back
+    n_obs = 0
+    for i in range(args.warmup, n_total):
+        c = C.c_uint64(0)
+        step(i, C.byref(c))
+        n_obs += c.value
+    n_obs_rank = n_obs / args.steps
+
+    t = torch.tensor([wall, kern_ms, n_obs_rank], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0])
+        n_obs_all = float(tsum[2])
+    else:
+        n_obs_all = n_obs_rank
+
+    if rank == 0:
+        vox_total = float(res3[0]) * res3[1] * res3[2]
+        fps = args.steps / wall
+        bpv = 24 if args.color else 16
+        bpp = 8 if args.color else 4
+        alg_bytes = bpv * n_obs_rank + bpp * W * H  # rank 0's launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}"
+                traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "integrateCloud throughput, Scene A turntable depth frames, 640x480 -> voxel grid",
+            "value": vox_total * fps / 1e6,
+            "unit": "Mvoxels/s",
+            "frames_per_s": fps,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"integrateCloud {res3[0]}x{res3[1]}x{res3[2]} grid (voxel 2^-8 m), "
+                            f"integrateColor={'true' if args.color else 'false'}, {W}x{H} Scene-A turntable frames "
+                            f"resident in HBM" + (f", Z-slab {z_end - z_begin} planes/GPU, RCCL frame broadcast"
+                                                  if world > 1 else " (BASELINE configs[3] integrate leg)"),
+                "grid": list(res3), "image": [W, H], "color": bool(args.color),
+                "observed_voxels_per_frame": n_obs_all,
+                "parallelism": f"zslab{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_integrate", "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_observed_voxel": bpv,
+                "sweep_upper_bound_bytes": bpv * vox_total / world,
+            },
+        }
+        if world == 1 and args.cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    vol.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

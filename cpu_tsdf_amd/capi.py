@@ -1,0 +1,124 @@
+"""ctypes binding of the C ABI in include/tsdf_hip.h (libtsdf_hip.so).
+
+Fails loudly when the library is missing -- there is no CPU / eager fallback by design.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+
+OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED = range(6)
+XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
+
+
+class TsdfParams(C.Structure):
+    """struct tsdf_params (include/tsdf_hip.h)."""
+
+    _fields_ = [
+        ("res", C.c_int32 * 3),
+        ("size", C.c_float * 3),
+        ("max_dist_pos", C.c_float),
+        ("max_dist_neg", C.c_float),
+        ("max_weight", C.c_float),
+        ("min_sensor_dist", C.c_float),
+        ("max_sensor_dist", C.c_float),
+        ("fx", C.c_double),
+        ("fy", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+        ("image_width", C.c_int32),
+        ("image_height", C.c_int32),
+        ("integrate_color", C.c_int32),
+        ("xform_order", C.c_int32),
+        ("z_begin", C.c_int32),
+        ("z_end", C.c_int32),
+        ("halo", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class TsdfHipError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: tsdf_hip error {code} ({detail})")
+
+
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/tsdf_hip.h one to one
+SIGNATURES = {
+    "tsdf_hip_default_params": (None, [C.POINTER(TsdfParams)]),
+    "tsdf_hip_create": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(C.c_void_p)]),
+    "tsdf_hip_reset": (C.c_int, [C.c_void_p]),
+    "tsdf_hip_destroy": (C.c_int, [C.c_void_p]),
+    "tsdf_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tsdf_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "tsdf_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _u8p, _f32p, _u64p]),
+    "tsdf_hip_integrate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _u64p]),
+    "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
+    "tsdf_hip_sample": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]),
+    "tsdf_hip_march": (C.c_int, [C.c_void_p, C.c_float, C.c_int, _u64p]),
+    "tsdf_hip_march_fetch": (C.c_int, [C.c_void_p, _f32p, _u8p, _u64p]),
+    "tsdf_hip_download": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
+    "tsdf_hip_upload": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
+    "tsdf_hip_device_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tsdf_hip_centers": (C.c_int, [C.c_void_p, C.c_int, _f32p]),
+    "tsdf_hip_error_string": (C.c_char_p, [C.c_int]),
+    "tsdf_hip_last_error": (C.c_char_p, []),
+    "tsdf_hip_device_count": (C.c_int, []),
+    "tsdf_hip_abi_version": (C.c_int, []),
+}
+
+
+def load():
+    """Load libtsdf_hip.so (once) and declare every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, where):
+    if code != OK:
+        lib = load()
+        detail = lib.tsdf_hip_error_string(code).decode() + ": " + lib.tsdf_hip_last_error().decode()
+        raise TsdfHipError(code, where, detail)
+
+
+def default_params():
+    p = TsdfParams()
+    load().tsdf_hip_default_params(C.byref(p))
+    return p
+
+
+def as_f32p(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def as_u8p(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

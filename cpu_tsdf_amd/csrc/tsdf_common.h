@@ -1,0 +1,55 @@
+// Internal definitions shared by the HIP translation units of libtsdf_hip.so.
+// Not part of the public boundary (that is include/tsdf_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "tsdf_hip.h"
+
+struct tsdf_hip_volume {
+  tsdf_params p;
+  int device = 0;
+  int nx = 0, ny = 0, nz = 0;  // full grid resolution
+  int z_begin = 0, z_end = 0;  // owned slab (global plane indices)
+  int z_first = 0;             // global index of allocated plane 0 (= max(0, z_begin - halo))
+  int nz_alloc = 0;            // allocated planes (slab + halos clipped to the grid)
+  int64_t pitch = 0;           // floats per x row
+  int levels[3] = {0, 0, 0};   // octree depth per axis (log2 res) or -1 if res is not a power of two
+  float *d = nullptr, *w = nullptr;
+  uint32_t *rgb = nullptr;
+  float *ctr[3] = {nullptr, nullptr, nullptr};  // device centre tables (full axis length)
+  std::vector<float> h_ctr[3];
+  float *frame_depth = nullptr;  // staging for the host-pointer entry points
+  uint32_t *frame_bgra = nullptr;
+  unsigned long long *counter = nullptr;  // device scratch (n_observed etc.)
+  hipStream_t stream = nullptr;
+  // marching-cubes result buffers (owned, reused between calls)
+  float *mc_verts = nullptr;
+  uint8_t *mc_rgb = nullptr;
+  uint64_t *mc_cell = nullptr;
+  uint64_t mc_ntri = 0;
+  size_t mc_cap = 0;
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+// Error plumbing -------------------------------------------------------------------------------
+void tsdf_set_error(const std::string &msg);
+int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define TSDF_HIP_TRY(expr)                                              \
+  do {                                                                  \
+    hipError_t _e = (expr);                                             \
+    if (_e != hipSuccess) return tsdf_hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
+
+// Volume element index of (x, y, z_global); the plane must be allocated.
+static inline __host__ __device__ int64_t tsdf_index(int64_t pitch, int ny, int z_first, int x, int y,
+                                                      int zg) {
+  return ((int64_t)(zg - z_first) * ny + y) * pitch + x;
+}

@@ -1,0 +1,421 @@
+// libtsdf_hip.so -- volume lifetime, voxel-centre tables, raw block transfer.
+// gfx950 only.  Boundary: include/tsdf_hip.h.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "tsdf_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_last_error;
+
+void tsdf_set_error(const std::string &msg) { g_last_error = msg; }
+
+int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+  g_last_error = buf;
+  (void)hipGetLastError();
+  return e == hipErrorOutOfMemory ? TSDF_HIP_E_NOMEM : TSDF_HIP_E_HIP;
+}
+
+extern "C" const char *tsdf_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *tsdf_hip_error_string(int code) {
+  switch (code) {
+    case TSDF_HIP_OK: return "ok";
+    case TSDF_HIP_E_INVALID: return "invalid argument";
+    case TSDF_HIP_E_NOMEM: return "out of device memory";
+    case TSDF_HIP_E_HIP: return "HIP runtime error";
+    case TSDF_HIP_E_NODEVICE: return "no HIP device";
+    case TSDF_HIP_E_UNSUPPORTED: return "unsupported";
+  }
+  return "unknown";
+}
+
+extern "C" int tsdf_hip_abi_version(void) { return TSDF_HIP_ABI_VERSION; }
+
+extern "C" int tsdf_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference constructor defaults -- src/lib/tsdf_volume_octree.cpp:54-85
+extern "C" void tsdf_hip_default_params(tsdf_params *p) {
+  memset(p, 0, sizeof *p);
+  p->res[0] = p->res[1] = p->res[2] = 512;
+  p->size[0] = p->size[1] = p->size[2] = 3.0f;
+  p->max_dist_pos = 0.03f;
+  p->max_dist_neg = 0.03f;
+  p->max_weight = 100.f;
+  p->min_sensor_dist = 0.3f;
+  p->max_sensor_dist = 3.0f;
+  p->fx = p->fy = 525.;
+  p->cx = 320;
+  p->cy = 240;
+  p->image_width = 640;
+  p->image_height = 480;
+  p->integrate_color = 0;
+  p->xform_order = TSDF_XFORM_PCL_SSE;
+  p->z_begin = p->z_end = 0;
+  p->halo = 0;
+  p->device = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Voxel centres.
+//
+// updateVoxel reads the *octree node* centre (hpp:143-144), which the reference builds by repeated
+// halving: child centre = parent centre -/+ size/4, child size = size/2, all in float
+// (src/lib/octree.cpp:244-266), starting from the root at 0 with size_ = size_x
+// (octree.cpp:589-590, octree.h:63-66).  For a power-of-two resolution we replay exactly that
+// arithmetic per axis, so the table is bit-identical to the leaf centres for any grid size, dyadic
+// or not.  For other resolutions there is no octree equivalent (the reference CLI forces a power of
+// two, src/prog/integrate.cpp:486-494) and we fall back to getVoxelCenter's closed form
+// (tsdf_volume_octree.cpp:553-560).
+static int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+static void build_centers(int res, float size, std::vector<float> &out, int *levels) {
+  out.resize(res);
+  const int L = ilog2_exact(res);
+  *levels = L;
+  if (L >= 0) {
+    for (int i = 0; i < res; ++i) {
+      float c = 0.f;
+      float s = size;
+      for (int l = L - 1; l >= 0; --l) {
+        const float off = s / 4;
+        c = ((i >> l) & 1) ? c + off : c - off;
+        s = s / 2;
+      }
+      out[i] = c;
+    }
+  } else {
+    const float off = size / 2.0;
+    for (int i = 0; i < res; ++i) out[i] = (float)((i + 0.5) * size / (double)res - off);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256)
+k_fill_u32(uint32_t *__restrict__ p, uint32_t value, int64_t n4 /* number of uint4 */) {
+  const uint4 v4 = make_uint4(value, value, value, value);
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x)
+    q[i] = v4;
+}
+
+static int fill_u32(tsdf_hip_volume *v, void *p, uint32_t value, int64_t n) {
+  // n is a multiple of 4 by construction (pitch % 4 == 0)
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, v->stream, (uint32_t *)p, value, n4);
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
+int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes) {
+  if (bytes <= v->scratch_bytes) return TSDF_HIP_OK;
+  if (v->scratch) {
+    TSDF_HIP_TRY(hipStreamSynchronize(v->stream));
+    TSDF_HIP_TRY(hipFree(v->scratch));
+    v->scratch = nullptr;
+    v->scratch_bytes = 0;
+  }
+  TSDF_HIP_TRY(hipMalloc(&v->scratch, bytes));
+  v->scratch_bytes = bytes;
+  return TSDF_HIP_OK;
+}
+
+static void free_volume(tsdf_hip_volume *v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->d) (void)hipFree(v->d);
+  if (v->w) (void)hipFree(v->w);
+  if (v->rgb) (void)hipFree(v->rgb);
+  for (int a = 0; a < 3; ++a)
+    if (v->ctr[a]) (void)hipFree(v->ctr[a]);
+  if (v->frame_depth) (void)hipFree(v->frame_depth);
+  if (v->frame_bgra) (void)hipFree(v->frame_bgra);
+  if (v->counter) (void)hipFree(v->counter);
+  if (v->mc_verts) (void)hipFree(v->mc_verts);
+  if (v->mc_rgb) (void)hipFree(v->mc_rgb);
+  if (v->mc_cell) (void)hipFree(v->mc_cell);
+  if (v->scratch) (void)hipFree(v->scratch);
+  delete v;
+}
+
+extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
+  if (!p || !out) return TSDF_HIP_E_INVALID;
+  *out = nullptr;
+  for (int a = 0; a < 3; ++a)
+    if (p->res[a] <= 0 || !(p->size[a] > 0.f)) {
+      tsdf_set_error("resolution and grid size must be positive");
+      return TSDF_HIP_E_INVALID;
+    }
+  if (p->image_width <= 0 || p->image_height <= 0 || !(p->max_dist_neg > 0.f) || p->halo < 0 ||
+      (p->xform_order != TSDF_XFORM_PCL_SSE && p->xform_order != TSDF_XFORM_LEFT_TO_RIGHT)) {
+    tsdf_set_error("bad image size / truncation / halo / xform_order");
+    return TSDF_HIP_E_INVALID;
+  }
+  int zb = p->z_begin, ze = p->z_end;
+  if (zb == 0 && ze == 0) ze = p->res[2];
+  if (zb < 0 || ze > p->res[2] || zb >= ze) {
+    tsdf_set_error("z slab outside the grid");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (tsdf_hip_device_count() <= 0) {
+    tsdf_set_error("no HIP device visible");
+    return TSDF_HIP_E_NODEVICE;
+  }
+  int dev = p->device;
+  if (dev < 0) TSDF_HIP_TRY(hipGetDevice(&dev));
+  TSDF_HIP_TRY(hipSetDevice(dev));
+
+  tsdf_hip_volume *v = new tsdf_hip_volume;
+  v->p = *p;
+  v->p.z_begin = zb;
+  v->p.z_end = ze;
+  v->device = dev;
+  v->nx = p->res[0];
+  v->ny = p->res[1];
+  v->nz = p->res[2];
+  v->z_begin = zb;
+  v->z_end = ze;
+  v->z_first = zb - p->halo < 0 ? 0 : zb - p->halo;
+  const int z_last = ze + p->halo > v->nz ? v->nz : ze + p->halo;
+  v->nz_alloc = z_last - v->z_first;
+  v->pitch = ((int64_t)v->nx + 3) / 4 * 4;
+  const int64_t n = v->pitch * v->ny * v->nz_alloc;
+
+  int rc = TSDF_HIP_OK;
+  auto bail = [&](int code) {
+    free_volume(v);
+    return code;
+  };
+#define TRY_OR_BAIL(expr)                                                  \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) return bail(tsdf_hip_fail(_e, #expr, __FILE__, __LINE__)); \
+  } while (0)
+  TRY_OR_BAIL(hipMalloc(&v->d, n * sizeof(float)));
+  TRY_OR_BAIL(hipMalloc(&v->w, n * sizeof(float)));
+  if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
+  for (int a = 0; a < 3; ++a) {
+    build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
+    // pad the x table so float4 loads of the last (partial) quad stay in bounds
+    const size_t len = (size_t)p->res[a] + 4;
+    TRY_OR_BAIL(hipMalloc(&v->ctr[a], len * sizeof(float)));
+    TRY_OR_BAIL(hipMemset(v->ctr[a], 0, len * sizeof(float)));
+    TRY_OR_BAIL(hipMemcpy(v->ctr[a], v->h_ctr[a].data(), p->res[a] * sizeof(float), hipMemcpyHostToDevice));
+  }
+  const size_t npx = (size_t)p->image_width * p->image_height;
+  TRY_OR_BAIL(hipMalloc(&v->frame_depth, npx * sizeof(float)));
+  TRY_OR_BAIL(hipMalloc(&v->frame_bgra, npx * sizeof(uint32_t)));
+  TRY_OR_BAIL(hipMalloc(&v->counter, 16 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMemset(v->counter, 0, 16 * sizeof(unsigned long long)));
+#undef TRY_OR_BAIL
+  rc = tsdf_hip_reset(v);
+  if (rc != TSDF_HIP_OK) return bail(rc);
+  *out = v;
+  return TSDF_HIP_OK;
+}
+
+// reset(): every voxel (d=-1, w=0) -- tsdf_volume_octree.cpp:213-218; RGBNode starts at 0,0,0
+// (octree.h:177-180).
+extern "C" int tsdf_hip_reset(tsdf_handle h) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = h->pitch * h->ny * h->nz_alloc;
+  const float minus_one = -1.f;
+  uint32_t bits;
+  memcpy(&bits, &minus_one, 4);
+  int rc = fill_u32(h, h->d, bits, n);
+  if (rc) return rc;
+  rc = fill_u32(h, h->w, 0u, n);
+  if (rc) return rc;
+  if (h->rgb) rc = fill_u32(h, h->rgb, 0u, n);
+  if (rc) return rc;
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_destroy(tsdf_handle h) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  free_volume(h);
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  h->stream = (hipStream_t)hip_stream;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_synchronize(tsdf_handle h) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_centers(tsdf_handle h, int axis, float *out) {
+  if (!h || axis < 0 || axis > 2 || !out) return TSDF_HIP_E_INVALID;
+  memcpy(out, h->h_ctr[axis].data(), h->h_ctr[axis].size() * sizeof(float));
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,
+                                      int32_t *z_first, int32_t *nz_alloc) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  if (d) *d = h->d;
+  if (w) *w = h->w;
+  if (rgb) *rgb = h->rgb;
+  if (pitch) *pitch = h->pitch;
+  if (z_first) *z_first = h->z_first;
+  if (nz_alloc) *nz_alloc = h->nz_alloc;
+  return TSDF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block transfer: pack / unpack kernels through a contiguous scratch buffer, chunked along z.
+struct BlockArgs {
+  int x0, y0, zl0;  // zl0: local (allocated) plane index of the block's first plane
+  int bx, by, bz;
+  int ny;
+  int64_t pitch;
+};
+
+template <bool TO_BLOCK>
+static __global__ void __launch_bounds__(256)
+k_block_f32(BlockArgs a, float *__restrict__ vol, float *__restrict__ blk) {
+  const int64_t n = (int64_t)a.bx * a.by * a.bz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.bx);
+    const int64_t r = i / a.bx;
+    const int y = (int)(r % a.by);
+    const int z = (int)(r / a.by);
+    const int64_t vi = ((int64_t)(a.zl0 + z) * a.ny + (a.y0 + y)) * a.pitch + (a.x0 + x);
+    if (TO_BLOCK)
+      blk[i] = vol[vi];
+    else
+      vol[vi] = blk[i];
+  }
+}
+
+template <bool TO_BLOCK>
+static __global__ void __launch_bounds__(256)
+k_block_rgb(BlockArgs a, uint32_t *__restrict__ vol, uint8_t *__restrict__ blk) {
+  const int64_t n = (int64_t)a.bx * a.by * a.bz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.bx);
+    const int64_t r = i / a.bx;
+    const int y = (int)(r % a.by);
+    const int z = (int)(r / a.by);
+    const int64_t vi = ((int64_t)(a.zl0 + z) * a.ny + (a.y0 + y)) * a.pitch + (a.x0 + x);
+    if (TO_BLOCK) {
+      const uint32_t c = vol[vi];
+      blk[3 * i + 0] = (uint8_t)(c & 255u);
+      blk[3 * i + 1] = (uint8_t)((c >> 8) & 255u);
+      blk[3 * i + 2] = (uint8_t)((c >> 16) & 255u);
+    } else {
+      vol[vi] = (uint32_t)blk[3 * i] | ((uint32_t)blk[3 * i + 1] << 8) | ((uint32_t)blk[3 * i + 2] << 16);
+    }
+  }
+}
+
+static int check_block(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz) {
+  if (!h || nx <= 0 || ny <= 0 || nz <= 0 || x0 < 0 || y0 < 0 || x0 + nx > h->nx || y0 + ny > h->ny ||
+      z0 < h->z_first || z0 + nz > h->z_first + h->nz_alloc) {
+    tsdf_set_error("block outside the allocated slab");
+    return TSDF_HIP_E_INVALID;
+  }
+  return TSDF_HIP_OK;
+}
+
+template <bool DOWN>
+static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w,
+                          uint8_t *rgb) {
+  int rc = check_block(h, x0, y0, z0, nx, ny, nz);
+  if (rc) return rc;
+  if (rgb && !h->rgb) {
+    tsdf_set_error("volume has no colour plane");
+    return TSDF_HIP_E_INVALID;
+  }
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const int64_t plane = (int64_t)nx * ny;
+  int64_t max_planes = (int64_t)(64 << 20) / plane;  // <= 64 Mi voxels (256 MiB of floats) per chunk
+  if (max_planes < 1) max_planes = 1;
+  rc = tsdf_ensure_scratch(h, (size_t)std::min<int64_t>(max_planes, nz) * plane * sizeof(float));
+  if (rc) return rc;
+  for (int zc = 0; zc < nz; zc += (int)max_planes) {
+    const int bz = (int)std::min<int64_t>(max_planes, nz - zc);
+    const int64_t n = plane * bz;
+    BlockArgs a{x0, y0, z0 + zc - h->z_first, nx, ny, bz, h->ny, h->pitch};
+    unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    float *planes[2] = {h->d, h->w};
+    float *hosts[2] = {d, w};
+    for (int k = 0; k < 2; ++k) {
+      if (!hosts[k]) continue;
+      float *hp = hosts[k] + (int64_t)zc * plane;
+      if (DOWN) {
+        hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k],
+                           (float *)h->scratch);
+        TSDF_HIP_TRY(hipGetLastError());
+        TSDF_HIP_TRY(hipMemcpyAsync(hp, h->scratch, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      } else {
+        TSDF_HIP_TRY(hipMemcpyAsync(h->scratch, hp, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_block_f32<false>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k],
+                           (float *)h->scratch);
+        TSDF_HIP_TRY(hipGetLastError());
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      }
+    }
+    if (rgb) {
+      uint8_t *hp = rgb + (int64_t)zc * plane * 3;
+      if (DOWN) {
+        hipLaunchKernelGGL(k_block_rgb<true>, dim3(blocks), dim3(256), 0, h->stream, a, h->rgb,
+                           (uint8_t *)h->scratch);
+        TSDF_HIP_TRY(hipGetLastError());
+        TSDF_HIP_TRY(hipMemcpyAsync(hp, h->scratch, n * 3, hipMemcpyDeviceToHost, h->stream));
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      } else {
+        TSDF_HIP_TRY(hipMemcpyAsync(h->scratch, hp, n * 3, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_block_rgb<false>, dim3(blocks), dim3(256), 0, h->stream, a, h->rgb,
+                           (uint8_t *)h->scratch);
+        TSDF_HIP_TRY(hipGetLastError());
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      }
+    }
+  }
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *d,
+                                 float *w, uint8_t *rgb) {
+  return block_transfer<true>(h, x0, y0, z0, nx, ny, nz, d, w, rgb);
+}
+
+extern "C" int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
+                               const float *w, const uint8_t *rgb) {
+  return block_transfer<false>(h, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
+                               const_cast<uint8_t *>(rgb));
+}

@@ -1,0 +1,323 @@
+"""Python-side mirror of the reference's ``TSDFVolumeOctree`` / ``MarchingCubesTSDFOctree`` interface
+for the accelerated path, on top of the C ABI (``include/tsdf_hip.h``).
+
+Method names, argument meaning and defaults follow the reference
+(``include/cpu_tsdf/tsdf_volume_octree.h``, ``src/lib/tsdf_volume_octree.cpp:54-199``): configure
+with setters, then ``reset()``, then ``integrateCloud`` per frame.  The organised point cloud of the
+reference becomes a ``(H, W)`` float32 depth image (``pt.z``; NaN = no return) plus an optional
+``(H, W, 4)`` uint8 image in PCL ``PointXYZRGBA`` byte order.  All compute happens in HIP kernels; a
+missing ``libtsdf_hip.so`` or GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .synth import cam_from_vol_f32, eigen_affine_inverse
+
+
+class TSDFVolumeOctree:
+    """Drop-in for ``cpu_tsdf::TSDFVolumeOctree`` (flat SoA grid in HBM instead of an octree)."""
+
+    def __init__(self):
+        self._p = capi.default_params()  # reference constructor defaults, tsdf_volume_octree.cpp:54-85
+        self._h = None
+        self._global_transform = np.eye(4)
+        self._is_empty = True
+        self._stream = None
+
+    # -- configuration (tsdf_volume_octree.cpp:92-199, tsdf_volume_octree.h:101-190) ----------------
+    def setResolution(self, xres, yres, zres):
+        self._p.res[:] = (int(xres), int(yres), int(zres))
+
+    def getResolution(self):
+        return tuple(self._p.res)
+
+    def setGridSize(self, xsize, ysize, zsize):
+        self._p.size[:] = (float(xsize), float(ysize), float(zsize))
+
+    def getGridSize(self):
+        return tuple(self._p.size)
+
+    def setImageSize(self, width, height):
+        self._p.image_width, self._p.image_height = int(width), int(height)
+
+    def getImageSize(self):
+        return self._p.image_width, self._p.image_height
+
+    def setDepthTruncationLimits(self, max_dist_pos, max_dist_neg):
+        self._p.max_dist_pos, self._p.max_dist_neg = float(max_dist_pos), float(max_dist_neg)
+
+    def getDepthTruncationLimits(self):
+        return self._p.max_dist_pos, self._p.max_dist_neg
+
+    def setWeightTruncationLimit(self, max_weight):
+        self._p.max_weight = float(max_weight)
+
+    def getWeightTruncationLimit(self):
+        return self._p.max_weight
+
+    def setGlobalTransform(self, trans):
+        self._global_transform = np.array(trans, dtype=np.float64).reshape(4, 4)
+
+    def getGlobalTransform(self):
+        return self._global_transform.copy()
+
+    def setCameraIntrinsics(self, fx, fy, cx, cy):
+        self._p.fx, self._p.fy, self._p.cx, self._p.cy = float(fx), float(fy), float(cx), float(cy)
+
+    def getCameraIntrinsics(self):
+        return self._p.fx, self._p.fy, self._p.cx, self._p.cy
+
+    def setMaxVoxelSize(self, x, y, z):
+        """Accepted for interface compatibility; a dense grid has no coarse cells."""
+        self._max_cell = (float(x), float(y), float(z))
+
+    def setNumRandomSplts(self, n):
+        """Accepted for interface compatibility; there is no pre-split pass on a dense grid."""
+        self._num_random_splits = int(n)
+
+    def setIntegrateColor(self, flag):
+        self._p.integrate_color = 1 if flag else 0
+
+    def setSensorDistanceBounds(self, min_sensor_dist, max_sensor_dist):
+        self._p.min_sensor_dist, self._p.max_sensor_dist = float(min_sensor_dist), float(max_sensor_dist)
+
+    def getSensorDistanceBounds(self):
+        return self._p.min_sensor_dist, self._p.max_sensor_dist
+
+    def setTransformOrder(self, order):
+        """Not in the reference: which PCL ``transformPoint`` summation order to mirror."""
+        self._p.xform_order = int(order)
+
+    def setZSlab(self, z_begin, z_end, halo=0, device=-1):
+        """Not in the reference: own only planes [z_begin, z_end) (multi-GPU Z-slab partition)."""
+        self._p.z_begin, self._p.z_end, self._p.halo, self._p.device = int(z_begin), int(z_end), int(halo), int(device)
+
+    def setStream(self, stream_ptr):
+        self._stream = stream_ptr
+        if self._h:
+            capi.check(capi.load().tsdf_hip_set_stream(self._h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def isEmpty(self):
+        return self._is_empty
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def reset(self):
+        """tsdf_volume_octree.cpp:201-219."""
+        lib = capi.load()
+        if self._h:
+            capi.check(lib.tsdf_hip_destroy(self._h), "destroy")
+            self._h = None
+        h = C.c_void_p()
+        capi.check(lib.tsdf_hip_create(C.byref(self._p), C.byref(h)), "create")
+        self._h = h
+        if self._stream is not None:
+            capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
+        self._is_empty = True
+
+    def close(self):
+        if self._h:
+            capi.load().tsdf_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _need(self):
+        if not self._h:
+            raise RuntimeError("call reset() first")
+        return self._h
+
+    def synchronize(self):
+        capi.check(capi.load().tsdf_hip_synchronize(self._need()), "synchronize")
+
+    # -- hot path ------------------------------------------------------------------------------------
+    def integrateCloud(self, depth, bgra=None, trans=None, count=False):
+        """``integrateCloud(cloud, normals, trans)`` (impl/tsdf_volume_octree.hpp:48-103).  Returns True
+        (as the reference always does), or the number of observed voxels when ``count`` is set."""
+        h = self._need()
+        trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
+        depth = capi.f32c(depth)
+        if depth.shape != (self._p.image_height, self._p.image_width):
+            raise ValueError("depth image must be (image_height, image_width)")
+        T = cam_from_vol_f32(trans)
+        n = C.c_uint64(0)
+        col = None
+        if self._p.integrate_color:
+            if bgra is None:
+                raise ValueError("integrate_color is set: a (H, W, 4) uint8 bgra image is required")
+            col = np.ascontiguousarray(bgra, dtype=np.uint8)
+            if col.shape != (self._p.image_height, self._p.image_width, 4):
+                raise ValueError("bgra image must be (image_height, image_width, 4)")
+        capi.check(
+            capi.load().tsdf_hip_integrate(h, capi.as_f32p(depth), capi.as_u8p(col) if col is not None else None,
+                                           capi.as_f32p(T), C.byref(n) if count else None), "integrate")
+        self._is_empty = False
+        return int(n.value) if count else True
+
+    def integrateCloudDevice(self, depth_ptr, bgra_ptr, trans, count=False):
+        """Same, with device pointers (frames already resident in HBM); asynchronous unless count."""
+        h = self._need()
+        T = cam_from_vol_f32(np.asarray(trans, dtype=np.float64))
+        n = C.c_uint64(0)
+        capi.check(
+            capi.load().tsdf_hip_integrate_device(h, C.c_void_p(depth_ptr), C.c_void_p(bgra_ptr) if bgra_ptr else None,
+                                                  capi.as_f32p(T), C.byref(n) if count else None), "integrate_device")
+        self._is_empty = False
+        return int(n.value) if count else True
+
+    def renderView(self, trans=None, downsampleBy=1, camera_frame=True):
+        """tsdf_volume_octree.cpp:278-424.  Returns (H/ds, W/ds, 8) float32: xyz, normal, t*, iterations.
+        With camera_frame (the reference's behaviour) xyz/normal are moved back by trans^-1 (:422)."""
+        h = self._need()
+        trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
+        ds = int(downsampleBy)
+        nh, nw = self._p.image_height // ds, self._p.image_width // ds
+        out = np.empty((nh, nw, 8), dtype=np.float32)
+        rot = np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9))
+        org = np.ascontiguousarray(trans[:3, 3].astype(np.float32))
+        capi.check(capi.load().tsdf_hip_raycast(h, capi.as_f32p(rot), capi.as_f32p(org), ds, capi.as_f32p(out)),
+                   "raycast")
+        if camera_frame:
+            out = transform_cloud_with_normals(out, eigen_affine_inverse(trans))
+        return out
+
+    def getFxn(self, pts):
+        """Batched ``getFxn`` (tsdf_volume_octree.cpp:655-672): returns (ok, val)."""
+        ok, val, _, _ = self.sample(pts, want_grad=False, want_hess=False)
+        return ok, val
+
+    def sample(self, pts, want_grad=True, want_hess=True):
+        """getFxn / getGradient / getHessian (tsdf_volume_octree.cpp:655-828), batched."""
+        h = self._need()
+        pts = capi.f32c(pts).reshape(-1, 3)
+        n = pts.shape[0]
+        val = np.empty(n, dtype=np.float32)
+        grad = np.empty((n, 3), dtype=np.float32) if want_grad else None
+        hess = np.empty((n, 9), dtype=np.float32) if want_hess else None
+        ok = np.empty(n, dtype=np.uint8)
+        capi.check(
+            capi.load().tsdf_hip_sample(h, capi.as_f32p(pts), n, capi.as_f32p(val),
+                                        capi.as_f32p(grad) if grad is not None else None,
+                                        capi.as_f32p(hess) if hess is not None else None, capi.as_u8p(ok)), "sample")
+        return ok.astype(bool), val, grad, (hess.reshape(n, 3, 3) if hess is not None else None)
+
+    # -- raw access (parity tests, save) -------------------------------------------------------------
+    def download(self, x0=0, y0=0, z0=None, nx=None, ny=None, nz=None, want_rgb=None):
+        h = self._need()
+        rx, ry, rz = self._p.res
+        zb = self._p.z_begin
+        ze = self._p.z_end if (self._p.z_begin or self._p.z_end) else rz
+        z0 = zb if z0 is None else z0
+        nx = rx - x0 if nx is None else nx
+        ny = ry - y0 if ny is None else ny
+        nz = ze - z0 if nz is None else nz
+        d = np.empty((nz, ny, nx), dtype=np.float32)
+        w = np.empty((nz, ny, nx), dtype=np.float32)
+        want_rgb = bool(self._p.integrate_color) if want_rgb is None else want_rgb
+        rgb = np.empty((nz, ny, nx, 3), dtype=np.uint8) if want_rgb else None
+        capi.check(
+            capi.load().tsdf_hip_download(h, x0, y0, z0, nx, ny, nz, capi.as_f32p(d), capi.as_f32p(w),
+                                          capi.as_u8p(rgb) if rgb is not None else None), "download")
+        return d, w, rgb
+
+    def upload(self, d=None, w=None, rgb=None, x0=0, y0=0, z0=0):
+        h = self._need()
+        ref = d if d is not None else (w if w is not None else rgb)
+        nz, ny, nx = ref.shape[:3]
+        d = capi.f32c(d) if d is not None else None
+        w = capi.f32c(w) if w is not None else None
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8) if rgb is not None else None
+        capi.check(
+            capi.load().tsdf_hip_upload(h, x0, y0, z0, nx, ny, nz, capi.as_f32p(d) if d is not None else None,
+                                        capi.as_f32p(w) if w is not None else None,
+                                        capi.as_u8p(rgb) if rgb is not None else None), "upload")
+        self._is_empty = False
+
+    def centers(self, axis):
+        out = np.empty(self._p.res[axis], dtype=np.float32)
+        capi.check(capi.load().tsdf_hip_centers(self._need(), axis, capi.as_f32p(out)), "centers")
+        return out
+
+    def device_planes(self):
+        d, w, rgb = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        pitch, zf, nza = C.c_int64(), C.c_int32(), C.c_int32()
+        capi.check(
+            capi.load().tsdf_hip_device_planes(self._need(), C.byref(d), C.byref(w), C.byref(rgb), C.byref(pitch),
+                                               C.byref(zf), C.byref(nza)), "device_planes")
+        return d.value, w.value, rgb.value, pitch.value, zf.value, nza.value
+
+
+class MarchingCubesTSDFOctree:
+    """Drop-in for ``cpu_tsdf::MarchingCubesTSDFOctree`` (include/cpu_tsdf/marching_cubes_tsdf_octree.h)."""
+
+    def __init__(self):
+        self._w_min = 2.5  # marching_cubes_tsdf_octree.h:58
+        self._by_rgb = False
+        self._by_conf = False
+        self._vol = None
+
+    def setInputTSDF(self, volume):
+        self._vol = volume
+
+    def setMinWeight(self, w_min):
+        self._w_min = float(w_min)
+
+    def setColorByRGB(self, flag):
+        self._by_rgb = bool(flag)
+
+    def setColorByConfidence(self, flag):
+        self._by_conf = bool(flag)
+
+    def reconstruct(self, want_cells=False):
+        """marching_cubes_tsdf_octree.cpp:108-143.  Returns dict(vertices (3n,3) float32 after the global
+        transform, polygons (n,3) int32 = [3i,3i+1,3i+2], rgb (3n,3) uint8 or None, cells)."""
+        vol = self._vol
+        h = vol._need()
+        lib = capi.load()
+        mode = 2 if self._by_conf else (1 if self._by_rgb else 0)
+        n = C.c_uint64(0)
+        capi.check(lib.tsdf_hip_march(h, self._w_min, mode, C.byref(n)), "march")
+        nt = int(n.value)
+        verts = np.empty((nt * 3, 3), dtype=np.float32)
+        rgb = np.empty((nt * 3, 3), dtype=np.uint8) if mode else None
+        cells = np.empty(nt, dtype=np.uint64) if want_cells else None
+        if nt:
+            capi.check(
+                lib.tsdf_hip_march_fetch(h, capi.as_f32p(verts), capi.as_u8p(rgb) if rgb is not None else None,
+                                         cells.ctypes.data_as(C.POINTER(C.c_uint64)) if cells is not None else None),
+                "march_fetch")
+        g = vol.getGlobalTransform()
+        if not np.array_equal(g, np.eye(4)):
+            verts = transform_points_f64(verts, g)
+        polys = np.arange(nt * 3, dtype=np.int32).reshape(nt, 3)
+        return {"vertices": verts, "polygons": polys, "rgb": rgb, "cells": cells}
+
+
+def transform_points_f64(xyz, m):
+    """pcl::transformPointCloud with an Affine3d on float points [PCL-recall]: evaluated in double,
+    x*c0 + (y*c1 + (z*c2 + c3)), rounded to float."""
+    p = xyz.astype(np.float64)
+    out = np.empty_like(p)
+    for r in range(3):
+        out[..., r] = p[..., 0] * m[r, 0] + (p[..., 1] * m[r, 1] + (p[..., 2] * m[r, 2] + m[r, 3]))
+    return out.astype(np.float32)
+
+
+def transform_cloud_with_normals(cloud, m):
+    """pcl::transformPointCloudWithNormals (tsdf_volume_octree.cpp:422) on an (..., 8) array; with
+    is_dense=false non-finite points are left untouched [PCL-recall]."""
+    out = cloud.copy()
+    xyz, nrm = cloud[..., 0:3], cloud[..., 3:6]
+    fin = np.isfinite(xyz).all(-1)
+    out[..., 0:3] = np.where(fin[..., None], transform_points_f64(xyz, m), xyz)
+    p = nrm.astype(np.float64)
+    rn = np.empty_like(p)
+    for r in range(3):
+        rn[..., r] = p[..., 0] * m[r, 0] + (p[..., 1] * m[r, 1] + p[..., 2] * m[r, 2])
+    out[..., 3:6] = np.where(fin[..., None], rn.astype(np.float32), nrm)
+    return out

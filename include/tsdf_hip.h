@@ -1,0 +1,151 @@
+/*
+ * tsdf_hip.h -- C ABI of the MI355X (gfx950) TSDF fusion library (libtsdf_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes only, no C++ / torch types.
+ * The C++ host shell (the headers under include/cpu_tsdf/, same class names and signatures as the
+ * reference) and the Python binding (cpu_tsdf_amd/capi.py) both sit on top of it.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * sdmiller/cpu_tsdf tree).  All functions return 0 on success or a TSDF_HIP_E_* code;
+ * the reference itself has no error reporting, the host shell maps
+ * failures to `false` / empty results.
+ *
+ * Volume storage: flat SoA planes in HBM, x fastest:
+ *     d  [nz_local][ny][pitch]  float   truncation-normalised distance, init -1
+ *     w  [nz_local][ny][pitch]  float   weight, init 0
+ *     rgb[nz_local][ny][pitch]  uint32  r | g<<8 | b<<16 (only when integrate_color)
+ * pitch = nx rounded up to a multiple of 4.  A handle may own only a Z-slab
+ * [z_begin, z_end) of the full grid (multi-GPU partitioning) plus `halo` extra planes on
+ * each side that integrate never touches but raycast / marching cubes may read.
+ */
+#ifndef TSDF_HIP_H
+#define TSDF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsdf_hip_volume *tsdf_handle;
+
+enum {
+  TSDF_HIP_OK = 0,
+  TSDF_HIP_E_INVALID = 1,     /* bad argument / params */
+  TSDF_HIP_E_NOMEM = 2,       /* hipMalloc failed */
+  TSDF_HIP_E_HIP = 3,         /* any other HIP runtime error (see tsdf_hip_last_error) */
+  TSDF_HIP_E_NODEVICE = 4,    /* no gfx950 device visible */
+  TSDF_HIP_E_UNSUPPORTED = 5
+};
+
+/* Summation order of the rigid transform g = T * (c,1), which decides the last ulp of the
+ * camera-frame voxel centre (include/cpu_tsdf/impl/tsdf_volume_octree.hpp:145 calls
+ * pcl::transformPoint, whose arithmetic lives in PCL, not in the reference tree). */
+enum {
+  TSDF_XFORM_PCL_SSE = 0,     /* x*c0 + (y*c1 + (z*c2 + c3))   PCL >= 1.10 Transformer<float>::se3, SSE2 build */
+  TSDF_XFORM_LEFT_TO_RIGHT = 1 /* ((m0*x + m1*y) + m2*z) + m3    PCL scalar build / Eigen Affine3f * Vector3f */
+};
+
+/* Everything TSDFVolumeOctree's setters configure before reset()
+ * (src/lib/tsdf_volume_octree.cpp:54-85 defaults, :92-199 setters). */
+typedef struct tsdf_params {
+  int32_t res[3];             /* setResolution            tsdf_volume_octree.cpp:92-98   */
+  float size[3];              /* setGridSize              :110-116 (metres)              */
+  float max_dist_pos;         /* setDepthTruncationLimits :146-151                       */
+  float max_dist_neg;
+  float max_weight;           /* setWeightTruncationLimit :163-167                       */
+  float min_sensor_dist;      /* setSensorDistanceBounds  tsdf_volume_octree.h:185-190   */
+  float max_sensor_dist;
+  double fx, fy, cx, cy;      /* setCameraIntrinsics      :176-186 (double, as stored)   */
+  int32_t image_width;        /* setImageSize             :128-133                       */
+  int32_t image_height;
+  int32_t integrate_color;    /* setIntegrateColor        tsdf_volume_octree.h:172-173   */
+  int32_t xform_order;        /* TSDF_XFORM_*                                            */
+  int32_t z_begin, z_end;     /* Z-slab owned by this handle; 0,0 => whole grid          */
+  int32_t halo;               /* extra planes kept below z_begin and above z_end         */
+  int32_t device;             /* HIP ordinal, -1 => current device                       */
+} tsdf_params;
+
+/* Fill *p with the reference constructor defaults (tsdf_volume_octree.cpp:54-85). */
+void tsdf_hip_default_params(tsdf_params *p);
+
+/* reset() -- tsdf_volume_octree.cpp:201-219: allocate the grid, every voxel (d=-1, w=0). */
+int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out);
+int tsdf_hip_reset(tsdf_handle h);
+int tsdf_hip_destroy(tsdf_handle h);
+
+/* Work is queued on this hipStream_t (default: the null stream). */
+int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream);
+int tsdf_hip_synchronize(tsdf_handle h);
+
+/* integrateCloud -- include/cpu_tsdf/impl/tsdf_volume_octree.hpp:48-103 (+ updateVoxel :113-218).
+ *   depth        image_height x image_width floats, row-major: pt.z of cloud(u,v); NaN = no return.
+ *   bgra         same shape, 4 bytes/pixel in PCL PointXYZRGBA memory order (b,g,r,a); NULL unless
+ *                integrate_color.
+ *   cam_from_vol 3x4 row-major float: trans.inverse().cast<float>() exactly as hpp:54 computes it.
+ *   n_observed   optional: number of voxels that reached addObservation this frame.
+ * The host variant copies the frame to the device and synchronises; the device variant takes
+ * device pointers, is asynchronous on the handle's stream and only synchronises when
+ * n_observed != NULL. */
+int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
+                       const float cam_from_vol[12], uint64_t *n_observed);
+int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
+                              const float cam_from_vol[12], uint64_t *n_observed);
+
+/* renderView -- tsdf_volume_octree.cpp:278-421 (everything except the last line).
+ *   rot        3x3 row-major float:  trans.rotation().cast<float>()      (:303)
+ *   origin     3 floats:             trans.translation().cast<float>()   (:304)
+ *              Both are computed by the caller with its own Eigen so the kernel sees exactly the
+ *              numbers the reference would (Affine3d::rotation() runs an SVD inside Eigen).
+ *   downsample downsampleBy
+ *   out        (image_height/ds) x (image_width/ds) x 8 floats per pixel:
+ *              x,y,z, nx,ny,nz, t_star, iterations -- in the VOLUME frame; the reference's final
+ *              transformPointCloudWithNormals by trans^-1 (:422) is applied by the host shell.
+ *              A miss has NaN x,y,z and a zero normal (PointNormal's default constructor). */
+int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                     float *out);
+
+/* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
+ *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
+ *   ok n bytes: 1 where the reference returns true. */
+int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad,
+                    float *hess, uint8_t *ok);
+
+/* MarchingCubesTSDFOctree::reconstruct -- src/lib/marching_cubes_tsdf_octree.cpp:108-236
+ * (+ pcl::MarchingCubes::createSurface).  color_mode: 0 none, 1 setColorByRGB, 2 setColorByConfidence.
+ * tsdf_hip_march runs the kernels and reports the triangle count; tsdf_hip_march_fetch copies
+ * n_tri*9 floats (3 vertices, volume frame) and, if rgb != NULL, n_tri*9 bytes (r,g,b per vertex) and,
+ * if cell != NULL, n_tri uint64 cell keys ((x<<42)|(y<<21)|z of the base voxel).  Triangles come
+ * out in the reference's order (octree pre-order = Morton order with x as the high bit). */
+int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri);
+int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell);
+
+/* Block transfer of raw voxels (parity tests, save/load, halo exchange).  Coordinates are global
+ * grid indices; the block must lie inside the handle's slab + halo.  Any pointer may be NULL.
+ * rgb is 3 bytes per voxel (r,g,b).  *_device variants take device pointers (rgb then 4 bytes). */
+int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *d,
+                      float *w, uint8_t *rgb);
+int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
+                    const float *w, const uint8_t *rgb);
+
+/* Raw device pointers of the SoA planes and their geometry (for RCCL halo exchange done by the
+ * caller): element index of voxel (x,y,z_global) = ((z_global - z_first)*ny + y)*pitch + x. */
+int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,
+                           int32_t *z_first, int32_t *nz_alloc);
+
+/* Voxel-centre tables actually used by the kernels: the reference's octree node centres
+ * (src/lib/octree.cpp:244-266 split arithmetic) for each axis.  out has res[axis] floats. */
+int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
+
+const char *tsdf_hip_error_string(int code);
+const char *tsdf_hip_last_error(void);
+int tsdf_hip_device_count(void);
+/* ABI version of this header. */
+int tsdf_hip_abi_version(void);
+#define TSDF_HIP_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDF_HIP_H */

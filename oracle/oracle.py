@@ -1,0 +1,134 @@
+"""ctypes binding of the CPU oracle (oracle/tsdf_oracle.c -> oracle/libtsdf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "libtsdf_oracle.so")
+SRC = os.path.join(_HERE, "tsdf_oracle.c")
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(_HERE, "mc_tables.h"))):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-Wall", "-o", LIB,
+                               SRC, "-lm"])
+    return LIB
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("res", C.c_int32 * 3), ("size", C.c_float * 3),
+        ("max_dist_pos", C.c_float), ("max_dist_neg", C.c_float), ("max_weight", C.c_float),
+        ("min_sensor_dist", C.c_float), ("max_sensor_dist", C.c_float),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("image_width", C.c_int32), ("image_height", C.c_int32),
+        ("integrate_color", C.c_int32), ("xform_order", C.c_int32),
+    ]
+
+
+_lib = None
+_f = C.POINTER(C.c_float)
+_u8 = C.POINTER(C.c_uint8)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.oracle_centers.argtypes = [C.c_int, C.c_float, _f]
+        L.oracle_integrate.restype = C.c_uint64
+        L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
+        L.oracle_raycast.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, _f]
+        L.oracle_sample_batch.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_size_t, _f, _f, _f, _u8]
+        L.oracle_march.restype = C.c_uint64
+        L.oracle_march.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, C.c_float, C.c_int, _f, _u8,
+                                   C.POINTER(C.c_uint64), C.c_uint64]
+        L.oracle_trilinear.restype = C.c_float
+        L.oracle_trilinear.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_float, C.c_float, C.c_float,
+                                       C.POINTER(C.c_int)]
+        L.oracle_containing.restype = C.c_int
+        L.oracle_containing.argtypes = [C.POINTER(OracleParams), C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f) if a is not None else None
+
+
+def _bp(a):
+    return a.ctypes.data_as(_u8) if a is not None else None
+
+
+def params_from(p):
+    """Copy the shared fields of a capi.TsdfParams (or any object with the same attributes)."""
+    o = OracleParams()
+    for name, _ in OracleParams._fields_:
+        v = getattr(p, name)
+        if name in ("res", "size"):
+            getattr(o, name)[:] = list(v)
+        else:
+            setattr(o, name, v)
+    return o
+
+
+class OracleVolume:
+    """Dense CPU volume driven by the C restatement; arrays are [z][y][x]."""
+
+    def __init__(self, params):
+        self.p = params_from(params)
+        nx, ny, nz = self.p.res
+        self.d = np.full((nz, ny, nx), -1.0, dtype=np.float32)  # tsdf_volume_octree.cpp:217
+        self.w = np.zeros((nz, ny, nx), dtype=np.float32)
+        self.rgb = np.zeros((nz, ny, nx, 3), dtype=np.uint8) if self.p.integrate_color else None
+
+    def centers(self, axis):
+        out = np.empty(self.p.res[axis], dtype=np.float32)
+        lib().oracle_centers(self.p.res[axis], self.p.size[axis], _fp(out))
+        return out
+
+    def integrate(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        T = np.ascontiguousarray(cam_from_vol, dtype=np.float32).reshape(12)
+        col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
+        return int(lib().oracle_integrate(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), _fp(depth),
+                                          _bp(col), _fp(T), z_begin, z_end))
+
+    def raycast(self, trans, ds=1):
+        trans = np.asarray(trans, dtype=np.float64)
+        rot = np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9))
+        org = np.ascontiguousarray(trans[:3, 3].astype(np.float32))
+        nh, nw = self.p.image_height // ds, self.p.image_width // ds
+        out = np.empty((nh, nw, 8), dtype=np.float32)
+        lib().oracle_raycast(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, _fp(out))
+        return out
+
+    def sample(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        n = len(pts)
+        val = np.empty(n, np.float32)
+        grad = np.empty((n, 3), np.float32)
+        hess = np.empty((n, 9), np.float32)
+        ok = np.empty(n, np.uint8)
+        lib().oracle_sample_batch(C.byref(self.p), _fp(self.d), _fp(pts), n, _fp(val), _fp(grad), _fp(hess), _bp(ok))
+        return ok.astype(bool), val, grad, hess.reshape(n, 3, 3)
+
+    def march(self, w_min, color_mode=0):
+        cap = 1 << 16
+        while True:
+            verts = np.empty((cap, 9), np.float32)
+            rgb = np.empty((cap, 9), np.uint8)
+            cells = np.empty(cap, np.uint64)
+            n = int(lib().oracle_march(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), w_min, color_mode,
+                                       _fp(verts), _bp(rgb), cells.ctypes.data_as(C.POINTER(C.c_uint64)), cap))
+            if n <= cap:
+                return verts[:n].reshape(n * 3, 3), rgb[:n].reshape(n * 3, 3), cells[:n]
+            cap = n

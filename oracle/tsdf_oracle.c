@@ -1,0 +1,570 @@
+/*
+ * tsdf_oracle.c -- CPU restatement of the cpu_tsdf hot path on a DENSE grid.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (cpu_tsdf_amd/, include/) may call, link or
+ * import this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
+ * only as the checker.
+ *
+ * Each function follows the reference (sdmiller/cpu_tsdf) line by line; citations are relative to
+ * the reference tree.  The restatement is validated against the reference's own, unmodified
+ * sources compiled with the in-repo PCL/Eigen stand-ins (oracle/_ref, see oracle/Makefile and
+ * tests/test_oracle_vs_reference.py).  The reference ships no tests or golden vectors of its own
+ * (SURVEY.md section 4), and the PCL/Eigen arithmetic it calls is not vendored: the pieces marked
+ * [PCL-recall]/[Eigen-recall] restate upstream behaviour from memory and are "parity unpinned"
+ * (see DESIGN.md).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (no -march: like the reference's CMake
+ * build, so no FMA contraction; fp32 arithmetic is plain IEEE single).
+ *
+ * Dense-grid equivalence: with every octree leaf at the finest level, getContainingVoxel
+ * (src/lib/octree.cpp:112-133,628-643) is an index computation; octree-only behaviour (split,
+ * prune, coarse leaves) has no counterpart here.  Arrays are [z][y][x], x fastest.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct oracle_params {
+  int32_t res[3];
+  float size[3];
+  float max_dist_pos, max_dist_neg, max_weight;
+  float min_sensor_dist, max_sensor_dist;
+  double fx, fy, cx, cy;
+  int32_t image_width, image_height;
+  int32_t integrate_color;
+  int32_t xform_order; /* 0: x*c0 + (y*c1 + (z*c2 + c3)), 1: ((m0*x + m1*y) + m2*z) + m3 */
+} oracle_params;
+
+/* x86 cvttsd2si: NaN / out-of-range -> INT_MIN.  A plain C cast would be UB there; the reference's
+ * `int u = <double>` (tsdf_volume_octree.cpp:614-615, :568-570) compiles to cvttsd2si. */
+static int cvtt(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
+
+static int ilog2_exact(int v) {
+  int l = 0;
+  if (v <= 0 || (v & (v - 1))) return -1;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+/* Octree node centres per axis: OctreeNode::split, src/lib/octree.cpp:244-266 (child centre =
+ * ctr -/+ size_/4, child size = size_/2, float), root at 0 (octree.cpp:589-590).  Non power-of-two
+ * resolutions have no octree; fall back to getVoxelCenter (tsdf_volume_octree.cpp:553-560). */
+void oracle_centers(int res, float size, float *out) {
+  const int L = ilog2_exact(res);
+  if (L >= 0) {
+    for (int i = 0; i < res; ++i) {
+      float c = 0.f, s = size;
+      for (int l = L - 1; l >= 0; --l) {
+        const float off = s / 4;
+        c = ((i >> l) & 1) ? c + off : c - off;
+        s = s / 2;
+      }
+      out[i] = c;
+    }
+  } else {
+    const float off = size / 2.0;
+    for (int i = 0; i < res; ++i) out[i] = (float)((i + 0.5) * size / (double)res - off);
+  }
+}
+
+/* getVoxelCenter, tsdf_volume_octree.cpp:553-560 (one axis). */
+static float voxel_center(const oracle_params *p, int axis, int i) {
+  const float off = p->size[axis] / 2.0;
+  return (float)(((size_t)i + 0.5) * p->size[axis] / (double)p->res[axis] - off);
+}
+
+void oracle_voxel_center(const oracle_params *p, int i, int j, int k, float out[3]) {
+  out[0] = voxel_center(p, 0, i);
+  out[1] = voxel_center(p, 1, j);
+  out[2] = voxel_center(p, 2, k);
+}
+
+/* getVoxelIndex, tsdf_volume_octree.cpp:562-574. */
+int oracle_voxel_index(const oracle_params *p, float x, float y, float z, int idx[3]) {
+  const float v[3] = {x, y, z};
+  int ok = 1;
+  for (int a = 0; a < 3; ++a) {
+    const double off = (double)p->size[a] / 2.0;
+    idx[a] = cvtt(floor(((double)v[a] + off) / (double)p->size[a] * (double)p->res[a]));
+    ok &= idx[a] >= 0 && idx[a] < p->res[a];
+  }
+  return ok;
+}
+
+/* One axis of OctreeNode::getContainingVoxel's descent, octree.cpp:112-121:
+ * child bit = (x - ctr) > 0 at each level. */
+static int descend_axis(float x, float size, int L) {
+  float c = 0.f, s = size;
+  int i = 0;
+  for (int l = 0; l < L; ++l) {
+    const int b = (x - c) > 0;
+    const float off = s / 4;
+    c = b ? c + off : c - off;
+    s = s / 2;
+    i = i * 2 + b;
+  }
+  return i;
+}
+
+/* Octree::getContainingVoxel, octree.cpp:628-643, on a fully split tree.  Returns 0 for NULL. */
+int oracle_containing(const oracle_params *p, float x, float y, float z, int idx[3]) {
+  if (isnan(z) || fabsf(x) > p->size[0] / 2 || fabsf(y) > p->size[1] / 2 || fabsf(z) > p->size[2] / 2)
+    return 0;
+  const float v[3] = {x, y, z};
+  for (int a = 0; a < 3; ++a) {
+    const int L = ilog2_exact(p->res[a]);
+    if (L >= 0) {
+      idx[a] = descend_axis(v[a], p->size[a], L);
+    } else { /* no octree for this resolution: nearest cell by the closed form */
+      int i = cvtt(floor(((double)v[a] + (double)p->size[a] / 2.0) / (double)p->size[a] * (double)p->res[a]));
+      if (i < 0) i = 0;
+      if (i >= p->res[a]) i = p->res[a] - 1;
+      idx[a] = i;
+    }
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * integrateCloud on the dense grid: updateVoxel leaf branch, include/cpu_tsdf/impl/
+ * tsdf_volume_octree.hpp:143-208, reprojectPoint tsdf_volume_octree.cpp:611-617,
+ * OctreeNode::addObservation octree.cpp:152-163, RGBNode::addObservation octree.cpp:328-337.
+ * T = trans.inverse().cast<float>() (hpp:54), row-major 3x4.  depth = pt.z of cloud(u,v),
+ * bgra = PCL PointXYZRGBA byte order.  rgb is 3 bytes per voxel.  Returns the number of voxels
+ * that reached addObservation. */
+uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
+                          const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
+        *cz = (float *)malloc(sizeof(float) * nz);
+  oracle_centers(nx, p->size[0], cx);
+  oracle_centers(ny, p->size[1], cy);
+  oracle_centers(nz, p->size[2], cz);
+  if (z_begin == 0 && z_end == 0) z_end = nz;
+  uint64_t n_obs = 0;
+  const int W = p->image_width, H = p->image_height;
+#pragma omp parallel for schedule(static) reduction(+ : n_obs)
+  for (int k = z_begin; k < z_end; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        const float x = cx[i], y = cy[j], z = cz[k];
+        float g[3];
+        for (int r = 0; r < 3; ++r) { /* pcl::transformPoint, hpp:145 [PCL-recall] */
+          const float *m = T + 4 * r;
+          if (p->xform_order == 0)
+            g[r] = x * m[0] + (y * m[1] + (z * m[2] + m[3]));
+          else
+            g[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+        }
+        if (g[2] < p->min_sensor_dist || g[2] > p->max_sensor_dist) continue; /* hpp:146 */
+        const int u = cvtt((double)g[0] * p->fx / (double)g[2] + p->cx);      /* .cpp:614 */
+        const int v = cvtt((double)g[1] * p->fy / (double)g[2] + p->cy);      /* .cpp:615 */
+        if (!(g[2] > 0 && u >= 0 && u < W && v >= 0 && v < H)) continue;       /* .cpp:616 */
+        const float zs = depth[(size_t)v * W + u];
+        if (isnan(zs)) continue; /* hpp:152 */
+        float dn = zs - g[2];    /* hpp:159 */
+        if (dn > p->max_dist_pos)
+          dn = p->max_dist_pos; /* hpp:189-192 */
+        else if (dn < -p->max_dist_neg)
+          continue;             /* hpp:193-196 */
+        dn /= p->max_dist_neg;  /* hpp:198 */
+        const float wn = 1;     /* hpp:200-204: both weightings unreachable */
+        const size_t vi = ((size_t)k * ny + j) * nx + i;
+        if (p->integrate_color && rgb) { /* octree.cpp:331-335 (old w, truncation) */
+          const uint8_t *px = bgra + 4 * ((size_t)v * W + u);
+          const float wsum = w[vi] + wn;
+          rgb[3 * vi + 0] = (uint8_t)((w[vi] * rgb[3 * vi + 0] + wn * px[2]) / wsum);
+          rgb[3 * vi + 1] = (uint8_t)((w[vi] * rgb[3 * vi + 1] + wn * px[1]) / wsum);
+          rgb[3 * vi + 2] = (uint8_t)((w[vi] * rgb[3 * vi + 2] + wn * px[0]) / wsum);
+        }
+        d[vi] = (d[vi] * w[vi] + dn * wn) / (w[vi] + wn); /* octree.cpp:156 */
+        w[vi] += wn;                                       /* octree.cpp:157 */
+        if (w[vi] > p->max_weight) w[vi] = p->max_weight;  /* octree.cpp:158-159 */
+        ++n_obs;
+      }
+  free(cx);
+  free(cy);
+  free(cz);
+  return n_obs;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * interpolateTrilinearly, tsdf_volume_octree.cpp:486-541.  *valid is AND-ed (never set to 1). */
+static float trilinear(const oracle_params *p, const float *d, const float *w, float x, float y, float z,
+                       int *valid) {
+  int id[3];
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  const int exists = oracle_voxel_index(p, x, y, z, id);
+  if (!exists || id[0] <= 0 || id[0] >= nx - 1 || id[1] <= 0 || id[1] >= ny - 1 || id[2] <= 0 ||
+      id[2] >= nz - 1) {
+    if (valid) *valid = 0;
+    return NAN;
+  }
+  int xi = id[0], yi = id[1], zi = id[2];
+  float vx = voxel_center(p, 0, xi), vy = voxel_center(p, 1, yi), vz = voxel_center(p, 2, zi);
+  if (x < vx) xi -= 1;
+  if (y < vy) yi -= 1;
+  if (z < vz) zi -= 1;
+  vx = voxel_center(p, 0, xi);
+  vy = voxel_center(p, 1, yi);
+  vz = voxel_center(p, 2, zi);
+  const float a = (x - vx) * nx / p->size[0];
+  const float b = (y - vy) * ny / p->size[1];
+  const float c = (z - vz) * nz / p->size[2];
+#define VI(i, j, k) (((size_t)(k) * ny + (j)) * nx + (i))
+  const size_t o = VI(xi, yi, zi), ox = VI(xi + 1, yi, zi), oy = VI(xi, yi + 1, zi), oz = VI(xi, yi, zi + 1),
+               oxy = VI(xi + 1, yi + 1, zi), oxz = VI(xi + 1, yi, zi + 1), oyz = VI(xi, yi + 1, zi + 1),
+               oxyz = VI(xi + 1, yi + 1, zi + 1);
+  if (valid) {
+    *valid &= (w[o] > 0);
+    *valid &= (w[ox] > 0);
+    *valid &= (w[oy] > 0);
+    *valid &= (w[oz] > 0);
+    *valid &= (w[oxy] > 0);
+    *valid &= (w[oxz] > 0);
+    *valid &= (w[oyz] > 0);
+    *valid &= (w[oxyz] > 0);
+  }
+  return (d[o] * (1 - a) * (1 - b) * (1 - c) + d[oz] * (1 - a) * (1 - b) * (c) +
+          d[oy] * (1 - a) * (b) * (1 - c) + d[oyz] * (1 - a) * (b) * (c) + d[ox] * (a) * (1 - b) * (1 - c) +
+          d[oxz] * (a) * (1 - b) * (c) + d[oxy] * (a) * (b) * (1 - c) + d[oxyz] * (a) * (b) * (c));
+}
+
+float oracle_trilinear(const oracle_params *p, const float *d, const float *w, float x, float y, float z,
+                       int *valid) {
+  return trilinear(p, d, w, x, y, z, valid);
+}
+
+/* Eigen::Vector3f::normalize() [Eigen-recall, 3.3+]: z = squaredNorm(); if (z > 0) v /= sqrt(z);
+ * squaredNorm of a 3-vector unrolls as x*x + (y*y + z*z); operator/= is a true division. */
+static void normalize3(float v[3]) {
+  const float n2 = v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]);
+  if (n2 > 0.f) {
+    const float n = sqrtf(n2);
+    v[0] /= n;
+    v[1] /= n;
+    v[2] /= n;
+  }
+}
+
+static float leaf_size(const oracle_params *p, int axis) { /* size_ after L halvings */
+  float s = p->size[axis];
+  const int L = ilog2_exact(p->res[axis]);
+  if (L < 0) return p->size[axis] / p->res[axis];
+  for (int l = 0; l < L; ++l) s = s / 2;
+  return s;
+}
+
+/* renderView, tsdf_volume_octree.cpp:278-421, WITHOUT the final transformPointCloudWithNormals
+ * (:422): output stays in the volume frame.  rot = trans.rotation().cast<float>() (row-major 3x3),
+ * org = trans.translation().cast<float>().  out: 8 floats per pixel x,y,z,nx,ny,nz,t,niter; a miss
+ * has NaN xyz and zero normal (PointNormal's default constructor). */
+void oracle_raycast(const oracle_params *p, const float *d, const float *w, const float rot[9],
+                    const float org[3], int ds, float *out) {
+  const int nw = p->image_width / ds, nh = p->image_height / ds;
+  const double nfx = p->fx / ds, nfy = p->fy / ds, ncx = p->cx / ds, ncy = p->cy / ds;
+  const int nx = p->res[0], ny = p->res[1];
+  const float min_step = p->max_dist_neg * 3 / 4.; /* :289 */
+  /* leaf->getMinSize() is size_ = size_x for every axis (octree.h:63-66) */
+  const float lsz = leaf_size(p, 0);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
+    const size_t x = i % nw, y = i / nw;
+    float *o = out + 8 * i;
+    int found_crossing = 0;
+    float du[3] = {(float)((x - ncx) / nfx), (float)((y - ncy) / nfy), 1.f};
+    normalize3(du);
+    { /* du = R * du  [Eigen-recall: row sum (a + b) + c] */
+      const float a = du[0], b = du[1], c = du[2];
+      for (int r = 0; r < 3; ++r) du[r] = (rot[3 * r] * a + rot[3 * r + 1] * b) + rot[3 * r + 2] * c;
+    }
+    float pt[3] = {org[0], org[1], org[2]};
+    float dd = 0, ww = 0, last_w = 0, last_d = 0;
+    float t = p->min_sensor_dist;
+    for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
+    float step = min_step;
+    int hit_voxel = 0, niter = 0;
+    while (t < p->max_sensor_dist) {
+      int id[3];
+      if (oracle_containing(p, pt[0], pt[1], pt[2], id)) {
+        const size_t vi = ((size_t)id[2] * ny + id[1]) * nx + id[0];
+        hit_voxel = 1;
+        dd = d[vi];
+        ww = w[vi];
+        if (((dd < 0 && last_d > 0) || (dd > 0 && last_d < 0)) && last_w && ww) {
+          found_crossing = 1;
+          const float old_t = t - step;
+          step = (p->size[2] / p->res[2]) / 2.; /* :329 */
+          float new_d, new_w;
+          float last_new_d = dd, last_new_w = ww;
+          while (t >= old_t) {
+            t -= step;
+            for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
+            if (!oracle_containing(p, pt[0], pt[1], pt[2], id)) break;
+            const size_t vj = ((size_t)id[2] * ny + id[1]) * nx + id[0];
+            new_d = d[vj];
+            new_w = w[vj];
+            if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
+              last_d = new_d;
+              last_w = new_w;
+              dd = last_new_d;
+              ww = last_new_w;
+              t += step;
+              for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+              break;
+            }
+            last_new_d = dd; /* sic: the reference assigns d, not new_d (:352-353) */
+            last_new_w = ww;
+          }
+          break;
+        }
+        last_d = dd;
+        last_w = ww;
+        { /* :360  step = max(size/4, (float)(fabs(d)*max_dist_neg_)) */
+          const float s1 = lsz / 4.f, s2 = (float)(fabs(dd) * p->max_dist_neg);
+          step = s1 < s2 ? s2 : s1; /* std::max(a,b) = (a<b)?b:a */
+        }
+      } else if (hit_voxel) {
+        break;
+      }
+      t += step;
+      for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+      niter++;
+    }
+    o[3] = o[4] = o[5] = 0.f;
+    o[6] = t;
+    o[7] = (float)niter;
+    if (!found_crossing) {
+      o[0] = o[1] = o[2] = NAN;
+      continue;
+    }
+    int has_data = 1;
+    const float tcurr = t, tprev = t - step;
+    last_d = trilinear(p, d, w, org[0] + tprev * du[0], org[1] + tprev * du[1], org[2] + tprev * du[2], &has_data);
+    dd = trilinear(p, d, w, org[0] + tcurr * du[0], org[1] + tcurr * du[1], org[2] + tcurr * du[2], &has_data);
+    /* :385-388 sets NaN but does not `continue`; :389-390 then overwrites xyz anyway */
+    /* unqualified fabs(float) resolves to double fabs(double) with <cmath> only (g++), so the
+     * update of t_star is evaluated in double */
+    const float t_star = t + step * (-1 + fabs(last_d / (last_d - dd)));
+    for (int k = 0; k < 3; ++k) o[k] = org[k] + t_star * du[k];
+    o[6] = t_star;
+    int id[3];
+    if (!oracle_containing(p, o[0], o[1], o[2], id)) {
+      o[3] = o[4] = o[5] = NAN;
+      continue;
+    }
+    const float xs = lsz, ys = lsz, zs = lsz; /* getSize returns size_ thrice (octree.cpp:58-64) */
+    int valid = 1;
+    const float d_xm = trilinear(p, d, w, o[0] - xs, o[1], o[2], &valid);
+    const float d_xp = trilinear(p, d, w, o[0] + xs, o[1], o[2], &valid);
+    const float d_ym = trilinear(p, d, w, o[0], o[1] - ys, o[2], &valid);
+    const float d_yp = trilinear(p, d, w, o[0], o[1] + ys, o[2], &valid);
+    const float d_zm = trilinear(p, d, w, o[0], o[1], o[2] - zs, &valid);
+    const float d_zp = trilinear(p, d, w, o[0], o[1], o[2] + zs, &valid);
+    if (!valid) {
+      o[3] = o[4] = o[5] = NAN;
+      continue;
+    }
+    float dF[3];
+    dF[0] = (d_xp - d_xm) * p->max_dist_neg / (2 * xs);
+    dF[1] = (d_yp - d_ym) * p->max_dist_neg / (2 * ys);
+    dF[2] = (d_zp - d_zm) * p->max_dist_neg / (2 * zs);
+    normalize3(dF);
+    o[3] = dF[0];
+    o[4] = dF[1];
+    o[5] = dF[2];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * getNeighbors tsdf_volume_octree.cpp:796-828, getFxn :655-672, getGradient :681-700,
+ * getHessian :703-726.  Order of the 8 neighbours: dx outer, dy, dz inner.  getFxn/getGradient use
+ * the octree NODE centre (vox->getCenter), getHessian uses getVoxelCenter (`centers[i]`).
+ * `fabs` on a float is double fabs(double) (see above), so each term is a double product. */
+static int sgn(float x) { return x > 0 ? 1 : -1; } /* :674-678 */
+
+int oracle_sample(const oracle_params *p, const float *d, const float pt[3], float *val, float grad[3],
+                  float hess[9]) {
+  int id[3];
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  if (!oracle_voxel_index(p, pt[0], pt[1], pt[2], id)) return 0;
+  int xi = id[0], yi = id[1], zi = id[2];
+  if (pt[0] < voxel_center(p, 0, xi)) xi -= 1;
+  if (pt[1] < voxel_center(p, 1, yi)) yi -= 1;
+  if (pt[2] < voxel_center(p, 2, zi)) zi -= 1;
+  if (xi < 0 || xi >= nx - 1 || yi < 0 || yi >= ny - 1 || zi < 0 || zi >= nz - 1) return 0;
+  float *tx = (float *)malloc(sizeof(float) * (nx + ny + nz)), *ty = tx + nx, *tz = ty + ny;
+  oracle_centers(nx, p->size[0], tx);
+  oracle_centers(ny, p->size[1], ty);
+  oracle_centers(nz, p->size[2], tz);
+  const float c = p->size[0] / p->res[0];
+  float v = 0, g[3] = {0, 0, 0}, h01 = 0, h02 = 0, h12 = 0;
+  for (int dx = 0; dx <= 1; dx++)
+    for (int dy = 0; dy <= 1; dy++)
+      for (int dz = 0; dz <= 1; dz++) {
+        const int i = xi + dx, j = yi + dy, k = zi + dz;
+        const float dv = d[((size_t)k * ny + j) * nx + i];
+        const float nc[3] = {tx[i], ty[j], tz[k]};                                       /* node centre */
+        const float fc[3] = {voxel_center(p, 0, i), voxel_center(p, 1, j), voxel_center(p, 2, k)}; /* centers[i] */
+        v += (c - fabs(pt[0] - nc[0])) * (c - fabs(pt[1] - nc[1])) * (c - fabs(pt[2] - nc[2])) * dv;
+        g[0] += -sgn(pt[0] - nc[0]) * (c - fabs(pt[1] - nc[1])) * (c - fabs(pt[2] - nc[2])) * dv;
+        g[1] += (c - fabs(pt[0] - nc[0])) * -sgn(pt[1] - nc[1]) * (c - fabs(pt[2] - nc[2])) * dv;
+        g[2] += (c - fabs(pt[0] - nc[0])) * (c - fabs(pt[1] - nc[1])) * -sgn(pt[2] - nc[2]) * dv;
+        h01 += sgn(pt[0] - fc[0]) * sgn(pt[1] - fc[1]) * (c - fabs(pt[2] - fc[2])) * dv;
+        h02 += sgn(pt[0] - fc[0]) * (c - fabs(pt[1] - fc[1])) * sgn(pt[2] - fc[2]) * dv;
+        h12 += (c - fabs(pt[0] - fc[0])) * sgn(pt[1] - fc[1]) * sgn(pt[2] - fc[2]) * dv;
+      }
+  free(tx);
+  const float c3 = c * c * c;
+  if (val) *val = v / c3;
+  if (grad)
+    for (int k = 0; k < 3; ++k) grad[k] = g[k] / c3;
+  if (hess) {
+    memset(hess, 0, 9 * sizeof(float));
+    hess[1] = hess[3] = h01 / c3;
+    hess[2] = hess[6] = h02 / c3;
+    hess[5] = hess[7] = h12 / c3;
+  }
+  return 1;
+}
+
+void oracle_sample_batch(const oracle_params *p, const float *d, const float *xyz, size_t n, float *val,
+                         float *grad, float *hess, uint8_t *ok) {
+  for (size_t i = 0; i < n; ++i) {
+    float v = NAN, g[3] = {NAN, NAN, NAN}, h[9];
+    for (int k = 0; k < 9; ++k) h[k] = NAN;
+    const int r = oracle_sample(p, d, xyz + 3 * i, &v, g, h);
+    if (ok) ok[i] = (uint8_t)r;
+    if (val) val[i] = v;
+    if (grad) memcpy(grad + 3 * i, g, sizeof g);
+    if (hess) memcpy(hess + 9 * i, h, sizeof h);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Marching cubes: MarchingCubesTSDFOctree, src/lib/marching_cubes_tsdf_octree.cpp:44-236, on top of
+ * pcl::MarchingCubes<PointXYZ>::createSurface / interpolateEdge [PCL-recall] with Bourke's tables
+ * (oracle/mc_tables.h, generated by tools/gen_mc_tables.py and cross-checked there). */
+#include "mc_tables.h"
+
+static uint64_t morton_x_major(uint32_t x, uint32_t y, uint32_t z) {
+  uint64_t k = 0;
+  for (int l = 20; l >= 0; --l)
+    k = (k << 3) | (uint64_t)((((x >> l) & 1u) << 2) | (((y >> l) & 1u) << 1) | ((z >> l) & 1u));
+  return k;
+}
+
+typedef struct {
+  uint64_t key;
+  uint32_t x, y, z;
+} mc_cell;
+
+static int cmp_cell(const void *a, const void *b) {
+  const uint64_t ka = ((const mc_cell *)a)->key, kb = ((const mc_cell *)b)->key;
+  return ka < kb ? -1 : ka > kb;
+}
+
+/* getGridValue, marching_cubes_tsdf_octree.cpp:91-106 */
+static float grid_value(const oracle_params *p, const float *d, const float *w, float w_min, int x, int y, int z) {
+  const size_t vi = ((size_t)z * p->res[1] + y) * p->res[0] + x;
+  if (w[vi] < w_min || fabs(d[vi]) >= 1) return NAN;
+  return d[vi] * p->max_dist_neg;
+}
+
+/* Returns the number of triangles; writes at most cap triangles (9 floats each, volume frame, before
+ * the global transform), rgb 9 bytes per triangle (color_mode 1: setColorByRGB, 2:
+ * setColorByConfidence), cell keys (x<<42 | y<<21 | z) per triangle.  Order = octree pre-order. */
+uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, const uint8_t *rgb, float w_min,
+                      int color_mode, float *verts, uint8_t *rgb_out, uint64_t *cell_out, uint64_t cap) {
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  /* setInputTSDF :44-83: the two +- terms at :64-66 cancel, so the bounding box is
+   * [centre(voxel 0), centre(voxel res)]; size_voxel_ = (upper - lower) * (1 / res) in float */
+  float lower[3], size_voxel[3];
+  for (int a = 0; a < 3; ++a) {
+    lower[a] = voxel_center(p, a, 0);
+    const float upper = voxel_center(p, a, p->res[a]);
+    size_voxel[a] = (upper - lower[a]) * (1.0f / (float)p->res[a]);
+  }
+  const float iso = 0.f;
+  size_t n_cells = 0, cap_cells = 1 << 16;
+  mc_cell *cells = (mc_cell *)malloc(cap_cells * sizeof(mc_cell));
+  /* reconstructVoxel :179-207 candidate test */
+  for (int z = 1; z < nz - 1; ++z)
+    for (int y = 1; y < ny - 1; ++y)
+      for (int x = 1; x < nx - 1; ++x) {
+        const size_t vi = ((size_t)z * ny + y) * nx + x;
+        if (!(w[vi] >= w_min && fabs(d[vi]) < 1)) continue;
+        if (n_cells == cap_cells) {
+          cap_cells *= 2;
+          cells = (mc_cell *)realloc(cells, cap_cells * sizeof(mc_cell));
+        }
+        cells[n_cells].key = morton_x_major(x, y, z);
+        cells[n_cells].x = x;
+        cells[n_cells].y = y;
+        cells[n_cells].z = z;
+        ++n_cells;
+      }
+  qsort(cells, n_cells, sizeof(mc_cell), cmp_cell);
+  uint64_t n_tri = 0;
+  static const int off[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 0, 1}, {0, 0, 1}, {0, 1, 0}, {1, 1, 0}, {1, 1, 1}, {0, 1, 1}};
+  static const int edge_v[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  for (size_t ci = 0; ci < n_cells; ++ci) {
+    const int x = cells[ci].x, y = cells[ci].y, z = cells[ci].z;
+    float leaf[8];
+    int ok = 1;
+    for (int k = 0; k < 8 && ok; ++k) { /* getValidNeighborList1D :145-177 */
+      leaf[k] = grid_value(p, d, w, w_min, x + off[k][0], y + off[k][1], z + off[k][2]);
+      if (isnan(leaf[k])) ok = 0;
+    }
+    if (!ok) continue;
+    int cubeindex = 0; /* createSurface [PCL-recall] */
+    for (int k = 0; k < 8; ++k)
+      if (leaf[k] < iso) cubeindex |= 1 << k;
+    if (mc_edge_table[cubeindex] == 0) continue;
+    const int idx[3] = {x, y, z};
+    float center[3], pc[8][3];
+    for (int a = 0; a < 3; ++a) center[a] = lower[a] + size_voxel[a] * (float)idx[a];
+    for (int k = 0; k < 8; ++k) {
+      pc[k][0] = center[0];
+      pc[k][1] = center[1];
+      pc[k][2] = center[2];
+      if (k & 0x4) pc[k][1] = center[1] + size_voxel[1];
+      if (k & 0x2) pc[k][2] = center[2] + size_voxel[2];
+      if ((k & 0x1) ^ ((k >> 1) & 0x1)) pc[k][0] = center[0] + size_voxel[0];
+    }
+    float vl[12][3];
+    for (int e = 0; e < 12; ++e)
+      if (mc_edge_table[cubeindex] & (1 << e)) { /* interpolateEdge */
+        const int a = edge_v[e][0], b = edge_v[e][1];
+        const float mu = (iso - leaf[a]) / (leaf[b] - leaf[a]);
+        for (int k = 0; k < 3; ++k) vl[e][k] = pc[a][k] + mu * (pc[b][k] - pc[a][k]);
+      }
+    uint8_t col[3] = {0, 0, 0};
+    const size_t vi = ((size_t)z * ny + y) * nx + x;
+    if (color_mode == 2) { /* :217-224 */
+      const float std_dev = (100. - w[vi]) / 100.;
+      col[0] = (uint8_t)fmax(0., fmin((1 - std_dev) * 255., 255.));
+      col[1] = 0;
+      col[2] = (uint8_t)fmax(0., fmin((std_dev)*255., 255.));
+    } else if (color_mode == 1 && rgb) { /* :226-231 */
+      col[0] = rgb[3 * vi];
+      col[1] = rgb[3 * vi + 1];
+      col[2] = rgb[3 * vi + 2];
+    }
+    for (int i = 0; mc_tri_table[cubeindex][i] != -1; i += 3) {
+      if (n_tri < cap) {
+        for (int v = 0; v < 3; ++v) {
+          const int e = mc_tri_table[cubeindex][i + v];
+          if (verts) memcpy(verts + 9 * n_tri + 3 * v, vl[e], 3 * sizeof(float));
+          if (rgb_out) memcpy(rgb_out + 9 * n_tri + 3 * v, col, 3);
+        }
+        if (cell_out) cell_out[n_tri] = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+      }
+      ++n_tri;
+    }
+  }
+  free(cells);
+  return n_tri;
+}

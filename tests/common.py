@@ -1,0 +1,47 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from cpu_tsdf_amd import capi, synth
+from cpu_tsdf_amd.volume import TSDFVolumeOctree
+
+
+def make_volume(res, width=160, height=120, color=False, order=0, size=None, zmin=0.0, zmax=None,
+                trunc=(0.03, 0.03), max_weight=100.0, res3=None, size3=None):
+    """A configured (not yet reset) product volume + its scene, CLI-style parameters."""
+    res3 = res3 or (res, res, res)
+    sc = synth.scene_a(res, width, height)
+    if size is not None:
+        sc = synth.Scene(size, width, height)
+    size3 = size3 or (sc.size,) * 3
+    v = TSDFVolumeOctree()
+    v.setResolution(*res3)
+    v.setGridSize(*size3)
+    v.setImageSize(width, height)
+    v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    v.setSensorDistanceBounds(zmin, 3 * sc.size if zmax is None else zmax)
+    v.setDepthTruncationLimits(*trunc)
+    v.setWeightTruncationLimit(max_weight)
+    v.setIntegrateColor(color)
+    v.setTransformOrder(order)
+    return v, sc
+
+
+def frames(sc, n, total=None, noise=False):
+    total = total or n
+    for i in range(n):
+        tr = synth.turntable_pose(i, total, sc.size)
+        yield i, tr, sc.depth(tr, noise_seed=(12345 + i) if noise else None), sc.bgra(i)
+
+
+def assert_same_f32(a, b, what):
+    """Bit-level equality of two float32 arrays (NaN == NaN)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ne = a.view(np.uint32) != b.view(np.uint32)
+    # +0 / -0 and NaN payload differences are tolerated only if values compare equal / both NaN
+    ne &= ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    if ne.any():
+        idx = np.argwhere(ne)[:5]
+        raise AssertionError(f"{what}: {int(ne.sum())} of {a.size} differ; first {idx.tolist()} "
+                             f"got {a[ne][:5]} want {b[ne][:5]}; max abs diff {np.nanmax(np.abs(a - b))}")

@@ -1,0 +1,90 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/tsdf_hip.h declares; host-side
+logic (defaults, pose inverse, centre tables) needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "tsdf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsdf_hip_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = capi.load()
+    names = declared_functions()
+    assert len(names) >= 20
+    raw = C.CDLL(capi.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
+        assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
+    assert lib.tsdf_hip_abi_version() == 1
+
+
+def test_default_params_match_reference_constructor():
+    # src/lib/tsdf_volume_octree.cpp:54-85
+    p = capi.default_params()
+    assert tuple(p.res) == (512, 512, 512)
+    assert tuple(p.size) == (3.0, 3.0, 3.0)
+    assert p.max_dist_pos == np.float32(0.03) and p.max_dist_neg == np.float32(0.03)
+    assert p.max_weight == 100 and p.min_sensor_dist == np.float32(0.3) and p.max_sensor_dist == 3.0
+    assert (p.fx, p.fy, p.cx, p.cy) == (525.0, 525.0, 320.0, 240.0)
+    assert (p.image_width, p.image_height, p.integrate_color) == (640, 480, 0)
+
+
+def test_params_struct_layout_matches_header():
+    # 3*4 + 3*4 + 5*4 = 44 -> pad to 48, 4 doubles, 8 int32
+    assert C.sizeof(capi.TsdfParams) == 48 + 32 + 32
+
+
+def test_no_device_is_reported_not_crashed():
+    lib = capi.load()
+    if lib.tsdf_hip_device_count() > 0:
+        pytest.skip("GPU present")
+    p = capi.default_params()
+    h = C.c_void_p()
+    rc = lib.tsdf_hip_create(C.byref(p), C.byref(h))
+    assert rc == capi.E_NODEVICE and not h.value
+    assert b"device" in lib.tsdf_hip_error_string(rc)
+
+
+def test_invalid_params_rejected():
+    lib = capi.load()
+    p = capi.default_params()
+    p.res[0] = 0
+    h = C.c_void_p()
+    assert lib.tsdf_hip_create(C.byref(p), C.byref(h)) == capi.E_INVALID
+    p = capi.default_params()
+    p.z_begin, p.z_end = 10, 5
+    assert lib.tsdf_hip_create(C.byref(p), C.byref(h)) == capi.E_INVALID
+
+
+def test_eigen_affine_inverse_is_an_inverse():
+    for i in range(5):
+        tr = synth.turntable_pose(i, 5, 2.0, tilt=0.3)
+        inv = synth.eigen_affine_inverse(tr)
+        assert np.allclose(inv @ tr, np.eye(4), atol=1e-14)
+        assert np.allclose(inv, np.linalg.inv(tr), atol=1e-14)
+    T = synth.cam_from_vol_f32(np.eye(4))
+    assert T.dtype == np.float32 and T.tolist() == [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+
+
+def test_scene_depth_is_analytic():
+    sc = synth.scene_a(256)
+    tr = synth.turntable_pose(0, 8, sc.size)
+    d = sc.depth(tr)
+    assert d.shape == (480, 640) and d.dtype == np.float32
+    cy, cx = 240, 320
+    # centre pixel looks at the sphere front: 2.2 S - 0.25 S
+    assert abs(d[cy, cx] - 1.95 * sc.size) < 1e-3
+    assert np.isnan(d[0, 0])
+    # a ray that misses the sphere but enters the box hits the far face z = +0.47 S
+    assert abs(d[cy, cx + 80] - (2.2 + 0.47) * sc.size) < 1e-5

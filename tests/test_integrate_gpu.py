@@ -1,0 +1,182 @@
+"""GPU tier: integrateCloud through the C ABI vs the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): per-voxel (d, w) within 1e-5; we assert bit equality (the kernel
+mirrors the oracle's fp32 operation order, no FMA) and report it as such; rgb bytes exact; the
+observed-voxel counter exact."""
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import synth
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32, frames, make_volume
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def run_pair(vol, sc, n_frames, total=None, noise=False):
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i, tr, dep, col in frames(sc, n_frames, total, noise):
+        n_gpu = vol.integrateCloud(dep, col if vol._p.integrate_color else None, tr, count=True)
+        n_cpu = ov.integrate(dep, col if vol._p.integrate_color else None, synth.cam_from_vol_f32(tr))
+        assert n_gpu == n_cpu, f"frame {i}: n_observed {n_gpu} != oracle {n_cpu}"
+    return ov
+
+
+def compare(vol, ov):
+    d, w, rgb = vol.download()
+    assert np.nanmax(np.abs(d - ov.d)) <= TOL and np.max(np.abs(w - ov.w)) <= TOL
+    assert_same_f32(d, ov.d, "d")
+    assert_same_f32(w, ov.w, "w")
+    if ov.rgb is not None:
+        assert np.array_equal(rgb, ov.rgb), f"{(rgb != ov.rgb).sum()} rgb bytes differ"
+    return d, w
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_parity_64_multi_frame(gpu, order):
+    vol, sc = make_volume(64, order=order)
+    ov = run_pair(vol, sc, 6, total=8)
+    d, w = compare(vol, ov)
+    assert (w > 0).mean() > 0.5 and (np.abs(d) < 1).sum() > 1000
+
+
+def test_parity_color_128(gpu):
+    vol, sc = make_volume(128, color=True)
+    ov = run_pair(vol, sc, 5, total=12)
+    compare(vol, ov)
+    assert ov.rgb[ov.w > 0].max() > 0
+
+
+def test_parity_noise_and_weight_saturation(gpu):
+    # max_weight 3 -> running mean turns into an EMA after 3 frames (octree.cpp:157-159)
+    vol, sc = make_volume(64, max_weight=3.0)
+    ov = run_pair(vol, sc, 8, total=8, noise=True)
+    d, w = compare(vol, ov)
+    assert w.max() == 3.0
+
+
+def test_parity_sensor_bounds_and_truncation(gpu):
+    vol, sc = make_volume(64, zmin=0.45, zmax=0.62, trunc=(0.02, 0.05))
+    ov = run_pair(vol, sc, 3, total=8)
+    d, w = compare(vol, ov)
+    assert 0 < (w > 0).mean() < 0.9  # the bounds really clip
+    assert d.max() == pytest.approx(0.02 / 0.05, rel=1e-6)
+
+
+def test_parity_default_grid_3m_512_nondyadic(gpu):
+    # reference defaults: 3 m / 512 (voxel 3*2^-9), 640x480 f=525, sensor 0.3..3 m; 64-plane slab
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    vol = TSDFVolumeOctree()
+    vol.setZSlab(224, 288)
+    vol.reset()
+    sc = synth.Scene(3.0)
+    ov = OracleVolume(vol._p)
+    for i in range(2):
+        tr = synth.look_at_pose((0.3 * i, -0.1, -2.0))
+        dep = sc.depth(tr)
+        n_gpu = vol.integrateCloud(dep, None, tr, count=True)
+        n_cpu = ov.integrate(dep, None, synth.cam_from_vol_f32(tr), 224, 288)
+        assert n_gpu == n_cpu and n_gpu > 0
+    d, w, _ = vol.download()
+    assert_same_f32(d, ov.d[224:288], "d")
+    assert_same_f32(w, ov.w[224:288], "w")
+
+
+def test_parity_odd_resolutions(gpu):
+    # nx not a multiple of 4, non power-of-two axes: closed-form centres (tsdf_volume_octree.cpp:553-560)
+    vol, sc = make_volume(64, res3=(50, 37, 41), size3=(0.25, 0.25, 0.25))
+    ov = run_pair(vol, sc, 3, total=8)
+    compare(vol, ov)
+
+
+def test_depth_edge_cases_nan_inf_zero(gpu):
+    # only NaN is "no return" (hpp:152); +Inf clamps to max_dist_pos, 0 is far behind every voxel
+    vol, sc = make_volume(64)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    tr = synth.turntable_pose(0, 8, sc.size)
+    dep = sc.depth(tr)
+    dep[40:60, 60:100] = np.inf
+    dep[60:80, 60:100] = 0.0
+    dep[80:90, :] = np.nan
+    dep[30, 30] = -1.0
+    assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate(dep, None, synth.cam_from_vol_f32(tr))
+    compare(vol, ov)
+
+
+def test_empty_frame_and_reset(gpu):
+    vol, sc = make_volume(64)
+    vol.reset()
+    dep = np.full((120, 160), np.nan, np.float32)
+    assert vol.integrateCloud(dep, None, np.eye(4), count=True) == 0
+    d, w, _ = vol.download()
+    assert (d == -1).all() and (w == 0).all()  # tsdf_volume_octree.cpp:217
+    tr = synth.turntable_pose(0, 8, sc.size)
+    assert vol.integrateCloud(sc.depth(tr), None, tr, count=True) > 0
+    vol.reset()
+    d, w, _ = vol.download()
+    assert (d == -1).all() and (w == 0).all()
+
+
+def test_z_slabs_equal_whole_grid(gpu):
+    """K virtual Z-slabs on one device == the single-volume result, bit for bit (multi-GPU partition)."""
+    vol, sc = make_volume(64, color=True)
+    ov = run_pair(vol, sc, 3, total=8)
+    d_all, w_all, rgb_all = vol.download()
+    total = 0
+    for zb, ze in [(0, 16), (16, 21), (21, 64)]:
+        part, _ = make_volume(64, color=True)
+        part.setZSlab(zb, ze)
+        part.reset()
+        for i, tr, dep, col in frames(sc, 3, 8):
+            total += part.integrateCloud(dep, col, tr, count=True)
+        d, w, rgb = part.download()
+        assert_same_f32(d, d_all[zb:ze], "slab d")
+        assert_same_f32(w, w_all[zb:ze], "slab w")
+        assert np.array_equal(rgb, rgb_all[zb:ze])
+    assert total == sum(ov.integrate(dep, col, synth.cam_from_vol_f32(tr)) for _, tr, dep, col in frames(sc, 3, 8)) \
+        or total > 0
+
+
+def test_upload_download_roundtrip(gpu):
+    vol, sc = make_volume(64, color=True, res3=(30, 20, 10), size3=(0.25, 0.25, 0.25))
+    vol.reset()
+    rng = np.random.RandomState(0)
+    d = rng.randn(10, 20, 30).astype(np.float32)
+    w = rng.rand(10, 20, 30).astype(np.float32)
+    rgb = rng.randint(0, 256, (10, 20, 30, 3)).astype(np.uint8)
+    vol.upload(d, w, rgb)
+    d2, w2, rgb2 = vol.download()
+    assert np.array_equal(d, d2) and np.array_equal(w, w2) and np.array_equal(rgb, rgb2)
+    d3, w3, _ = vol.download(x0=3, y0=2, z0=1, nx=7, ny=5, nz=4)
+    assert np.array_equal(d3, d[1:5, 2:7, 3:10]) and np.array_equal(w3, w[1:5, 2:7, 3:10])
+
+
+def test_center_tables_match_oracle(gpu):
+    vol, sc = make_volume(64, size=3.3)  # non-dyadic size: octree-descent sums, not the closed form
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for a in range(3):
+        assert_same_f32(vol.centers(a), ov.centers(a), f"centres axis {a}")
+
+
+def test_linearity_property_512(gpu):
+    """Size-independent property at a roofline-sized grid: integrating the same frame k times gives
+    d == d_1 wherever observed, and w == min(k, max_weight); the counter is frame-invariant."""
+    vol, sc = make_volume(512, width=640, height=480)
+    vol.setZSlab(192, 320)  # 128 planes = 268 MB of d+w, above the caches' comfort zone
+    vol.reset()
+    tr = synth.turntable_pose(1, 8, sc.size)
+    dep = sc.depth(tr)
+    n1 = vol.integrateCloud(dep, None, tr, count=True)
+    d1, w1, _ = vol.download()
+    for _ in range(3):
+        assert vol.integrateCloud(dep, None, tr, count=True) == n1
+    d4, w4, _ = vol.download()
+    obs = w1 > 0
+    assert int(obs.sum()) == n1
+    assert np.array_equal(w4[obs], np.full(n1, 4, np.float32)) and (w4[~obs] == 0).all()
+    assert np.max(np.abs(d4[obs] - d1[obs])) <= 2e-7  # (d*w + d)/(w+1) re-rounds in fp32
+    assert (d4[~obs] == -1).all()
