@@ -48,6 +48,14 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 
+// Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_PIPELINE,
+// TSDF_HIP_BLOCKS_PER_CU); read once.
+struct TsdfTuning {
+  int pipeline;       // software-pipelined integrate loop
+  int blocks_per_cu;  // persistent grid = 256 CUs x this
+};
+const TsdfTuning &tsdf_tuning();
+
 // Volume element index of (x, y, z_global); the plane must be allocated.
 static inline __host__ __device__ int64_t tsdf_index(int64_t pitch, int ny, int z_first, int x, int y,
                                                       int zg) {

@@ -1,6 +1,8 @@
 // libtsdf_hip.so -- volume lifetime, voxel-centre tables, raw block transfer.
 // gfx950 only.  Boundary: include/tsdf_hip.h.
 #include <math.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include <mutex>
@@ -33,6 +35,16 @@ extern "C" const char *tsdf_hip_error_string(int code) {
     case TSDF_HIP_E_UNSUPPORTED: return "unsupported";
   }
   return "unknown";
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+const TsdfTuning &tsdf_tuning() {
+  static const TsdfTuning t = {env_int("TSDF_HIP_PIPELINE", 1), std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8))};
+  return t;
 }
 
 extern "C" int tsdf_hip_abi_version(void) { return TSDF_HIP_ABI_VERSION; }

@@ -16,6 +16,7 @@
 #include <limits.h>
 
 #include "tsdf_common.h"
+#include "tsdf_div.h"
 
 struct IntegrateArgs {
   float m[12];       // cam_from_vol, row-major 3x4
@@ -23,6 +24,7 @@ struct IntegrateArgs {
   float zmin, zmax;  // min/max_sensor_dist_
   float pos, neg;    // max_dist_pos_/neg_
   float wmax;        // max_weight_
+  float pos_over_neg; // max_dist_pos_ / max_dist_neg_ (IEEE fp32, host)
   int W, H;
   int nx, ny;
   int qpr;           // quads per row = ceil(nx/4)
@@ -41,65 +43,144 @@ static __device__ __forceinline__ int cvtt_f64_i32(double v) {
   return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
 }
 
-struct VoxelObs {
-  bool act;
-  float dn;
-  uint32_t bgra;
+// Per-voxel state carried between the pipeline stages.
+struct Obs {
+  int pix;     // v*W + u, or -1 if the voxel fails hpp:146 / reprojectPoint
+  float gz;    // camera-frame z of the voxel centre
+  float z;     // gathered depth
+  uint32_t c;  // gathered colour (PCL b,g,r,a bytes)
 };
 
-// One voxel of updateVoxel, leaf branch (hpp:143-198), everything except the read-modify-write.
-template <bool COLOR>
-static __device__ __forceinline__ VoxelObs
-observe(const IntegrateArgs &a, float gx, float gy, float gz, const float *__restrict__ depth,
-        const uint32_t *__restrict__ bgra) {
-  VoxelObs o;
-  o.act = false;
-  o.dn = 0.f;
-  o.bgra = 0u;
-  // hpp:146  if (v_g.z < min_sensor_dist_ || v_g.z > max_sensor_dist_) return 0
-  if (gz < a.zmin || gz > a.zmax) return o;
-  // reprojectPoint, tsdf_volume_octree.cpp:611-617 -- float * double / float + double, then (int)
-  const int u = cvtt_f64_i32((double)gx * a.fx / (double)gz + a.cx);
-  const int v = cvtt_f64_i32((double)gy * a.fy / (double)gz + a.cy);
-  if (!(gz > 0.f && u >= 0 && u < a.W && v >= 0 && v < a.H)) return o;
-  const int pix = v * a.W + u;
-  const float z = depth[pix];
-  if (isnan(z)) return o;  // hpp:152 (only NaN is rejected; 0 and Inf are not)
-  float dn = z - gz;       // hpp:159
-  if (dn > a.pos)
-    dn = a.pos;            // hpp:189-192
-  else if (dn < -a.neg)
-    return o;              // hpp:193-196
-  dn = dn / a.neg;         // hpp:198
-  o.act = true;
-  o.dn = dn;
-  if (COLOR) o.bgra = bgra[pix];
-  return o;
+// hpp:143-149 + reprojectPoint (tsdf_volume_octree.cpp:611-617): which pixel does the voxel see?
+// u and v divide by the same g.z, so the fp64 reciprocal is refined once (tsdf_div.h).
+static __device__ __forceinline__ int project(const IntegrateArgs &a, float gx, float gy, float gz) {
+  // hpp:146  if (v_g.z < min_sensor_dist_ || v_g.z > max_sensor_dist_) return 0;  .cpp:616 pt.z > 0
+  if (gz < a.zmin || gz > a.zmax || !(gz > 0.f)) return -1;
+  const Rcp64 rz = rcp64_prepare((double)gz);
+  const int u = cvtt_f64_i32(div64((double)gx * a.fx, rz) + a.cx);
+  const int v = cvtt_f64_i32(div64((double)gy * a.fy, rz) + a.cy);
+  if (!(u >= 0 && u < a.W && v >= 0 && v < a.H)) return -1;
+  return v * a.W + u;
 }
 
-// OctreeNode::addObservation with w_new = 1 (octree.cpp:152-163; both weightings of hpp:200-204
-// are unreachable: no setter for weight_by_depth_/weight_by_variance_).
-static __device__ __forceinline__ void add_observation(float &d, float &w, float dn, float wmax) {
+// hpp:152-198: NaN test, projective SDF, hinge, normalisation.  Returns false if the voxel is not
+// observed.  pos_over_neg = max_dist_pos_/max_dist_neg_ computed once on the host with the same IEEE
+// division the per-voxel `d_new /= max_dist_neg_` would do on a clamped value.
+static __device__ __forceinline__ bool sdf(const IntegrateArgs &a, float z, float gz, const Rcp32 &rneg,
+                                           float &dn) {
+  if (isnan(z)) return false;  // hpp:152 (only NaN is rejected; 0 and Inf are not)
+  const float raw = z - gz;    // hpp:159
+  if (raw > a.pos) {           // hpp:189-192
+    dn = a.pos_over_neg;
+    return true;
+  }
+  if (raw < -a.neg) return false;  // hpp:193-196
+  dn = div32(raw, a.neg, rneg);    // hpp:198
+  return true;
+}
+
+// OctreeNode::addObservation with w_new = 1 (octree.cpp:152-163; both weightings of hpp:200-204 are
+// unreachable: no setter for weight_by_depth_/weight_by_variance_), and RGBNode::addObservation
+// (octree.cpp:328-337): per channel (uint8)((w*c + w_new*c_new)/(w+w_new)) with the OLD w,
+// truncating.  All four quotients share the divisor w + 1.
+template <bool COLOR>
+static __device__ __forceinline__ void add_observation(float &d, float &w, uint32_t &rgb, float dn,
+                                                       uint32_t bgra, float wmax) {
   const float wn = 1.f;
-  d = (d * w + dn * wn) / (w + wn);
-  w = w + wn;
+  const float wsum = w + wn;
+  const Rcp32 rs = rcp32_prepare(wsum);
+  if (COLOR) {
+    const uint32_t r0 = rgb & 255u, g0 = (rgb >> 8) & 255u, b0 = (rgb >> 16) & 255u;
+    const uint32_t bn = bgra & 255u, gn = (bgra >> 8) & 255u, rn = (bgra >> 16) & 255u;
+    const uint32_t r = (uint32_t)(uint8_t)div32(w * (float)r0 + wn * (float)rn, wsum, rs);
+    const uint32_t g = (uint32_t)(uint8_t)div32(w * (float)g0 + wn * (float)gn, wsum, rs);
+    const uint32_t b = (uint32_t)(uint8_t)div32(w * (float)b0 + wn * (float)bn, wsum, rs);
+    rgb = r | (g << 8) | (b << 16);
+  }
+  // (1*w + 1)/(w + 1): numerator and denominator are the same float, so the quotient is exactly 1
+  // whenever that float is a positive finite number -- the common case in free space.
+  if (!(d == 1.f && dn == 1.f && wsum > 0.f && wsum < INFINITY)) d = div32(d * w + dn * wn, wsum, rs);
+  w = wsum;
   if (w > wmax) w = wmax;
 }
 
-// RGBNode::addObservation (octree.cpp:328-337): per channel (uint8)((w*c + w_new*c_new)/(w+w_new))
-// with the OLD w, truncating.
-static __device__ __forceinline__ uint32_t blend_rgb(uint32_t rgb, uint32_t bgra, float w) {
-  const float wn = 1.f;
-  const float wsum = w + wn;
-  const uint32_t r0 = rgb & 255u, g0 = (rgb >> 8) & 255u, b0 = (rgb >> 16) & 255u;
-  const uint32_t bn = bgra & 255u, gn = (bgra >> 8) & 255u, rn = (bgra >> 16) & 255u;
-  const uint32_t r = (uint32_t)(uint8_t)((w * (float)r0 + wn * (float)rn) / wsum);
-  const uint32_t g = (uint32_t)(uint8_t)((w * (float)g0 + wn * (float)gn) / wsum);
-  const uint32_t b = (uint32_t)(uint8_t)((w * (float)b0 + wn * (float)bn) / wsum);
-  return r | (g << 8) | (b << 16);
+struct Tile {
+  int x4;       // first voxel x of this thread's quad, -1 if the thread has no quad in this tile
+  int64_t idx;  // element index of that voxel in the SoA planes
+};
+
+static __device__ __forceinline__ Tile locate(const IntegrateArgs &a, unsigned t, unsigned tx, unsigned ty,
+                                               unsigned &y, unsigned &zl) {
+  Tile tl;
+  tl.x4 = -1;
+  tl.idx = 0;
+  const unsigned rg = t / a.xchunks;
+  const unsigned xc = t - rg * a.xchunks;
+  const unsigned row = rg * (unsigned)a.TY + ty;
+  const unsigned xq = xc * (unsigned)a.TX + tx;
+  if (row >= (unsigned)a.rows || xq >= (unsigned)a.qpr) return tl;
+  zl = row / (unsigned)a.ny;
+  y = row - zl * (unsigned)a.ny;
+  tl.x4 = (int)xq * 4;
+  tl.idx = ((int64_t)(a.zl0 + (int)zl) * a.ny + y) * a.pitch + tl.x4;
+  return tl;
 }
 
+// Stage 1 for one quad: transform the four centres (pcl::transformPoint, hpp:145), project, and issue
+// the depth (+colour) gathers.
 template <int ORDER, bool COLOR>
+static __device__ __forceinline__ void stage_project(const IntegrateArgs &a, const Tile &tl, unsigned y,
+                                                     unsigned zl, const float *__restrict__ depth,
+                                                     const uint32_t *__restrict__ bgra,
+                                                     const float *__restrict__ ctrx,
+                                                     const float *__restrict__ ctry,
+                                                     const float *__restrict__ ctrz, Obs obs[4]) {
+  if (tl.x4 < 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) obs[j].pix = -1;
+    return;
+  }
+  const float cy = ctry[y];
+  const float cz = ctrz[a.z_global0 + (int)zl];
+  const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + tl.x4);
+  const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+  float s[3], p1[3], p2[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (ORDER == TSDF_XFORM_PCL_SSE) {
+      s[r] = cy * a.m[4 * r + 1] + (cz * a.m[4 * r + 2] + a.m[4 * r + 3]);
+    } else {
+      p1[r] = a.m[4 * r + 1] * cy;
+      p2[r] = a.m[4 * r + 2] * cz;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float g[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (ORDER == TSDF_XFORM_PCL_SSE)
+        g[r] = cxs[j] * a.m[4 * r] + s[r];
+      else
+        g[r] = ((a.m[4 * r] * cxs[j] + p1[r]) + p2[r]) + a.m[4 * r + 3];
+    }
+    int pix = project(a, g[0], g[1], g[2]);
+    if (tl.x4 + j >= a.nx) pix = -1;  // padding lanes of a partial quad
+    obs[j].pix = pix;
+    obs[j].gz = g[2];
+    obs[j].z = 0.f;
+    obs[j].c = 0u;
+    if (pix >= 0) {
+      obs[j].z = depth[pix];
+      if (COLOR) obs[j].c = bgra[pix];
+    }
+  }
+}
+
+// PIPE = software-pipelined tile loop: while the d/w/rgb loads of tile t are in flight the thread
+// projects tile t+1 and issues its depth gathers, so the two memory latencies of a tile (L2 gather,
+// HBM read-modify-write) overlap the ALU work of its neighbours.
+template <int ORDER, bool COLOR, bool PIPE>
 static __global__ void __launch_bounds__(256)
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
@@ -108,74 +189,66 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   const unsigned tid = threadIdx.x;
   const unsigned tx = tid & (unsigned)(a.TX - 1);
   const unsigned ty = tid >> a.log2TX;
+  const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0;
 
-  for (unsigned t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-    const unsigned rg = t / a.xchunks;
-    const unsigned xc = t - rg * a.xchunks;
-    const unsigned row = rg * (unsigned)a.TY + ty;
-    const unsigned xq = xc * (unsigned)a.TX + tx;
-    if (row >= (unsigned)a.rows || xq >= (unsigned)a.qpr) continue;
-    const unsigned zl = row / (unsigned)a.ny;
-    const unsigned y = row - zl * (unsigned)a.ny;
-    const int x4 = (int)xq * 4;
-
-    const float cy = ctry[y];
-    const float cz = ctrz[a.z_global0 + (int)zl];
-    const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
-    const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
-
-    // pcl::transformPoint (hpp:145).  Row-shared partial sums first.
-    float s[3], p1[3], p2[3];
+  unsigned y = 0, zl = 0;
+  Obs nxt[4];
+  Tile tl_n;
+  unsigned t = blockIdx.x;
+  if (PIPE && t < a.n_tiles) {
+    tl_n = locate(a, t, tx, ty, y, zl);
+    stage_project<ORDER, COLOR>(a, tl_n, y, zl, depth, bgra, ctrx, ctry, ctrz, nxt);
+  }
+  for (; t < a.n_tiles; t += gridDim.x) {
+    Obs cur[4];
+    Tile tl;
+    if (PIPE) {
+      tl = tl_n;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      if (ORDER == TSDF_XFORM_PCL_SSE) {
-        s[r] = cy * a.m[4 * r + 1] + (cz * a.m[4 * r + 2] + a.m[4 * r + 3]);
-      } else {
-        p1[r] = a.m[4 * r + 1] * cy;
-        p2[r] = a.m[4 * r + 2] * cz;
-      }
+      for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    } else {
+      tl = locate(a, t, tx, ty, y, zl);
+      stage_project<ORDER, COLOR>(a, tl, y, zl, depth, bgra, ctrx, ctry, ctrz, cur);
     }
-
-    VoxelObs obs[4];
-    bool any = false;
+    // stage 2: which of the four voxels are observed, and with what distance
+    float dn[4];
+    bool act[4], any = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float g[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (ORDER == TSDF_XFORM_PCL_SSE)
-          g[r] = cxs[j] * a.m[4 * r] + s[r];
-        else
-          g[r] = ((a.m[4 * r] * cxs[j] + p1[r]) + p2[r]) + a.m[4 * r + 3];
-      }
-      obs[j] = observe<COLOR>(a, g[0], g[1], g[2], depth, bgra);
-      if (x4 + j >= a.nx) obs[j].act = false;  // padding lanes of a partial quad
-      any |= obs[j].act;
+      act[j] = cur[j].pix >= 0 && sdf(a, cur[j].z, cur[j].gz, rneg, dn[j]);
+      any |= act[j];
     }
-    if (!any) continue;
-
-    const int64_t idx = ((int64_t)(a.zl0 + (int)zl) * a.ny + y) * a.pitch + x4;
-    float4 d4 = *reinterpret_cast<const float4 *>(D + idx);
-    float4 w4 = *reinterpret_cast<const float4 *>(Wt + idx);
-    float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-    float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    if (COLOR) {
-      uint4 c4 = *reinterpret_cast<const uint4 *>(RGB + idx);
+    // stage 3: issue the read half of the read-modify-write
+    float4 d4 = make_float4(0, 0, 0, 0), w4 = d4;
+    uint4 c4 = make_uint4(0, 0, 0, 0);
+    if (any) {
+      d4 = *reinterpret_cast<const float4 *>(D + tl.idx);
+      w4 = *reinterpret_cast<const float4 *>(Wt + tl.idx);
+      if (COLOR) c4 = *reinterpret_cast<const uint4 *>(RGB + tl.idx);
+    }
+    if (PIPE) {  // stage 1 of the NEXT tile, overlapping the loads above
+      const unsigned tn = t + gridDim.x;
+      if (tn < a.n_tiles) {
+        tl_n = locate(a, tn, tx, ty, y, zl);
+        stage_project<ORDER, COLOR>(a, tl_n, y, zl, depth, bgra, ctrx, ctry, ctrz, nxt);
+      }
+    }
+    // stage 4: running average and write-back
+    if (any) {
+      float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+      float wv[4] = {w4.x, w4.y, w4.z, w4.w};
       uint32_t cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (obs[j].act) cv[j] = blend_rgb(cv[j], obs[j].bgra, wv[j]);
-      *reinterpret_cast<uint4 *>(RGB + idx) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        if (act[j]) {
+          add_observation<COLOR>(dv[j], wv[j], cv[j], dn[j], cur[j].c, a.wmax);
+          ++cnt;
+        }
+      *reinterpret_cast<float4 *>(D + tl.idx) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      *reinterpret_cast<float4 *>(Wt + tl.idx) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      if (COLOR) *reinterpret_cast<uint4 *>(RGB + tl.idx) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (obs[j].act) {
-        add_observation(dv[j], wv[j], obs[j].dn, a.wmax);
-        ++cnt;
-      }
-    *reinterpret_cast<float4 *>(D + idx) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-    *reinterpret_cast<float4 *>(Wt + idx) = make_float4(wv[0], wv[1], wv[2], wv[3]);
   }
 
   // one atomic per block
@@ -201,6 +274,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   a.pos = p.max_dist_pos;
   a.neg = p.max_dist_neg;
   a.wmax = p.max_weight;
+  a.pos_over_neg = p.max_dist_pos / p.max_dist_neg;
   a.W = p.image_width;
   a.H = p.image_height;
   a.nx = h->nx;
@@ -226,26 +300,35 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   a.pitch = h->pitch;
 
   TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * 8);
+  const unsigned grid = (unsigned)std::min<int64_t>(tiles, (int64_t)256 * tsdf_tuning().blocks_per_cu);
   const bool color = p.integrate_color != 0;
   if (color && !d_bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
   }
-#define LAUNCH(ORDER, COLOR)                                                                               \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR>), dim3(grid), dim3(256), 0, h->stream, a, h->d, h->w, h->rgb, \
-                     d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+  const bool pipe = tsdf_tuning().pipeline != 0;
+#define LAUNCH(ORDER, COLOR, PIPE)                                                                          \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, PIPE>), dim3(grid), dim3(256), 0, h->stream, a, h->d, h->w, \
+                     h->rgb, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+#define LAUNCH2(ORDER, COLOR) \
+  do {                        \
+    if (pipe)                 \
+      LAUNCH(ORDER, COLOR, true); \
+    else                      \
+      LAUNCH(ORDER, COLOR, false); \
+  } while (0)
   if (p.xform_order == TSDF_XFORM_PCL_SSE) {
     if (color)
-      LAUNCH(TSDF_XFORM_PCL_SSE, true);
+      LAUNCH2(TSDF_XFORM_PCL_SSE, true);
     else
-      LAUNCH(TSDF_XFORM_PCL_SSE, false);
+      LAUNCH2(TSDF_XFORM_PCL_SSE, false);
   } else {
     if (color)
-      LAUNCH(TSDF_XFORM_LEFT_TO_RIGHT, true);
+      LAUNCH2(TSDF_XFORM_LEFT_TO_RIGHT, true);
     else
-      LAUNCH(TSDF_XFORM_LEFT_TO_RIGHT, false);
+      LAUNCH2(TSDF_XFORM_LEFT_TO_RIGHT, false);
   }
+#undef LAUNCH2
 #undef LAUNCH
   TSDF_HIP_TRY(hipGetLastError());
   if (n_observed) {
@@ -282,4 +365,47 @@ extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8
   if (rc) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test hooks: run the shared-reciprocal dividers of tsdf_div.h on arbitrary operands so the tests
+// can compare them bit for bit with IEEE division done on the host.
+static __global__ void k_selftest_div32(const float *a, const float *b, float *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Rcp32 r = rcp32_prepare(b[i]);
+  out[i] = div32(a[i], b[i], r);
+}
+
+static __global__ void k_selftest_div64(const double *a, const double *b, double *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Rcp64 r = rcp64_prepare(b[i]);
+  out[i] = div64(a[i], r);
+}
+
+template <typename T, typename K>
+static int selftest_div(K kernel, const T *a, const T *b, T *out, size_t n) {
+  if (!a || !b || !out || !n) return TSDF_HIP_E_INVALID;
+  T *da = nullptr, *db = nullptr, *dout = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&da, n * sizeof(T)));
+  TSDF_HIP_TRY(hipMalloc(&db, n * sizeof(T)));
+  TSDF_HIP_TRY(hipMalloc(&dout, n * sizeof(T)));
+  TSDF_HIP_TRY(hipMemcpy(da, a, n * sizeof(T), hipMemcpyHostToDevice));
+  TSDF_HIP_TRY(hipMemcpy(db, b, n * sizeof(T), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, dout, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, dout, n * sizeof(T), hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_selftest_div_f32(const float *a, const float *b, float *out, size_t n) {
+  return selftest_div<float>(k_selftest_div32, a, b, out, n);
+}
+
+extern "C" int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, size_t n) {
+  return selftest_div<double>(k_selftest_div64, a, b, out, n);
 }

@@ -138,6 +138,13 @@ int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, 
  * (src/lib/octree.cpp:244-266 split arithmetic) for each axis.  out has res[axis] floats. */
 int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
 
+/* Test hooks (not part of the cpu_tsdf interface): the kernels' shared-reciprocal dividers applied
+ * element-wise to host arrays, out[i] = a[i] / b[i]; the f64 variant requires b > 0 finite with a
+ * float-sized exponent (it is only ever used on (double)g.z).  Used by tests/test_div_gpu.py to prove
+ * bit equality with IEEE division. */
+int tsdf_hip_selftest_div_f32(const float *a, const float *b, float *out, size_t n);
+int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, size_t n);
+
 const char *tsdf_hip_error_string(int code);
 const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);

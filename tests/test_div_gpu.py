@@ -1,0 +1,84 @@
+"""GPU tier: the shared-reciprocal dividers used inside the integrate kernel (csrc/tsdf_div.h) are
+bit-identical to IEEE division (numpy on the host) over the operand ranges the kernel feeds them and
+over adversarial values (zeros, denormals, huge, inf, NaN) where they must fall back to `/`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_div32(a, b):
+    out = np.empty_like(a)
+    capi.check(capi.load().tsdf_hip_selftest_div_f32(capi.as_f32p(a), capi.as_f32p(b), capi.as_f32p(out), a.size), "div32")
+    return out
+
+
+def gpu_div64(a, b):
+    out = np.empty_like(a)
+    p = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    capi.check(capi.load().tsdf_hip_selftest_div_f64(p(a), p(b), p(out), a.size), "div64")
+    return out
+
+
+def same_bits(x, y):
+    return (x.view(np.uint32 if x.dtype == np.float32 else np.uint64) ==
+            y.view(np.uint32 if y.dtype == np.float32 else np.uint64)) | (np.isnan(x) & np.isnan(y))
+
+
+def test_div32_kernel_ranges(gpu):
+    rng = np.random.RandomState(1)
+    n = 1 << 22
+    # d update: (d*w + dn) / (w + 1), colour: (w*c + cn) / (w + 1), normalisation: raw / neg
+    w = rng.randint(0, 101, n).astype(np.float32)
+    num = np.concatenate([(rng.uniform(-1, 1, n // 2) * (w[: n // 2] + 1)).astype(np.float32),
+                          (rng.randint(0, 256, n // 2) * (w[n // 2:] + 1) - rng.randint(0, 255, n // 2)).astype(np.float32)])
+    den = (w + 1).astype(np.float32)
+    with np.errstate(all="ignore"):
+        want = num / den
+    assert same_bits(gpu_div32(num, den), want).all()
+    raw = rng.uniform(-0.05, 0.05, n).astype(np.float32)
+    neg = np.full(n, 0.03, np.float32)
+    assert same_bits(gpu_div32(raw, neg), raw / neg).all()
+
+
+def test_div32_random_and_adversarial(gpu):
+    rng = np.random.RandomState(2)
+    n = 1 << 22
+    a = rng.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 1e-38, 3e38, 2.0 ** -40, 2.0 ** 40,
+                        float.fromhex('0x1.fffffep-41'), float.fromhex('0x1.000002p40'), 1.0000001, 0.99999994], np.float32)
+    a[: special.size ** 2] = np.repeat(special, special.size)
+    b[: special.size ** 2] = np.tile(special, special.size)
+    with np.errstate(all="ignore"):
+        want = a / b
+    got = gpu_div32(a, b)
+    ok = same_bits(got, want)
+    assert ok.all(), (a[~ok][:5], b[~ok][:5], got[~ok][:5], want[~ok][:5])
+
+
+def test_div64_projection_ranges(gpu):
+    rng = np.random.RandomState(3)
+    n = 1 << 22
+    gz = rng.uniform(1e-3, 200.0, n).astype(np.float32).astype(np.float64)
+    gx = (rng.uniform(-1, 1, n) * gz * 2).astype(np.float32).astype(np.float64)
+    fx = 525.0 * rng.choice([1.0, 2.0, 1.0 / 3.0, 0.977], n)
+    num = gx * fx
+    want = num / gz
+    assert same_bits(gpu_div64(num, gz), want).all()
+    # wide float-sized exponents, exact-integer quotients (pixel boundaries), tiny / huge numerators
+    gz = np.exp2(rng.uniform(-120, 120, n)).astype(np.float32).astype(np.float64)
+    num = np.exp2(rng.uniform(-140, 140, n)) * rng.choice([-1.0, 1.0], n)
+    num[: n // 4] = gz[: n // 4] * rng.randint(-2000, 2000, n // 4)
+    num[n // 4: n // 4 + 8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1.7e308, -1.7e308]
+    with np.errstate(all="ignore"):
+        want = num / gz
+    got = gpu_div64(num, gz)
+    ok = same_bits(got, want)
+    # non-finite numerators never reach an accepted pixel; both sides just have to stay non-finite
+    nonfin = ~np.isfinite(num)
+    assert (ok | (nonfin & ~np.isfinite(got))).all(), (num[~ok][:5], gz[~ok][:5], got[~ok][:5], want[~ok][:5])
