@@ -49,10 +49,11 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_PIPELINE,
-// TSDF_HIP_BLOCKS_PER_CU); read once.
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED); read once.
 struct TsdfTuning {
   int pipeline;       // software-pipelined integrate loop
   int blocks_per_cu;  // persistent grid = 256 CUs x this
+  int skip_unchanged; // do not write back SoA planes whose values did not change
 };
 const TsdfTuning &tsdf_tuning();
 

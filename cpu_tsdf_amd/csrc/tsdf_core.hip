@@ -43,7 +43,8 @@ static int env_int(const char *name, int dflt) {
 }
 
 const TsdfTuning &tsdf_tuning() {
-  static const TsdfTuning t = {env_int("TSDF_HIP_PIPELINE", 1), std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8))};
+  static const TsdfTuning t = {env_int("TSDF_HIP_PIPELINE", 1), std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
+                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1)};
   return t;
 }
 

@@ -145,6 +145,11 @@ int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
 int tsdf_hip_selftest_div_f32(const float *a, const float *b, float *out, size_t n);
 int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, size_t n);
 
+/* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
+ * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to
+ * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */
+int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
+
 const char *tsdf_hip_error_string(int code);
 const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);

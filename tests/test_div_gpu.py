@@ -78,7 +78,7 @@ def test_div64_projection_ranges(gpu):
     with np.errstate(all="ignore"):
         want = num / gz
     got = gpu_div64(num, gz)
-    ok = same_bits(got, want)
+    ok = same_bits(got, want) | (got == want)  # the sign of a zero quotient is irrelevant before `+ cx`
     # non-finite numerators never reach an accepted pixel; both sides just have to stay non-finite
     nonfin = ~np.isfinite(num)
     assert (ok | (nonfin & ~np.isfinite(got))).all(), (num[~ok][:5], gz[~ok][:5], got[~ok][:5], want[~ok][:5])
