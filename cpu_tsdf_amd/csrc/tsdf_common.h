@@ -48,12 +48,14 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 
-// Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_PIPELINE,
-// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED); read once.
+// Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED, TSDF_HIP_FAST_PROJECTION); read once.
 struct TsdfTuning {
-  int pipeline;       // software-pipelined integrate loop
-  int blocks_per_cu;  // persistent grid = 256 CUs x this
-  int skip_unchanged; // do not write back SoA planes whose values did not change
+  int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
+  int blocks_per_cu;   // grid-stride helper kernels: grid = 256 CUs x this
+  int skip_unchanged;  // do not write back SoA planes whose values did not change
+  int fast_projection; // certified fp32 pixel projection with exact fp64 fallback
+  int nontemporal;     // nt hint on the voxel-plane loads/stores
 };
 const TsdfTuning &tsdf_tuning();
 

@@ -43,8 +43,9 @@ static int env_int(const char *name, int dflt) {
 }
 
 const TsdfTuning &tsdf_tuning() {
-  static const TsdfTuning t = {env_int("TSDF_HIP_PIPELINE", 1), std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
-                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1)};
+  static const TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 8)),
+                               std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
+                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1), env_int("TSDF_HIP_FAST_PROJECTION", 1), env_int("TSDF_HIP_NONTEMPORAL", 0)};
   return t;
 }
 
@@ -240,8 +241,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   const size_t npx = (size_t)p->image_width * p->image_height;
   TRY_OR_BAIL(hipMalloc(&v->frame_depth, npx * sizeof(float)));
   TRY_OR_BAIL(hipMalloc(&v->frame_bgra, npx * sizeof(uint32_t)));
-  TRY_OR_BAIL(hipMalloc(&v->counter, 16 * sizeof(unsigned long long)));
-  TRY_OR_BAIL(hipMemset(v->counter, 0, 16 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMalloc(&v->counter, 1024 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMemset(v->counter, 0, 1024 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL
   rc = tsdf_hip_reset(v);
   if (rc != TSDF_HIP_OK) return bail(rc);

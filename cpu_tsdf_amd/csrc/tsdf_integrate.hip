@@ -22,25 +22,27 @@
 #include "tsdf_div.h"
 
 struct IntegrateArgs {
-  float m[12];       // cam_from_vol, row-major 3x4
+  float m[12];        // cam_from_vol, row-major 3x4
   double fx, fy, cx, cy;
-  float zmin, zmax;  // min/max_sensor_dist_
-  float pos, neg;    // max_dist_pos_/neg_
-  float wmax;        // max_weight_
+  float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path)
+  float band_u, band_v;      // half-width of the "too close to an integer to trust fp32" zone, in pixels
+  float zmin, zmax;   // min/max_sensor_dist_
+  float pos, neg;     // max_dist_pos_/neg_
+  float wmax;         // max_weight_
   float pos_over_neg; // max_dist_pos_ / max_dist_neg_ (IEEE fp32, host)
   int W, H;
   int nx, ny;
-  int qpr;           // quads per row = ceil(nx/4)
-  int rows;          // ny * planes to integrate
-  int z_global0;     // global z of the first integrated plane
-  int zl0;           // allocated-plane index of the first integrated plane
-  int log2TX, TX, TY;
-  unsigned xchunks;  // ceil(qpr / TX)
-  unsigned n_tiles;
+  int qpr;            // quads per row = ceil(nx/4)
+  int planes;         // planes to integrate
+  int z_global0;      // global z of the first integrated plane
+  int zl0;            // allocated-plane index of the first integrated plane
+  int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
+  int rpb;            // row groups (of TY rows) per block
+  int nontemporal;    // nt hint on the SoA plane loads/stores (streamed once per frame)
   int64_t pitch;
 };
 
-// Per-voxel state carried between the pipeline stages.
+// Per-voxel observation: which pixel the voxel projects to and what the sensor saw there.
 struct Obs {
   int pix;     // v*W + u, or -1 if the voxel fails hpp:146 / reprojectPoint
   float gz;    // camera-frame z of the voxel centre
@@ -48,16 +50,38 @@ struct Obs {
   uint32_t c;  // gathered colour (PCL b,g,r,a bytes)
 };
 
-// reprojectPoint (tsdf_volume_octree.cpp:611-617) for a voxel that already passed the range test
-// (so g.z > 0 and finite): u = (int)(x*fx/z + cx) evaluated in double, truncation toward zero.
+// reprojectPoint (tsdf_volume_octree.cpp:611-617), EXACT: u = (int)(x*fx/z + cx) evaluated in double,
+// truncation toward zero, for a voxel that already passed the range test (g.z > 0, finite).
 // u and v divide by the same g.z, so the fp64 reciprocal is refined once (tsdf_div.h).
 // v_cvt_i32_f64 saturates where x86's cvttsd2si returns INT_MIN; both land outside [0, W), and NaN
-// cannot occur here (the host rejects non-finite / absurd poses before launching).
-static __device__ __forceinline__ int project(const IntegrateArgs &a, float gx, float gy, float gz) {
+// cannot occur (the host rejects non-finite / absurd poses before launching).
+static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, float gx, float gy, float gz) {
   const Rcp64 rz = rcp64_prepare((double)gz);
   const int u = (int)(div64((double)gx * a.fx, rz) + a.cx);
   const int v = (int)(div64((double)gy * a.fy, rz) + a.cy);
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
+  return in ? v * a.W + u : -1;
+}
+
+// The same in fp32, with a certificate.  R~ = (g*f~)*rcp(z) + c~ differs from the reference's double
+// value R by less than `band` whenever R~ lies in [-1-band, W+band] (derivation in DESIGN.md: three
+// roundings of 2^-24, v_rcp_f32's 1 ulp taken as 2^-22, fx/cx conversion, the final add; host computes
+// band with a 1.5x margin).  Therefore: R~ outside that interval => the pixel is outside the image in
+// the reference too; R~ farther than band from every integer => trunc(R~) == trunc(R).  Anything else
+// (including a non-finite R~) is flagged ambiguous and recomputed by project_exact.
+static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float gx, float gy, float gz,
+                                                   bool &ambiguous) {
+  const float y = __builtin_amdgcn_rcpf(gz);
+  const float ru = (gx * a.fxf) * y + a.cxf;
+  const float rv = (gy * a.fyf) * y + a.cyf;
+  const bool out_u = ru < -1.f - a.band_u || ru > (float)a.W + a.band_u;
+  const bool out_v = rv < -1.f - a.band_v || rv > (float)a.H + a.band_v;
+  const bool far_u = fabsf(ru - rintf(ru)) > a.band_u;  // false for NaN/Inf
+  const bool far_v = fabsf(rv - rintf(rv)) > a.band_v;
+  const bool out = out_u || out_v;
+  ambiguous = !out && !(far_u && far_v);
+  const int u = (int)ru, v = (int)rv;
+  const bool in = !out && (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? v * a.W + u : -1;
 }
 
@@ -76,10 +100,6 @@ static __device__ __forceinline__ float div32_fast(float a, const Rcp32 &r) {
   return __builtin_fmaf(r1, r.y, q1);
 }
 
-static __device__ __forceinline__ uint32_t unpack_rgb_new(uint32_t bgra, int ch) {  // ch 0:r 1:g 2:b
-  return (bgra >> (16 - 8 * ch)) & 255u;
-}
-
 // OctreeNode::addObservation with w_new = 1 (octree.cpp:152-163; both weightings of hpp:200-204 are
 // unreachable: no setter for weight_by_depth_/weight_by_variance_), and RGBNode::addObservation
 // (octree.cpp:328-337): per channel (uint8)((w*c + w_new*c_new)/(w+w_new)) with the OLD w, truncating.
@@ -96,7 +116,9 @@ static __device__ __forceinline__ void add_observation(float &d, float &w, uint3
     uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float num = w * (float)((rgb >> (8 * ch)) & 255u) + wn * (float)unpack_rgb_new(bgra, ch);
+      const float c_old = (float)((rgb >> (8 * ch)) & 255u);
+      const float c_new = (float)((bgra >> (16 - 8 * ch)) & 255u);  // PCL b,g,r,a -> r,g,b
+      const float num = w * c_old + wn * c_new;
       const float q = FAST ? div32_fast(num, rs) : num / wsum;
       out |= ((uint32_t)(uint8_t)q) << (8 * ch);
     }
@@ -119,48 +141,28 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
   return w_ok && n_ok;
 }
 
-struct Tile {
-  int x4;       // first voxel x of this thread's quad, -1 if the thread has no quad in this tile
-  int64_t idx;  // element index of that voxel in the SoA planes
-};
-
-static __device__ __forceinline__ Tile locate(const IntegrateArgs &a, unsigned t, unsigned tx, unsigned ty,
-                                               unsigned &y, unsigned &zl) {
-  Tile tl;
-  tl.x4 = -1;
-  tl.idx = 0;
-  const unsigned rg = t / a.xchunks;
-  const unsigned xc = t - rg * a.xchunks;
-  const unsigned row = rg * (unsigned)a.TY + ty;
-  const unsigned xq = xc * (unsigned)a.TX + tx;
-  if (row >= (unsigned)a.rows || xq >= (unsigned)a.qpr) return tl;
-  zl = row / (unsigned)a.ny;
-  y = row - zl * (unsigned)a.ny;
-  tl.x4 = (int)xq * 4;
-  tl.idx = ((int64_t)(a.zl0 + (int)zl) * a.ny + y) * a.pitch + tl.x4;
-  return tl;
+// One quad (4 x-consecutive voxels of one row).  FASTPROJ selects the certified fp32 projection with
+// exact fallback; otherwise every voxel goes through project_exact.
+template <typename V>
+static __device__ __forceinline__ V ld_plane(const V *p, bool nt) {
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
+template <typename V>
+static __device__ __forceinline__ void st_plane(V *p, V v, bool nt) {
+  if (nt)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
 }
 
-// Stage 1 for one quad: transform the four centres (pcl::transformPoint, hpp:145), range-test
-// (hpp:146, .cpp:616), project, and issue the depth (+colour) gathers.
-template <int ORDER, bool COLOR>
-static __device__ __forceinline__ void stage_project(const IntegrateArgs &a, const Tile &tl, unsigned y,
-                                                     unsigned zl, const float *__restrict__ depth,
-                                                     const uint32_t *__restrict__ bgra,
-                                                     const float *__restrict__ ctrx,
-                                                     const float *__restrict__ ctry,
-                                                     const float *__restrict__ ctrz, Obs obs[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    obs[j].pix = -1;
-    obs[j].gz = 0.f;
-    obs[j].z = 0.f;
-    obs[j].c = 0u;
-  }
-  if (tl.x4 < 0) return;
-  const float cy = ctry[y];
-  const float cz = ctrz[a.z_global0 + (int)zl];
-  const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + tl.x4);
+template <int ORDER, bool COLOR, bool SKIP, bool FASTPROJ>
+static __device__ __forceinline__ unsigned
+integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, const Rcp32 &rneg,
+               float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+               const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
+               const float *__restrict__ ctrx) {
+  // ---- pcl::transformPoint (hpp:145) + reprojectPoint (.cpp:611-617), voxel by voxel ------------------
+  const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
   const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
   float s[3], p1[3], p2[3];
 #pragma unroll
@@ -172,158 +174,172 @@ static __device__ __forceinline__ void stage_project(const IntegrateArgs &a, con
       p2[r] = a.m[4 * r + 2] * cz;
     }
   }
-  float g[4][3];
-  bool in[4], any = false;
+  auto transform = [&](float cx, int r) -> float {
+    if (ORDER == TSDF_XFORM_PCL_SSE) return cx * a.m[4 * r] + s[r];
+    return ((a.m[4 * r] * cx + p1[r]) + p2[r]) + a.m[4 * r + 3];
+  };
+  Obs obs[4];
+  unsigned amb_mask = 0;
+  bool any = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      if (ORDER == TSDF_XFORM_PCL_SSE)
-        g[j][r] = cxs[j] * a.m[4 * r] + s[r];
-      else
-        g[j][r] = ((a.m[4 * r] * cxs[j] + p1[r]) + p2[r]) + a.m[4 * r + 3];
-    }
+    const float gx = transform(cxs[j], 0), gy = transform(cxs[j], 1), gz = transform(cxs[j], 2);
     // hpp:146  if (v_g.z < min_sensor_dist_ || v_g.z > max_sensor_dist_) return 0;  .cpp:616  pt.z > 0
-    in[j] = !(g[j][2] < a.zmin || g[j][2] > a.zmax) && g[j][2] > 0.f && (tl.x4 + j < a.nx);
-    any |= in[j];
+    const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f && (x4 + j < a.nx);
+    obs[j].gz = gz;
+    int pix;
+    if (FASTPROJ) {
+      bool amb;
+      pix = project_fast(a, gx, gy, in ? gz : 1.f, amb);
+      if (amb && in) amb_mask |= 1u << j;
+    } else {
+      pix = project_exact(a, gx, gy, in ? gz : 1.f);
+    }
+    obs[j].pix = in ? pix : -1;
+    any |= in;
   }
-  if (!any) return;
+  if (!any) return 0;
+  // Voxels whose fp32 projection could not be certified: redo them exactly, one at a time through a
+  // single copy of the fp64 code (rare: a fraction ~4*band of the voxels).
+  while (FASTPROJ && amb_mask) {
+    const int j = __builtin_ctz(amb_mask);
+    amb_mask &= amb_mask - 1;
+    const float cx = j == 0 ? cxs[0] : j == 1 ? cxs[1] : j == 2 ? cxs[2] : cxs[3];
+    const int pix = project_exact(a, transform(cx, 0), transform(cx, 1), transform(cx, 2));
+    if (j == 0) obs[0].pix = pix;
+    if (j == 1) obs[1].pix = pix;
+    if (j == 2) obs[2].pix = pix;
+    if (j == 3) obs[3].pix = pix;
+  }
+  // ---- gather the frame (L2-resident) ---------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int pix = project(a, g[j][0], g[j][1], in[j] ? g[j][2] : 1.f);
-    obs[j].pix = in[j] ? pix : -1;
-    obs[j].gz = g[j][2];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
+    obs[j].z = 0.f;
+    obs[j].c = 0u;
     if (obs[j].pix >= 0) {
       obs[j].z = depth[obs[j].pix];
       if (COLOR) obs[j].c = bgra[obs[j].pix];
     }
+  }
+  // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
+  float dn[4];
+  bool act[4], band_safe = true;
+  any = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float raw = obs[j].z - obs[j].gz;                            // hpp:159
+    act[j] = obs[j].pix >= 0 && !isnan(obs[j].z) && !(raw < -a.neg);   // hpp:152, :193-196
+    const bool clamped = raw > a.pos;                                  // hpp:189-192
+    dn[j] = clamped ? a.pos_over_neg : div32_fast(raw, rneg);          // hpp:198
+    band_safe &= !act[j] || clamped || __float_as_uint(raw) == 0u || in_window(raw);
+    any |= act[j];
+  }
+  if (!any) return 0;
+  if (!band_safe) {  // operands outside the scale-free window: redo with the compiler's IEEE division
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (act[j] && !(obs[j].z - obs[j].gz > a.pos)) dn[j] = (obs[j].z - obs[j].gz) / a.neg;
+  }
+  // ---- read-modify-write -------------------------------------------------------------------------------
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const bool nt = a.nontemporal != 0;
+  const f4 d4 = ld_plane(reinterpret_cast<const f4 *>(D + idx), nt);
+  const f4 w4 = ld_plane(reinterpret_cast<const f4 *>(Wt + idx), nt);
+  u4 c4 = {0u, 0u, 0u, 0u};
+  if (COLOR) c4 = ld_plane(reinterpret_cast<const u4 *>(RGB + idx), nt);
+  const float d0[4] = {d4.x, d4.y, d4.z, d4.w};
+  const float w0[4] = {w4.x, w4.y, w4.z, w4.w};
+  const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
+  float dv[4], wv[4];
+  uint32_t cv[4];
+  bool safe = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) safe &= !act[j] || update_is_safe(d0[j], w0[j], dn[j]);
+  if (safe) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dv[j] = d0[j];
+      wv[j] = w0[j];
+      cv[j] = c0[j];
+      add_observation<COLOR, true>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dv[j] = d0[j];
+      wv[j] = w0[j];
+      cv[j] = c0[j];
+      add_observation<COLOR, false>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
+    }
+  }
+  bool chg_d = false, chg_w = false, chg_c = false;
+  unsigned cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dv[j] = act[j] ? dv[j] : d0[j];
+    wv[j] = act[j] ? wv[j] : w0[j];
+    cv[j] = act[j] ? cv[j] : c0[j];
+    chg_d |= __float_as_uint(dv[j]) != __float_as_uint(d0[j]);
+    chg_w |= __float_as_uint(wv[j]) != __float_as_uint(w0[j]);
+    chg_c |= cv[j] != c0[j];
+    cnt += act[j] ? 1u : 0u;
+  }
+  if (!SKIP || chg_d) st_plane(reinterpret_cast<f4 *>(D + idx), (f4){dv[0], dv[1], dv[2], dv[3]}, nt);
+  if (!SKIP || chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
+  if (COLOR && (!SKIP || chg_c)) st_plane(reinterpret_cast<u4 *>(RGB + idx), (u4){cv[0], cv[1], cv[2], cv[3]}, nt);
+  return cnt;
 }
 
-// PIPE = software-pipelined tile loop: while the d/w/rgb loads of tile t are in flight the thread
-// projects tile t+1 and issues its depth gathers.  SKIP = do not write back planes whose four values
-// did not change (free space: d stays at the hinge value; after weight saturation nothing changes).
-template <int ORDER, bool COLOR, bool PIPE, bool SKIP>
+// Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
+// blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
+// SKIP = do not write back planes whose four values did not change (free space: d stays at the hinge
+// value; after weight saturation nothing changes).  COUNT = accumulate the observed-voxel counter.
+template <int ORDER, bool COLOR, bool SKIP, bool FASTPROJ, bool COUNT>
 static __global__ void __launch_bounds__(256)
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
             unsigned long long *__restrict__ n_obs) {
   const unsigned tid = threadIdx.x;
-  const unsigned tx = tid & (unsigned)(a.TX - 1);
-  const unsigned ty = tid >> a.log2TX;
+  const int tx = (int)(tid & (unsigned)(a.TX - 1));
+  const int ty = (int)(tid >> a.log2TX);
+  const int xq = (int)blockIdx.x * a.TX + tx;
+  const int zl = (int)blockIdx.z;
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0;
-
-  unsigned y = 0, zl = 0;
-  Obs nxt[4];
-  Tile tl_n;
-  unsigned t = blockIdx.x;
-  if (PIPE && t < a.n_tiles) {
-    tl_n = locate(a, t, tx, ty, y, zl);
-    stage_project<ORDER, COLOR>(a, tl_n, y, zl, depth, bgra, ctrx, ctry, ctrz, nxt);
-  }
-  for (; t < a.n_tiles; t += gridDim.x) {
-    Obs cur[4];
-    Tile tl;
-    if (PIPE) {
-      tl = tl_n;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-    } else {
-      tl = locate(a, t, tx, ty, y, zl);
-      stage_project<ORDER, COLOR>(a, tl, y, zl, depth, bgra, ctrx, ctry, ctrz, cur);
-    }
-    // stage 2 (hpp:152-198): NaN test, projective SDF, hinge, normalisation
-    float dn[4];
-    bool act[4], any = false, band_safe = true;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float raw = cur[j].z - cur[j].gz;                       // hpp:159
-      act[j] = cur[j].pix >= 0 && !isnan(cur[j].z) && !(raw < -a.neg);  // hpp:152, :193-196
-      const bool clamped = raw > a.pos;                              // hpp:189-192
-      dn[j] = clamped ? a.pos_over_neg : div32_fast(raw, rneg);      // hpp:198
-      band_safe &= !act[j] || clamped || __float_as_uint(raw) == 0u || in_window(raw);
-      any |= act[j];
-    }
-    if (!band_safe) {  // operands outside the scale-free window: redo with the compiler's IEEE division
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (act[j] && !(cur[j].z - cur[j].gz > a.pos)) dn[j] = (cur[j].z - cur[j].gz) / a.neg;
-    }
-    // stage 3: issue the read half of the read-modify-write
-    float4 d4 = make_float4(0, 0, 0, 0), w4 = d4;
-    uint4 c4 = make_uint4(0, 0, 0, 0);
-    if (any) {
-      d4 = *reinterpret_cast<const float4 *>(D + tl.idx);
-      w4 = *reinterpret_cast<const float4 *>(Wt + tl.idx);
-      if (COLOR) c4 = *reinterpret_cast<const uint4 *>(RGB + tl.idx);
-    }
-    if (PIPE) {  // stage 1 of the NEXT tile, overlapping the loads above
-      const unsigned tn = t + gridDim.x;
-      if (tn < a.n_tiles) {
-        tl_n = locate(a, tn, tx, ty, y, zl);
-        stage_project<ORDER, COLOR>(a, tl_n, y, zl, depth, bgra, ctrx, ctry, ctrz, nxt);
-      }
-    }
-    // stage 4: running average and write-back
-    if (any) {
-      const float d0[4] = {d4.x, d4.y, d4.z, d4.w};
-      const float w0[4] = {w4.x, w4.y, w4.z, w4.w};
-      const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
-      float dv[4], wv[4];
-      uint32_t cv[4];
-      bool safe = true;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) safe &= !act[j] || update_is_safe(d0[j], w0[j], dn[j]);
-      if (safe) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          dv[j] = d0[j];
-          wv[j] = w0[j];
-          cv[j] = c0[j];
-          add_observation<COLOR, true>(dv[j], wv[j], cv[j], dn[j], cur[j].c, a.wmax);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          dv[j] = d0[j];
-          wv[j] = w0[j];
-          cv[j] = c0[j];
-          add_observation<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cur[j].c, a.wmax);
-        }
-      }
-      bool chg_d = false, chg_w = false, chg_c = false;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dv[j] = act[j] ? dv[j] : d0[j];
-        wv[j] = act[j] ? wv[j] : w0[j];
-        cv[j] = act[j] ? cv[j] : c0[j];
-        chg_d |= __float_as_uint(dv[j]) != __float_as_uint(d0[j]);
-        chg_w |= __float_as_uint(wv[j]) != __float_as_uint(w0[j]);
-        chg_c |= cv[j] != c0[j];
-        cnt += act[j] ? 1u : 0u;
-      }
-      if (!SKIP || chg_d) *reinterpret_cast<float4 *>(D + tl.idx) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-      if (!SKIP || chg_w) *reinterpret_cast<float4 *>(Wt + tl.idx) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-      if (COLOR && (!SKIP || chg_c))
-        *reinterpret_cast<uint4 *>(RGB + tl.idx) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  if (xq < a.qpr) {
+    const int x4 = xq * 4;
+    const float cz = ctrz[a.z_global0 + zl];
+    const int64_t plane_base = (int64_t)(a.zl0 + zl) * a.ny;
+    const int y0 = (int)blockIdx.y * a.rpb * a.TY + ty;
+    for (int r = 0; r < a.rpb; ++r) {
+      const int y = y0 + r * a.TY;
+      if (y >= a.ny) break;
+      const int64_t idx = (plane_base + y) * a.pitch + x4;
+      cnt += integrate_quad<ORDER, COLOR, SKIP, FASTPROJ>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, depth, bgra,
+                                                          ctrx);
     }
   }
-
-  // one atomic per block
-  __shared__ unsigned s_cnt;
-  if (tid == 0) s_cnt = 0;
-  __syncthreads();
-  if (cnt) atomicAdd(&s_cnt, cnt);
-  __syncthreads();
-  if (tid == 0 && s_cnt) atomicAdd(n_obs, (unsigned long long)s_cnt);
+  if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host)
+    __shared__ unsigned s_cnt;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0 && s_cnt) {
+      const unsigned b = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
+      atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
+    }
+  }
 }
 
-static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
-                            uint64_t *n_observed) {
+static float f32_ulp(float v) {
+  const float a = fabsf(v);
+  return nextafterf(a, INFINITY) - a;
+}
+
+static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   const tsdf_params &p = h->p;
   IntegrateArgs a;
   for (int i = 0; i < 12; ++i) a.m[i] = T[i];
@@ -331,6 +347,22 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   a.fy = p.fy;
   a.cx = p.cx;
   a.cy = p.cy;
+  a.fxf = (float)p.fx;
+  a.fyf = (float)p.fy;
+  a.cxf = (float)p.cx;
+  a.cyf = (float)p.cy;
+  {
+    // |R~ - R| <= |q|*(3*2^-24 + 2^-22) + (|c| + |R~|)*2^-24 + conversion of f and c, for R~ within one
+    // pixel of the image; see project_fast.  1.5x margin on top.
+    auto band = [](double c, int n) {
+      const double q = std::max(fabs(c) + 1.0, fabs((double)n + 1.0 - c));
+      const double e = q * (3.0 / 16777216.0 + 1.0 / 4194304.0) * 1.0000005 + (fabs(c) + n + 1.0) / 16777216.0 +
+                       f32_ulp((float)c) + 1e-9;
+      return (float)(1.5 * e);
+    };
+    a.band_u = band(p.cx, p.image_width);
+    a.band_v = band(p.cy, p.image_height);
+  }
   a.zmin = p.min_sensor_dist;
   a.zmax = p.max_sensor_dist;
   a.pos = p.max_dist_pos;
@@ -342,8 +374,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   a.nx = h->nx;
   a.ny = h->ny;
   a.qpr = (h->nx + 3) / 4;
-  const int planes = h->z_end - h->z_begin;
-  a.rows = h->ny * planes;
+  a.planes = h->z_end - h->z_begin;
   a.z_global0 = h->z_begin;
   a.zl0 = h->z_begin - h->z_first;
   int l2 = 0;
@@ -351,70 +382,93 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   a.log2TX = l2;
   a.TX = 1 << l2;
   a.TY = 256 / a.TX;
-  a.xchunks = (unsigned)((a.qpr + a.TX - 1) / a.TX);
-  const int64_t row_groups = ((int64_t)a.rows + a.TY - 1) / a.TY;
-  const int64_t tiles = row_groups * a.xchunks;
-  if (tiles > 0xFFFFFFFFll) {
-    tsdf_set_error("slab too large for one launch");
+  a.rpb = std::max(1, tsdf_tuning().rows_per_block / a.TY);
+  a.nontemporal = tsdf_tuning().nontemporal;
+  a.pitch = h->pitch;
+  return a;
+}
+
+static bool fast_projection_ok(const IntegrateArgs &a) {
+  // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
+  return tsdf_tuning().fast_projection != 0 && std::isfinite(a.band_u) && std::isfinite(a.band_v) &&
+         a.band_u < 0.05f && a.band_v < 0.05f && fabs(a.fx) < 1e6 && fabs(a.fy) < 1e6;
+}
+
+static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
+                            uint64_t *n_observed) {
+  const tsdf_params &p = h->p;
+  const IntegrateArgs a = make_args(h, T);
+  const unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
+  const unsigned gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
+  const unsigned gz = (unsigned)a.planes;
+  if (gy > 65535u || gz > 65535u) {
+    tsdf_set_error("grid too large for one launch");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  a.n_tiles = (unsigned)tiles;
-  a.pitch = h->pitch;
-
-  TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
-  // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
-  // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
-  // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
-  bool pose_ok = true;
-  for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
-  if (!pose_ok) {
-    if (n_observed) {
-      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-      *n_observed = 0;
-    }
-    return TSDF_HIP_OK;
-  }
-  const unsigned grid = (unsigned)std::min<int64_t>(tiles, (int64_t)256 * tsdf_tuning().blocks_per_cu);
   const bool color = p.integrate_color != 0;
   if (color && !d_bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
   }
-  const bool pipe = tsdf_tuning().pipeline != 0;
+  const bool count = n_observed != nullptr;
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
+  // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
+  // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
+  // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
+  bool pose_ok = true;
+  for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
+  const bool fastproj = fast_projection_ok(a);
   const bool skip = tsdf_tuning().skip_unchanged != 0;
-#define LAUNCH(ORDER, COLOR, PIPE, SKIP)                                                                   \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, PIPE, SKIP>), dim3(grid), dim3(256), 0, h->stream, a, h->d, \
-                     h->w, h->rgb, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
-#define LAUNCH2(ORDER, COLOR)             \
-  do {                                    \
-    if (pipe && skip)                     \
-      LAUNCH(ORDER, COLOR, true, true);   \
-    else if (pipe)                        \
-      LAUNCH(ORDER, COLOR, true, false);  \
-    else if (skip)                        \
-      LAUNCH(ORDER, COLOR, false, true);  \
-    else                                  \
-      LAUNCH(ORDER, COLOR, false, false); \
+  if (pose_ok) {
+    const dim3 grid(gx, gy, gz), block(256);
+#define LAUNCH(ORDER, COLOR, SKIP, FP, COUNT)                                                                  \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, SKIP, FP, COUNT>), grid, block, 0, h->stream, a, h->d, h->w, \
+                     h->rgb, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+#define L4(ORDER, COLOR, SKIP, FP) \
+  do {                             \
+    if (count)                     \
+      LAUNCH(ORDER, COLOR, SKIP, FP, true);  \
+    else                           \
+      LAUNCH(ORDER, COLOR, SKIP, FP, false); \
   } while (0)
-  if (p.xform_order == TSDF_XFORM_PCL_SSE) {
-    if (color)
-      LAUNCH2(TSDF_XFORM_PCL_SSE, true);
-    else
-      LAUNCH2(TSDF_XFORM_PCL_SSE, false);
-  } else {
-    if (color)
-      LAUNCH2(TSDF_XFORM_LEFT_TO_RIGHT, true);
-    else
-      LAUNCH2(TSDF_XFORM_LEFT_TO_RIGHT, false);
-  }
-#undef LAUNCH2
+#define L3(ORDER, COLOR, SKIP) \
+  do {                         \
+    if (fastproj)              \
+      L4(ORDER, COLOR, SKIP, true);  \
+    else                       \
+      L4(ORDER, COLOR, SKIP, false); \
+  } while (0)
+#define L2(ORDER, COLOR) \
+  do {                   \
+    if (skip)            \
+      L3(ORDER, COLOR, true);  \
+    else                 \
+      L3(ORDER, COLOR, false); \
+  } while (0)
+    if (p.xform_order == TSDF_XFORM_PCL_SSE) {
+      if (color)
+        L2(TSDF_XFORM_PCL_SSE, true);
+      else
+        L2(TSDF_XFORM_PCL_SSE, false);
+    } else {
+      if (color)
+        L2(TSDF_XFORM_LEFT_TO_RIGHT, true);
+      else
+        L2(TSDF_XFORM_LEFT_TO_RIGHT, false);
+    }
+#undef L2
+#undef L3
+#undef L4
 #undef LAUNCH
-  TSDF_HIP_TRY(hipGetLastError());
+    TSDF_HIP_TRY(hipGetLastError());
+  }
   if (n_observed) {
-    unsigned long long c = 0;
-    TSDF_HIP_TRY(hipMemcpyAsync(&c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long c[1024];
+    TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
     TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-    *n_observed = c;
+    unsigned long long sum = 0;
+    for (int i = 0; i < 1024; ++i) sum += c[i];
+    *n_observed = pose_ok ? sum : 0;
   }
   return TSDF_HIP_OK;
 }
@@ -531,5 +585,51 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
   const uint64_t planes = h->rgb ? 3 : 2;
   if (bytes_read) *bytes_read = planes * (uint64_t)n4 * 16u;
   if (bytes_written) *bytes_written = planes * (uint64_t)n4 * 16u;
+  return TSDF_HIP_OK;
+}
+
+// Test hook: the kernel's pixel projection (certified fp32 path and exact fp64 path) on arbitrary
+// camera-frame points g (n x 3), with this volume's intrinsics and image size.
+static __global__ void k_selftest_project(const IntegrateArgs a, const float *g, size_t n, int *pix_fast,
+                                          int *pix_exact, unsigned char *ambiguous) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
+  bool amb = false;
+  int pf = project_fast(a, gx, gy, gz, amb);
+  const int pe = project_exact(a, gx, gy, gz);
+  if (amb) pf = pe;  // what integrate_quad does
+  pix_fast[i] = pf;
+  pix_exact[i] = pe;
+  ambiguous[i] = amb ? 1 : 0;
+}
+
+extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
+                                         int32_t *pix_exact, uint8_t *ambiguous) {
+  if (!h || !g || !n || !pix_fast || !pix_exact || !ambiguous) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const IntegrateArgs a = make_args(h, ident);
+  if (!fast_projection_ok(a)) {
+    tsdf_set_error("fast projection disabled for this camera");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  float *dg = nullptr;
+  int *dpf = nullptr, *dpe = nullptr;
+  unsigned char *da = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&dg, n * 12));
+  TSDF_HIP_TRY(hipMalloc(&dpf, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&dpe, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&da, n));
+  TSDF_HIP_TRY(hipMemcpy(dg, g, n * 12, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, dg, n, dpf, dpe, da);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(pix_fast, dpf, n * 4, hipMemcpyDeviceToHost));
+  TSDF_HIP_TRY(hipMemcpy(pix_exact, dpe, n * 4, hipMemcpyDeviceToHost));
+  TSDF_HIP_TRY(hipMemcpy(ambiguous, da, n, hipMemcpyDeviceToHost));
+  (void)hipFree(dg);
+  (void)hipFree(dpf);
+  (void)hipFree(dpe);
+  (void)hipFree(da);
   return TSDF_HIP_OK;
 }

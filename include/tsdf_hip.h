@@ -145,6 +145,13 @@ int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
 int tsdf_hip_selftest_div_f32(const float *a, const float *b, float *out, size_t n);
 int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, size_t n);
 
+/* Test hook: the integrate kernel's pixel projection (reprojectPoint, tsdf_volume_octree.cpp:611-617) on
+ * n arbitrary camera-frame points g (x,y,z triples, z > 0) with this volume's intrinsics: pix_fast =
+ * certified-fp32 path with exact fallback (what the kernel uses), pix_exact = fp64 path, both v*W+u or
+ * -1; ambiguous[i] = 1 where the fp32 path declined to decide. */
+int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
+                              int32_t *pix_exact, uint8_t *ambiguous);
+
 /* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */

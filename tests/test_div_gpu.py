@@ -82,3 +82,58 @@ def test_div64_projection_ranges(gpu):
     # non-finite numerators never reach an accepted pixel; both sides just have to stay non-finite
     nonfin = ~np.isfinite(num)
     assert (ok | (nonfin & ~np.isfinite(got))).all(), (num[~ok][:5], gz[~ok][:5], got[~ok][:5], want[~ok][:5])
+
+
+def _project_reference(g, fx, fy, cx, cy, W, H):
+    """reprojectPoint in IEEE double exactly as the C++ evaluates it (tsdf_volume_octree.cpp:611-617)."""
+    gx, gy, gz = (g[:, k].astype(np.float64) for k in range(3))
+    with np.errstate(all="ignore"):
+        ru = gx * fx / gz + cx
+        rv = gy * fy / gz + cy
+
+    def cvtt(v):
+        ok = (v > -2147483649.0) & (v < 2147483648.0)
+        return np.where(ok, np.trunc(np.where(ok, v, 0.0)), -2147483648.0).astype(np.int64)
+
+    u, v = cvtt(ru), cvtt(rv)
+    inside = (u >= 0) & (u < W) & (v >= 0) & (v < H)
+    return np.where(inside, v * W + u, -1).astype(np.int32), ru, rv
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (1280, 960), (160, 120)])
+def test_certified_fp32_projection_matches_double(gpu, W, H):
+    """The fp32 projection + ambiguity band + fp64 fallback must give the reference's pixel for every
+    point, including points engineered to sit within a few ulps of pixel boundaries."""
+    from cpu_tsdf_amd import synth
+    from tests.common import make_volume
+    vol, sc = make_volume(64, width=W, height=H)
+    vol.reset()
+    fx, fy, cx, cy = vol.getCameraIntrinsics()
+    rng = np.random.RandomState(7)
+    n = 1 << 22
+    gz = rng.uniform(0.05, 60.0, n)
+    u_t = rng.uniform(-3, W + 3, n)
+    v_t = rng.uniform(-3, H + 3, n)
+    # a quarter of the points sit (almost) exactly on integer pixel boundaries in u or v
+    k = n // 4
+    u_t[:k] = np.round(u_t[:k]) + rng.choice([0.0, 1e-7, -1e-7, 3e-5, -3e-5, 2e-4, -2e-4], k)
+    v_t[k:2 * k] = np.round(v_t[k:2 * k]) + rng.choice([0.0, 1e-7, -1e-7, 3e-5, -3e-5], k)
+    g = np.stack([(u_t - cx) / fx * gz, (v_t - cy) / fy * gz, gz], 1).astype(np.float32)
+    g[:8, 2] = [1e-30, 1e-38, 1e-44, 3e38, 1e-20, 1.0, 1.0, 1.0]
+    g[5, 0] = 0.0
+    g[6, 0] = 3e38
+    g[7, 1] = -3e38
+    want, ru, rv = _project_reference(g, fx, fy, cx, cy, W, H)
+    pf = np.empty(n, np.int32)
+    pe = np.empty(n, np.int32)
+    amb = np.empty(n, np.uint8)
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    capi.check(capi.load().tsdf_hip_selftest_project(vol._need(), capi.as_f32p(np.ascontiguousarray(g)), n, i32(pf),
+                                                     i32(pe), capi.as_u8p(amb)), "selftest_project")
+    assert np.array_equal(pe, want), f"exact path: {(pe != want).sum()} mismatches"
+    bad = pf != want
+    assert not bad.any(), (int(bad.sum()), g[bad][:4], pf[bad][:4], want[bad][:4], ru[bad][:4], rv[bad][:4])
+    frac = amb.mean()
+    assert 0.0 < frac < 0.5  # boundary-engineered points are flagged, random ones almost never
+    rnd = amb[2 * k + 8:]
+    assert rnd.mean() < 0.01
