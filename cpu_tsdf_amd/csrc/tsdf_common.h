@@ -54,7 +54,8 @@ struct TsdfTuning {
   int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
   int blocks_per_cu;   // grid-stride helper kernels: grid = 256 CUs x this
   int skip_unchanged;  // do not write back SoA planes whose values did not change
-  int fast_projection; // certified fp32 pixel projection with exact fp64 fallback
+  int fast_projection; // certified fp32 pixel projection with exact fp64 fallback: 1 on, 0 off,
+                       // -1 auto (only with colour, where VALU load is highest; measured, profiles/)
   int nontemporal;     // nt hint on the voxel-plane loads/stores
 };
 const TsdfTuning &tsdf_tuning();

@@ -388,9 +388,11 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   return a;
 }
 
-static bool fast_projection_ok(const IntegrateArgs &a) {
+static bool fast_projection_ok(const IntegrateArgs &a, bool color, bool force = false) {
   // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
-  return tsdf_tuning().fast_projection != 0 && std::isfinite(a.band_u) && std::isfinite(a.band_v) &&
+  const int knob = tsdf_tuning().fast_projection;
+  const bool want = force || knob > 0 || (knob < 0 && color);
+  return want && std::isfinite(a.band_u) && std::isfinite(a.band_v) &&
          a.band_u < 0.05f && a.band_v < 0.05f && fabs(a.fx) < 1e6 && fabs(a.fy) < 1e6;
 }
 
@@ -417,7 +419,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
   bool pose_ok = true;
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
-  const bool fastproj = fast_projection_ok(a);
+  const bool fastproj = fast_projection_ok(a, p.integrate_color != 0);
   const bool skip = tsdf_tuning().skip_unchanged != 0;
   if (pose_ok) {
     const dim3 grid(gx, gy, gz), block(256);
@@ -610,7 +612,7 @@ extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n
   TSDF_HIP_TRY(hipSetDevice(h->device));
   const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const IntegrateArgs a = make_args(h, ident);
-  if (!fast_projection_ok(a)) {
+  if (!fast_projection_ok(a, true, true)) {
     tsdf_set_error("fast projection disabled for this camera");
     return TSDF_HIP_E_UNSUPPORTED;
   }

@@ -276,9 +276,9 @@ void oracle_raycast(const oracle_params *p, const float *d, const float *w, cons
     int found_crossing = 0;
     float du[3] = {(float)((x - ncx) / nfx), (float)((y - ncy) / nfy), 1.f};
     normalize3(du);
-    { /* du = R * du  [Eigen-recall: row sum (a + b) + c] */
+    { /* du = R * du  [Eigen-recall 3.3: each coefficient is a 3-term reduction p0 + (p1 + p2)] */
       const float a = du[0], b = du[1], c = du[2];
-      for (int r = 0; r < 3; ++r) du[r] = (rot[3 * r] * a + rot[3 * r + 1] * b) + rot[3 * r + 2] * c;
+      for (int r = 0; r < 3; ++r) du[r] = rot[3 * r] * a + (rot[3 * r + 1] * b + rot[3 * r + 2] * c);
     }
     float pt[3] = {org[0], org[1], org[2]};
     float dd = 0, ww = 0, last_w = 0, last_d = 0;
