@@ -31,7 +31,10 @@ struct tsdf_hip_volume {
   uint8_t *mc_rgb = nullptr;
   uint64_t *mc_cell = nullptr;
   uint64_t mc_ntri = 0;
-  size_t mc_cap = 0;
+  size_t mc_cap = 0;       // triangles the output buffers hold
+  bool mc_has_rgb = false;
+  uint64_t *mc_keys = nullptr, *mc_vals = nullptr;  // active-cell list (Morton key, packed cell)
+  size_t mc_cells_cap = 0;
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
 };

@@ -170,6 +170,8 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->mc_verts) (void)hipFree(v->mc_verts);
   if (v->mc_rgb) (void)hipFree(v->mc_rgb);
   if (v->mc_cell) (void)hipFree(v->mc_cell);
+  if (v->mc_keys) (void)hipFree(v->mc_keys);
+  if (v->mc_vals) (void)hipFree(v->mc_vals);
   if (v->scratch) (void)hipFree(v->scratch);
   delete v;
 }

@@ -1,0 +1,359 @@
+// libtsdf_hip.so -- marching cubes on the flat SoA grid.
+//
+// Replaces MarchingCubesTSDFOctree::reconstruct (src/lib/marching_cubes_tsdf_octree.cpp:108-236) and the
+// PCL pieces it calls (pcl::MarchingCubes::createSurface / interpolateEdge, Bourke's tables).
+//   k_mc_classify  one thread per grid cell: candidate test (:192-202), 8 corner values
+//                  (getValidNeighborList1D :145-177 / getGridValue :91-106), case index, triangle count;
+//                  active cells are compacted per wavefront into (Morton key, packed cell) pairs
+//   rocprim sort   by key: the reference emits triangles in octree pre-order with child index
+//                  4*(x>cx) + 2*(y>cy) + (z>cz) (octree.cpp:119,257-264) = Morton order, x the high bit
+//   rocprim scan   triangle offsets
+//   k_mc_emit      one thread per active cell: edge interpolation + triangle/colour output
+// Case tables live in LDS.  Streaming stencil read of d and w: HBM-bound, no MFMA.
+#include <string.h>
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+// only the device-wide sort and scan are needed (rocprim.hpp also drags in texture iterators)
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "tsdf_common.h"
+#define TSDF_MC_TABLE_QUALIFIER __device__
+#include "mc_tables.h"
+
+struct McArgs {
+  int nx, ny, nz;
+  int z_first;            // global index of allocated plane 0
+  int z_lo, z_hi;         // cells with z in [z_lo, z_hi)
+  int64_t pitch;
+  const float *d, *w;
+  const uint32_t *rgb;
+  float w_min, neg;
+  int color_mode;
+  float lower[3], size_voxel[3];
+};
+
+// getGridValue (:91-106): NaN if w < w_min or |d| >= 1, else d * max_dist_neg.
+static __device__ __forceinline__ float grid_value(const McArgs &a, int64_t vi) {
+  const float d = a.d[vi], w = a.w[vi];
+  if (w < a.w_min || fabsf(d) >= 1.f) return NAN;
+  return d * a.neg;
+}
+
+static __device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+// Corner order of pcl::MarchingCubes: (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1)
+static __device__ __forceinline__ bool corner_values(const McArgs &a, int x, int y, int z, float leaf[8]) {
+  const int64_t sy = a.pitch, sz = (int64_t)a.ny * a.pitch;
+  const int64_t o = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+  const int64_t off[8] = {0, 1, 1 + sz, sz, sy, 1 + sy, 1 + sy + sz, sy + sz};
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    leaf[k] = grid_value(a, o + off[k]);
+    ok = ok && !isnan(leaf[k]);
+  }
+  return ok;
+}
+
+static __device__ __forceinline__ int cube_index(const float leaf[8]) {
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (leaf[k] < 0.f) c |= 1 << k;  // iso level 0 (:74-78)
+  return c;
+}
+
+// counters[0] = active cells, counters[1] = triangles
+static __global__ void __launch_bounds__(256)
+k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, uint64_t capacity,
+              unsigned long long *__restrict__ counters) {
+  __shared__ unsigned char s_ntri[256];
+  s_ntri[threadIdx.x] = mc_ntri_table[threadIdx.x];
+  __syncthreads();
+  const int x = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int y = 1 + (int)blockIdx.y;
+  const int z = a.z_lo + (int)blockIdx.z;
+  unsigned ntri = 0;
+  if (x < a.nx - 1 && y < a.ny - 1 && z < a.z_hi) {
+    const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+    const float d = a.d[vi], w = a.w[vi];
+    if (w >= a.w_min && fabsf(d) < 1.f) {  // :192
+      float leaf[8];
+      if (corner_values(a, x, y, z, leaf)) ntri = s_ntri[cube_index(leaf)];
+    }
+  }
+  // wave-level compaction: one atomic pair per wavefront
+  const unsigned long long active = __ballot(ntri > 0);
+  if (active == 0) return;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned tri_sum = ntri;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) tri_sum += __shfl_xor(tri_sum, s);
+  unsigned long long base = 0;
+  if (lane == 0) {
+    base = atomicAdd(&counters[0], (unsigned long long)__popcll(active));
+    atomicAdd(&counters[1], (unsigned long long)tri_sum);
+  }
+  base = __shfl(base, 0);
+  if (ntri > 0) {
+    const unsigned long long slot = base + __popcll(active & ((1ull << lane) - 1ull));
+    if (slot < capacity) {
+      keys[slot] = (spread3((uint64_t)x) << 2) | (spread3((uint64_t)y) << 1) | spread3((uint64_t)z);
+      vals[slot] = (uint64_t)x | ((uint64_t)y << 20) | ((uint64_t)z << 40) | ((uint64_t)ntri << 60);
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256)
+k_mc_counts(const uint64_t *__restrict__ vals, uint32_t *__restrict__ counts, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) counts[i] = (uint32_t)(vals[i] >> 60);
+}
+
+static __global__ void __launch_bounds__(256)
+k_mc_emit(const McArgs a, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ offsets, uint64_t n_cells,
+          float *__restrict__ verts, unsigned char *__restrict__ rgb_out, uint64_t *__restrict__ cell_out) {
+  __shared__ signed char s_tri[256 * 16];
+  __shared__ unsigned short s_edge[256];
+  for (int i = threadIdx.x; i < 256 * 16; i += blockDim.x) s_tri[i] = mc_tri_table[i >> 4][i & 15];
+  s_edge[threadIdx.x] = mc_edge_table[threadIdx.x];
+  __syncthreads();
+  const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= n_cells) return;
+  const uint64_t v = vals[ci];
+  const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
+  float leaf[8];
+  corner_values(a, x, y, z, leaf);
+  const int cubeindex = cube_index(leaf);
+  // createSurface [PCL-recall]: centre = lower_boundary_ + size_voxel_ * index; corner k adds size_voxel_
+  // in y if k&4, in z if k&2, in x if (k&1)^((k>>1)&1)
+  const int idx[3] = {x, y, z};
+  float center[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) center[k] = a.lower[k] + a.size_voxel[k] * (float)idx[k];
+  float pc[8][3];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pc[k][0] = ((k & 1) ^ ((k >> 1) & 1)) ? center[0] + a.size_voxel[0] : center[0];
+    pc[k][1] = (k & 4) ? center[1] + a.size_voxel[1] : center[1];
+    pc[k][2] = (k & 2) ? center[2] + a.size_voxel[2] : center[2];
+  }
+  const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+  float vl[12][3];
+  const unsigned edges = s_edge[cubeindex];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    // interpolateEdge: mu = (iso - v1) / (v2 - v1); out = p1 + mu * (p2 - p1)
+    const float mu = (0.f - leaf[ea[e]]) / (leaf[eb[e]] - leaf[ea[e]]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vl[e][k] = pc[ea[e]][k] + mu * (pc[eb[e]][k] - pc[ea[e]][k]);
+  }
+  (void)edges;  // unused edges produce garbage that no triangle references
+  unsigned char col[3] = {0, 0, 0};
+  const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+  if (a.color_mode == 2) {  // :217-224 colour by confidence, evaluated in double like the reference
+    const float std_dev = (float)((100. - (double)a.w[vi]) / 100.);
+    const double r = (double)(1 - std_dev) * 255., b = (double)std_dev * 255.;
+    const double rmin = (255. < r) ? 255. : r, bmin = (255. < b) ? 255. : b;  // std::min(x, 255.)
+    col[0] = (unsigned char)((0. < rmin) ? rmin : 0.);                        // std::max(0., x)
+    col[2] = (unsigned char)((0. < bmin) ? bmin : 0.);
+  } else if (a.color_mode == 1 && a.rgb) {  // :226-231
+    const uint32_t c = a.rgb[vi];
+    col[0] = (unsigned char)(c & 255u);
+    col[1] = (unsigned char)((c >> 8) & 255u);
+    col[2] = (unsigned char)((c >> 16) & 255u);
+  }
+  uint64_t t = offsets[ci];
+  const signed char *tri = s_tri + cubeindex * 16;
+  for (int i = 0; tri[i] != -1; i += 3, ++t) {
+#pragma unroll
+    for (int vtx = 0; vtx < 3; ++vtx) {
+      const int e = tri[i + vtx];
+      float *o = verts + 9 * t + 3 * vtx;
+      // select the edge vertex without dynamic register indexing
+      float vx = 0, vy = 0, vz = 0;
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+        if (q == e) {
+          vx = vl[q][0];
+          vy = vl[q][1];
+          vz = vl[q][2];
+        }
+      o[0] = vx;
+      o[1] = vy;
+      o[2] = vz;
+      if (rgb_out) {
+        unsigned char *c = rgb_out + 9 * t + 3 * vtx;
+        c[0] = col[0];
+        c[1] = col[1];
+        c[2] = col[2];
+      }
+    }
+    if (cell_out) cell_out[t] = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+  }
+}
+
+static float host_voxel_center(const tsdf_params &p, int a, int i) {  // tsdf_volume_octree.cpp:553-560
+  const float off = p.size[a] / 2.0;
+  return (float)(((size_t)i + 0.5) * p.size[a] / (double)p.res[a] - off);
+}
+
+template <typename T>
+static int ensure_buf(T **buf, size_t *cap_elems, size_t need, hipStream_t s) {
+  if (need <= *cap_elems && *buf) return TSDF_HIP_OK;
+  if (*buf) {
+    TSDF_HIP_TRY(hipStreamSynchronize(s));
+    TSDF_HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *cap_elems = 0;
+  }
+  TSDF_HIP_TRY(hipMalloc(buf, need * sizeof(T)));
+  *cap_elems = need;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
+  if (!h || color_mode < 0 || color_mode > 2) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const tsdf_params &p = h->p;
+  if (p.res[0] >= (1 << 20) || p.res[1] >= (1 << 20) || p.res[2] >= (1 << 20)) return TSDF_HIP_E_UNSUPPORTED;
+  McArgs a;
+  a.nx = h->nx;
+  a.ny = h->ny;
+  a.nz = h->nz;
+  a.z_first = h->z_first;
+  a.pitch = h->pitch;
+  a.d = h->d;
+  a.w = h->w;
+  a.rgb = h->rgb;
+  a.w_min = w_min;
+  a.neg = p.max_dist_neg;
+  a.color_mode = color_mode;
+  // setInputTSDF (:44-83): the two +- terms at :64-66 cancel, so the bounding box is [centre(voxel 0),
+  // centre(voxel res)] and size_voxel_ = (upper - lower) * (1 / res) in float
+  for (int k = 0; k < 3; ++k) {
+    a.lower[k] = host_voxel_center(p, k, 0);
+    const float upper = host_voxel_center(p, k, p.res[k]);
+    a.size_voxel[k] = (upper - a.lower[k]) * (1.0f / (float)p.res[k]);
+  }
+  // cells owned by this handle: base voxel z in the slab, strictly inside the grid (:199-202), and plane
+  // z+1 must be allocated (own slab or halo)
+  a.z_lo = std::max(1, h->z_begin);
+  a.z_hi = std::min(h->nz - 1, h->z_end);
+  if (a.z_hi > a.z_lo && a.z_hi + 1 > h->z_first + h->nz_alloc) {
+    tsdf_set_error("marching cubes needs plane z_end as a halo (create the handle with halo >= 1)");
+    return TSDF_HIP_E_INVALID;
+  }
+  h->mc_ntri = 0;
+  if (n_tri) *n_tri = 0;
+  if (a.z_hi <= a.z_lo || a.nx < 3 || a.ny < 3) return TSDF_HIP_OK;
+
+  const dim3 block(256), grid((unsigned)((a.nx - 2 + 255) / 256), (unsigned)(a.ny - 2), (unsigned)(a.z_hi - a.z_lo));
+  if (grid.y > 65535u || grid.z > 65535u) return TSDF_HIP_E_UNSUPPORTED;
+  unsigned long long counts[2] = {0, 0};
+  // pass 1 with the capacity we already have; if the surface turned out larger, grow and repeat
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t cap = h->mc_cells_cap;
+    TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2 * sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(k_mc_classify, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+    TSDF_HIP_TRY(hipGetLastError());
+    TSDF_HIP_TRY(hipMemcpyAsync(counts, h->counter, sizeof counts, hipMemcpyDeviceToHost, h->stream));
+    TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (counts[0] <= cap) break;
+    const size_t need = (size_t)counts[0] + (size_t)counts[0] / 8 + 1024;
+    size_t c1 = h->mc_cells_cap, c2 = h->mc_cells_cap;
+    int rc = ensure_buf(&h->mc_keys, &c1, need, h->stream);
+    if (rc) return rc;
+    rc = ensure_buf(&h->mc_vals, &c2, need, h->stream);
+    if (rc) return rc;
+    h->mc_cells_cap = need;
+  }
+  const uint64_t n_cells = counts[0], ntri = counts[1];
+  if (n_cells == 0) return TSDF_HIP_OK;
+  if (n_cells > 0xffffffffull || ntri > 0xffffffffull) {
+    tsdf_set_error("mesh too large (more than 2^32 cells or triangles)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+
+  // sort (key, val) by Morton key -> reference triangle order
+  uint64_t *keys_out = nullptr, *vals_out = nullptr;
+  uint32_t *cnt = nullptr, *off = nullptr;
+  size_t tmp_bytes_sort = 0, tmp_bytes_scan = 0;
+  TSDF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
+                                         (size_t)n_cells, 0, 63, h->stream));
+  TSDF_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
+                                       rocprim::plus<uint32_t>(), h->stream));
+  const size_t al = 256;
+  auto up = [&](size_t v) { return (v + al - 1) / al * al; };
+  const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4);
+  const size_t total = 2 * b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan));
+  int rc = tsdf_ensure_scratch(h, total);
+  if (rc) return rc;
+  char *sp = (char *)h->scratch;
+  keys_out = (uint64_t *)sp;
+  vals_out = (uint64_t *)(sp + b_keys);
+  cnt = (uint32_t *)(sp + 2 * b_keys);
+  off = (uint32_t *)(sp + 2 * b_keys + b_cnt);
+  void *tmp = sp + 2 * b_keys + 2 * b_cnt;
+  TSDF_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
+                                         (size_t)n_cells, 0, 63, h->stream));
+  const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
+  hipLaunchKernelGGL(k_mc_counts, dim3(cell_blocks), dim3(256), 0, h->stream, vals_out, cnt, n_cells);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
+                                       rocprim::plus<uint32_t>(), h->stream));
+
+  // output buffers
+  if (ntri > h->mc_cap) {
+    TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->mc_verts) (void)hipFree(h->mc_verts);
+    if (h->mc_rgb) (void)hipFree(h->mc_rgb);
+    if (h->mc_cell) (void)hipFree(h->mc_cell);
+    h->mc_verts = nullptr;
+    h->mc_rgb = nullptr;
+    h->mc_cell = nullptr;
+    h->mc_cap = 0;
+    const size_t cap = (size_t)ntri + (size_t)ntri / 8 + 1024;
+    TSDF_HIP_TRY(hipMalloc(&h->mc_verts, cap * 9 * sizeof(float)));
+    TSDF_HIP_TRY(hipMalloc(&h->mc_rgb, cap * 9));
+    TSDF_HIP_TRY(hipMalloc(&h->mc_cell, cap * sizeof(uint64_t)));
+    h->mc_cap = cap;
+  }
+  hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts,
+                     color_mode ? h->mc_rgb : nullptr, h->mc_cell);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->mc_ntri = ntri;
+  h->mc_has_rgb = color_mode != 0;
+  if (n_tri) *n_tri = ntri;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)h->mc_ntri;
+  if (!n) return TSDF_HIP_OK;
+  if (verts) TSDF_HIP_TRY(hipMemcpyAsync(verts, h->mc_verts, n * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (rgb) {
+    if (!h->mc_has_rgb) {
+      tsdf_set_error("the last tsdf_hip_march ran without a colour mode");
+      return TSDF_HIP_E_INVALID;
+    }
+    TSDF_HIP_TRY(hipMemcpyAsync(rgb, h->mc_rgb, n * 9, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (cell) TSDF_HIP_TRY(hipMemcpyAsync(cell, h->mc_cell, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}

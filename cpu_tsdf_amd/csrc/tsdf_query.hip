@@ -1,6 +1,428 @@
-// placeholder -- replaced below by raycast / sample / marching cubes kernels
+// libtsdf_hip.so -- renderView (one thread per ray) and getFxn/getGradient/getHessian (one thread per
+// query point) on the flat SoA grid.
+//
+// Replaces TSDFVolumeOctree::renderView (src/lib/tsdf_volume_octree.cpp:278-421),
+// getTSDFValue/interpolateTrilinearly (:453-541), getFxn/getGradient/getHessian/getNeighbors (:655-828).
+// Every root-to-leaf pointer chase of the reference (Octree::getContainingVoxel, src/lib/octree.cpp:
+// 112-133,628-643) becomes an index computation that replays the octree's descent comparisons exactly,
+// so a ray visits the same voxels and takes the same steps as on the CPU.  Both kernels are
+// gather/latency-bound (dependent loads along the ray); no roofline claim is made for them.
+// Compiled with -ffp-contract=off; float/double operation order follows the reference line by line.
+#include <limits.h>
+#include <math.h>
+
+#include <algorithm>
+
 #include "tsdf_common.h"
-extern "C" int tsdf_hip_raycast(tsdf_handle, const float *, const float *, int, float *) { return TSDF_HIP_E_UNSUPPORTED; }
-extern "C" int tsdf_hip_sample(tsdf_handle, const float *, size_t, float *, float *, float *, uint8_t *) { return TSDF_HIP_E_UNSUPPORTED; }
-extern "C" int tsdf_hip_march(tsdf_handle, float, int, uint64_t *) { return TSDF_HIP_E_UNSUPPORTED; }
-extern "C" int tsdf_hip_march_fetch(tsdf_handle, float *, uint8_t *, uint64_t *) { return TSDF_HIP_E_UNSUPPORTED; }
+
+struct GridView {
+  int nx, ny, nz;        // full resolution
+  int z_first, nz_alloc; // allocated plane range
+  int lv[3];             // octree levels per axis (log2 res) or -1
+  float size[3];
+  float half[3];         // size/2 in float (root bounds test, octree.cpp:630)
+  int64_t pitch;
+  const float *d, *w;
+  const uint32_t *rgb;
+  const float *ctr[3];   // octree node-centre tables
+};
+
+static GridView make_view(const tsdf_hip_volume *v) {
+  GridView g;
+  g.nx = v->nx;
+  g.ny = v->ny;
+  g.nz = v->nz;
+  g.z_first = v->z_first;
+  g.nz_alloc = v->nz_alloc;
+  for (int a = 0; a < 3; ++a) {
+    g.lv[a] = v->levels[a];
+    g.size[a] = v->p.size[a];
+    g.half[a] = v->p.size[a] / 2;
+    g.ctr[a] = v->ctr[a];
+  }
+  g.pitch = v->pitch;
+  g.d = v->d;
+  g.w = v->w;
+  g.rgb = v->rgb;
+  return g;
+}
+
+// x86 cvttsd2si semantics (see tsdf_integrate.hip)
+static __device__ __forceinline__ int cvtt(double v) {
+  return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
+}
+
+// One axis of OctreeNode::getContainingVoxel's descent (octree.cpp:112-121): child bit = (x - ctr) > 0.
+static __device__ __forceinline__ int descend_axis(float x, float size, int L) {
+  float c = 0.f, s = size;
+  int i = 0;
+  for (int l = 0; l < L; ++l) {
+    const bool b = (x - c) > 0.f;
+    const float off = s / 4;
+    c = b ? c + off : c - off;
+    s = s / 2;
+    i = i * 2 + (b ? 1 : 0);
+  }
+  return i;
+}
+
+static __device__ __forceinline__ int axis_index(const GridView &g, int a, float x) {
+  if (g.lv[a] >= 0) return descend_axis(x, g.size[a], g.lv[a]);
+  const int res = a == 0 ? g.nx : a == 1 ? g.ny : g.nz;
+  int i = cvtt(floor(((double)x + (double)g.size[a] / 2.0) / (double)g.size[a] * (double)res));
+  return i < 0 ? 0 : (i >= res ? res - 1 : i);
+}
+
+// Octree::getContainingVoxel (octree.cpp:628-643) on a fully refined tree; false == NULL.
+// `local` reports whether the voxel's plane is held by this handle (always true for a whole grid).
+static __device__ __forceinline__ bool containing(const GridView &g, float x, float y, float z, int64_t &vi,
+                                                  bool &local) {
+  local = true;
+  if (isnan(z) || fabsf(x) > g.half[0] || fabsf(y) > g.half[1] || fabsf(z) > g.half[2]) return false;
+  const int i = axis_index(g, 0, x), j = axis_index(g, 1, y), k = axis_index(g, 2, z);
+  const int kl = k - g.z_first;
+  local = kl >= 0 && kl < g.nz_alloc;
+  vi = ((int64_t)(local ? kl : 0) * g.ny + j) * g.pitch + i;
+  return true;
+}
+
+// getVoxelCenter (tsdf_volume_octree.cpp:553-560), one axis: double formula rounded to float.
+static __device__ __forceinline__ float voxel_center(const GridView &g, int a, int i) {
+  const int res = a == 0 ? g.nx : a == 1 ? g.ny : g.nz;
+  const float off = g.size[a] / 2.0;
+  return (float)(((size_t)i + 0.5) * g.size[a] / (double)res - off);
+}
+
+// getVoxelIndex (tsdf_volume_octree.cpp:562-574), one axis.
+static __device__ __forceinline__ int voxel_index(const GridView &g, int a, float x) {
+  const int res = a == 0 ? g.nx : a == 1 ? g.ny : g.nz;
+  const double off = (double)g.size[a] / 2.0;
+  return cvtt(floor(((double)x + off) / (double)g.size[a] * (double)res));
+}
+
+// interpolateTrilinearly (tsdf_volume_octree.cpp:486-541).  *valid is only ever AND-ed, as in the
+// reference.  `local` is cleared if a corner plane is not held by this handle.
+static __device__ float trilinear(const GridView &g, float x, float y, float z, bool &valid, bool &local) {
+  int xi = voxel_index(g, 0, x), yi = voxel_index(g, 1, y), zi = voxel_index(g, 2, z);
+  const bool exists = xi >= 0 && yi >= 0 && zi >= 0 && xi < g.nx && yi < g.ny && zi < g.nz;
+  if (!exists || xi <= 0 || xi >= g.nx - 1 || yi <= 0 || yi >= g.ny - 1 || zi <= 0 || zi >= g.nz - 1) {
+    valid = false;
+    return NAN;
+  }
+  float vx = voxel_center(g, 0, xi), vy = voxel_center(g, 1, yi), vz = voxel_center(g, 2, zi);
+  if (x < vx) xi -= 1;
+  if (y < vy) yi -= 1;
+  if (z < vz) zi -= 1;
+  vx = voxel_center(g, 0, xi);
+  vy = voxel_center(g, 1, yi);
+  vz = voxel_center(g, 2, zi);
+  const float a = (x - vx) * g.nx / g.size[0];
+  const float b = (y - vy) * g.ny / g.size[1];
+  const float c = (z - vz) * g.nz / g.size[2];
+  const int kl = zi - g.z_first;
+  if (kl < 0 || kl + 1 >= g.nz_alloc) {
+    local = false;
+    valid = false;
+    return NAN;
+  }
+  const int64_t o = ((int64_t)kl * g.ny + yi) * g.pitch + xi;
+  const int64_t sy = g.pitch, sz = (int64_t)g.ny * g.pitch;
+  const int64_t ox = o + 1, oy = o + sy, oz = o + sz, oxy = o + sy + 1, oxz = o + sz + 1, oyz = o + sz + sy,
+                oxyz = o + sz + sy + 1;
+  valid = valid && (g.w[o] > 0);
+  valid = valid && (g.w[ox] > 0);
+  valid = valid && (g.w[oy] > 0);
+  valid = valid && (g.w[oz] > 0);
+  valid = valid && (g.w[oxy] > 0);
+  valid = valid && (g.w[oxz] > 0);
+  valid = valid && (g.w[oyz] > 0);
+  valid = valid && (g.w[oxyz] > 0);
+  return (g.d[o] * (1 - a) * (1 - b) * (1 - c) + g.d[oz] * (1 - a) * (1 - b) * (c) +
+          g.d[oy] * (1 - a) * (b) * (1 - c) + g.d[oyz] * (1 - a) * (b) * (c) +
+          g.d[ox] * (a) * (1 - b) * (1 - c) + g.d[oxz] * (a) * (1 - b) * (c) + g.d[oxy] * (a) * (b) * (1 - c) +
+          g.d[oxyz] * (a) * (b) * (c));
+}
+
+// Eigen::Vector3f::normalize() [Eigen-recall 3.3]: z = x*x + (y*y + z*z); if (z > 0) v /= sqrt(z)
+static __device__ __forceinline__ void normalize3(float v[3]) {
+  const float n2 = v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]);
+  if (n2 > 0.f) {
+    const float n = sqrtf(n2);
+    v[0] /= n;
+    v[1] /= n;
+    v[2] /= n;
+  }
+}
+
+struct RayArgs {
+  float rot[9], org[3];
+  double nfx, nfy, ncx, ncy;
+  int nw, nh;
+  float zmin, zmax, neg;
+  float min_step;     // max_dist_neg_ * 3/4.           (:289)
+  float refine_step;  // (zsize_/zres_)/2.              (:329)
+  float leaf;         // finest leaf size_ (size_x halved L times; getMinSize/getSize, octree.cpp:58-78)
+};
+
+// renderView, tsdf_volume_octree.cpp:290-421, one ray per thread.  The while loop runs until every lane
+// of the wavefront has left it (the hardware's exec-mask loop is the ballot); a finished lane idles.
+// out: 8 floats per pixel: x,y,z, nx,ny,nz, t (t_star on a hit), iterations; `incomplete` counts rays
+// that touched a plane this handle does not hold (only possible for Z-slab handles).
+static __global__ void __launch_bounds__(256)
+k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *__restrict__ incomplete) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.nw * a.nh) return;
+  const size_t x = (size_t)(i % a.nw), y = (size_t)(i / a.nw);
+  float *o = out + 8 * i;
+  bool found_crossing = false, all_local = true;
+  float du[3] = {(float)((x - a.ncx) / a.nfx), (float)((y - a.ncy) / a.nfy), 1.f};
+  normalize3(du);
+  {  // du = R * du: each coefficient p0 + (p1 + p2) [Eigen-recall 3.3 reduction tree]
+    const float p = du[0], q = du[1], r = du[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) du[k] = a.rot[3 * k] * p + (a.rot[3 * k + 1] * q + a.rot[3 * k + 2] * r);
+  }
+  float pt[3] = {a.org[0], a.org[1], a.org[2]};
+  float dd = 0, ww = 0, last_w = 0, last_d = 0;
+  float t = a.zmin;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
+  float step = a.min_step;
+  bool hit_voxel = false;
+  int niter = 0;
+  while (t < a.zmax) {
+    int64_t vi;
+    bool local;
+    if (containing(g, pt[0], pt[1], pt[2], vi, local)) {
+      all_local = all_local && local;
+      hit_voxel = true;
+      dd = local ? g.d[vi] : -1.f;
+      ww = local ? g.w[vi] : 0.f;
+      if (((dd < 0 && last_d > 0) || (dd > 0 && last_d < 0)) && last_w && ww) {
+        found_crossing = true;
+        const float old_t = t - step;
+        step = a.refine_step;
+        float last_new_d = dd, last_new_w = ww;
+        while (t >= old_t) {
+          t -= step;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
+          if (!containing(g, pt[0], pt[1], pt[2], vi, local)) break;
+          all_local = all_local && local;
+          const float new_d = local ? g.d[vi] : -1.f, new_w = local ? g.w[vi] : 0.f;
+          if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
+            last_d = new_d;
+            last_w = new_w;
+            dd = last_new_d;
+            ww = last_new_w;
+            t += step;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+            break;
+          }
+          last_new_d = dd;  // sic (:352-353)
+          last_new_w = ww;
+        }
+        break;
+      }
+      last_d = dd;
+      last_w = ww;
+      const float s1 = a.leaf / 4.f, s2 = fabsf(dd) * a.neg;  // :360 (the double product rounds to this)
+      step = s1 < s2 ? s2 : s1;
+    } else if (hit_voxel) {
+      break;
+    }
+    t += step;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+    niter++;
+  }
+  o[3] = o[4] = o[5] = 0.f;
+  o[6] = t;
+  o[7] = (float)niter;
+  if (!found_crossing) {
+    o[0] = o[1] = o[2] = NAN;
+  } else {
+    bool has_data = true;
+    const float tcurr = t, tprev = t - step;
+    last_d = trilinear(g, a.org[0] + tprev * du[0], a.org[1] + tprev * du[1], a.org[2] + tprev * du[2], has_data,
+                       all_local);
+    dd = trilinear(g, a.org[0] + tcurr * du[0], a.org[1] + tcurr * du[1], a.org[2] + tcurr * du[2], has_data,
+                   all_local);
+    // :389  evaluated in double: unqualified fabs(float) is double fabs(double) under <cmath>
+    const float t_star = (float)((double)t + (double)step * (-1 + fabs((double)(last_d / (last_d - dd)))));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = a.org[k] + t_star * du[k];
+    o[6] = t_star;
+    int64_t vi;
+    bool local;
+    if (!containing(g, o[0], o[1], o[2], vi, local)) {
+      o[3] = o[4] = o[5] = NAN;
+    } else {
+      const float s = a.leaf;
+      bool valid = true;
+      const float d_xm = trilinear(g, o[0] - s, o[1], o[2], valid, all_local);
+      const float d_xp = trilinear(g, o[0] + s, o[1], o[2], valid, all_local);
+      const float d_ym = trilinear(g, o[0], o[1] - s, o[2], valid, all_local);
+      const float d_yp = trilinear(g, o[0], o[1] + s, o[2], valid, all_local);
+      const float d_zm = trilinear(g, o[0], o[1], o[2] - s, valid, all_local);
+      const float d_zp = trilinear(g, o[0], o[1], o[2] + s, valid, all_local);
+      if (!valid) {
+        o[3] = o[4] = o[5] = NAN;
+      } else {
+        float dF[3];
+        dF[0] = (d_xp - d_xm) * a.neg / (2 * s);
+        dF[1] = (d_yp - d_ym) * a.neg / (2 * s);
+        dF[2] = (d_zp - d_zm) * a.neg / (2 * s);
+        normalize3(dF);
+        o[3] = dF[0];
+        o[4] = dF[1];
+        o[5] = dF[2];
+      }
+    }
+  }
+  if (!all_local) atomicAdd(incomplete, 1u);
+}
+
+extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                float *out) {
+  if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const tsdf_params &p = h->p;
+  RayArgs a;
+  for (int i = 0; i < 9; ++i) a.rot[i] = rot[i];
+  for (int i = 0; i < 3; ++i) a.org[i] = origin[i];
+  a.nw = p.image_width / downsample;
+  a.nh = p.image_height / downsample;
+  a.nfx = p.fx / downsample;
+  a.nfy = p.fy / downsample;
+  a.ncx = p.cx / downsample;
+  a.ncy = p.cy / downsample;
+  a.zmin = p.min_sensor_dist;
+  a.zmax = p.max_sensor_dist;
+  a.neg = p.max_dist_neg;
+  a.min_step = p.max_dist_neg * 3 / 4.;
+  a.refine_step = (p.size[2] / p.res[2]) / 2.;
+  {
+    float s = p.size[0];
+    if (h->levels[0] >= 0)
+      for (int l = 0; l < h->levels[0]; ++l) s = s / 2;
+    else
+      s = p.size[0] / p.res[0];
+    a.leaf = s;
+  }
+  const int64_t n = (int64_t)a.nw * a.nh;
+  if (n <= 0) return TSDF_HIP_E_INVALID;
+  int rc = tsdf_ensure_scratch(h, (size_t)n * 8 * sizeof(float) + 16);
+  if (rc) return rc;
+  float *d_out = (float *)h->scratch;
+  unsigned *d_inc = (unsigned *)((char *)h->scratch + (size_t)n * 8 * sizeof(float));
+  TSDF_HIP_TRY(hipMemsetAsync(d_inc, 0, sizeof(unsigned), h->stream));
+  const GridView g = make_view(h);
+  hipLaunchKernelGGL(k_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a, d_out, d_inc);
+  TSDF_HIP_TRY(hipGetLastError());
+  unsigned inc = 0;
+  TSDF_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipMemcpyAsync(&inc, d_inc, sizeof inc, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (inc) {
+    tsdf_set_error("raycast touched planes outside this handle's Z-slab (+halo)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  return TSDF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getNeighbors :796-828, getFxn :655-672, getGradient :681-700, getHessian :703-726.
+// Neighbour order: dx outer, dy, dz inner.  getFxn/getGradient read the octree NODE centre
+// (vox->getCenter), getHessian reads getVoxelCenter (`centers[i]`).  Unqualified fabs(float) is
+// double fabs(double), so every term is a double product accumulated into a float.
+static __device__ __forceinline__ int sgn(float x) { return x > 0 ? 1 : -1; }  // :674-678
+
+static __global__ void __launch_bounds__(256)
+k_sample(const GridView g, const float *__restrict__ xyz, size_t n, float *__restrict__ val,
+         float *__restrict__ grad, float *__restrict__ hess, unsigned char *__restrict__ ok) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float px = xyz[3 * idx], py = xyz[3 * idx + 1], pz = xyz[3 * idx + 2];
+  bool good = true;
+  int xi = voxel_index(g, 0, px), yi = voxel_index(g, 1, py), zi = voxel_index(g, 2, pz);
+  if (!(xi >= 0 && yi >= 0 && zi >= 0 && xi < g.nx && yi < g.ny && zi < g.nz)) good = false;
+  if (good) {
+    if (px < voxel_center(g, 0, xi)) xi -= 1;
+    if (py < voxel_center(g, 1, yi)) yi -= 1;
+    if (pz < voxel_center(g, 2, zi)) zi -= 1;
+    if (xi < 0 || xi >= g.nx - 1 || yi < 0 || yi >= g.ny - 1 || zi < 0 || zi >= g.nz - 1) good = false;
+  }
+  const int kl = zi - g.z_first;
+  if (good && (kl < 0 || kl + 1 >= g.nz_alloc)) good = false;  // not held by this handle
+  float v = NAN, gr[3] = {NAN, NAN, NAN}, h01 = NAN, h02 = NAN, h12 = NAN;
+  if (good) {
+    const float c = g.size[0] / g.nx;
+    v = 0;
+    gr[0] = gr[1] = gr[2] = 0;
+    h01 = h02 = h12 = 0;
+    for (int dx = 0; dx <= 1; dx++)
+      for (int dy = 0; dy <= 1; dy++)
+        for (int dz = 0; dz <= 1; dz++) {
+          const int i = xi + dx, j = yi + dy, k = zi + dz;
+          const float dv = g.d[((int64_t)(k - g.z_first) * g.ny + j) * g.pitch + i];
+          const float nc[3] = {g.ctr[0][i], g.ctr[1][j], g.ctr[2][k]};
+          const float fc[3] = {voxel_center(g, 0, i), voxel_center(g, 1, j), voxel_center(g, 2, k)};
+          v += (c - fabs((double)(px - nc[0]))) * (c - fabs((double)(py - nc[1]))) *
+               (c - fabs((double)(pz - nc[2]))) * dv;
+          gr[0] += -sgn(px - nc[0]) * (c - fabs((double)(py - nc[1]))) * (c - fabs((double)(pz - nc[2]))) * dv;
+          gr[1] += (c - fabs((double)(px - nc[0]))) * -sgn(py - nc[1]) * (c - fabs((double)(pz - nc[2]))) * dv;
+          gr[2] += (c - fabs((double)(px - nc[0]))) * (c - fabs((double)(py - nc[1]))) * -sgn(pz - nc[2]) * dv;
+          h01 += sgn(px - fc[0]) * sgn(py - fc[1]) * (c - fabs((double)(pz - fc[2]))) * dv;
+          h02 += sgn(px - fc[0]) * (c - fabs((double)(py - fc[1]))) * sgn(pz - fc[2]) * dv;
+          h12 += (c - fabs((double)(px - fc[0]))) * sgn(py - fc[1]) * sgn(pz - fc[2]) * dv;
+        }
+    const float c3 = c * c * c;
+    v /= c3;
+    gr[0] /= c3;
+    gr[1] /= c3;
+    gr[2] /= c3;
+    h01 /= c3;
+    h02 /= c3;
+    h12 /= c3;
+  }
+  if (ok) ok[idx] = good ? 1 : 0;
+  if (val) val[idx] = v;
+  if (grad) {
+    grad[3 * idx] = gr[0];
+    grad[3 * idx + 1] = gr[1];
+    grad[3 * idx + 2] = gr[2];
+  }
+  if (hess) {
+    float *hp = hess + 9 * idx;
+    const float z = good ? 0.f : NAN;
+    hp[0] = hp[4] = hp[8] = z;
+    hp[1] = hp[3] = h01;
+    hp[2] = hp[6] = h02;
+    hp[5] = hp[7] = h12;
+  }
+}
+
+extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess,
+                               uint8_t *ok) {
+  if (!h || !xyz || !n) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  // scratch layout: xyz[3n] val[n] grad[3n] hess[9n] floats, ok[n] bytes
+  const size_t fl = 16 * n;
+  int rc = tsdf_ensure_scratch(h, fl * sizeof(float) + n + 16);
+  if (rc) return rc;
+  float *d_xyz = (float *)h->scratch, *d_val = d_xyz + 3 * n, *d_grad = d_val + n, *d_hess = d_grad + 3 * n;
+  unsigned char *d_ok = (unsigned char *)(d_hess + 9 * n);
+  TSDF_HIP_TRY(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const GridView g = make_view(h);
+  hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, d_xyz, n, d_val,
+                     d_grad, d_hess, d_ok);
+  TSDF_HIP_TRY(hipGetLastError());
+  if (val) TSDF_HIP_TRY(hipMemcpyAsync(val, d_val, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (grad) TSDF_HIP_TRY(hipMemcpyAsync(grad, d_grad, 3 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (hess) TSDF_HIP_TRY(hipMemcpyAsync(hess, d_hess, 9 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (ok) TSDF_HIP_TRY(hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}
