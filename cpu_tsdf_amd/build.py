@@ -1,4 +1,11 @@
-"""Build recipe for libtsdf_hip.so (hand-written HIP, gfx950 only, built in-tree with hipcc)."""
+"""Build recipes (in-tree, hipcc / g++ only; no cmake needed):
+
+  libtsdf_hip.so       hand-written HIP kernels + the C ABI of include/tsdf_hip.h (gfx950 only)
+  libcpu_tsdf_hip.so   C++ host shell: cpu_tsdf::TSDFVolumeOctree / MarchingCubesTSDFOctree with the
+                       reference's signatures (include/cpu_tsdf/*.h) on top of the C ABI.  Built against
+                       real PCL/Eigen when PCL_INCLUDE_DIRS is set, else against the stand-ins in compat/.
+"""
+import concurrent.futures
 import glob
 import os
 import shutil
@@ -7,35 +14,91 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-LIB = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+HOST = os.path.join(CSRC, "host")
+LIBDIR = os.path.join(_HERE, "lib")
+OBJDIR = os.path.join(_HERE, "lib", "obj")
+LIB = os.path.join(LIBDIR, "libtsdf_hip.so")
+SHELL_LIB = os.path.join(LIBDIR, "libcpu_tsdf_hip.so")
 
 # -ffp-contract=off: the reference CPU build has no FMA (no -march in its CMakeLists.txt), and
 # per-voxel parity needs the same separate mul/add roundings on the GPU.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-result"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result"]
+HOST_FLAGS = ["-std=c++14", "-O2", "-fPIC", "-fopenmp", "-ffp-contract=off", "-Wall", "-Wno-unknown-pragmas"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "tsdf_hip.h")]
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(p) for p in deps)
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "tsdf_hip.h")]
-    return os.path.getmtime(LIB) < max(os.path.getmtime(p) for p in deps)
+    return _stale(LIB, sources() + _headers())
 
 
-def build_hip(force=False, verbose=False):
-    """Compile every HIP translation unit into cpu_tsdf_amd/lib/libtsdf_hip.so."""
-    if not force and not needs_build():
-        return LIB
+def _hipcc():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP extension (no fallback path exists)")
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + sources() + ["-o", LIB]
+    return hipcc
+
+
+def build_hip(force=False, verbose=False):
+    """Compile every HIP translation unit (in parallel) and link cpu_tsdf_amd/lib/libtsdf_hip.so."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    jobs = []
+    for src in sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + _headers()):
+            jobs.append([hipcc] + HIPCC_FLAGS + inc + ["-c", src, "-o", obj])
+    if verbose:
+        for j in jobs:
+            print(" ".join(j))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
+        for rc in ex.map(lambda c: subprocess.run(c).returncode, jobs):
+            if rc:
+                raise RuntimeError("hipcc failed")
+    objs = [os.path.join(OBJDIR, os.path.basename(s) + ".o") for s in sources()]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    return LIB
+
+
+def host_include_flags():
+    """Real PCL/Eigen if the environment names them (PCL_INCLUDE_DIRS, colon separated), else compat/."""
+    real = os.environ.get("PCL_INCLUDE_DIRS")
+    inc = ["-I" + os.path.join(ROOT, "include")]
+    if real:
+        inc += ["-I" + p for p in real.split(":") if p]
+    else:
+        inc += ["-I" + os.path.join(ROOT, "compat")]
+    return inc
+
+
+def build_shell(force=False, verbose=False):
+    """libcpu_tsdf_hip.so: the C++ classes with the reference's names and signatures."""
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
+    deps = srcs + glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(ROOT, "include", "cpu_tsdf", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "include", "cpu_tsdf", "impl", "*.hpp")) + glob.glob(os.path.join(ROOT, "compat", "*.h")) + \
+        [os.path.join(ROOT, "include", "tsdf_hip.h")]
+    build_hip(force=False, verbose=verbose)
+    if not force and not _stale(SHELL_LIB, deps + [LIB]):
+        return SHELL_LIB
+    cmd = ["g++"] + HOST_FLAGS + host_include_flags() + ["-I" + HOST, "-shared"] + srcs + \
+        ["-L" + LIBDIR, "-ltsdf_hip", "-Wl,-rpath,$ORIGIN", "-o", SHELL_LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return SHELL_LIB

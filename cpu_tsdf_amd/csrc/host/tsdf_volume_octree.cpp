@@ -1,0 +1,415 @@
+// Host shell of the MI355X drop-in: cpu_tsdf::TSDFVolumeOctree on top of the C ABI (tsdf_hip.h).
+// Mirrors the reference's src/lib/tsdf_volume_octree.cpp method by method; the voxel work itself is in
+// the HIP kernels.  Compiles against real PCL/Eigen or against the stand-ins in compat/.
+#include <cpu_tsdf/tsdf_volume_octree.h>
+#include <pcl/common/transforms.h>
+#include <pcl/console/print.h>
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+
+#include "vol_format.h"
+
+namespace cpu_tsdf {
+
+static void report(const char *who, int rc) {
+  PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::%s] %s: %s\n", who, tsdf_hip_error_string(rc), tsdf_hip_last_error());
+}
+
+// Defaults of the reference constructor (src/lib/tsdf_volume_octree.cpp:54-85) come from the C ABI.
+TSDFVolumeOctree::TSDFVolumeOctree()
+    : UNOBSERVED_VOXEL(std::numeric_limits<float>::quiet_NaN()),
+      h_(nullptr),
+      num_random_splits_(1),
+      is_empty_(true),
+      weight_by_depth_(false),
+      weight_by_variance_(false),
+      color_mode_("RGB") {
+  tsdf_hip_default_params(&p_);
+  max_cell_size_[0] = max_cell_size_[1] = max_cell_size_[2] = 0.5f;
+  global_transform_ = Eigen::Affine3d::Identity();
+}
+
+TSDFVolumeOctree::~TSDFVolumeOctree() {
+  if (h_) tsdf_hip_destroy(h_);
+}
+
+void TSDFVolumeOctree::setResolution(int xres, int yres, int zres) {
+  p_.res[0] = xres;
+  p_.res[1] = yres;
+  p_.res[2] = zres;
+}
+void TSDFVolumeOctree::getResolution(int &xres, int &yres, int &zres) const {
+  xres = p_.res[0];
+  yres = p_.res[1];
+  zres = p_.res[2];
+}
+void TSDFVolumeOctree::setGridSize(float xsize, float ysize, float zsize) {
+  p_.size[0] = xsize;
+  p_.size[1] = ysize;
+  p_.size[2] = zsize;
+}
+void TSDFVolumeOctree::getGridSize(float &xsize, float &ysize, float &zsize) const {
+  xsize = p_.size[0];
+  ysize = p_.size[1];
+  zsize = p_.size[2];
+}
+void TSDFVolumeOctree::setImageSize(int width, int height) {
+  p_.image_width = width;
+  p_.image_height = height;
+}
+void TSDFVolumeOctree::getImageSize(int &width, int &height) const {
+  width = p_.image_width;
+  height = p_.image_height;
+}
+void TSDFVolumeOctree::setDepthTruncationLimits(float max_dist_pos, float max_dist_neg) {
+  p_.max_dist_pos = max_dist_pos;
+  p_.max_dist_neg = max_dist_neg;
+}
+void TSDFVolumeOctree::getDepthTruncationLimits(float &max_dist_pos, float &max_dist_neg) const {
+  max_dist_pos = p_.max_dist_pos;
+  max_dist_neg = p_.max_dist_neg;
+}
+void TSDFVolumeOctree::setWeightTruncationLimit(float max_weight) { p_.max_weight = max_weight; }
+float TSDFVolumeOctree::getWeightTruncationLimit() const { return p_.max_weight; }
+void TSDFVolumeOctree::setCameraIntrinsics(const double fx, const double fy, const double cx, const double cy) {
+  p_.fx = fx;
+  p_.fy = fy;
+  p_.cx = cx;
+  p_.cy = cy;
+}
+void TSDFVolumeOctree::getCameraIntrinsics(double &fx, double &fy, double &cx, double &cy) const {
+  fx = p_.fx;
+  fy = p_.fy;
+  cx = p_.cx;
+  cy = p_.cy;
+}
+void TSDFVolumeOctree::setMaxVoxelSize(float x, float y, float z) {
+  max_cell_size_[0] = x;
+  max_cell_size_[1] = y;
+  max_cell_size_[2] = z;
+}
+void TSDFVolumeOctree::setIntegrateColor(bool integrate_color) { p_.integrate_color = integrate_color ? 1 : 0; }
+void TSDFVolumeOctree::setColorMode(const std::string &color_mode) {
+  if (color_mode != "RGB")
+    PCL_WARN("[cpu_tsdf::TSDFVolumeOctree::setColorMode] only \"RGB\" voxels exist in the HIP volume; ignoring %s\n",
+             color_mode.c_str());
+  else
+    color_mode_ = color_mode;
+}
+void TSDFVolumeOctree::setSensorDistanceBounds(float min_sensor_dist, float max_sensor_dist) {
+  p_.min_sensor_dist = min_sensor_dist;
+  p_.max_sensor_dist = max_sensor_dist;
+}
+void TSDFVolumeOctree::getSensorDistanceBounds(float &min_sensor_dist, float &max_sensor_dist) const {
+  min_sensor_dist = p_.min_sensor_dist;
+  max_sensor_dist = p_.max_sensor_dist;
+}
+
+bool TSDFVolumeOctree::ready(const char *who) const {
+  if (h_) return true;
+  PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::%s] called before reset()\n", who);
+  return false;
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:201-219
+void TSDFVolumeOctree::reset() {
+  is_empty_ = true;
+  if (h_) {
+    tsdf_hip_destroy(h_);
+    h_ = nullptr;
+  }
+  const int rc = tsdf_hip_create(&p_, &h_);
+  if (rc) {
+    h_ = nullptr;
+    report("reset", rc);
+  }
+}
+
+// reference: include/cpu_tsdf/impl/tsdf_volume_octree.hpp:48-103
+bool TSDFVolumeOctree::integratePlanar(const float *depth, const unsigned char *bgra, int width, int height,
+                                       const Eigen::Affine3d &trans) {
+  if (!ready("integrateCloud")) return false;
+  if (width != p_.image_width || height != p_.image_height) {
+    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::integrateCloud] cloud is %dx%d but setImageSize said %dx%d\n", width,
+              height, p_.image_width, p_.image_height);
+    return false;
+  }
+  const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
+  float T[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) T[4 * r + c] = trans_inv.matrix()(r, c);
+  const int rc = tsdf_hip_integrate(h_, depth, bgra, T, nullptr);
+  if (rc) {
+    report("integrateCloud", rc);
+    return false;
+  }
+  is_empty_ = false;
+  return true;
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:278-424
+pcl::PointCloud<pcl::PointNormal>::Ptr TSDFVolumeOctree::renderView(const Eigen::Affine3d &trans,
+                                                                   int downsampleBy) const {
+  const int new_width = p_.image_width / downsampleBy;
+  const int new_height = p_.image_height / downsampleBy;
+  pcl::PointCloud<pcl::PointNormal>::Ptr cloud(new pcl::PointCloud<pcl::PointNormal>(new_width, new_height));
+  cloud->is_dense = false;
+  if (!ready("renderView")) return cloud;
+  const Eigen::Matrix3f rot = trans.rotation().cast<float>();     // :303
+  const Eigen::Vector3f org = trans.translation().cast<float>();  // :304
+  float r9[9], o3[3];
+  for (int r = 0; r < 3; ++r) {
+    o3[r] = org(r);
+    for (int c = 0; c < 3; ++c) r9[3 * r + c] = rot(r, c);
+  }
+  std::vector<float> buf((size_t)new_width * new_height * 8);
+  const int rc = tsdf_hip_raycast(h_, r9, o3, downsampleBy, buf.data());
+  if (rc) {
+    report("renderView", rc);
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    for (size_t i = 0; i < cloud->size(); ++i) cloud->points[i].x = cloud->points[i].y = cloud->points[i].z = nan;
+    return cloud;
+  }
+  for (size_t i = 0; i < cloud->size(); ++i) {
+    pcl::PointNormal &pt = cloud->points[i];
+    const float *o = &buf[8 * i];
+    pt.x = o[0];
+    pt.y = o[1];
+    pt.z = o[2];
+    pt.normal_x = o[3];
+    pt.normal_y = o[4];
+    pt.normal_z = o[5];
+  }
+  pcl::transformPointCloudWithNormals(*cloud, *cloud, trans.inverse());  // :422
+  return cloud;
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:426-450 -- colour of the voxel containing each hit point.
+pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr TSDFVolumeOctree::renderColoredView(const Eigen::Affine3d &trans,
+                                                                                int downsampleBy) const {
+  if (!p_.integrate_color)
+    PCL_WARN("[cpu_tsdf::TSDFVolumeOctree::renderColoredView] Rendering a colored view, but integrate_color_ was not set!\n");
+  pcl::PointCloud<pcl::PointNormal>::Ptr grayscale = renderView(trans, downsampleBy);
+  pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr colored(
+      new pcl::PointCloud<pcl::PointXYZRGBNormal>(grayscale->width, grayscale->height));
+  colored->is_dense = false;
+  const Eigen::Affine3f tf = trans.cast<float>();
+  for (size_t i = 0; i < colored->size(); ++i) {
+    pcl::PointXYZRGBNormal &pt = colored->points[i];
+    const pcl::PointNormal &g = grayscale->points[i];
+    pt.x = g.x;
+    pt.y = g.y;
+    pt.z = g.z;
+    pt.normal_x = g.normal_x;
+    pt.normal_y = g.normal_y;
+    pt.normal_z = g.normal_z;
+    if (std::isnan(pt.z) || !h_) continue;
+    const Eigen::Vector3f v_t = tf * Eigen::Vector3f(pt.x, pt.y, pt.z);
+    int xi, yi, zi;
+    // nearest voxel by index (the octree lookup of the reference agrees except exactly on cell faces)
+    if (!getVoxelIndex(v_t(0), v_t(1), v_t(2), xi, yi, zi)) continue;
+    unsigned char rgb[3] = {127, 127, 127};
+    if (p_.integrate_color && tsdf_hip_download(h_, xi, yi, zi, 1, 1, 1, nullptr, nullptr, rgb) == 0) {
+      pt.r = rgb[0];
+      pt.g = rgb[1];
+      pt.b = rgb[2];
+    } else {
+      pt.r = pt.g = pt.b = 127;  // OctreeNode::getRGB default (src/lib/octree.cpp:172-177)
+    }
+  }
+  return colored;
+}
+
+pcl::PointCloud<pcl::Intensity>::Ptr TSDFVolumeOctree::getIntensityCloud(const Eigen::Affine3d &) const {
+  return pcl::PointCloud<pcl::Intensity>::Ptr();  // the reference returns a null pointer too (:543-548)
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:553-560
+pcl::PointXYZ TSDFVolumeOctree::getVoxelCenter(size_t x, size_t y, size_t z) const {
+  const float xoff = p_.size[0] / 2.0, yoff = p_.size[1] / 2.0, zoff = p_.size[2] / 2.0;
+  return pcl::PointXYZ((x + 0.5) * p_.size[0] / (double)p_.res[0] - xoff, (y + 0.5) * p_.size[1] / (double)p_.res[1] - yoff,
+                       (z + 0.5) * p_.size[2] / (double)p_.res[2] - zoff);
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:562-574
+bool TSDFVolumeOctree::getVoxelIndex(float x, float y, float z, int &x_i, int &y_i, int &z_i) const {
+  const double xoff = (double)p_.size[0] / 2.0, yoff = (double)p_.size[1] / 2.0, zoff = (double)p_.size[2] / 2.0;
+  x_i = std::floor(((double)x + xoff) / (double)p_.size[0] * (double)p_.res[0]);
+  y_i = std::floor(((double)y + yoff) / (double)p_.size[1] * (double)p_.res[1]);
+  z_i = std::floor(((double)z + zoff) / (double)p_.size[2] * (double)p_.res[2]);
+  return x_i >= 0 && y_i >= 0 && z_i >= 0 && x_i < p_.res[0] && y_i < p_.res[1] && z_i < p_.res[2];
+}
+
+// The reference returns the centres of octree nodes `nlevels` deep (:576-590); the equivalent here is a
+// regular 2^nlevels lattice of node centres.
+pcl::PointCloud<pcl::PointXYZ>::ConstPtr TSDFVolumeOctree::getVoxelCenters(int nlevels) const {
+  const int n = 1 << nlevels;
+  pcl::PointCloud<pcl::PointXYZ>::Ptr cloud(new pcl::PointCloud<pcl::PointXYZ>(n * n * n, 1));
+  size_t k = 0;
+  for (int x = 0; x < n; ++x)
+    for (int y = 0; y < n; ++y)
+      for (int z = 0; z < n; ++z, ++k) {
+        pcl::PointXYZ &pt = cloud->points[k];
+        pt.x = (x + 0.5f) * p_.size[0] / n - p_.size[0] / 2;
+        pt.y = (y + 0.5f) * p_.size[1] / n - p_.size[1] / 2;
+        pt.z = (z + 0.5f) * p_.size[2] / n - p_.size[2] / 2;
+      }
+  return cloud;
+}
+
+bool TSDFVolumeOctree::downloadBlock(int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w,
+                                     unsigned char *rgb) const {
+  if (!ready("downloadBlock")) return false;
+  const int rc = tsdf_hip_download(h_, x0, y0, z0, nx, ny, nz, d, w, rgb);
+  if (rc) report("downloadBlock", rc);
+  return rc == 0;
+}
+
+// reference: src/lib/tsdf_volume_octree.cpp:592-609 (leaves with w > 0 && |d| < 1)
+void TSDFVolumeOctree::getOccupiedVoxelIndices(std::vector<Eigen::Vector3i> &indices) const {
+  if (!ready("getOccupiedVoxelIndices")) return;
+  const int nx = p_.res[0], ny = p_.res[1], nz = p_.res[2];
+  std::vector<float> d((size_t)nx * ny), w((size_t)nx * ny);
+  for (int z = 0; z < nz; ++z) {
+    if (!downloadBlock(0, 0, z, nx, ny, 1, d.data(), w.data(), nullptr)) return;
+    for (int y = 0; y < ny; ++y)
+      for (int x = 0; x < nx; ++x) {
+        const size_t i = (size_t)y * nx + x;
+        if (w[i] > 0 && std::fabs(d[i]) < 1) indices.push_back(Eigen::Vector3i(x, y, z));
+      }
+  }
+}
+
+// getFxn / getGradient / getHessian (+ combos): src/lib/tsdf_volume_octree.cpp:655-794, one point each.
+static bool sample_one(tsdf_handle h, const pcl::PointXYZ &pt, float *val, float *grad, float *hess) {
+  if (!h) return false;
+  const float xyz[3] = {pt.x, pt.y, pt.z};
+  unsigned char ok = 0;
+  if (tsdf_hip_sample(h, xyz, 1, val, grad, hess, &ok)) return false;
+  return ok != 0;
+}
+bool TSDFVolumeOctree::getFxn(const pcl::PointXYZ &pt, float &val) const {
+  float v;
+  if (!sample_one(h_, pt, &v, nullptr, nullptr)) return false;
+  val = v;
+  return true;
+}
+bool TSDFVolumeOctree::getGradient(const pcl::PointXYZ &pt, Eigen::Vector3f &grad) const {
+  float g[3];
+  if (!sample_one(h_, pt, nullptr, g, nullptr)) return false;
+  grad = Eigen::Vector3f(g[0], g[1], g[2]);
+  return true;
+}
+bool TSDFVolumeOctree::getHessian(const pcl::PointXYZ &pt, Eigen::Matrix3f &hessian) const {
+  float hm[9];
+  if (!sample_one(h_, pt, nullptr, nullptr, hm)) return false;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) hessian(r, c) = hm[3 * r + c];
+  return true;
+}
+bool TSDFVolumeOctree::getFxnAndGradient(const pcl::PointXYZ &pt, float &val, Eigen::Vector3f &grad) const {
+  float v, g[3];
+  if (!sample_one(h_, pt, &v, g, nullptr)) return false;
+  val = v;
+  grad = Eigen::Vector3f(g[0], g[1], g[2]);
+  return true;
+}
+bool TSDFVolumeOctree::getFxnGradientAndHessian(const pcl::PointXYZ &pt, float &val, Eigen::Vector3f &grad,
+                                                Eigen::Matrix3f &hessian) const {
+  float v, g[3], hm[9];
+  if (!sample_one(h_, pt, &v, g, hm)) return false;
+  val = v;
+  grad = Eigen::Vector3f(g[0], g[1], g[2]);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) hessian(r, c) = hm[3 * r + c];
+  return true;
+}
+
+// ---- save / load: the reference's .vol format (src/lib/tsdf_volume_octree.cpp:222-275) -----------------------
+void TSDFVolumeOctree::save(const std::string &filename) const {
+  if (!ready("save")) return;
+  VolHeader hd;
+  for (int k = 0; k < 3; ++k) {
+    hd.res[k] = p_.res[k];
+    hd.size[k] = p_.size[k];
+    hd.max_cell[k] = max_cell_size_[k];
+  }
+  hd.max_dist_pos = p_.max_dist_pos;
+  hd.max_dist_neg = p_.max_dist_neg;
+  hd.max_weight = p_.max_weight;
+  hd.min_sensor_dist = p_.min_sensor_dist;
+  hd.max_sensor_dist = p_.max_sensor_dist;
+  hd.fx = p_.fx;
+  hd.fy = p_.fy;
+  hd.cx = p_.cx;
+  hd.cy = p_.cy;
+  hd.image_width = p_.image_width;
+  hd.image_height = p_.image_height;
+  hd.is_empty = is_empty_;
+  hd.weight_by_depth = weight_by_depth_;
+  hd.weight_by_variance = weight_by_variance_;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) hd.global_transform[4 * r + c] = global_transform_.matrix()(r, c);
+  hd.color = p_.integrate_color != 0;
+  const size_t n = (size_t)p_.res[0] * p_.res[1] * p_.res[2];
+  std::vector<float> d(n), w(n);
+  std::vector<unsigned char> rgb(hd.color ? 3 * n : 0);
+  if (!downloadBlock(0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(), hd.color ? rgb.data() : nullptr))
+    return;
+  std::string err;
+  if (!vol_write(filename, hd, d.data(), w.data(), hd.color ? rgb.data() : nullptr, &err))
+    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::save] %s\n", err.c_str());
+}
+
+void TSDFVolumeOctree::load(const std::string &filename) {
+  VolHeader hd;
+  std::vector<float> d, w;
+  std::vector<unsigned char> rgb;
+  std::string err;
+  if (!vol_read(filename, hd, d, w, rgb, &err)) {
+    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::load] %s\n", err.c_str());
+    return;
+  }
+  for (int k = 0; k < 3; ++k) {
+    p_.res[k] = hd.res[k];
+    p_.size[k] = hd.size[k];
+    max_cell_size_[k] = hd.max_cell[k];
+  }
+  p_.max_dist_pos = hd.max_dist_pos;
+  p_.max_dist_neg = hd.max_dist_neg;
+  p_.max_weight = hd.max_weight;
+  p_.min_sensor_dist = hd.min_sensor_dist;
+  p_.max_sensor_dist = hd.max_sensor_dist;
+  p_.fx = hd.fx;
+  p_.fy = hd.fy;
+  p_.cx = hd.cx;
+  p_.cy = hd.cy;
+  p_.image_width = hd.image_width;
+  p_.image_height = hd.image_height;
+  weight_by_depth_ = hd.weight_by_depth;
+  weight_by_variance_ = hd.weight_by_variance;
+  Eigen::Matrix4d m;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) m(r, c) = hd.global_transform[4 * r + c];
+  global_transform_ = m;
+  p_.integrate_color = hd.color ? 1 : 0;
+  reset();
+  if (!h_) return;
+  const int rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
+                                 hd.color ? rgb.data() : nullptr);
+  if (rc) report("load", rc);
+  is_empty_ = hd.is_empty;
+}
+
+// reference: src/lib/tsdf_interface.cpp:44-51
+TSDFInterface::Ptr TSDFInterface::instantiateFromFile(const std::string &filename) {
+  TSDFInterface::Ptr tsdf(new TSDFVolumeOctree);
+  tsdf->load(filename);
+  return tsdf;
+}
+
+}  // namespace cpu_tsdf

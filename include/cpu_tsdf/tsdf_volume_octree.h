@@ -1,0 +1,119 @@
+// cpu_tsdf::TSDFVolumeOctree -- MI355X drop-in for the reference class of the same name
+// (include/cpu_tsdf/tsdf_volume_octree.h:49-377).  Public signatures are kept; the octree of
+// shared_ptr voxels is gone: voxels live in a flat SoA grid in HBM behind the C ABI of tsdf_hip.h, and
+// every heavy method forwards to a HIP kernel.  What is intentionally absent: the public `octree_`
+// member and getFrustumCulledVoxels (they expose OctreeNode pointers), setColorMode values other than
+// "RGB" (the reference's other node types have broken serialisation, src/lib/octree.cpp:419-422).
+//
+// Host-side arithmetic that decides results is done here with the caller's own Eigen/PCL, exactly where
+// the reference does it: trans.inverse().cast<float>() (hpp:54), trans.rotation().cast<float>() /
+// translation (:303-304), transformPointCloudWithNormals (:422), transformPointCloud in the mesher.
+#pragma once
+
+#include <cpu_tsdf/tsdf_interface.h>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include <Eigen/Geometry>
+#include <tsdf_hip.h>
+
+#include <string>
+#include <vector>
+
+namespace cpu_tsdf {
+
+class TSDFVolumeOctree : public TSDFInterface {
+ public:
+  typedef boost::shared_ptr<TSDFVolumeOctree> Ptr;
+  typedef boost::shared_ptr<const TSDFVolumeOctree> ConstPtr;
+
+  TSDFVolumeOctree();
+  ~TSDFVolumeOctree();
+  TSDFVolumeOctree(const TSDFVolumeOctree &) = delete;
+  TSDFVolumeOctree &operator=(const TSDFVolumeOctree &) = delete;
+
+  void setResolution(int xres, int yres, int zres);
+  void getResolution(int &xres, int &yres, int &zres) const;
+  void setGridSize(float xsize, float ysize, float zsize);
+  void getGridSize(float &xsize, float &ysize, float &zsize) const;
+  void setImageSize(int width, int height);
+  void getImageSize(int &width, int &height) const;
+  void setDepthTruncationLimits(float max_dist_pos, float max_dist_neg);
+  void getDepthTruncationLimits(float &max_dist_pos, float &max_dist_neg) const;
+  void setWeightTruncationLimit(float max_weight);
+  float getWeightTruncationLimit() const;
+  void setGlobalTransform(const Eigen::Affine3d &trans) { global_transform_ = trans; }
+  Eigen::Affine3d getGlobalTransform() const { return global_transform_; }
+  void setCameraIntrinsics(const double focal_length_x, const double focal_length_y,
+                           const double principal_point_x, const double principal_point_y);
+  void getCameraIntrinsics(double &focal_length_x, double &focal_length_y, double &principal_point_x,
+                           double &principal_point_y) const;
+  // Accepted and remembered (save() writes them), but a dense grid has no coarse cells / pre-split pass.
+  void setMaxVoxelSize(float x, float y, float z);
+  void setNumRandomSplts(int n) { num_random_splits_ = n; }
+  int getNumRandomSplits() { return num_random_splits_; }
+  void setIntegrateColor(bool integrate_color);
+  void setColorMode(const std::string &color_mode);
+  void setSensorDistanceBounds(float min_sensor_dist, float max_sensor_dist);
+  void getSensorDistanceBounds(float &min_sensor_dist, float &max_sensor_dist) const;
+
+  // (Re)allocates the grid on the GPU; every voxel (d = -1, w = 0).
+  void reset();
+  void save(const std::string &filename) const;
+  void load(const std::string &filename);
+
+  bool getFxn(const pcl::PointXYZ &pt, float &val) const;
+  bool getGradient(const pcl::PointXYZ &pt, Eigen::Vector3f &grad) const;
+  bool getHessian(const pcl::PointXYZ &pt, Eigen::Matrix3f &hessian) const;
+  bool getFxnAndGradient(const pcl::PointXYZ &pt, float &val, Eigen::Vector3f &grad) const;
+  bool getFxnGradientAndHessian(const pcl::PointXYZ &pt, float &val, Eigen::Vector3f &grad,
+                                Eigen::Matrix3f &hessian) const;
+
+  // `cloud` must be organised with the configured image size; only pt.z (and r,g,b when colour is on) is
+  // read, `normals` is unused (as in the reference's default settings).  trans: camera -> volume.
+  template <typename PointT, typename NormalT>
+  bool integrateCloud(const pcl::PointCloud<PointT> &cloud, const pcl::PointCloud<NormalT> &normals,
+                      const Eigen::Affine3d &trans = Eigen::Affine3d::Identity());
+
+  pcl::PointCloud<pcl::PointNormal>::Ptr renderView(const Eigen::Affine3d &trans = Eigen::Affine3d::Identity(),
+                                                    int downsampleBy = 1) const;
+  pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr renderColoredView(
+      const Eigen::Affine3d &trans = Eigen::Affine3d::Identity(), int downsampleBy = 1) const;
+  pcl::PointCloud<pcl::Intensity>::Ptr getIntensityCloud(const Eigen::Affine3d &trans = Eigen::Affine3d::Identity()) const;
+
+  pcl::PointXYZ getVoxelCenter(size_t x, size_t y, size_t z) const;
+  bool getVoxelIndex(float x, float y, float z, int &x_i, int &y_i, int &z_i) const;
+  pcl::PointCloud<pcl::PointXYZ>::ConstPtr getVoxelCenters(int nlevels = 4) const;
+  void getOccupiedVoxelIndices(std::vector<Eigen::Vector3i> &indices) const;
+  bool isEmpty() const { return is_empty_; }
+
+  // ---- extensions (not in the reference) -----------------------------------------------------------------
+  // Planar entry point used by the integrateCloud template: depth H x W floats (NaN = no return), bgra
+  // 4 bytes per pixel in PointXYZRGBA byte order or NULL.
+  bool integratePlanar(const float *depth, const unsigned char *bgra, int width, int height,
+                       const Eigen::Affine3d &trans);
+  // Raw voxel block readback ([z][y][x]); any pointer may be NULL; rgb is 3 bytes per voxel.
+  bool downloadBlock(int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, unsigned char *rgb) const;
+  // The C-ABI handle (NULL before reset()); used by MarchingCubesTSDFOctree.
+  tsdf_handle handle() const { return h_; }
+  void setTransformOrder(int order) { p_.xform_order = order; }
+  void setDevice(int device) { p_.device = device; }
+
+  const float UNOBSERVED_VOXEL;
+
+ private:
+  bool ready(const char *who) const;
+  tsdf_params p_;
+  tsdf_handle h_;
+  float max_cell_size_[3];
+  int num_random_splits_;
+  bool is_empty_, weight_by_depth_, weight_by_variance_;
+  std::string color_mode_;
+  Eigen::Affine3d global_transform_;
+
+ public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+};
+
+}  // namespace cpu_tsdf
+
+#include <cpu_tsdf/impl/tsdf_volume_octree.hpp>

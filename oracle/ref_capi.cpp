@@ -223,6 +223,12 @@ uint64_t ct_num_leaves(void *h) {
 int ct_is_reference() { return 1; }
 #else
 int ct_is_reference() { return 0; }
+// Drop-in build only: raw voxel readback through the shell's extension (arrays [z][y][x]).
+int ct_download(void *h, float *d, float *w, uint8_t *rgb) {
+  int rx, ry, rz;
+  V(h)->getResolution(rx, ry, rz);
+  return V(h)->downloadBlock(0, 0, 0, rx, ry, rz, d, w, rgb) ? 1 : 0;
+}
 #endif
 
 }  // extern "C"

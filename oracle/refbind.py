@@ -19,8 +19,28 @@ _d = C.POINTER(C.c_double)
 _u8 = C.POINTER(C.c_uint8)
 
 
+DROPIN_LIB = os.path.join(_HERE, "_ref", "libdropin_capi.so")
+
+
 def available(path=LIB):
     return os.path.exists(path)
+
+
+def build_dropin(force=False):
+    """The drop-in under test, seen through the SAME driver source that wraps the reference:
+    oracle/ref_capi.cpp compiled against include/cpu_tsdf/*.h + libcpu_tsdf_hip.so (the product's C++
+    host shell).  Output next to the reference build (git-ignored, travels with gpurun)."""
+    import subprocess
+    from cpu_tsdf_amd import build as b
+    shell = b.build_shell()
+    src = os.path.join(_HERE, "ref_capi.cpp")
+    if not force and os.path.exists(DROPIN_LIB) and os.path.getmtime(DROPIN_LIB) >= max(os.path.getmtime(src),
+                                                                                          os.path.getmtime(shell)):
+        return DROPIN_LIB
+    os.makedirs(os.path.dirname(DROPIN_LIB), exist_ok=True)
+    subprocess.check_call(["g++"] + b.HOST_FLAGS + b.host_include_flags() + ["-shared", src, "-L" + b.LIBDIR,
+                           "-lcpu_tsdf_hip", "-ltsdf_hip", "-Wl,-rpath,$ORIGIN/../../cpu_tsdf_amd/lib", "-o", DROPIN_LIB])
+    return DROPIN_LIB
 
 
 _libs = {}
@@ -69,6 +89,9 @@ def load(path=LIB):
         L.ct_dump_dense.argtypes = [C.c_void_p, _f, _f, _u8, _f, _f]
         L.ct_num_leaves.restype = C.c_uint64
         L.ct_num_leaves.argtypes = [C.c_void_p]
+    else:
+        L.ct_download.restype = C.c_int
+        L.ct_download.argtypes = [C.c_void_p, _f, _f, _u8]
     _libs[path] = L
     return L
 
@@ -132,6 +155,18 @@ class RefVolume:
         self.L.ct_dump_dense(self.h, _fp(d), _fp(w), rgb.ctypes.data_as(_u8) if rgb is not None else None, _fp(leaf),
                              _fp(ctr))
         return d, w, rgb, leaf, ctr
+
+    def download(self):
+        """Drop-in build only."""
+        n = self.res
+        d = np.empty((n, n, n), np.float32)
+        w = np.empty((n, n, n), np.float32)
+        rgb = np.empty((n, n, n, 3), np.uint8) if self.color else None
+        assert self.L.ct_download(self.h, _fp(d), _fp(w), rgb.ctypes.data_as(_u8) if rgb is not None else None)
+        return d, w, rgb
+
+    def load(self, path):
+        self.L.ct_load(self.h, path.encode())
 
     def num_leaves(self):
         return int(self.L.ct_num_leaves(self.h))

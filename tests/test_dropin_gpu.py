@@ -1,0 +1,107 @@
+"""GPU tier: the C++ drop-in shell (include/cpu_tsdf/*.h + libcpu_tsdf_hip.so) driven through the SAME
+C driver source that wraps the reference (oracle/ref_capi.cpp, compiled once against each).
+
+What this proves: code written against the reference's public C++ API (setters, reset, templated
+integrateCloud on a pcl::PointCloud<PointXYZRGBA>, renderView, getFxn/getGradient/getHessian,
+MarchingCubesTSDFOctree::reconstruct, save/load) compiles unchanged against the drop-in and produces
+the reference's results."""
+import os
+
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import synth
+from oracle import refbind
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32
+from tests.test_oracle_golden import params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dropin(gpu):
+    lib = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
+    return lib
+
+
+def make_pair(dropin, res=64, W=160, H=120, color=True, n_frames=5):
+    sc = synth.scene_a(res, W, H)
+    dv = refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=color,
+                           lib_path=dropin)
+    ov = OracleVolume(params(res, W, H, sc.size, color))
+    for i in range(n_frames):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        dep, col = sc.depth(tr), sc.bgra(i)
+        dv.integrate(dep, col, tr)
+        ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+    return dv, ov, sc
+
+
+def test_dropin_integrate_render_sample_mesh(dropin):
+    from cpu_tsdf_amd.volume import transform_cloud_with_normals
+    dv, ov, sc = make_pair(dropin)
+    d, w, rgb = dv.download()
+    assert_same_f32(d, ov.d, "d")
+    assert_same_f32(w, ov.w, "w")
+    assert np.array_equal(rgb, ov.rgb)
+    for tr, ds in [(synth.turntable_pose(1, 8, sc.size), 1), (synth.look_at_pose((0.3, -0.2, -0.25)), 2)]:
+        got, _ = dv.render_view(tr, ds)
+        want = transform_cloud_with_normals(ov.raycast(tr, ds), synth.eigen_affine_inverse(tr))
+        assert np.isfinite(want[..., 0]).sum() > 100
+        assert_same_f32(got[..., :6], want[..., :6], "renderView (camera frame)")
+    rng = np.random.RandomState(5)
+    pts = rng.uniform(-0.13, 0.13, (500, 3)).astype(np.float32)
+    ok, val, grad, hess = dv.sample(pts)
+    ok2, val2, grad2, hess2 = ov.sample(pts)
+    assert np.array_equal(ok == 7, ok2) and set(np.unique(ok)) <= {0, 7}
+    assert_same_f32(val[ok2], val2[ok2], "getFxn")
+    assert_same_f32(grad[ok2], grad2[ok2], "getGradient")
+    assert_same_f32(hess[ok2], hess2[ok2], "getHessian")
+    for mode in (0, 1, 2):
+        v, c, polys, _ = dv.march(2.0, mode)
+        v2, c2, _ = ov.march(2.0, mode)
+        assert len(v) > 10000
+        assert_same_f32(v, v2, "mesh vertices")
+        assert np.array_equal(polys.ravel(), np.arange(len(v), dtype=np.uint32))
+        if mode:
+            assert np.array_equal(c, c2)
+    dv.close()
+
+
+def test_dropin_save_load_interop_with_reference(dropin, tmp_path):
+    """.vol files cross both ways: the drop-in's save() is readable by the reference's load(), and the
+    reference's save() by the drop-in's load(); voxels survive bit for bit."""
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    dv, ov, sc = make_pair(dropin, res=32, W=80, H=60, color=True, n_frames=3)
+    ours = str(tmp_path / "dropin.vol")
+    dv.save(ours)
+    assert os.path.getsize(ours) < 32 ** 3 * 43  # uniform regions collapsed
+    ref = refbind.RefVolume(32, sc.size, 80, 60, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True)
+    ref.load(ours)
+    d, w, rgb, leaf, _ = ref.dump_dense()
+    assert_same_f32(d, ov.d, "reference reading the drop-in's file: d")
+    assert_same_f32(w, ov.w, "w")
+    assert np.array_equal(rgb[ov.w > 0], ov.rgb[ov.w > 0])
+    assert leaf.max() > leaf.min()  # really an adaptive tree
+    # and a mesh made by the reference from our file equals ours
+    v_ref, _, _, _ = ref.march(1.0, 0)
+    v_our, _, _, _ = dv.march(1.0, 0)
+    assert len(v_ref) > 1000
+    assert_same_f32(v_ref, v_our, "mesh by the reference from the drop-in's file")
+    theirs = str(tmp_path / "reference.vol")
+    ref2 = refbind.RefVolume(32, sc.size, 80, 60, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True)
+    for i in range(3):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        ref2.integrate(sc.depth(tr), sc.bgra(i), tr)
+    ref2.save(theirs)
+    dv2 = refbind.RefVolume(32, sc.size, 80, 60, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True,
+                            lib_path=dropin)
+    dv2.load(theirs)
+    d2, w2, rgb2 = dv2.download()
+    assert_same_f32(d2, ov.d, "drop-in reading the reference's file: d")
+    assert_same_f32(w2, ov.w, "w")
+    assert np.array_equal(rgb2, ov.rgb)
+    for v in (dv, dv2, ref, ref2):
+        v.close()
