@@ -70,6 +70,8 @@ SIGNATURES = {
     "tsdf_hip_march_fetch": (C.c_int, [C.c_void_p, _f32p, _u8p, _u64p]),
     "tsdf_hip_download": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
     "tsdf_hip_upload": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
+    "tsdf_hip_get_planes_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsdf_hip_set_planes_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsdf_hip_device_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -435,3 +435,56 @@ extern "C" int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, in
   return block_transfer<false>(h, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
                                const_cast<uint8_t *>(rgb));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Whole-plane transfer between the SoA volume and packed DEVICE buffers ([nz][ny][nx], rgb as the
+// volume's uint32 r|g<<8|b<<16), asynchronous on the handle's stream: the halo-exchange primitive.  The
+// caller owns the buffers (e.g. torch CUDA tensors handed to RCCL send/recv).
+template <bool TO_PACKED>
+static __global__ void __launch_bounds__(256)
+k_planes_u32(uint32_t *__restrict__ vol, uint32_t *__restrict__ packed, int nx, int ny, int nz, int zl0,
+             int64_t pitch) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx);
+    const int64_t r = i / nx;
+    const int64_t vi = ((int64_t)zl0 * ny + r) * pitch + x;  // r = z*ny + y
+    if (TO_PACKED)
+      packed[i] = vol[vi];
+    else
+      vol[vi] = packed[i];
+  }
+}
+
+template <bool TO_PACKED>
+static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *rgb) {
+  if (!h || nz <= 0 || z0 < h->z_first || z0 + nz > h->z_first + h->nz_alloc) {
+    tsdf_set_error("planes outside the allocated slab");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (rgb && !h->rgb) {
+    tsdf_set_error("volume has no colour plane");
+    return TSDF_HIP_E_INVALID;
+  }
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = (int64_t)h->nx * h->ny * nz;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
+  void *vols[3] = {h->d, h->w, h->rgb};
+  void *bufs[3] = {d, w, rgb};
+  for (int k = 0; k < 3; ++k) {
+    if (!bufs[k]) continue;
+    hipLaunchKernelGGL(k_planes_u32<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, (uint32_t *)vols[k],
+                       (uint32_t *)bufs[k], h->nx, h->ny, nz, z0 - h->z_first, h->pitch);
+    TSDF_HIP_TRY(hipGetLastError());
+  }
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_get_planes_device(tsdf_handle h, int z0, int nz, float *d, float *w, uint32_t *rgb) {
+  return planes_device<true>(h, z0, nz, d, w, rgb);
+}
+
+extern "C" int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const float *d, const float *w,
+                                          const uint32_t *rgb) {
+  return planes_device<false>(h, z0, nz, const_cast<float *>(d), const_cast<float *>(w), const_cast<uint32_t *>(rgb));
+}

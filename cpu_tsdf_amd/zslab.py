@@ -1,0 +1,234 @@
+"""Z-slab partition of one TSDF grid over the GPUs of a node: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The reference has no distributed code at all; this layer is new.  Voxels are
+independent during integration, so the grid is cut into contiguous Z-slabs and the only traffic is
+
+* ``integrateCloud``: one broadcast of the depth (+ colour) frame from the rank that ingested it
+  (1.2 MB + 1.2 MB at 640x480) -- no voxel ever crosses a link;
+* ``reconstruct`` (marching cubes): a cell reads planes z and z+1, so every rank receives ONE plane
+  (the first plane of the next slab: res^2 * 8..12 B) from its +z neighbour by point-to-point send/recv,
+  meshes its own cells, and the per-rank triangle lists are merged by the reference's Morton key;
+* ``sample`` (getFxn...): a point is answered by the rank that owns the lower-corner plane.
+
+``renderView`` needs each ray's step sequence to continue across slab boundaries (the step rule depends
+on the last voxel visited); it is implemented for world_size == 1 and refuses otherwise (DESIGN.md,
+"what comes next").
+
+The slab backend is injected (``slab_factory``) so the N > 1 logic is testable on CPU with gloo; the
+default backend is the HIP volume.  There is no CPU fallback in the product: the default factory raises
+without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+from .volume import MarchingCubesTSDFOctree, TSDFVolumeOctree
+
+
+def slab_range(nz, world, rank):
+    """Contiguous, balanced split of nz planes: the first nz % world ranks get one extra plane."""
+    base, extra = divmod(nz, world)
+    z0 = rank * base + min(rank, extra)
+    return z0, z0 + base + (1 if rank < extra else 0)
+
+
+def morton_x_major(cells):
+    """Sort key of the reference's triangle order (octree pre-order, child index 4*(x>cx)+2*(y>cy)+(z>cz),
+    src/lib/octree.cpp:119,257-264) from packed cells (x<<42 | y<<21 | z)."""
+    c = np.asarray(cells, dtype=np.uint64)
+    x, y, z = (c >> np.uint64(42)) & np.uint64(0x1FFFFF), (c >> np.uint64(21)) & np.uint64(0x1FFFFF), c & np.uint64(0x1FFFFF)
+
+    def spread(v):
+        v = v & np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    return (spread(x) << np.uint64(2)) | (spread(y) << np.uint64(1)) | spread(z)
+
+
+class HipSlab:
+    """Slab backend on one MI355X: a TSDFVolumeOctree restricted to [z_begin, z_end) (+ one halo plane
+    above for marching cubes / sampling), exchanging planes as torch CUDA tensors."""
+
+    def __init__(self, configure, z_begin, z_end, nz, device_index):
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.vol = TSDFVolumeOctree()
+        configure(self.vol)
+        self.res = self.vol.getResolution()
+        self.color = bool(self.vol._p.integrate_color)
+        self.z_begin, self.z_end = z_begin, z_end
+        self.vol.setZSlab(z_begin, z_end, halo=1 if z_end < nz else 0, device=device_index)
+        self.vol.setStream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.vol.reset()
+
+    def frame_buffers(self):
+        W, H = self.vol.getImageSize()
+        depth = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        bgra = torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) if self.color else None
+        return depth, bgra
+
+    def integrate_tensor(self, depth, bgra, trans):
+        self.vol.integrateCloudDevice(depth.data_ptr(), bgra.data_ptr() if bgra is not None else 0, trans)
+
+    def get_planes(self, z0, nz):
+        nx, ny, _ = self.res
+        d = torch.empty((nz, ny, nx), dtype=torch.float32, device=self.device)
+        w = torch.empty_like(d)
+        rgb = torch.empty((nz, ny, nx), dtype=torch.int32, device=self.device) if self.color else None
+        capi.check(capi.load().tsdf_hip_get_planes_device(self.vol._need(), z0, nz, C.c_void_p(d.data_ptr()),
+                                                          C.c_void_p(w.data_ptr()),
+                                                          C.c_void_p(rgb.data_ptr()) if rgb is not None else None),
+                   "get_planes_device")
+        return d, w, rgb
+
+    def plane_buffers(self, nz):
+        nx, ny, _ = self.res
+        d = torch.empty((nz, ny, nx), dtype=torch.float32, device=self.device)
+        return d, torch.empty_like(d), (torch.empty((nz, ny, nx), dtype=torch.int32, device=self.device) if self.color else None)
+
+    def set_planes(self, z0, d, w, rgb):
+        capi.check(capi.load().tsdf_hip_set_planes_device(self.vol._need(), z0, d.shape[0], C.c_void_p(d.data_ptr()),
+                                                          C.c_void_p(w.data_ptr()),
+                                                          C.c_void_p(rgb.data_ptr()) if rgb is not None else None),
+                   "set_planes_device")
+
+    def march(self, w_min, by_rgb, by_confidence):
+        mc = MarchingCubesTSDFOctree()
+        mc.setInputTSDF(self.vol)
+        mc.setMinWeight(w_min)
+        mc.setColorByRGB(by_rgb)
+        mc.setColorByConfidence(by_confidence)
+        return mc.reconstruct(want_cells=True)
+
+    def sample(self, pts):
+        return self.vol.sample(pts)
+
+    def render(self, trans, ds):
+        return self.vol.renderView(trans, ds)
+
+    def synchronize(self):
+        self.vol.synchronize()
+
+    def close(self):
+        self.vol.close()
+
+
+def _default_factory(configure, z_begin, z_end, nz, rank):
+    if capi.load().tsdf_hip_device_count() <= 0:
+        raise RuntimeError("ZSlabVolume needs a HIP device per rank (there is no CPU fallback)")
+    return HipSlab(configure, z_begin, z_end, nz, int(torch.cuda.current_device()))
+
+
+class ZSlabVolume:
+    """One logical TSDF volume, Z-slab partitioned over the ranks of `group`.
+
+    configure(vol) applies the usual setters (setResolution, setGridSize, ...) to a volume object; it is
+    called once per rank.  All methods are collective: every rank calls them in the same order."""
+
+    def __init__(self, configure, resolution_z, group=None, slab_factory=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.nz = int(resolution_z)
+        self.z_begin, self.z_end = slab_range(self.nz, self.world, self.rank)
+        factory = slab_factory or _default_factory
+        self.slab = factory(configure, self.z_begin, self.z_end, self.nz, self.rank)
+        self._frame = self.slab.frame_buffers()
+        self.global_transform = np.eye(4)
+
+    # -- integrateCloud -------------------------------------------------------------------------------
+    def integrateCloud(self, depth, bgra, trans, src=0):
+        """`depth`/`bgra` are only read on rank `src` (numpy arrays or tensors); everyone gets the frame by
+        one broadcast each, then integrates its own slab."""
+        fd, fc = self._frame
+        if self.rank == src:
+            fd.copy_(torch.as_tensor(depth).reshape(fd.shape))
+            if fc is not None:
+                fc.copy_(torch.as_tensor(bgra).reshape(fc.shape))
+        if self.world > 1:
+            dist.broadcast(fd, src=src, group=self.group)
+            if fc is not None:
+                dist.broadcast(fc, src=src, group=self.group)
+        self.slab.integrate_tensor(fd, fc, np.asarray(trans, dtype=np.float64))
+        return True
+
+    # -- marching cubes ---------------------------------------------------------------------------------
+    def exchange_halo(self):
+        """Every rank receives the first plane of its +z neighbour into its upper halo."""
+        if self.world == 1:
+            return
+        ops, recv = [], None
+        if self.rank > 0:  # my first plane goes down to rank - 1
+            send = self.slab.get_planes(self.z_begin, 1)
+            self.slab.synchronize()
+            for t in send:
+                if t is not None:
+                    ops.append(dist.P2POp(dist.isend, t, self.rank - 1, self.group))
+        if self.rank < self.world - 1:
+            recv = self.slab.plane_buffers(1)
+            for t in recv:
+                if t is not None:
+                    ops.append(dist.P2POp(dist.irecv, t, self.rank + 1, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if recv is not None:
+            self.slab.set_planes(self.z_end, *recv)
+
+    def reconstruct(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0):
+        """MarchingCubesTSDFOctree::reconstruct over all slabs.  Returns the merged mesh on rank `dst`
+        (vertices (3n,3) float32, polygons, rgb, cells) in the reference's triangle order; None elsewhere."""
+        self.exchange_halo()
+        part = self.slab.march(w_min, color_by_rgb, color_by_confidence)
+        if self.world == 1:
+            parts = [part]
+        else:
+            parts = [None] * self.world if self.rank == dst else None
+            dist.gather_object(part, parts, dst=dst, group=self.group)
+            if self.rank != dst:
+                return None
+        cells = np.concatenate([p["cells"] for p in parts])
+        verts = np.concatenate([p["vertices"].reshape(-1, 3, 3) for p in parts])
+        order = np.argsort(morton_x_major(cells), kind="stable")
+        has_rgb = parts[0]["rgb"] is not None
+        rgb = np.concatenate([p["rgb"].reshape(-1, 3, 3) for p in parts])[order].reshape(-1, 3) if has_rgb else None
+        n = len(cells)
+        return {"vertices": verts[order].reshape(-1, 3), "polygons": np.arange(3 * n, dtype=np.int32).reshape(n, 3),
+                "rgb": rgb, "cells": cells[order]}
+
+    # -- getFxn / getGradient / getHessian -------------------------------------------------------------------
+    def sample(self, pts, dst=0):
+        """Every rank evaluates the points whose 8 neighbours it holds; rank `dst` returns the union."""
+        self.exchange_halo()
+        ok, val, grad, hess = self.slab.sample(np.asarray(pts, dtype=np.float32))
+        if self.world == 1:
+            return ok, val, grad, hess
+        parts = [None] * self.world if self.rank == dst else None
+        dist.gather_object((ok, val, grad, hess), parts, dst=dst, group=self.group)
+        if self.rank != dst:
+            return None
+        ok, val, grad, hess = [np.array(a) for a in parts[0]]
+        for o, v, g, h in parts[1:]:
+            take = o & ~ok
+            val[take], grad[take], hess[take] = v[take], g[take], h[take]
+            ok |= o
+        return ok, val, grad, hess
+
+    def renderView(self, trans, downsampleBy=1):
+        if self.world != 1:
+            raise NotImplementedError("renderView across Z-slabs needs ray hand-off between ranks (DESIGN.md)")
+        return self.slab.render(trans, downsampleBy)
+
+    def download_local(self):
+        return self.slab.vol.download()
+
+    def close(self):
+        self.slab.close()

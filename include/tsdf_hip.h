@@ -129,6 +129,13 @@ int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int
 int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
                     const float *w, const uint8_t *rgb);
 
+/* Whole planes [z0, z0+nz) to / from packed DEVICE buffers ([nz][ny][nx]; rgb as uint32 r|g<<8|b<<16),
+ * asynchronous on the handle's stream.  This is the halo-exchange primitive: the buffers are what the
+ * caller hands to RCCL send/recv.  Planes may lie in the halo.  Any pointer may be NULL. */
+int tsdf_hip_get_planes_device(tsdf_handle h, int z0, int nz, float *d, float *w, uint32_t *rgb);
+int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const float *d, const float *w,
+                               const uint32_t *rgb);
+
 /* Raw device pointers of the SoA planes and their geometry (for RCCL halo exchange done by the
  * caller): element index of voxel (x,y,z_global) = ((z_global - z_first)*ny + y)*pitch + x. */
 int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,

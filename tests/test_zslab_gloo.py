@@ -1,0 +1,101 @@
+"""CPU tier: the Z-slab multi-GPU layer (cpu_tsdf_amd/zslab.py) with world_size 2 and 3 over gloo.  The slab
+backend is the CPU oracle (tests/fake_slab.py), so this exercises exactly the host logic the GPU ranks run:
+slab split, frame broadcast from the ingest rank, one-plane halo exchange, per-rank meshing, Morton merge,
+sample routing -- and checks the result against a single unpartitioned volume."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpu_tsdf_amd import synth
+from cpu_tsdf_amd.zslab import ZSlabVolume, morton_x_major, slab_range
+
+RES, W, H, NF = 32, 80, 60, 4
+
+
+def configure(v):
+    sc = synth.scene_a(RES, W, H)
+    v.setResolution(RES, RES, RES)
+    v.setGridSize(sc.size, sc.size, sc.size)
+    v.setImageSize(W, H)
+    v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    v.setSensorDistanceBounds(0.0, 3 * sc.size)
+    v.setIntegrateColor(True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.fake_slab import OracleSlab
+    vol = ZSlabVolume(configure, RES, slab_factory=OracleSlab)
+    sc = synth.scene_a(RES, W, H)
+    src = world - 1  # ingest on the LAST rank to prove src is honoured
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        if rank == src:
+            vol.integrateCloud(sc.depth(tr), sc.bgra(i), tr, src=src)
+        else:
+            vol.integrateCloud(None, None, tr, src=src)
+    mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
+    samp = vol.sample(pts)
+    zb, ze = vol.z_begin, vol.z_end
+    d, w = vol.slab.ov.d[zb:ze].copy(), vol.slab.ov.w[zb:ze].copy()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((zb, ze, d, w), gathered, dst=0)
+    if rank == 0:
+        np.savez(out_path, verts=mesh["vertices"], rgb=mesh["rgb"], cells=mesh["cells"], ok=samp[0], val=samp[1],
+                 grad=samp[2], d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
+                 bounds=np.array([[g[0], g[1]] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_range_and_morton_key():
+    for nz, world in [(2048, 8), (10, 3), (7, 7), (64, 1)]:
+        cuts = [slab_range(nz, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == nz
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    # x is the most significant bit of each octree level (src/lib/octree.cpp:119)
+    cells = np.array([(1 << 42), (1 << 21), 1, (1 << 42) | (1 << 21) | 1, 2], dtype=np.uint64)
+    assert morton_x_major(cells).tolist() == [4, 2, 1, 7, 8]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    # single-volume truth
+    from oracle.oracle import OracleVolume
+    from tests.fake_slab import _Cfg
+    cfg = _Cfg()
+    configure(cfg)
+    ov = OracleVolume(cfg._p)
+    sc = synth.scene_a(RES, W, H)
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        ov.integrate(sc.depth(tr), sc.bgra(i), synth.cam_from_vol_f32(tr))
+    assert got["bounds"].tolist() == [list(slab_range(RES, world, r)) for r in range(world)]
+    assert np.array_equal(got["d"], ov.d) and np.array_equal(got["w"], ov.w)
+    verts, rgb, cells = ov.march(1.0, 1)
+    assert len(cells) > 1000
+    assert np.array_equal(got["cells"], cells), "merged triangle order"
+    assert np.array_equal(got["verts"], verts) and np.array_equal(got["rgb"], rgb)
+    pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
+    ok, val, grad, _ = ov.sample(pts)
+    assert np.array_equal(got["ok"], ok)
+    assert np.array_equal(got["val"][ok], val[ok]) and np.array_equal(got["grad"][ok], grad[ok])
