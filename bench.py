@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=0, help="distinct frames on the turntable (default steps+warmup)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--extras", type=int, default=1, help="also time renderView + marching cubes once (N=1, untimed region)")
     return ap.parse_args()
 
 
@@ -83,6 +84,41 @@ def cpu_baseline(args, sc, res3, size3, budget_s):
             "kind": "port",
             "sample": f"dense C restatement (OpenMP, {cores} threads), planes [{zb},{zb + planes}) of the "
                       f"{res3[0]}x{res3[1]}x{res3[2]} grid, {n} frames, extrapolated x{res3[2] / planes:.0f}"}
+
+
+def extras(vol, pose, W, H):
+    """Report-only timings of the other two kernels of the path on the fused volume (outside the timed
+    region; gather/latency-bound raycast, streaming marching cubes): not part of `value`."""
+    from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree
+    out = {}
+    try:
+        vol.renderView(pose, 1, camera_frame=False)  # warm-up (scratch allocation)
+        t0 = time.perf_counter()
+        img = vol.renderView(pose, 1, camera_frame=False)
+        dt = time.perf_counter() - t0
+        out["renderView_ms"] = dt * 1e3
+        out["renderView_rays_per_s"] = W * H / dt
+        out["renderView_hits"] = int(np.isfinite(img[..., 0]).sum())
+        out["renderView_mean_steps"] = float(img[..., 7].mean())
+        lib = capi_mod().load()
+        n = C.c_uint64(0)
+        lib.tsdf_hip_march(vol._need(), C.c_float(1.0), 1, C.byref(n))  # warm-up (buffer growth)
+        t0 = time.perf_counter()
+        rc = lib.tsdf_hip_march(vol._need(), C.c_float(1.0), 1, C.byref(n))
+        dt = time.perf_counter() - t0
+        if rc == 0:
+            rx, ry, rz = vol.getResolution()
+            out["reconstruct_ms"] = dt * 1e3
+            out["reconstruct_triangles"] = int(n.value)
+            out["reconstruct_Mvoxels_per_s"] = rx * ry * float(rz) / dt / 1e6
+    except Exception as e:  # never let a report-only leg break the bench line
+        out["error"] = repr(e)
+    return out
+
+
+def capi_mod():
+    from cpu_tsdf_amd import capi
+    return capi
 
 
 class SlabOracle:
@@ -291,6 +327,8 @@ def main():
                 "sweep_upper_bound_bytes": bpv * vox_total / world,
             },
         }
+        if world == 1 and args.extras:
+            out["extras"] = extras(vol, poses[-1], W, H)
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -218,9 +218,11 @@ def time_integrate(sc, res3, size3, color, budget_s, cores):
         n += 1
     leaves = v.num_leaves()
     v.close()
+    import resource
+    rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     fps = n / spent
     vox = float(res3[0]) * res3[1] * res3[2]
     return {"value": vox * fps / 1e6, "unit": "Mvoxels/s", "frames_per_s": fps, "cores": cores, "kind": "reference",
             "sample": f"reference TSDFVolumeOctree (own sources + PCL/Eigen stand-ins, -O3 -fopenmp, {cores} threads), "
                       f"native adaptive octree (max cell 0.5 m), first {n} frames of the same {res}^3 workload, "
-                      f"{spent:.1f} s in integrateCloud, {leaves} leaves at the end; nominal-grid Mvoxels/s"}
+                      f"{spent:.1f} s in integrateCloud, {leaves} leaves at the end, peak RSS {rss_gb:.1f} GB; nominal-grid Mvoxels/s"}
