@@ -45,7 +45,8 @@ static int env_int(const char *name, int dflt) {
 const TsdfTuning &tsdf_tuning() {
   static const TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
                                std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
-                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1), env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_NONTEMPORAL", 0)};
+                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1), env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_NONTEMPORAL", 0),
+                               env_int("TSDF_HIP_MC_FLUSH_AT", 256)};
   return t;
 }
 

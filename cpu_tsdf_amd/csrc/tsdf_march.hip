@@ -2,9 +2,10 @@
 //
 // Replaces MarchingCubesTSDFOctree::reconstruct (src/lib/marching_cubes_tsdf_octree.cpp:108-236) and the
 // PCL pieces it calls (pcl::MarchingCubes::createSurface / interpolateEdge, Bourke's tables).
-//   k_mc_classify  one thread per grid cell: candidate test (:192-202), 8 corner values
-//                  (getValidNeighborList1D :145-177 / getGridValue :91-106), case index, triangle count;
-//                  active cells are compacted per wavefront into (Morton key, packed cell) pairs
+//   k_mc_classify  streaming pass, one thread per quad of 4 x-consecutive cells: candidate test (:192-202),
+//                  8 corner values (getValidNeighborList1D :145-177 / getGridValue :91-106), case index,
+//                  triangle count; active cells are compacted through wave-private LDS lists into
+//                  (Morton key, packed cell) pairs
 //   rocprim sort   by key: the reference emits triangles in octree pre-order with child index
 //                  4*(x>cx) + 2*(y>cy) + (z>cz) (octree.cpp:119,257-264) = Morton order, x the high bit
 //   rocprim scan   triangle offsets
@@ -33,6 +34,8 @@ struct McArgs {
   float w_min, neg;
   int color_mode;
   float lower[3], size_voxel[3];
+  int flush_at;                  // flush a wave's LDS list once it holds more than this many cells
+  int qpr, log2TX, TX, TY, rpb;  // classify launch shape: TX quads along x, TY rows, rpb row groups per block
 };
 
 // getGridValue (:91-106): NaN if w < w_min or |d| >= 1, else d * max_dist_neg.
@@ -74,44 +77,127 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
   return c;
 }
 
-// counters[0] = active cells, counters[1] = triangles
+// One value of the corner grid: getGridValue (:91-106) on registers.
+static __device__ __forceinline__ float grid_value_reg(float d, float w, float w_min, float neg) {
+  return (w < w_min || fabsf(d) >= 1.f) ? NAN : d * neg;
+}
+
+// Five x-consecutive grid values x4 .. x4+4 of one row (a float4 pair plus the first voxel of the next
+// quad; `tail` says whether that voxel exists in the row).
+static __device__ __forceinline__ void row_values(const McArgs &a, const float *__restrict__ drow,
+                                                  const float *__restrict__ wrow, bool tail, float v[5]) {
+  const float4 d4 = *reinterpret_cast<const float4 *>(drow);
+  const float4 w4 = *reinterpret_cast<const float4 *>(wrow);
+  v[0] = grid_value_reg(d4.x, w4.x, a.w_min, a.neg);
+  v[1] = grid_value_reg(d4.y, w4.y, a.w_min, a.neg);
+  v[2] = grid_value_reg(d4.z, w4.z, a.w_min, a.neg);
+  v[3] = grid_value_reg(d4.w, w4.w, a.w_min, a.neg);
+  v[4] = tail ? grid_value_reg(drow[4], wrow[4], a.w_min, a.neg) : NAN;
+}
+
+// Classify: a streaming pass over d and w.  A thread owns a quad of 4 x-consecutive base voxels (one
+// 16-byte load per plane) and walks `rpb` rows; a wave touches 1 KiB contiguous per plane, like
+// k_integrate.  Quads with no candidate voxel (:192: w >= w_min && |d| < 1) -- almost all of the grid --
+// cost exactly those two loads.  A quad with a candidate fetches the other three rows of its 2x2 row
+// bundle (L1/L2 hits: the neighbouring thread / the block one plane up streams them anyway), builds the
+// case index of its up to 4 cells and appends the active ones to a wave-private LDS list, flushed to the
+// global (Morton key, packed cell) arrays with ONE atomic per flush and coalesced stores.
+// counters[0] = active cells, counters[1] = triangles.
+#define MC_WAVE_BUF 512  // entries per wave; one append adds at most 256
 static __global__ void __launch_bounds__(256)
 k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, uint64_t capacity,
               unsigned long long *__restrict__ counters) {
   __shared__ unsigned char s_ntri[256];
+  __shared__ uint64_t s_buf[4][MC_WAVE_BUF];
   s_ntri[threadIdx.x] = mc_ntri_table[threadIdx.x];
   __syncthreads();
-  const int x = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  const int y = 1 + (int)blockIdx.y;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  volatile uint64_t *buf = s_buf[tid >> 6];
+  const int tx = (int)(tid & (unsigned)(a.TX - 1));
+  const int ty = (int)(tid >> a.log2TX);
+  const int xq = (int)blockIdx.x * a.TX + tx;
+  const int x4 = xq * 4;
   const int z = a.z_lo + (int)blockIdx.z;
-  unsigned ntri = 0;
-  if (x < a.nx - 1 && y < a.ny - 1 && z < a.z_hi) {
-    const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
-    const float d = a.d[vi], w = a.w[vi];
-    if (w >= a.w_min && fabsf(d) < 1.f) {  // :192
-      float leaf[8];
-      if (corner_values(a, x, y, z, leaf)) ntri = s_ntri[cube_index(leaf)];
+  const int64_t sz = (int64_t)a.ny * a.pitch;
+  const float *__restrict__ dz = a.d + (int64_t)(z - a.z_first) * sz;
+  const float *__restrict__ wz = a.w + (int64_t)(z - a.z_first) * sz;
+  const bool tail = x4 + 4 < (int)a.pitch;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  unsigned n_buf = 0;    // wave-uniform: entries waiting in buf
+  unsigned tri_sum = 0;  // per lane
+
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)n_buf);
+    base = __shfl(base, 0);
+    for (unsigned i = lane; i < n_buf; i += 64u) {
+      const uint64_t v = buf[i];
+      const unsigned long long slot = base + i;
+      if (slot < capacity) {
+        const uint64_t x = v & 0xfffffull, y = (v >> 20) & 0xfffffull, zz = (v >> 40) & 0xfffffull;
+        keys[slot] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(zz);
+        vals[slot] = v;
+      }
     }
-  }
-  // wave-level compaction: one atomic pair per wavefront
-  const unsigned long long active = __ballot(ntri > 0);
-  if (active == 0) return;
-  const unsigned lane = threadIdx.x & 63u;
-  unsigned tri_sum = ntri;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads done before the next append overwrites
+    n_buf = 0;
+  };
+
+  const int y0 = 1 + (int)blockIdx.y * a.rpb * a.TY + ty;
+  for (int r = 0; r < a.rpb; ++r) {
+    const int y = y0 + r * a.TY;
+    if (y0 - ty + r * a.TY >= a.ny - 1) break;  // whole block past the last cell row (uniform)
+    unsigned nt[4] = {0u, 0u, 0u, 0u};
+    if (xq < a.qpr && y < a.ny - 1) {
+      const int64_t o = (int64_t)y * a.pitch + x4;
+      const float4 d4 = *reinterpret_cast<const float4 *>(dz + o);
+      const float4 w4 = *reinterpret_cast<const float4 *>(wz + o);
+      const float dq[4] = {d4.x, d4.y, d4.z, d4.w}, wq[4] = {w4.x, w4.y, w4.z, w4.w};
+      bool cand[4], any = false;
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) tri_sum += __shfl_xor(tri_sum, s);
-  unsigned long long base = 0;
-  if (lane == 0) {
-    base = atomicAdd(&counters[0], (unsigned long long)__popcll(active));
-    atomicAdd(&counters[1], (unsigned long long)tri_sum);
-  }
-  base = __shfl(base, 0);
-  if (ntri > 0) {
-    const unsigned long long slot = base + __popcll(active & ((1ull << lane) - 1ull));
-    if (slot < capacity) {
-      keys[slot] = (spread3((uint64_t)x) << 2) | (spread3((uint64_t)y) << 1) | spread3((uint64_t)z);
-      vals[slot] = (uint64_t)x | ((uint64_t)y << 20) | ((uint64_t)z << 40) | ((uint64_t)ntri << 60);
+      for (int j = 0; j < 4; ++j) {  // :192 and :199-202 (base voxel strictly inside the grid)
+        cand[j] = wq[j] >= a.w_min && fabsf(dq[j]) < 1.f && x4 + j >= 1 && x4 + j < a.nx - 1;
+        any |= cand[j];
+      }
+      if (any) {
+        float v00[5], v10[5], v01[5], v11[5];  // [dy][dz]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v00[j] = grid_value_reg(dq[j], wq[j], a.w_min, a.neg);
+        v00[4] = tail ? grid_value_reg(dz[o + 4], wz[o + 4], a.w_min, a.neg) : NAN;
+        row_values(a, dz + o + a.pitch, wz + o + a.pitch, tail, v10);
+        row_values(a, dz + o + sz, wz + o + sz, tail, v01);
+        row_values(a, dz + o + sz + a.pitch, wz + o + sz + a.pitch, tail, v11);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1)
+          const float leaf[8] = {v00[j], v00[j + 1], v01[j + 1], v01[j], v10[j], v10[j + 1], v11[j + 1], v11[j]};
+          bool ok = cand[j];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ok = ok && !isnan(leaf[k]);
+          if (ok) nt[j] = s_ntri[cube_index(leaf)];
+        }
+      }
     }
+    const unsigned cnt = (nt[0] > 0) + (nt[1] > 0) + (nt[2] > 0) + (nt[3] > 0);
+    const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+    if ((b0 | b1 | b2) == 0) continue;
+    unsigned pos = n_buf + (unsigned)__popcll(b0 & lanes_below) + 2u * (unsigned)__popcll(b1 & lanes_below) +
+                   4u * (unsigned)__popcll(b2 & lanes_below);
+    n_buf += (unsigned)__popcll(b0) + 2u * (unsigned)__popcll(b1) + 4u * (unsigned)__popcll(b2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (nt[j]) {
+        buf[pos++] = (uint64_t)(x4 + j) | ((uint64_t)y << 20) | ((uint64_t)z << 40) | ((uint64_t)nt[j] << 60);
+        tri_sum += nt[j];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((int)n_buf > a.flush_at) flush();
+  }
+  if (n_buf) flush();
+  if (__ballot(tri_sum > 0)) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) tri_sum += __shfl_xor(tri_sum, s);
+    if (lane == 0) atomicAdd(&counters[1], (unsigned long long)tri_sum);
   }
 }
 
@@ -259,7 +345,16 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   if (n_tri) *n_tri = 0;
   if (a.z_hi <= a.z_lo || a.nx < 3 || a.ny < 3) return TSDF_HIP_OK;
 
-  const dim3 block(256), grid((unsigned)((a.nx - 2 + 255) / 256), (unsigned)(a.ny - 2), (unsigned)(a.z_hi - a.z_lo));
+  a.qpr = (a.nx + 3) / 4;
+  a.log2TX = 0;
+  while ((1 << a.log2TX) < a.qpr && a.log2TX < 8) ++a.log2TX;
+  a.TX = 1 << a.log2TX;
+  a.TY = 256 / a.TX;
+  a.rpb = std::max(1, tsdf_tuning().rows_per_block / a.TY);
+  a.flush_at = std::min(MC_WAVE_BUF - 256, std::max(0, tsdf_tuning().mc_flush_at));
+  const int cell_rows = a.ny - 2;
+  const dim3 block(256), grid((unsigned)((a.qpr + a.TX - 1) / a.TX),
+                              (unsigned)((cell_rows + a.rpb * a.TY - 1) / (a.rpb * a.TY)), (unsigned)(a.z_hi - a.z_lo));
   if (grid.y > 65535u || grid.z > 65535u) return TSDF_HIP_E_UNSUPPORTED;
   unsigned long long counts[2] = {0, 0};
   // pass 1 with the capacity we already have; if the surface turned out larger, grow and repeat

@@ -93,6 +93,57 @@ def test_marching_cubes_matches_oracle(fused64, mode, wmin):
         assert np.array_equal(mesh["rgb"], rgb)
 
 
+def _mesh_vs_oracle(vol, ov, wmin, mode):
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(vol)
+    mc.setMinWeight(wmin)
+    mc.setColorByRGB(mode == 1)
+    mc.setColorByConfidence(mode == 2)
+    mesh = mc.reconstruct(want_cells=True)
+    verts, rgb, cells = ov.march(wmin, mode)
+    assert np.array_equal(mesh["cells"], cells), "cell sequence (topology + reference triangle order)"
+    assert_same_f32(mesh["vertices"], verts, "triangle vertices")
+    if mode:
+        assert np.array_equal(mesh["rgb"], rgb)
+    return len(verts)
+
+
+def test_marching_cubes_odd_resolutions(gpu):
+    # nx not a multiple of 4 (pitch > nx), three different non-power-of-two axes: the quad classify must
+    # not emit cells in the padding nor lose the last cells of a row
+    for res3 in [(50, 37, 41), (33, 64, 23), (7, 5, 6), (3, 3, 3), (4, 3, 9)]:
+        vol, sc = make_volume(64, color=True, res3=res3, size3=(0.25, 0.25, 0.25))
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        for i, tr, dep, col in frames(sc, 3, 8):
+            vol.integrateCloud(dep, col, tr)
+            ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+        n = _mesh_vs_oracle(vol, ov, 0.0, 1)
+        if min(res3) > 20:
+            assert n > 1000
+
+
+def test_marching_cubes_wave_list_flush_paths():
+    """The classify kernel's wave-private LDS list flushes mid-block only on dense surfaces; force a flush
+    after every append (TSDF_HIP_MC_FLUSH_AT=0, read once per process) and compare with the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\n"
+            "from tests.test_query_gpu import _mesh_vs_oracle\n"
+            "from tests.common import make_volume, frames\n"
+            "from cpu_tsdf_amd import synth\n"
+            "from oracle.oracle import OracleVolume\n"
+            "vol, sc = make_volume(64, color=True); vol.reset(); ov = OracleVolume(vol._p)\n"
+            "for i, tr, dep, col in frames(sc, 4, 8, noise=True):\n"
+            "    vol.integrateCloud(dep, col, tr); ov.integrate(dep, col, synth.cam_from_vol_f32(tr))\n"
+            "print('NVERT', _mesh_vs_oracle(vol, ov, 0.0, 1), _mesh_vs_oracle(vol, ov, 2.0, 0))\n")
+    env = dict(os.environ, TSDF_HIP_MC_FLUSH_AT="0", TSDF_HIP_ROWS_PER_BLOCK="64")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "NVERT" in out.stdout and int(out.stdout.split("NVERT")[1].split()[0]) > 30000
+
+
 def test_marching_cubes_empty_and_global_transform(gpu):
     vol, sc = make_volume(32)
     vol.reset()
