@@ -235,11 +235,12 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
   for (int a = 0; a < 3; ++a) {
     build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
-    // pad the x table so float4 loads of the last (partial) quad stay in bounds
-    const size_t len = (size_t)p->res[a] + 4;
-    TRY_OR_BAIL(hipMalloc(&v->ctr[a], len * sizeof(float)));
-    TRY_OR_BAIL(hipMemset(v->ctr[a], 0, len * sizeof(float)));
-    TRY_OR_BAIL(hipMemcpy(v->ctr[a], v->h_ctr[a].data(), p->res[a] * sizeof(float), hipMemcpyHostToDevice));
+    // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
+    // fails k_integrate's sensor-range test, so voxels of the pitch padding are never observed
+    std::vector<float> padded(v->h_ctr[a]);
+    padded.resize((size_t)p->res[a] + 4, NAN);
+    TRY_OR_BAIL(hipMalloc(&v->ctr[a], padded.size() * sizeof(float)));
+    TRY_OR_BAIL(hipMemcpy(v->ctr[a], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   const size_t npx = (size_t)p->image_width * p->image_height;
   TRY_OR_BAIL(hipMalloc(&v->frame_depth, npx * sizeof(float)));

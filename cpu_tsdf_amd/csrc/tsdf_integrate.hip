@@ -26,6 +26,8 @@ struct IntegrateArgs {
   double fx, fy, cx, cy;
   float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path)
   float band_u, band_v;      // half-width of the "too close to an integer to trust fp32" zone, in pixels
+  float hb_u, hb_v;          // 1/2 - band
+  int neg_in_window;         // max_dist_pos/neg inside the scale-free divider's window
   float zmin, zmax;   // min/max_sensor_dist_
   float pos, neg;     // max_dist_pos_/neg_
   float wmax;         // max_weight_
@@ -66,32 +68,28 @@ static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, floa
 // The same in fp32, with a certificate.  R~ = (g*f~)*rcp(z) + c~ differs from the reference's double
 // value R by less than `band` whenever R~ lies in [-1-band, W+band] (derivation in DESIGN.md: three
 // roundings of 2^-24, v_rcp_f32's 1 ulp taken as 2^-22, fx/cx conversion, the final add; host computes
-// band with a 1.5x margin).  Therefore: R~ outside that interval => the pixel is outside the image in
-// the reference too; R~ farther than band from every integer => trunc(R~) == trunc(R).  Anything else
-// (including a non-finite R~) is flagged ambiguous and recomputed by project_exact.
+// band with a 1.5x margin).  Therefore:
+//   * trunc(R~) outside [-1, W]  =>  R~ outside that interval  =>  R is outside the image too;
+//   * R~ farther than band from every integer (|fract(R~) - 1/2| < 1/2 - band)  =>  trunc(R~) == trunc(R).
+// Anything else (including a non-finite R~, whose fract is 0 or NaN) is flagged ambiguous and recomputed
+// by project_exact.  hb = 1/2 - band.
 static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float gx, float gy, float gz,
                                                    bool &ambiguous) {
   const float y = __builtin_amdgcn_rcpf(gz);
   const float ru = (gx * a.fxf) * y + a.cxf;
   const float rv = (gy * a.fyf) * y + a.cyf;
-  const bool out_u = ru < -1.f - a.band_u || ru > (float)a.W + a.band_u;
-  const bool out_v = rv < -1.f - a.band_v || rv > (float)a.H + a.band_v;
-  const bool far_u = fabsf(ru - rintf(ru)) > a.band_u;  // false for NaN/Inf
-  const bool far_v = fabsf(rv - rintf(rv)) > a.band_v;
-  const bool out = out_u || out_v;
-  ambiguous = !out && !(far_u && far_v);
-  const int u = (int)ru, v = (int)rv;
-  const bool in = !out && (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
+  const bool cert = fabsf(__builtin_amdgcn_fractf(ru) - 0.5f) < a.hb_u &&
+                    fabsf(__builtin_amdgcn_fractf(rv) - 0.5f) < a.hb_v;  // false for NaN
+  const int u = (int)ru, v = (int)rv;  // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+  const bool near = (unsigned)u + 1u < (unsigned)a.W + 2u && (unsigned)v + 1u < (unsigned)a.H + 2u;
+  ambiguous = near && !cert;
+  const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? v * a.W + u : -1;
 }
 
-// Is |v| inside the exponent window where the scale/fixup-free divider is exact (tsdf_div.h)?
-static __device__ __forceinline__ bool in_window(float v) {
-  const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
-  return b - 0x2b800000u <= 0x53800000u - 0x2b800000u;  // 2^-40 <= |v| <= 2^40
-}
-
-// Branch-free divider for operands already known to be in the window (or a == +0).
+// Scale-free divider (LLVM's fp32 division ladder without v_div_scale / v_div_fixup) for a divisor
+// prepared by rcp32_prepare.  Exact (== IEEE) when the divisor is in [2^-40, 2^40] and the numerator is +0
+// or has magnitude in [2^-100, 2^40]: nothing in the ladder can then overflow, underflow or go denormal.
 static __device__ __forceinline__ float div32_fast(float a, const Rcp32 &r) {
   const float q0 = a * r.y;
   const float r0 = __builtin_fmaf(r.nb, q0, a);
@@ -100,18 +98,20 @@ static __device__ __forceinline__ float div32_fast(float a, const Rcp32 &r) {
   return __builtin_fmaf(r1, r.y, q1);
 }
 
+static __device__ __forceinline__ bool numerator_ok(float v) {  // +0, or 2^-100 <= |v| <= 2^40 (no NaN/Inf)
+  const float m = fabsf(v);
+  return (m >= 0x1p-100f && m <= 0x1p40f) || __float_as_uint(v) == 0u;
+}
+
 // OctreeNode::addObservation with w_new = 1 (octree.cpp:152-163; both weightings of hpp:200-204 are
 // unreachable: no setter for weight_by_depth_/weight_by_variance_), and RGBNode::addObservation
 // (octree.cpp:328-337): per channel (uint8)((w*c + w_new*c_new)/(w+w_new)) with the OLD w, truncating.
-// All four quotients share the divisor w + 1.  FAST = scale-free shared-reciprocal ladder, valid when
-// update_is_safe(); otherwise the compiler's full IEEE division.
-template <bool COLOR, bool FAST>
-static __device__ __forceinline__ void add_observation(float &d, float &w, uint32_t &rgb, float dn,
-                                                       uint32_t bgra, float wmax) {
+// General version: the compiler's full IEEE divisions.
+template <bool COLOR>
+static __device__ __forceinline__ void add_observation_ieee(float &d, float &w, uint32_t &rgb, float dn,
+                                                            uint32_t bgra, float wmax) {
   const float wn = 1.f;
   const float wsum = w + wn;
-  Rcp32 rs;
-  if (FAST) rs = rcp32_prepare(wsum);
   if (COLOR) {
     uint32_t out = 0;
 #pragma unroll
@@ -119,30 +119,45 @@ static __device__ __forceinline__ void add_observation(float &d, float &w, uint3
       const float c_old = (float)((rgb >> (8 * ch)) & 255u);
       const float c_new = (float)((bgra >> (16 - 8 * ch)) & 255u);  // PCL b,g,r,a -> r,g,b
       const float num = w * c_old + wn * c_new;
-      const float q = FAST ? div32_fast(num, rs) : num / wsum;
-      out |= ((uint32_t)(uint8_t)q) << (8 * ch);
+      out |= ((uint32_t)(uint8_t)(num / wsum)) << (8 * ch);
     }
     rgb = out;
   }
-  const float num = d * w + dn * wn;
-  d = FAST ? div32_fast(num, rs) : num / wsum;
+  d = (d * w + dn * wn) / wsum;
   w = wsum;
   if (w > wmax) w = wmax;
 }
 
-// Conditions under which every quotient of add_observation<FAST> equals IEEE division bit for bit:
-// w == +0 or 2^-20 <= w <= 2^30 (then w+1 and every colour numerator w*c + c_new, c in 0..255, is +0
-// or inside the window) and the distance numerator d*w + dn is +0 or inside the window.
-static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn) {
-  const uint32_t wb = __float_as_uint(w);
-  const bool w_ok = wb == 0u || (wb - 0x35800000u <= 0x4e800000u - 0x35800000u);
-  const float num = d * w + dn;
-  const bool n_ok = __float_as_uint(num) == 0u || in_window(num);
-  return w_ok && n_ok;
+// Fast version, valid when update_is_safe(): w is an INTEGER in [0, 1024] and the distance numerator
+// passes numerator_ok().
+//  * distance: shared-reciprocal scale-free ladder == IEEE division (tests/test_div_gpu.py).
+//  * colour: N = w*c_old + c_new is an exact integer < 2^18 and D = w + 1 an integer <= 1025, so the
+//    reference's (uint8)fl(N/D) equals floor(N/D): fl() moves the quotient by < 2^-24 * 256, far less than
+//    the 1/D that separates a non-integer N/D from the next integer.  floor(N/D) is computed as
+//    trunc(fma(N, y, y/2)) = trunc((N + 1/2) * y): the true value lies >= 1/(2D) >= 4.8e-4 from the integers
+//    on either side, the two roundings and y's error move it by < 256 * 2^-23 = 3.1e-5.
+template <bool COLOR>
+static __device__ __forceinline__ void add_observation_fast(float &d, float &w, uint32_t &rgb, float dn,
+                                                            uint32_t bgra, float wmax) {
+  const float wsum = w + 1.f;
+  const Rcp32 rs = rcp32_prepare(wsum);
+  if (COLOR) {
+    const float hy = 0.5f * rs.y;
+    const uint32_t q0 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
+    const uint32_t q1 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 8) & 255u), (float)((bgra >> 8) & 255u)), rs.y, hy);
+    const uint32_t q2 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 16) & 255u), (float)(bgra & 255u)), rs.y, hy);
+    rgb = q0 | (q1 << 8) | (q2 << 16);
+  }
+  d = div32_fast(d * w + dn, rs);
+  w = wsum;
+  if (w > wmax) w = wmax;
 }
 
-// One quad (4 x-consecutive voxels of one row).  FASTPROJ selects the certified fp32 projection with
-// exact fallback; otherwise every voxel goes through project_exact.
+static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn) {
+  const bool w_ok = fabsf(w - 512.f) <= 512.f && __builtin_amdgcn_fractf(w) == 0.f;  // integer in [0, 1024]
+  return w_ok && numerator_ok(d * w + dn);
+}
+
 template <typename V>
 static __device__ __forceinline__ V ld_plane(const V *p, bool nt) {
   return nt ? __builtin_nontemporal_load(p) : *p;
@@ -155,7 +170,12 @@ static __device__ __forceinline__ void st_plane(V *p, V v, bool nt) {
     *p = v;
 }
 
-template <int ORDER, bool COLOR, bool SKIP, bool FASTPROJ>
+// One quad (4 x-consecutive voxels of one row).  FASTPROJ selects the certified fp32 projection with
+// exact fallback; otherwise every voxel goes through project_exact.  The x centre table is padded with
+// NaN beyond nx, which fails the range test, so a partial last quad needs no extra predicate.
+// Planes whose four values did not change are not written back (free space: d stays at the hinge value;
+// after weight saturation nothing changes).
+template <int ORDER, bool COLOR, bool FASTPROJ>
 static __device__ __forceinline__ unsigned
 integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, const Rcp32 &rneg,
                float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
@@ -180,13 +200,14 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
   };
   Obs obs[4];
   unsigned amb_mask = 0;
-  bool any = false;
+  bool any = false, lowz = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float gx = transform(cxs[j], 0), gy = transform(cxs[j], 1), gz = transform(cxs[j], 2);
     // hpp:146  if (v_g.z < min_sensor_dist_ || v_g.z > max_sensor_dist_) return 0;  .cpp:616  pt.z > 0
-    const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f && (x4 + j < a.nx);
+    const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f;
     obs[j].gz = gz;
+    lowz |= in && gz < 0x1p-14f;
     int pix;
     if (FASTPROJ) {
       bool amb;
@@ -217,13 +238,16 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
     obs[j].z = 0.f;
     obs[j].c = 0u;
     if (obs[j].pix >= 0) {
-      obs[j].z = depth[obs[j].pix];
-      if (COLOR) obs[j].c = bgra[obs[j].pix];
+      obs[j].z = depth[(unsigned)obs[j].pix];
+      if (COLOR) obs[j].c = bgra[(unsigned)obs[j].pix];
     }
   }
   // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
+  // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
+  // at least 2^-39 in magnitude (difference of two floats one of which is >= 2^-14), and at most
+  // max(pos, neg); the host checks pos/neg against the window.
   float dn[4];
-  bool act[4], band_safe = true;
+  bool act[4];
   any = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -231,11 +255,10 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
     act[j] = obs[j].pix >= 0 && !isnan(obs[j].z) && !(raw < -a.neg);   // hpp:152, :193-196
     const bool clamped = raw > a.pos;                                  // hpp:189-192
     dn[j] = clamped ? a.pos_over_neg : div32_fast(raw, rneg);          // hpp:198
-    band_safe &= !act[j] || clamped || __float_as_uint(raw) == 0u || in_window(raw);
     any |= act[j];
   }
   if (!any) return 0;
-  if (!band_safe) {  // operands outside the scale-free window: redo with the compiler's IEEE division
+  if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (act[j] && !(obs[j].z - obs[j].gz > a.pos)) dn[j] = (obs[j].z - obs[j].gz) / a.neg;
@@ -262,7 +285,7 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
       dv[j] = d0[j];
       wv[j] = w0[j];
       cv[j] = c0[j];
-      add_observation<COLOR, true>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
+      add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
     }
   } else {
 #pragma unroll
@@ -270,7 +293,7 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
       dv[j] = d0[j];
       wv[j] = w0[j];
       cv[j] = c0[j];
-      add_observation<COLOR, false>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
+      add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
     }
   }
   bool chg_d = false, chg_w = false, chg_c = false;
@@ -285,17 +308,16 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
     chg_c |= cv[j] != c0[j];
     cnt += act[j] ? 1u : 0u;
   }
-  if (!SKIP || chg_d) st_plane(reinterpret_cast<f4 *>(D + idx), (f4){dv[0], dv[1], dv[2], dv[3]}, nt);
-  if (!SKIP || chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
-  if (COLOR && (!SKIP || chg_c)) st_plane(reinterpret_cast<u4 *>(RGB + idx), (u4){cv[0], cv[1], cv[2], cv[3]}, nt);
+  if (chg_d) st_plane(reinterpret_cast<f4 *>(D + idx), (f4){dv[0], dv[1], dv[2], dv[3]}, nt);
+  if (chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
+  if (COLOR && chg_c) st_plane(reinterpret_cast<u4 *>(RGB + idx), (u4){cv[0], cv[1], cv[2], cv[3]}, nt);
   return cnt;
 }
 
 // Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
 // blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
-// SKIP = do not write back planes whose four values did not change (free space: d stays at the hinge
-// value; after weight saturation nothing changes).  COUNT = accumulate the observed-voxel counter.
-template <int ORDER, bool COLOR, bool SKIP, bool FASTPROJ, bool COUNT>
+// COUNT = accumulate the observed-voxel counter.
+template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT>
 static __global__ void __launch_bounds__(256)
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
@@ -317,7 +339,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const int y = y0 + r * a.TY;
       if (y >= a.ny) break;
       const int64_t idx = (plane_base + y) * a.pitch + x4;
-      cnt += integrate_quad<ORDER, COLOR, SKIP, FASTPROJ>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, depth, bgra,
+      cnt += integrate_quad<ORDER, COLOR, FASTPROJ>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, depth, bgra,
                                                           ctrx);
     }
   }
@@ -362,6 +384,8 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
     };
     a.band_u = band(p.cx, p.image_width);
     a.band_v = band(p.cy, p.image_height);
+    a.hb_u = nextafterf(0.5f - a.band_u, 0.f);  // rounded toward the conservative side
+    a.hb_v = nextafterf(0.5f - a.band_v, 0.f);
   }
   a.zmin = p.min_sensor_dist;
   a.zmax = p.max_sensor_dist;
@@ -369,6 +393,7 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   a.neg = p.max_dist_neg;
   a.wmax = p.max_weight;
   a.pos_over_neg = p.max_dist_pos / p.max_dist_neg;
+  a.neg_in_window = p.max_dist_neg >= 0x1p-20f && p.max_dist_neg <= 0x1p20f && p.max_dist_pos <= 0x1p20f;
   a.W = p.image_width;
   a.H = p.image_height;
   a.nx = h->nx;
@@ -420,32 +445,24 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   bool pose_ok = true;
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
   const bool fastproj = fast_projection_ok(a, p.integrate_color != 0);
-  const bool skip = tsdf_tuning().skip_unchanged != 0;
   if (pose_ok) {
     const dim3 grid(gx, gy, gz), block(256);
-#define LAUNCH(ORDER, COLOR, SKIP, FP, COUNT)                                                                  \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, SKIP, FP, COUNT>), grid, block, 0, h->stream, a, h->d, h->w, \
+#define LAUNCH(ORDER, COLOR, FP, COUNT)                                                                 \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT>), grid, block, 0, h->stream, a, h->d, h->w, \
                      h->rgb, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
-#define L4(ORDER, COLOR, SKIP, FP) \
-  do {                             \
-    if (count)                     \
-      LAUNCH(ORDER, COLOR, SKIP, FP, true);  \
-    else                           \
-      LAUNCH(ORDER, COLOR, SKIP, FP, false); \
-  } while (0)
-#define L3(ORDER, COLOR, SKIP) \
-  do {                         \
-    if (fastproj)              \
-      L4(ORDER, COLOR, SKIP, true);  \
-    else                       \
-      L4(ORDER, COLOR, SKIP, false); \
+#define L4(ORDER, COLOR, FP) \
+  do {                       \
+    if (count)               \
+      LAUNCH(ORDER, COLOR, FP, true);  \
+    else                     \
+      LAUNCH(ORDER, COLOR, FP, false); \
   } while (0)
 #define L2(ORDER, COLOR) \
   do {                   \
-    if (skip)            \
-      L3(ORDER, COLOR, true);  \
+    if (fastproj)        \
+      L4(ORDER, COLOR, true);  \
     else                 \
-      L3(ORDER, COLOR, false); \
+      L4(ORDER, COLOR, false); \
   } while (0)
     if (p.xform_order == TSDF_XFORM_PCL_SSE) {
       if (color)
@@ -459,7 +476,6 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
         L2(TSDF_XFORM_LEFT_TO_RIGHT, false);
     }
 #undef L2
-#undef L3
 #undef L4
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
