@@ -65,6 +65,9 @@ SIGNATURES = {
     "tsdf_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _u8p, _f32p, _u64p]),
     "tsdf_hip_integrate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
+    "tsdf_hip_raycast_begin": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_void_p]),
+    "tsdf_hip_raycast_advance": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tsdf_hip_render_halo": (C.c_int, [C.POINTER(TsdfParams)]),
     "tsdf_hip_sample": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]),
     "tsdf_hip_march": (C.c_int, [C.c_void_p, C.c_float, C.c_int, _u64p]),
     "tsdf_hip_march_fetch": (C.c_int, [C.c_void_p, _f32p, _u8p, _u64p]),
@@ -85,6 +88,9 @@ SIGNATURES = {
     "tsdf_hip_device_count": (C.c_int, []),
     "tsdf_hip_abi_version": (C.c_int, []),
 }
+
+
+RAY_RECORD_INTS = 24  # TSDF_HIP_RAY_RECORD_INTS
 
 
 def load():

@@ -76,10 +76,12 @@ static __device__ __forceinline__ int axis_index(const GridView &g, int a, float
 // Octree::getContainingVoxel (octree.cpp:628-643) on a fully refined tree; false == NULL.
 // `local` reports whether the voxel's plane is held by this handle (always true for a whole grid).
 static __device__ __forceinline__ bool containing(const GridView &g, float x, float y, float z, int64_t &vi,
-                                                  bool &local) {
+                                                  bool &local, int &k) {
   local = true;
+  k = -1;
   if (isnan(z) || fabsf(x) > g.half[0] || fabsf(y) > g.half[1] || fabsf(z) > g.half[2]) return false;
-  const int i = axis_index(g, 0, x), j = axis_index(g, 1, y), k = axis_index(g, 2, z);
+  const int i = axis_index(g, 0, x), j = axis_index(g, 1, y);
+  k = axis_index(g, 2, z);
   const int kl = k - g.z_first;
   local = kl >= 0 && kl < g.nz_alloc;
   vi = ((int64_t)(local ? kl : 0) * g.ny + j) * g.pitch + i;
@@ -164,36 +166,107 @@ struct RayArgs {
   float leaf;         // finest leaf size_ (size_x halved L times; getMinSize/getSize, octree.cpp:58-78)
 };
 
+// Ray hand-off between Z-slab handles (multi-GPU renderView).  A ray's step sequence depends on the last
+// voxel it visited, so slabs cannot march it independently; instead the ray's loop state travels.  One
+// record per ray, TSDF_HIP_RAY_RECORD_INTS 32-bit words:
+//   [0] status: 0 untouched (only in a delta buffer), 1 suspended, 2 finished
+//   [1] need_z: global plane of the voxel the main loop needs next (-1: none yet)
+//   [2] niter  [3] hit_voxel  [4] t  [5..7] pt  [8] last_d  [9] last_w  [10] step  [11..15] zero
+//   [16..23] the 8 output floats (valid when finished)
+// k_raycast<true> resumes every suspended ray this handle is responsible for -- need_z inside its OWNED
+// planes [z_begin, z_end), or ray index % world == rank while the ray has not needed a voxel yet -- and
+// marches it until it finishes or its main loop reaches a voxel of another slab.  The refinement walk
+// (:326-356) and the final trilinear samples read up to `halo` planes beyond the owned range; a read
+// outside the allocated planes sets `incomplete` (the caller then asks for a larger halo).
+struct RaySlab {
+  int rank, world, z_begin, z_end;
+};
+#define RAY_REC TSDF_HIP_RAY_RECORD_INTS
+
+static __device__ __forceinline__ void ray_direction(const RayArgs &a, int64_t i, float du[3]) {
+  const size_t x = (size_t)(i % a.nw), y = (size_t)(i / a.nw);
+  du[0] = (float)((x - a.ncx) / a.nfx);
+  du[1] = (float)((y - a.ncy) / a.nfy);
+  du[2] = 1.f;
+  normalize3(du);
+  // du = R * du: each coefficient p0 + (p1 + p2) [Eigen-recall 3.3 reduction tree]
+  const float p = du[0], q = du[1], r = du[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) du[k] = a.rot[3 * k] * p + (a.rot[3 * k + 1] * q + a.rot[3 * k + 2] * r);
+}
+
+// The state every ray starts from (:305-313).
+static __global__ void __launch_bounds__(256) k_ray_begin(const RayArgs a, int *__restrict__ state) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.nw * a.nh) return;
+  float du[3];
+  ray_direction(a, i, du);
+  int *r = state + RAY_REC * i;
+  const float t = a.zmin;
+  r[0] = 1;
+  r[1] = -1;
+  r[2] = 0;
+  r[3] = 0;
+  r[4] = __float_as_int(t);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float pt = a.org[k];
+    pt += t * du[k];
+    r[5 + k] = __float_as_int(pt);
+  }
+  r[8] = r[9] = 0;  // last_d, last_w = 0.f
+  r[10] = __float_as_int(a.min_step);
+  for (int k = 11; k < RAY_REC; ++k) r[k] = 0;
+}
+
 // renderView, tsdf_volume_octree.cpp:290-421, one ray per thread.  The while loop runs until every lane
 // of the wavefront has left it (the hardware's exec-mask loop is the ballot); a finished lane idles.
 // out: 8 floats per pixel: x,y,z, nx,ny,nz, t (t_star on a hit), iterations; `incomplete` counts rays
 // that touched a plane this handle does not hold (only possible for Z-slab handles).
+// RESUMABLE: see RaySlab above; `out` is unused, results go to the ray's record in `delta`.
+template <bool RESUMABLE>
 static __global__ void __launch_bounds__(256)
-k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *__restrict__ incomplete) {
+k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *__restrict__ incomplete,
+          const int *__restrict__ state, int *__restrict__ delta, const RaySlab rs) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)a.nw * a.nh) return;
-  const size_t x = (size_t)(i % a.nw), y = (size_t)(i / a.nw);
-  float *o = out + 8 * i;
   bool found_crossing = false, all_local = true;
-  float du[3] = {(float)((x - a.ncx) / a.nfx), (float)((y - a.ncy) / a.nfy), 1.f};
-  normalize3(du);
-  {  // du = R * du: each coefficient p0 + (p1 + p2) [Eigen-recall 3.3 reduction tree]
-    const float p = du[0], q = du[1], r = du[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) du[k] = a.rot[3 * k] * p + (a.rot[3 * k + 1] * q + a.rot[3 * k + 2] * r);
-  }
+  float du[3];
+  ray_direction(a, i, du);
   float pt[3] = {a.org[0], a.org[1], a.org[2]};
   float dd = 0, ww = 0, last_w = 0, last_d = 0;
   float t = a.zmin;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
   float step = a.min_step;
   bool hit_voxel = false;
   int niter = 0;
+  if (RESUMABLE) {
+    const int *r = state + RAY_REC * i;
+    if (r[0] != 1) return;
+    const int need_z = r[1];
+    const bool mine = need_z < 0 ? (int)(i % rs.world) == rs.rank : (need_z >= rs.z_begin && need_z < rs.z_end);
+    if (!mine) return;
+    niter = r[2];
+    hit_voxel = r[3] != 0;
+    t = __int_as_float(r[4]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pt[k] = __int_as_float(r[5 + k]);
+    last_d = __int_as_float(r[8]);
+    last_w = __int_as_float(r[9]);
+    step = __int_as_float(r[10]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
+  }
+  int suspend_z = -1;
   while (t < a.zmax) {
     int64_t vi;
     bool local;
-    if (containing(g, pt[0], pt[1], pt[2], vi, local)) {
+    int kz;
+    if (containing(g, pt[0], pt[1], pt[2], vi, local, kz)) {
+      if (RESUMABLE && (kz < rs.z_begin || kz >= rs.z_end)) {  // another slab's voxel: hand the ray over
+        suspend_z = kz;
+        break;
+      }
       all_local = all_local && local;
       hit_voxel = true;
       dd = local ? g.d[vi] : -1.f;
@@ -207,7 +280,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
           t -= step;
 #pragma unroll
           for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
-          if (!containing(g, pt[0], pt[1], pt[2], vi, local)) break;
+          if (!containing(g, pt[0], pt[1], pt[2], vi, local, kz)) break;
           all_local = all_local && local;
           const float new_d = local ? g.d[vi] : -1.f, new_w = local ? g.w[vi] : 0.f;
           if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
@@ -237,6 +310,21 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
     niter++;
   }
+  int *rec = RESUMABLE ? delta + RAY_REC * i : nullptr;
+  if (RESUMABLE) {
+    rec[1] = suspend_z;
+    rec[2] = niter;
+    rec[3] = hit_voxel ? 1 : 0;
+    rec[4] = __float_as_int(t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[5 + k] = __float_as_int(pt[k]);
+    rec[8] = __float_as_int(last_d);
+    rec[9] = __float_as_int(last_w);
+    rec[10] = __float_as_int(step);
+    rec[0] = suspend_z >= 0 ? 1 : 2;
+    if (suspend_z >= 0) return;
+  }
+  float *o = RESUMABLE ? reinterpret_cast<float *>(rec + 16) : out + 8 * i;
   o[3] = o[4] = o[5] = 0.f;
   o[6] = t;
   o[7] = (float)niter;
@@ -256,7 +344,8 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     o[6] = t_star;
     int64_t vi;
     bool local;
-    if (!containing(g, o[0], o[1], o[2], vi, local)) {
+    int kz;
+    if (!containing(g, o[0], o[1], o[2], vi, local, kz)) {
       o[3] = o[4] = o[5] = NAN;
     } else {
       const float s = a.leaf;
@@ -284,12 +373,8 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
   if (!all_local) atomicAdd(incomplete, 1u);
 }
 
-extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
-                                float *out) {
-  if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+static int make_ray_args(tsdf_handle h, const float rot[9], const float origin[3], int downsample, RayArgs &a) {
   const tsdf_params &p = h->p;
-  RayArgs a;
   for (int i = 0; i < 9; ++i) a.rot[i] = rot[i];
   for (int i = 0; i < 3; ++i) a.org[i] = origin[i];
   a.nw = p.image_width / downsample;
@@ -311,15 +396,24 @@ extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float o
       s = p.size[0] / p.res[0];
     a.leaf = s;
   }
+  return (int64_t)a.nw * a.nh > 0 ? TSDF_HIP_OK : TSDF_HIP_E_INVALID;
+}
+
+extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                float *out) {
+  if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  RayArgs a;
+  if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   const int64_t n = (int64_t)a.nw * a.nh;
-  if (n <= 0) return TSDF_HIP_E_INVALID;
   int rc = tsdf_ensure_scratch(h, (size_t)n * 8 * sizeof(float) + 16);
   if (rc) return rc;
   float *d_out = (float *)h->scratch;
   unsigned *d_inc = (unsigned *)((char *)h->scratch + (size_t)n * 8 * sizeof(float));
   TSDF_HIP_TRY(hipMemsetAsync(d_inc, 0, sizeof(unsigned), h->stream));
   const GridView g = make_view(h);
-  hipLaunchKernelGGL(k_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a, d_out, d_inc);
+  hipLaunchKernelGGL(k_raycast<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a, d_out, d_inc,
+                     (const int *)nullptr, (int *)nullptr, RaySlab{0, 1, 0, 0});
   TSDF_HIP_TRY(hipGetLastError());
   unsigned inc = 0;
   TSDF_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -330,6 +424,62 @@ extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float o
     return TSDF_HIP_E_UNSUPPORTED;
   }
   return TSDF_HIP_OK;
+}
+
+// Multi-slab renderView: ray records on the DEVICE (see RaySlab).  begin fills the start state of every
+// ray; advance zero-fills `d_delta`, resumes the rays this handle is responsible for and writes their new
+// records there.  The caller sums the deltas of all ranks (integer all-reduce: every ray is advanced by
+// exactly one rank) and overwrites the touched records.
+extern "C" int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                      int32_t *d_state) {
+  if (!h || !rot || !origin || !d_state || downsample < 1) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  RayArgs a;
+  if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  const int64_t n = (int64_t)a.nw * a.nh;
+  hipLaunchKernelGGL(k_ray_begin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, (int *)d_state);
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                        int rank, int world, const int32_t *d_state, int32_t *d_delta) {
+  if (!h || !rot || !origin || !d_state || !d_delta || downsample < 1 || world < 1 || rank < 0 || rank >= world)
+    return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  RayArgs a;
+  if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  const int64_t n = (int64_t)a.nw * a.nh;
+  int rc = tsdf_ensure_scratch(h, 16);
+  if (rc) return rc;
+  unsigned *d_inc = (unsigned *)h->scratch;
+  TSDF_HIP_TRY(hipMemsetAsync(d_inc, 0, sizeof(unsigned), h->stream));
+  TSDF_HIP_TRY(hipMemsetAsync(d_delta, 0, (size_t)n * RAY_REC * sizeof(int32_t), h->stream));
+  const GridView g = make_view(h);
+  hipLaunchKernelGGL(k_raycast<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a,
+                     (float *)nullptr, d_inc, (const int *)d_state, (int *)d_delta,
+                     RaySlab{rank, world, h->z_begin, h->z_end});
+  TSDF_HIP_TRY(hipGetLastError());
+  unsigned inc = 0;
+  TSDF_HIP_TRY(hipMemcpyAsync(&inc, d_inc, sizeof inc, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (inc) {
+    tsdf_set_error("ray hand-off: the refinement walk / trilinear samples left this handle's halo planes; "
+                   "create the slab with a larger halo (tsdf_hip_render_halo)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  return TSDF_HIP_OK;
+}
+
+// Planes of halo a Z-slab handle needs on each side for tsdf_hip_raycast_advance: the refinement walk goes
+// back at most one main-loop step (<= max(leaf/4, max_dist_neg) for |d| <= 1) plus one refinement step,
+// and the trilinear / central-difference samples reach two more voxels.
+extern "C" int tsdf_hip_render_halo(const tsdf_params *p) {
+  if (!p || p->res[2] <= 0 || !(p->size[2] > 0)) return -1;
+  const double vs = (double)p->size[2] / p->res[2];
+  const double leaf = (double)p->size[0] / p->res[0];
+  const double step = std::max(leaf / 4, (double)p->max_dist_neg);
+  return (int)ceil(step / vs) + 4;
 }
 
 // ---------------------------------------------------------------------------------------------

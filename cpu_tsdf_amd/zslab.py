@@ -11,9 +11,14 @@ independent during integration, so the grid is cut into contiguous Z-slabs and t
   meshes its own cells, and the per-rank triangle lists are merged by the reference's Morton key;
 * ``sample`` (getFxn...): a point is answered by the rank that owns the lower-corner plane.
 
-``renderView`` needs each ray's step sequence to continue across slab boundaries (the step rule depends
-on the last voxel visited); it is implemented for world_size == 1 and refuses otherwise (DESIGN.md,
-"what comes next").
+* ``renderView``: a ray's step sequence depends on the last voxel it visited (tsdf_volume_octree.cpp:360),
+  so slabs cannot march a ray independently and take the nearest hit.  Instead the ray's loop state
+  travels: every rank resumes the rays whose next voxel it owns until they finish or reach another slab
+  (``tsdf_hip_raycast_advance``), the per-rank deltas are merged by ONE integer SUM all-reduce per round
+  (each ray is advanced by exactly one rank), and this repeats until no ray is suspended -- at most
+  world + 1 rounds, since a ray crosses the slabs monotonically in z.  The refinement walk of a hit and
+  its trilinear samples look back/around by up to ``render_halo`` planes, which every rank refreshes from
+  both neighbours before rendering.  Results are bit-identical to the single-GPU kernel.
 
 The slab backend is injected (``slab_factory``) so the N > 1 logic is testable on CPU with gloo; the
 default backend is the HIP volume.  There is no CPU fallback in the product: the default factory raises
@@ -55,10 +60,11 @@ def morton_x_major(cells):
 
 
 class HipSlab:
-    """Slab backend on one MI355X: a TSDFVolumeOctree restricted to [z_begin, z_end) (+ one halo plane
-    above for marching cubes / sampling), exchanging planes as torch CUDA tensors."""
+    """Slab backend on one MI355X: a TSDFVolumeOctree restricted to [z_begin, z_end) (+ `halo` planes on each
+    side: 1 for marching cubes / sampling, tsdf_hip_render_halo() for renderView), exchanging planes as
+    torch CUDA tensors."""
 
-    def __init__(self, configure, z_begin, z_end, nz, device_index):
+    def __init__(self, configure, z_begin, z_end, nz, device_index, halo=1):
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.vol = TSDFVolumeOctree()
@@ -66,7 +72,7 @@ class HipSlab:
         self.res = self.vol.getResolution()
         self.color = bool(self.vol._p.integrate_color)
         self.z_begin, self.z_end = z_begin, z_end
-        self.vol.setZSlab(z_begin, z_end, halo=1 if z_end < nz else 0, device=device_index)
+        self.vol.setZSlab(z_begin, z_end, halo=halo if (z_end < nz or z_begin > 0) else 0, device=device_index)
         self.vol.setStream(torch.cuda.current_stream(self.device).cuda_stream)
         self.vol.reset()
 
@@ -115,6 +121,32 @@ class HipSlab:
     def render(self, trans, ds):
         return self.vol.renderView(trans, ds)
 
+    @staticmethod
+    def _rot_org(trans):
+        trans = np.asarray(trans, dtype=np.float64)
+        return (np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9)),
+                np.ascontiguousarray(trans[:3, 3].astype(np.float32)))
+
+    def ray_begin(self, trans, ds):
+        W, H = self.vol.getImageSize()
+        n = (H // ds) * (W // ds)
+        state = torch.empty((n, capi.RAY_RECORD_INTS), dtype=torch.int32, device=self.device)
+        rot, org = self._rot_org(trans)
+        capi.check(capi.load().tsdf_hip_raycast_begin(self.vol._need(), capi.as_f32p(rot), capi.as_f32p(org), ds,
+                                                      C.c_void_p(state.data_ptr())), "raycast_begin")
+        return state
+
+    def ray_advance(self, trans, ds, state, rank, world):
+        delta = torch.empty_like(state)
+        rot, org = self._rot_org(trans)
+        capi.check(capi.load().tsdf_hip_raycast_advance(self.vol._need(), capi.as_f32p(rot), capi.as_f32p(org), ds,
+                                                        rank, world, C.c_void_p(state.data_ptr()),
+                                                        C.c_void_p(delta.data_ptr())), "raycast_advance")
+        return delta
+
+    def image_size(self):
+        return self.vol.getImageSize()
+
     def synchronize(self):
         self.vol.synchronize()
 
@@ -122,10 +154,17 @@ class HipSlab:
         self.vol.close()
 
 
-def _default_factory(configure, z_begin, z_end, nz, rank):
+def _default_factory(configure, z_begin, z_end, nz, rank, halo=1):
     if capi.load().tsdf_hip_device_count() <= 0:
         raise RuntimeError("ZSlabVolume needs a HIP device per rank (there is no CPU fallback)")
-    return HipSlab(configure, z_begin, z_end, nz, int(torch.cuda.current_device()))
+    return HipSlab(configure, z_begin, z_end, nz, int(torch.cuda.current_device()), halo=halo)
+
+
+def render_halo(configure):
+    """Planes of halo per side that renderView across slabs needs for this configuration."""
+    probe = TSDFVolumeOctree()  # parameters only: no handle (and no GPU memory) until reset()
+    configure(probe)
+    return int(capi.load().tsdf_hip_render_halo(C.byref(probe._p)))
 
 
 class ZSlabVolume:
@@ -134,14 +173,18 @@ class ZSlabVolume:
     configure(vol) applies the usual setters (setResolution, setGridSize, ...) to a volume object; it is
     called once per rank.  All methods are collective: every rank calls them in the same order."""
 
-    def __init__(self, configure, resolution_z, group=None, slab_factory=None):
+    def __init__(self, configure, resolution_z, group=None, slab_factory=None, halo=None):
+        """halo: planes kept on each side of the slab; None = enough for renderView across slabs
+        (tsdf_hip_render_halo: ~12 planes at the default 3 cm truncation and 2^-8 m voxels); 1 is enough for
+        integrateCloud + reconstruct + sample only."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.nz = int(resolution_z)
         self.z_begin, self.z_end = slab_range(self.nz, self.world, self.rank)
         factory = slab_factory or _default_factory
-        self.slab = factory(configure, self.z_begin, self.z_end, self.nz, self.rank)
+        self.halo = 0 if self.world == 1 else (render_halo(configure) if halo is None else int(halo))
+        self.slab = factory(configure, self.z_begin, self.z_end, self.nz, self.rank, halo=self.halo)
         self._frame = self.slab.frame_buffers()
         self.global_transform = np.eye(4)
 
@@ -162,26 +205,42 @@ class ZSlabVolume:
         return True
 
     # -- marching cubes ---------------------------------------------------------------------------------
-    def exchange_halo(self):
-        """Every rank receives the first plane of its +z neighbour into its upper halo."""
+    def exchange_halo(self, planes=1, both=False):
+        """Every rank receives the first `planes` planes of its +z neighbour into its upper halo and, with
+        `both`, the last `planes` planes of its -z neighbour into its lower halo (point-to-point, one batch).
+        Slabs thinner than `planes` forward what they own; the rest of the halo then stays at its reset
+        value, and a ray that needs it fails loudly in tsdf_hip_raycast_advance."""
         if self.world == 1:
             return
-        ops, recv = [], None
-        if self.rank > 0:  # my first plane goes down to rank - 1
-            send = self.slab.get_planes(self.z_begin, 1)
-            self.slab.synchronize()
-            for t in send:
-                if t is not None:
-                    ops.append(dist.P2POp(dist.isend, t, self.rank - 1, self.group))
+        planes = min(int(planes), self.halo)
+        ops, recv_up, recv_dn = [], None, None
+        n_mine = min(planes, self.z_end - self.z_begin)
+        if self.rank > 0 and n_mine > 0:  # my first planes go down to rank - 1
+            send = self.slab.get_planes(self.z_begin, n_mine)
+            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self.group) for t in send if t is not None]
+        if both and self.rank < self.world - 1 and n_mine > 0:  # my last planes go up to rank + 1
+            send_up = self.slab.get_planes(self.z_end - n_mine, n_mine)
+            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self.group) for t in send_up if t is not None]
+        self.slab.synchronize()
         if self.rank < self.world - 1:
-            recv = self.slab.plane_buffers(1)
-            for t in recv:
-                if t is not None:
-                    ops.append(dist.P2POp(dist.irecv, t, self.rank + 1, self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        if recv is not None:
-            self.slab.set_planes(self.z_end, *recv)
+            nb = slab_range(self.nz, self.world, self.rank + 1)
+            n_up = min(planes, nb[1] - nb[0])
+            if n_up > 0:
+                recv_up = self.slab.plane_buffers(n_up)
+                ops += [dist.P2POp(dist.irecv, t, self.rank + 1, self.group) for t in recv_up if t is not None]
+        if both and self.rank > 0:
+            nb = slab_range(self.nz, self.world, self.rank - 1)
+            n_dn = min(planes, nb[1] - nb[0])
+            if n_dn > 0:
+                recv_dn = self.slab.plane_buffers(n_dn)
+                ops += [dist.P2POp(dist.irecv, t, self.rank - 1, self.group) for t in recv_dn if t is not None]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if recv_up is not None:
+            self.slab.set_planes(self.z_end, *recv_up)
+        if recv_dn is not None:
+            self.slab.set_planes(self.z_begin - recv_dn[0].shape[0], *recv_dn)
 
     def reconstruct(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0):
         """MarchingCubesTSDFOctree::reconstruct over all slabs.  Returns the merged mesh on rank `dst`
@@ -222,10 +281,34 @@ class ZSlabVolume:
             ok |= o
         return ok, val, grad, hess
 
-    def renderView(self, trans, downsampleBy=1):
-        if self.world != 1:
-            raise NotImplementedError("renderView across Z-slabs needs ray hand-off between ranks (DESIGN.md)")
-        return self.slab.render(trans, downsampleBy)
+    def renderView(self, trans, downsampleBy=1, camera_frame=True):
+        """TSDFVolumeOctree::renderView over all slabs (ray hand-off, see the module docstring).  Collective;
+        every rank returns the full (H/ds, W/ds, 8) image."""
+        if self.world == 1:
+            return self.slab.render(trans, downsampleBy)
+        from .volume import eigen_affine_inverse, transform_cloud_with_normals
+        trans = np.asarray(trans, dtype=np.float64)
+        ds = int(downsampleBy)
+        self.exchange_halo(self.halo, both=True)
+        state = self.slab.ray_begin(trans, ds)
+        self.last_render_rounds = 0
+        for _ in range(2 * self.world + 4):
+            delta = self.slab.ray_advance(trans, ds, state, self.rank, self.world)
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
+            state = torch.where(delta[:, :1] != 0, delta, state)
+            self.last_render_rounds += 1
+            if int((state[:, 0] == 1).sum().item()) == 0:
+                break
+        else:
+            raise RuntimeError("ray hand-off did not converge")
+        W, H = self.slab_image_size()
+        out = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(H // ds, W // ds, 8)
+        if camera_frame:
+            out = transform_cloud_with_normals(out, eigen_affine_inverse(trans))
+        return out
+
+    def slab_image_size(self):
+        return self.slab.image_size()
 
     def download_local(self):
         return self.slab.vol.download()

@@ -106,6 +106,29 @@ int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_
 int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
                      float *out);
 
+/* renderView across Z-slab handles (one handle per GPU): ray hand-off.  The reference's ray loop
+ * (tsdf_volume_octree.cpp:313-369) chooses each step from the voxel it last visited, so the loop state of a
+ * ray travels between the slabs it crosses instead of the voxels.  One record of
+ * TSDF_HIP_RAY_RECORD_INTS 32-bit words per ray, in DEVICE memory, row-major like the image:
+ *   [0] status (1 suspended, 2 finished; 0 = "not touched" in a delta buffer)   [1] global z plane of the
+ *   voxel the ray needs next, -1 before it needed any   [2] iterations   [3] hit_voxel   [4] t   [5..7] pt
+ *   [8] last_d   [9] last_w   [10] step   [11..15] zero   [16..23] the 8 output floats of tsdf_hip_raycast.
+ * tsdf_hip_raycast_begin   writes the start record of every ray (identical on every rank).
+ * tsdf_hip_raycast_advance zero-fills d_delta, then resumes every suspended ray of d_state that this
+ *   handle is responsible for (needed plane inside its OWNED slab; or ray index % world == rank while the
+ *   ray has not needed a voxel yet) until it finishes or needs another slab's voxel, and writes the new
+ *   record to d_delta.  Exactly one rank touches a ray per round, so the caller merges with an integer
+ *   SUM all-reduce of the deltas (RCCL) and overwrites the records whose status word is non-zero; it
+ *   repeats until no record is suspended.  The refinement walk and the trilinear samples of a hit read up
+ *   to tsdf_hip_render_halo(params) planes beyond the owned slab: create the handles with that halo and
+ *   refresh it (tsdf_hip_get/set_planes_device) before rendering.  Synchronises the stream. */
+#define TSDF_HIP_RAY_RECORD_INTS 24
+int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                           int32_t *d_state);
+int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                             int rank, int world, const int32_t *d_state, int32_t *d_delta);
+int tsdf_hip_render_halo(const tsdf_params *p);
+
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
  *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
  *   ok n bytes: 1 where the reference returns true. */

@@ -47,6 +47,10 @@ def lib():
         L.oracle_integrate.restype = C.c_uint64
         L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
         L.oracle_raycast.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, _f]
+        L.oracle_raycast_begin.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_int, C.c_void_p]
+        L.oracle_raycast_advance.restype = C.c_int
+        L.oracle_raycast_advance.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, C.POINTER(C.c_int),
+                                             C.c_void_p, C.c_void_p]
         L.oracle_sample_batch.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_size_t, _f, _f, _f, _u8]
         L.oracle_march.restype = C.c_uint64
         L.oracle_march.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, C.c_float, C.c_int, _f, _u8,
@@ -110,6 +114,31 @@ class OracleVolume:
         out = np.empty((nh, nw, 8), dtype=np.float32)
         lib().oracle_raycast(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, _fp(out))
         return out
+
+    RAY_REC = 24
+
+    def _rot_org(self, trans):
+        trans = np.asarray(trans, dtype=np.float64)
+        return (np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9)),
+                np.ascontiguousarray(trans[:3, 3].astype(np.float32)))
+
+    def raycast_begin(self, trans, ds=1):
+        """Start records of the multi-slab ray hand-off (include/tsdf_hip.h, tsdf_hip_raycast_begin)."""
+        rot, org = self._rot_org(trans)
+        n = (self.p.image_height // ds) * (self.p.image_width // ds)
+        state = np.empty((n, self.RAY_REC), dtype=np.int32)
+        lib().oracle_raycast_begin(C.byref(self.p), _fp(rot), _fp(org), ds, state.ctypes.data_as(C.c_void_p))
+        return state
+
+    def raycast_advance(self, trans, ds, state, rank, world, z_begin, z_end, alloc_lo, alloc_hi):
+        """One hand-off round of one slab; returns (delta, rays that read outside [alloc_lo, alloc_hi))."""
+        rot, org = self._rot_org(trans)
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        delta = np.empty_like(state)
+        slab = (C.c_int * 6)(rank, world, z_begin, z_end, alloc_lo, alloc_hi)
+        bad = lib().oracle_raycast_advance(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, slab,
+                                           state.ctypes.data_as(C.c_void_p), delta.ctypes.data_as(C.c_void_p))
+        return delta, int(bad)
 
     def sample(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)

@@ -192,6 +192,12 @@ uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *r
 
 /* ------------------------------------------------------------------------------------------
  * interpolateTrilinearly, tsdf_volume_octree.cpp:486-541.  *valid is AND-ed (never set to 1). */
+/* Slab bookkeeping for the ray hand-off restatement (oracle_raycast_advance): planes a slab may read. */
+static _Thread_local int tl_zlo = INT_MIN, tl_zhi = INT_MAX, tl_bad = 0;
+static void touch_plane(int z) {
+  if (z < tl_zlo || z >= tl_zhi) tl_bad = 1;
+}
+
 static float trilinear(const oracle_params *p, const float *d, const float *w, float x, float y, float z,
                        int *valid) {
   int id[3];
@@ -213,6 +219,8 @@ static float trilinear(const oracle_params *p, const float *d, const float *w, f
   const float a = (x - vx) * nx / p->size[0];
   const float b = (y - vy) * ny / p->size[1];
   const float c = (z - vz) * nz / p->size[2];
+  touch_plane(zi);
+  touch_plane(zi + 1);
 #define VI(i, j, k) (((size_t)(k) * ny + (j)) * nx + (i))
   const size_t o = VI(xi, yi, zi), ox = VI(xi + 1, yi, zi), oy = VI(xi, yi + 1, zi), oz = VI(xi, yi, zi + 1),
                oxy = VI(xi + 1, yi + 1, zi), oxz = VI(xi + 1, yi, zi + 1), oyz = VI(xi, yi + 1, zi + 1),
@@ -260,122 +268,218 @@ static float leaf_size(const oracle_params *p, int axis) { /* size_ after L halv
 /* renderView, tsdf_volume_octree.cpp:278-421, WITHOUT the final transformPointCloudWithNormals
  * (:422): output stays in the volume frame.  rot = trans.rotation().cast<float>() (row-major 3x3),
  * org = trans.translation().cast<float>().  out: 8 floats per pixel x,y,z,nx,ny,nz,t,niter; a miss
- * has NaN xyz and zero normal (PointNormal's default constructor). */
-void oracle_raycast(const oracle_params *p, const float *d, const float *w, const float rot[9],
-                    const float org[3], int ds, float *out) {
-  const int nw = p->image_width / ds, nh = p->image_height / ds;
+ * has NaN xyz and zero normal (PointNormal's default constructor).
+ *
+ * One ray.  With st == NULL this is the reference's loop start to finish.  With st != NULL it is the
+ * multi-slab restatement used by the gloo tests (same protocol as tsdf_hip_raycast_advance,
+ * include/tsdf_hip.h): the loop state is loaded from the ray's record, the main loop stops BEFORE it would
+ * read a voxel whose plane is outside [slab[2], slab[3]), and the new record goes to dl. */
+#define RAY_REC 24
+static float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
+static int32_t f2i(float f) { int32_t v; memcpy(&v, &f, 4); return v; }
+
+static void ray_direction(const oracle_params *p, const float rot[9], int ds, int64_t i, float du[3]) {
+  const int nw = p->image_width / ds;
   const double nfx = p->fx / ds, nfy = p->fy / ds, ncx = p->cx / ds, ncy = p->cy / ds;
+  const size_t x = i % nw, y = i / nw;
+  du[0] = (float)((x - ncx) / nfx);
+  du[1] = (float)((y - ncy) / nfy);
+  du[2] = 1.f;
+  normalize3(du);
+  /* du = R * du  [Eigen-recall 3.3: each coefficient is a 3-term reduction p0 + (p1 + p2)] */
+  const float a = du[0], b = du[1], c = du[2];
+  for (int r = 0; r < 3; ++r) du[r] = rot[3 * r] * a + (rot[3 * r + 1] * b + rot[3 * r + 2] * c);
+}
+
+static void ray_one(const oracle_params *p, const float *d, const float *w, const float rot[9],
+                    const float org[3], int ds, int64_t i, float *o, const int32_t *st, int32_t *dl,
+                    const int *slab /* rank, world, z_begin, z_end */) {
   const int nx = p->res[0], ny = p->res[1];
   const float min_step = p->max_dist_neg * 3 / 4.; /* :289 */
   /* leaf->getMinSize() is size_ = size_x for every axis (octree.h:63-66) */
   const float lsz = leaf_size(p, 0);
-#pragma omp parallel for schedule(dynamic, 64)
-  for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
-    const size_t x = i % nw, y = i / nw;
-    float *o = out + 8 * i;
-    int found_crossing = 0;
-    float du[3] = {(float)((x - ncx) / nfx), (float)((y - ncy) / nfy), 1.f};
-    normalize3(du);
-    { /* du = R * du  [Eigen-recall 3.3: each coefficient is a 3-term reduction p0 + (p1 + p2)] */
-      const float a = du[0], b = du[1], c = du[2];
-      for (int r = 0; r < 3; ++r) du[r] = rot[3 * r] * a + (rot[3 * r + 1] * b + rot[3 * r + 2] * c);
-    }
-    float pt[3] = {org[0], org[1], org[2]};
-    float dd = 0, ww = 0, last_w = 0, last_d = 0;
-    float t = p->min_sensor_dist;
+  int found_crossing = 0;
+  float du[3];
+  ray_direction(p, rot, ds, i, du);
+  float pt[3] = {org[0], org[1], org[2]};
+  float dd = 0, ww = 0, last_w = 0, last_d = 0;
+  float t = p->min_sensor_dist;
+  float step = min_step;
+  int hit_voxel = 0, niter = 0;
+  if (st) {
+    const int32_t *r = st + RAY_REC * i;
+    if (r[0] != 1) return;
+    const int mine = r[1] < 0 ? (int)(i % slab[1]) == slab[0] : (r[1] >= slab[2] && r[1] < slab[3]);
+    if (!mine) return;
+    niter = r[2];
+    hit_voxel = r[3];
+    t = i2f(r[4]);
+    for (int k = 0; k < 3; ++k) pt[k] = i2f(r[5 + k]);
+    last_d = i2f(r[8]);
+    last_w = i2f(r[9]);
+    step = i2f(r[10]);
+  } else {
     for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
-    float step = min_step;
-    int hit_voxel = 0, niter = 0;
-    while (t < p->max_sensor_dist) {
-      int id[3];
-      if (oracle_containing(p, pt[0], pt[1], pt[2], id)) {
-        const size_t vi = ((size_t)id[2] * ny + id[1]) * nx + id[0];
-        hit_voxel = 1;
-        dd = d[vi];
-        ww = w[vi];
-        if (((dd < 0 && last_d > 0) || (dd > 0 && last_d < 0)) && last_w && ww) {
-          found_crossing = 1;
-          const float old_t = t - step;
-          step = (p->size[2] / p->res[2]) / 2.; /* :329 */
-          float new_d, new_w;
-          float last_new_d = dd, last_new_w = ww;
-          while (t >= old_t) {
-            t -= step;
-            for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
-            if (!oracle_containing(p, pt[0], pt[1], pt[2], id)) break;
-            const size_t vj = ((size_t)id[2] * ny + id[1]) * nx + id[0];
-            new_d = d[vj];
-            new_w = w[vj];
-            if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
-              last_d = new_d;
-              last_w = new_w;
-              dd = last_new_d;
-              ww = last_new_w;
-              t += step;
-              for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
-              break;
-            }
-            last_new_d = dd; /* sic: the reference assigns d, not new_d (:352-353) */
-            last_new_w = ww;
-          }
-          break;
-        }
-        last_d = dd;
-        last_w = ww;
-        { /* :360  step = max(size/4, (float)(fabs(d)*max_dist_neg_)) */
-          const float s1 = lsz / 4.f, s2 = (float)(fabs(dd) * p->max_dist_neg);
-          step = s1 < s2 ? s2 : s1; /* std::max(a,b) = (a<b)?b:a */
-        }
-      } else if (hit_voxel) {
+  }
+  int suspend_z = -1;
+  while (t < p->max_sensor_dist) {
+    int id[3];
+    if (oracle_containing(p, pt[0], pt[1], pt[2], id)) {
+      if (st && (id[2] < slab[2] || id[2] >= slab[3])) {
+        suspend_z = id[2];
         break;
       }
-      t += step;
-      for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
-      niter++;
+      const size_t vi = ((size_t)id[2] * ny + id[1]) * nx + id[0];
+      hit_voxel = 1;
+      dd = d[vi];
+      ww = w[vi];
+      if (((dd < 0 && last_d > 0) || (dd > 0 && last_d < 0)) && last_w && ww) {
+        found_crossing = 1;
+        const float old_t = t - step;
+        step = (p->size[2] / p->res[2]) / 2.; /* :329 */
+        float new_d, new_w;
+        float last_new_d = dd, last_new_w = ww;
+        while (t >= old_t) {
+          t -= step;
+          for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
+          if (!oracle_containing(p, pt[0], pt[1], pt[2], id)) break;
+          touch_plane(id[2]);
+          const size_t vj = ((size_t)id[2] * ny + id[1]) * nx + id[0];
+          new_d = d[vj];
+          new_w = w[vj];
+          if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
+            last_d = new_d;
+            last_w = new_w;
+            dd = last_new_d;
+            ww = last_new_w;
+            t += step;
+            for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+            break;
+          }
+          last_new_d = dd; /* sic: the reference assigns d, not new_d (:352-353) */
+          last_new_w = ww;
+        }
+        break;
+      }
+      last_d = dd;
+      last_w = ww;
+      { /* :360  step = max(size/4, (float)(fabs(d)*max_dist_neg_)) */
+        const float s1 = lsz / 4.f, s2 = (float)(fabs(dd) * p->max_dist_neg);
+        step = s1 < s2 ? s2 : s1; /* std::max(a,b) = (a<b)?b:a */
+      }
+    } else if (hit_voxel) {
+      break;
     }
-    o[3] = o[4] = o[5] = 0.f;
-    o[6] = t;
-    o[7] = (float)niter;
-    if (!found_crossing) {
-      o[0] = o[1] = o[2] = NAN;
-      continue;
-    }
-    int has_data = 1;
-    const float tcurr = t, tprev = t - step;
-    last_d = trilinear(p, d, w, org[0] + tprev * du[0], org[1] + tprev * du[1], org[2] + tprev * du[2], &has_data);
-    dd = trilinear(p, d, w, org[0] + tcurr * du[0], org[1] + tcurr * du[1], org[2] + tcurr * du[2], &has_data);
-    /* :385-388 sets NaN but does not `continue`; :389-390 then overwrites xyz anyway */
-    /* unqualified fabs(float) resolves to double fabs(double) with <cmath> only (g++), so the
-     * update of t_star is evaluated in double */
-    const float t_star = t + step * (-1 + fabs(last_d / (last_d - dd)));
-    for (int k = 0; k < 3; ++k) o[k] = org[k] + t_star * du[k];
-    o[6] = t_star;
-    int id[3];
-    if (!oracle_containing(p, o[0], o[1], o[2], id)) {
-      o[3] = o[4] = o[5] = NAN;
-      continue;
-    }
-    const float xs = lsz, ys = lsz, zs = lsz; /* getSize returns size_ thrice (octree.cpp:58-64) */
-    int valid = 1;
-    const float d_xm = trilinear(p, d, w, o[0] - xs, o[1], o[2], &valid);
-    const float d_xp = trilinear(p, d, w, o[0] + xs, o[1], o[2], &valid);
-    const float d_ym = trilinear(p, d, w, o[0], o[1] - ys, o[2], &valid);
-    const float d_yp = trilinear(p, d, w, o[0], o[1] + ys, o[2], &valid);
-    const float d_zm = trilinear(p, d, w, o[0], o[1], o[2] - zs, &valid);
-    const float d_zp = trilinear(p, d, w, o[0], o[1], o[2] + zs, &valid);
-    if (!valid) {
-      o[3] = o[4] = o[5] = NAN;
-      continue;
-    }
-    float dF[3];
-    dF[0] = (d_xp - d_xm) * p->max_dist_neg / (2 * xs);
-    dF[1] = (d_yp - d_ym) * p->max_dist_neg / (2 * ys);
-    dF[2] = (d_zp - d_zm) * p->max_dist_neg / (2 * zs);
-    normalize3(dF);
-    o[3] = dF[0];
-    o[4] = dF[1];
-    o[5] = dF[2];
+    t += step;
+    for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
+    niter++;
   }
+  if (st) {
+    int32_t *r = dl + RAY_REC * i;
+    r[0] = suspend_z >= 0 ? 1 : 2;
+    r[1] = suspend_z;
+    r[2] = niter;
+    r[3] = hit_voxel;
+    r[4] = f2i(t);
+    for (int k = 0; k < 3; ++k) r[5 + k] = f2i(pt[k]);
+    r[8] = f2i(last_d);
+    r[9] = f2i(last_w);
+    r[10] = f2i(step);
+    if (suspend_z >= 0) return;
+    o = (float *)(r + 16);
+  }
+  o[3] = o[4] = o[5] = 0.f;
+  o[6] = t;
+  o[7] = (float)niter;
+  if (!found_crossing) {
+    o[0] = o[1] = o[2] = NAN;
+    return;
+  }
+  int has_data = 1;
+  const float tcurr = t, tprev = t - step;
+  last_d = trilinear(p, d, w, org[0] + tprev * du[0], org[1] + tprev * du[1], org[2] + tprev * du[2], &has_data);
+  dd = trilinear(p, d, w, org[0] + tcurr * du[0], org[1] + tcurr * du[1], org[2] + tcurr * du[2], &has_data);
+  /* :385-388 sets NaN but does not `continue`; :389-390 then overwrites xyz anyway */
+  /* unqualified fabs(float) resolves to double fabs(double) with <cmath> only (g++), so the
+   * update of t_star is evaluated in double */
+  const float t_star = t + step * (-1 + fabs(last_d / (last_d - dd)));
+  for (int k = 0; k < 3; ++k) o[k] = org[k] + t_star * du[k];
+  o[6] = t_star;
+  int id[3];
+  if (!oracle_containing(p, o[0], o[1], o[2], id)) {
+    o[3] = o[4] = o[5] = NAN;
+    return;
+  }
+  const float xs = lsz, ys = lsz, zs = lsz; /* getSize returns size_ thrice (octree.cpp:58-64) */
+  int valid = 1;
+  const float d_xm = trilinear(p, d, w, o[0] - xs, o[1], o[2], &valid);
+  const float d_xp = trilinear(p, d, w, o[0] + xs, o[1], o[2], &valid);
+  const float d_ym = trilinear(p, d, w, o[0], o[1] - ys, o[2], &valid);
+  const float d_yp = trilinear(p, d, w, o[0], o[1] + ys, o[2], &valid);
+  const float d_zm = trilinear(p, d, w, o[0], o[1], o[2] - zs, &valid);
+  const float d_zp = trilinear(p, d, w, o[0], o[1], o[2] + zs, &valid);
+  if (!valid) {
+    o[3] = o[4] = o[5] = NAN;
+    return;
+  }
+  float dF[3];
+  dF[0] = (d_xp - d_xm) * p->max_dist_neg / (2 * xs);
+  dF[1] = (d_yp - d_ym) * p->max_dist_neg / (2 * ys);
+  dF[2] = (d_zp - d_zm) * p->max_dist_neg / (2 * zs);
+  normalize3(dF);
+  o[3] = dF[0];
+  o[4] = dF[1];
+  o[5] = dF[2];
+}
+
+void oracle_raycast(const oracle_params *p, const float *d, const float *w, const float rot[9],
+                    const float org[3], int ds, float *out) {
+  const int nw = p->image_width / ds, nh = p->image_height / ds;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
+    tl_zlo = INT_MIN;
+    tl_zhi = INT_MAX;
+    ray_one(p, d, w, rot, org, ds, i, out + 8 * i, NULL, NULL, NULL);
+  }
+}
+
+/* Start record of every ray (same layout as tsdf_hip_raycast_begin). */
+void oracle_raycast_begin(const oracle_params *p, const float rot[9], const float org[3], int ds, int32_t *state) {
+  const int nw = p->image_width / ds, nh = p->image_height / ds;
+  for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
+    float du[3];
+    ray_direction(p, rot, ds, i, du);
+    int32_t *r = state + RAY_REC * i;
+    memset(r, 0, RAY_REC * sizeof(int32_t));
+    const float t = p->min_sensor_dist;
+    r[0] = 1;
+    r[1] = -1;
+    r[4] = f2i(t);
+    for (int k = 0; k < 3; ++k) {
+      float pt = org[k];
+      pt += t * du[k];
+      r[5 + k] = f2i(pt);
+    }
+    r[10] = f2i(p->max_dist_neg * 3 / 4.);
+  }
+}
+
+/* One hand-off round of one slab.  slab = {rank, world, z_begin, z_end, alloc_lo, alloc_hi}; returns the
+ * number of rays whose refinement walk / trilinear samples read a plane outside [alloc_lo, alloc_hi). */
+int oracle_raycast_advance(const oracle_params *p, const float *d, const float *w, const float rot[9],
+                           const float org[3], int ds, const int *slab, const int32_t *state, int32_t *delta) {
+  const int nw = p->image_width / ds, nh = p->image_height / ds;
+  int bad = 0;
+  memset(delta, 0, (size_t)nw * nh * RAY_REC * sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
+  for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
+    tl_zlo = slab[4];
+    tl_zhi = slab[5];
+    tl_bad = 0;
+    ray_one(p, d, w, rot, org, ds, i, NULL, state, delta, slab);
+    bad += tl_bad;
+  }
+  return bad;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -45,7 +45,8 @@ class _Cfg:
 
 
 class OracleSlab:
-    def __init__(self, configure, z_begin, z_end, nz, rank):
+    def __init__(self, configure, z_begin, z_end, nz, rank, halo=1):
+        self.halo = halo
         cfg = _Cfg()
         configure(cfg)
         self.p = cfg._p
@@ -101,6 +102,23 @@ class OracleSlab:
         zi = zi - (pts[:, 2] < ctr)
         mine = (zi >= self.z_begin) & (zi < self.z_end)
         return ok & mine, val, grad, hess
+
+    def image_size(self):
+        return self.p.image_width, self.p.image_height
+
+    def render(self, trans, ds):
+        from cpu_tsdf_amd.volume import eigen_affine_inverse, transform_cloud_with_normals
+        return transform_cloud_with_normals(self.ov.raycast(trans, ds), eigen_affine_inverse(np.asarray(trans, np.float64)))
+
+    def ray_begin(self, trans, ds):
+        return torch.from_numpy(self.ov.raycast_begin(trans, ds))
+
+    def ray_advance(self, trans, ds, state, rank, world):
+        lo, hi = max(0, self.z_begin - self.halo), min(self.nz, self.z_end + self.halo)
+        delta, bad = self.ov.raycast_advance(trans, ds, state.numpy(), rank, world, self.z_begin, self.z_end, lo, hi)
+        if bad:
+            raise RuntimeError(f"ray hand-off: {bad} rays read planes outside the slab's halo [{lo}, {hi})")
+        return torch.from_numpy(delta)
 
     def synchronize(self):
         pass

@@ -1,7 +1,7 @@
 """CPU tier: the Z-slab multi-GPU layer (cpu_tsdf_amd/zslab.py) with world_size 2 and 3 over gloo.  The slab
 backend is the CPU oracle (tests/fake_slab.py), so this exercises exactly the host logic the GPU ranks run:
 slab split, frame broadcast from the ingest rank, one-plane halo exchange, per-rank meshing, Morton merge,
-sample routing -- and checks the result against a single unpartitioned volume."""
+sample routing, renderView by ray hand-off (halo refresh, advance rounds, integer all-reduce merge) -- and checks the result against a single unpartitioned volume."""
 import os
 import socket
 
@@ -13,7 +13,13 @@ import torch.multiprocessing as mp
 from cpu_tsdf_amd import synth
 from cpu_tsdf_amd.zslab import ZSlabVolume, morton_x_major, slab_range
 
-RES, W, H, NF = 32, 80, 60, 4
+RES, W, H, NF = 64, 80, 60, 4
+
+
+def views(size):
+    return [synth.turntable_pose(1, 8, size), synth.turntable_pose(3, 16, size, tilt=0.5),
+            synth.look_at_pose((0.05, 0.02, -0.3)), synth.look_at_pose((0.0, 0.0, -0.05), target=(0.01, 0.0, 0.2)),
+            synth.look_at_pose((0.02, -0.2, 0.01), target=(0.0, 0.0, 0.0))]
 
 
 def configure(v):
@@ -50,6 +56,10 @@ def _worker(rank, world, port, out_path):
     mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     samp = vol.sample(pts)
+    renders, rounds = [], []
+    for k, tr in enumerate(views(sc.size)):
+        renders.append(vol.renderView(tr, 1 + (k == 1)))
+        rounds.append(vol.last_render_rounds)
     zb, ze = vol.z_begin, vol.z_end
     d, w = vol.slab.ov.d[zb:ze].copy(), vol.slab.ov.w[zb:ze].copy()
     gathered = [None] * world if rank == 0 else None
@@ -57,7 +67,8 @@ def _worker(rank, world, port, out_path):
     if rank == 0:
         np.savez(out_path, verts=mesh["vertices"], rgb=mesh["rgb"], cells=mesh["cells"], ok=samp[0], val=samp[1],
                  grad=samp[2], d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
-                 bounds=np.array([[g[0], g[1]] for g in gathered]))
+                 bounds=np.array([[g[0], g[1]] for g in gathered]), rounds=np.array(rounds),
+                 **{f"view{k}": r for k, r in enumerate(renders)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,3 +110,15 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     ok, val, grad, _ = ov.sample(pts)
     assert np.array_equal(got["ok"], ok)
     assert np.array_equal(got["val"][ok], val[ok]) and np.array_equal(got["grad"][ok], grad[ok])
+    # renderView by ray hand-off == the single-volume ray loop, bit for bit (NaN == NaN)
+    from cpu_tsdf_amd.volume import eigen_affine_inverse, transform_cloud_with_normals
+    hits = 0
+    for k, tr in enumerate(views(sc.size)):
+        want = transform_cloud_with_normals(ov.raycast(tr, 1 + (k == 1)), eigen_affine_inverse(tr))
+        have = got[f"view{k}"]
+        assert have.shape == want.shape
+        assert np.array_equal(have.view(np.uint32), want.view(np.uint32)) or \
+            np.array_equal(np.nan_to_num(have, nan=-7.0), np.nan_to_num(want, nan=-7.0)), f"view {k}"
+        hits += int(np.isfinite(want[..., 0]).sum())
+    assert hits > 2000
+    assert got["rounds"].max() <= world + 1 and got["rounds"].max() >= 2

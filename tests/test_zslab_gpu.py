@@ -6,10 +6,10 @@ import pytest
 import torch
 
 from cpu_tsdf_amd import synth
-from cpu_tsdf_amd.zslab import HipSlab, ZSlabVolume, morton_x_major
+from cpu_tsdf_amd.zslab import HipSlab, ZSlabVolume, morton_x_major, render_halo, slab_range
 from oracle.oracle import OracleVolume
 from tests.common import assert_same_f32
-from tests.test_zslab_gloo import H, NF, RES, W, configure
+from tests.test_zslab_gloo import H, NF, RES, W, configure, views
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,83 @@ def test_two_slab_handles_with_halo_exchange_equal_one_volume(gpu):
     assert np.array_equal(np.stack([cc & 255, (cc >> 8) & 255, (cc >> 16) & 255], -1).astype(np.uint8), ov.rgb[3:5])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_ray_handoff_between_slab_handles_equals_one_volume(gpu, world):
+    """renderView across Z-slabs on real device memory: `world` slab handles on the one GPU, halos refreshed
+    through get/set_planes_device, rays handed off with tsdf_hip_raycast_begin/advance, deltas merged by an
+    integer sum exactly as ZSlabVolume does with the RCCL all-reduce.  Must equal the whole-volume kernel
+    bit for bit."""
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    sc = synth.scene_a(RES, W, H)
+    halo = render_halo(configure)
+    assert 8 <= halo <= 16
+    whole = TSDFVolumeOctree()
+    configure(whole)
+    whole.reset()
+    cuts = [slab_range(RES, world, r) for r in range(world)]
+    slabs = [HipSlab(configure, zb, ze, RES, 0, halo=halo) for zb, ze in cuts]
+    fd, fc = slabs[0].frame_buffers()
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        dep, col = sc.depth(tr), sc.bgra(i)
+        whole.integrateCloud(dep, col, tr)
+        fd.copy_(torch.from_numpy(dep))
+        fc.copy_(torch.from_numpy(col))
+        for s in slabs:
+            s.integrate_tensor(fd, fc, tr)
+    # halo refresh: every slab takes its neighbours' boundary planes (clipped to what they own and to the grid)
+    for r, s in enumerate(slabs):
+        for nb in (r - 1, r + 1):
+            if 0 <= nb < world:
+                zb, ze = cuts[nb]
+                n = min(halo, ze - zb)
+                z0 = ze - n if nb < r else zb
+                planes = slabs[nb].get_planes(z0, n)
+                slabs[nb].synchronize()
+                s.set_planes(z0, *planes)
+    total_rounds = 0
+    for k, tr in enumerate(views(sc.size)):
+        ds = 1 + (k == 1)
+        want = whole.renderView(tr, ds, camera_frame=False)
+        state = slabs[0].ray_begin(tr, ds)
+        for rounds in range(1, 2 * world + 5):
+            delta = sum(s.ray_advance(tr, ds, state, r, world) for r, s in enumerate(slabs))
+            state = torch.where(delta[:, :1] != 0, delta, state)
+            if int((state[:, 0] == 1).sum()) == 0:
+                break
+        assert int((state[:, 0] == 2).sum()) == state.shape[0]
+        assert rounds <= world + 1
+        total_rounds += rounds
+        have = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(want.shape)
+        assert_same_f32(have, want, f"view {k} world {world}")
+    assert total_rounds > len(views(sc.size))  # rays really crossed slabs
+    for s in slabs:
+        s.close()
+    whole.close()
+
+
+def test_ray_handoff_refuses_a_halo_that_is_too_small(gpu):
+    from cpu_tsdf_amd.capi import TsdfHipError
+    sc = synth.scene_a(RES, W, H)
+    cuts = [slab_range(RES, 2, r) for r in range(2)]
+    slabs = [HipSlab(configure, zb, ze, RES, 0, halo=1) for zb, ze in cuts]
+    fd, fc = slabs[0].frame_buffers()
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        fd.copy_(torch.from_numpy(sc.depth(tr)))
+        fc.copy_(torch.from_numpy(sc.bgra(i)))
+        for s in slabs:
+            s.integrate_tensor(fd, fc, tr)
+    tr = views(sc.size)[0]
+    state = slabs[0].ray_begin(tr, 1)
+    with pytest.raises(TsdfHipError):
+        for _ in range(4):
+            delta = sum(s.ray_advance(tr, 1, state, r, 2) for r, s in enumerate(slabs))
+            state = torch.where(delta[:, :1] != 0, delta, state)
+    for s in slabs:
+        s.close()
 
 
 def test_zslab_volume_world1_end_to_end(gpu):
