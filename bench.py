@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--color", type=int, default=1)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--layout", choices=["auto", "f32w", "packed"], default="auto",
+                    help="HBM weight layout (include/tsdf_hip.h TSDF_LAYOUT_*); auto = packed when max_weight <= 255")
     ap.add_argument("--frames", type=int, default=0, help="distinct frames on the turntable (default steps+warmup)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -198,6 +200,7 @@ def main():
     vol.setSensorDistanceBounds(0.0, 3.0 * max(size3))  # CLI default min 0 (integrate.cpp:333)
     vol.setDepthTruncationLimits(0.03, 0.03)
     vol.setIntegrateColor(bool(args.color))
+    vol.setLayout({"auto": capi.LAYOUT_AUTO, "f32w": capi.LAYOUT_F32W, "packed": capi.LAYOUT_PACKED}[args.layout])
     vol.setZSlab(z_begin, z_end, 0, local_rank)
     stream = torch.cuda.current_stream(dev)
     vol.setStream(stream.cuda_stream)
@@ -286,12 +289,17 @@ def main():
         bpp = 8 if args.color else 4
         alg_bytes = bpv * n_obs_rank + bpp * W * H  # rank 0's launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # bytes the chosen HBM layout actually has to move per observed voxel (read + write back):
+        # F32W d,w(,rgb) = 16 (24); PACKED d + colour|count word = 16, d + count byte = 10
+        packed = vol.getLayout() == capi.LAYOUT_PACKED
+        lbpv = (16 if args.color else 10) if packed else bpv
+        layout_bytes = lbpv * n_obs_rank + bpp * W * H
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
-                key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}"
+                key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
                 traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -315,6 +323,7 @@ def main():
                             f"resident in HBM" + (f", Z-slab {z_end - z_begin} planes/GPU, RCCL frame broadcast"
                                                   if world > 1 else " (BASELINE configs[3] integrate leg)"),
                 "grid": list(res3), "image": [W, H], "color": bool(args.color),
+                "layout": "packed" if packed else "f32w",
                 "observed_voxels_per_frame": n_obs_all,
                 "parallelism": f"zslab{world}",
             },
@@ -324,6 +333,9 @@ def main():
                 "kernel": "k_integrate", "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_observed_voxel": bpv,
+                "layout_bytes_per_observed_voxel": lbpv,
+                "layout_bytes_per_launch": layout_bytes,
+                "frac_layout": layout_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "sweep_upper_bound_bytes": bpv * vox_total / world,
             },
         }

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
 
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED = range(6)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
+LAYOUT_AUTO, LAYOUT_F32W, LAYOUT_PACKED = 0, 1, 2
 
 
 class TsdfParams(C.Structure):
@@ -37,6 +38,7 @@ class TsdfParams(C.Structure):
         ("z_end", C.c_int32),
         ("halo", C.c_int32),
         ("device", C.c_int32),
+        ("layout", C.c_int32),
     ]
 
 
@@ -78,6 +80,7 @@ SIGNATURES = {
     "tsdf_hip_device_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tsdf_hip_layout": (C.c_int, [C.c_void_p]),
     "tsdf_hip_centers": (C.c_int, [C.c_void_p, C.c_int, _f32p]),
     "tsdf_hip_selftest_div_f32": (C.c_int, [_f32p, _f32p, _f32p, C.c_size_t]),
     "tsdf_hip_selftest_div_f64": (C.c_int, [_f64p, _f64p, _f64p, C.c_size_t]),

@@ -399,8 +399,16 @@ void TSDFVolumeOctree::load(const std::string &filename) {
   p_.integrate_color = hd.color ? 1 : 0;
   reset();
   if (!h_) return;
-  const int rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
-                                 hd.color ? rgb.data() : nullptr);
+  int rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
+                           hd.color ? rgb.data() : nullptr);
+  if (rc == TSDF_HIP_E_UNSUPPORTED && tsdf_hip_layout(h_) == TSDF_LAYOUT_PACKED) {
+    // weights that are not min(k, max_weight) (a file written with other weighting): float weight plane
+    p_.layout = TSDF_LAYOUT_F32W;
+    reset();
+    if (!h_) return;
+    rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
+                         hd.color ? rgb.data() : nullptr);
+  }
   if (rc) report("load", rc);
   is_empty_ = hd.is_empty;
 }

@@ -18,8 +18,14 @@ struct tsdf_hip_volume {
   int nz_alloc = 0;            // allocated planes (slab + halos clipped to the grid)
   int64_t pitch = 0;           // floats per x row
   int levels[3] = {0, 0, 0};   // octree depth per axis (log2 res) or -1 if res is not a power of two
+  // Voxel planes.  F32W layout: d, w (float) and, with colour, rgb (r | g<<8 | b<<16).
+  // PACKED layout: w is not stored; the observation count k (w == min(k, max_weight), saturating at
+  // kmax = ceil(max_weight)) lives in byte 3 of the colour word (rgb plane) or, without colour, in k8.
   float *d = nullptr, *w = nullptr;
   uint32_t *rgb = nullptr;
+  uint8_t *k8 = nullptr;
+  int packed = 0;
+  unsigned kmax = 0;
   float *ctr[3] = {nullptr, nullptr, nullptr};  // device centre tables (full axis length)
   std::vector<float> h_ctr[3];
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
@@ -63,6 +69,51 @@ struct TsdfTuning {
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
 };
 const TsdfTuning &tsdf_tuning();
+
+// Read-only view of the voxel planes for the gather kernels (raycast, sample, marching cubes, transfers).
+struct PlaneView {
+  const float *d, *w;
+  const uint32_t *rgb;
+  const uint8_t *k8;
+  float wmax;
+  unsigned kmax;
+  int packed;
+};
+
+static inline PlaneView tsdf_plane_view(const tsdf_hip_volume *v) {
+  return PlaneView{v->d, v->w, v->rgb, v->k8, v->p.max_weight, v->kmax, v->packed};
+}
+
+// w after k observations: each addObservation does w += 1; if (w > max_weight) w = max_weight
+// (octree.cpp:156-158 with w_new = 1), so w == min(k, max_weight) for every k while 0 <= max_weight.
+static __device__ __forceinline__ float tsdf_decode_w(unsigned k, float wmax) {
+  const float kf = (float)k;
+  return kf > wmax ? wmax : kf;
+}
+
+// Inverse of tsdf_decode_w; false if no count represents w (then the volume needs the F32W layout).
+static __device__ __forceinline__ bool tsdf_encode_w(float w, float wmax, unsigned kmax, unsigned &k) {
+  if (w == wmax) {
+    k = kmax;
+    return true;
+  }
+  if (w >= 0.f && w < (float)kmax && w == floorf(w)) {
+    k = (unsigned)w;
+    return true;
+  }
+  k = 0;
+  return false;
+}
+
+static __device__ __forceinline__ float tsdf_load_w(const PlaneView &v, int64_t i) {
+  if (!v.packed) return v.w[i];
+  const unsigned k = v.rgb ? (v.rgb[i] >> 24) : (unsigned)v.k8[i];
+  return tsdf_decode_w(k, v.wmax);
+}
+
+static __device__ __forceinline__ uint32_t tsdf_load_rgb(const PlaneView &v, int64_t i) {
+  return v.rgb[i] & 0xffffffu;
+}
 
 // Volume element index of (x, y, z_global); the plane must be allocated.
 static inline __host__ __device__ int64_t tsdf_index(int64_t pitch, int ny, int z_first, int x, int y,

@@ -1,6 +1,8 @@
 // libtsdf_hip.so -- volume lifetime, voxel-centre tables, raw block transfer.
 // gfx950 only.  Boundary: include/tsdf_hip.h.
 #include <math.h>
+
+#include <string>
 #include <stdlib.h>
 #include <algorithm>
 #include <string.h>
@@ -82,6 +84,7 @@ extern "C" void tsdf_hip_default_params(tsdf_params *p) {
   p->z_begin = p->z_end = 0;
   p->halo = 0;
   p->device = -1;
+  p->layout = TSDF_LAYOUT_AUTO;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -163,6 +166,7 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->d) (void)hipFree(v->d);
   if (v->w) (void)hipFree(v->w);
   if (v->rgb) (void)hipFree(v->rgb);
+  if (v->k8) (void)hipFree(v->k8);
   for (int a = 0; a < 3; ++a)
     if (v->ctr[a]) (void)hipFree(v->ctr[a]);
   if (v->frame_depth) (void)hipFree(v->frame_depth);
@@ -186,9 +190,15 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
       return TSDF_HIP_E_INVALID;
     }
   if (p->image_width <= 0 || p->image_height <= 0 || !(p->max_dist_neg > 0.f) || p->halo < 0 ||
-      (p->xform_order != TSDF_XFORM_PCL_SSE && p->xform_order != TSDF_XFORM_LEFT_TO_RIGHT)) {
-    tsdf_set_error("bad image size / truncation / halo / xform_order");
+      (p->xform_order != TSDF_XFORM_PCL_SSE && p->xform_order != TSDF_XFORM_LEFT_TO_RIGHT) ||
+      p->layout < TSDF_LAYOUT_AUTO || p->layout > TSDF_LAYOUT_PACKED) {
+    tsdf_set_error("bad image size / truncation / halo / xform_order / layout");
     return TSDF_HIP_E_INVALID;
+  }
+  const bool packable = p->max_weight >= 0.f && p->max_weight <= 255.f;  // false for NaN
+  if (p->layout == TSDF_LAYOUT_PACKED && !packable) {
+    tsdf_set_error("the PACKED layout needs 0 <= max_weight <= 255");
+    return TSDF_HIP_E_UNSUPPORTED;
   }
   int zb = p->z_begin, ze = p->z_end;
   if (zb == 0 && ze == 0) ze = p->res[2];
@@ -219,6 +229,9 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   v->nz_alloc = z_last - v->z_first;
   v->pitch = ((int64_t)v->nx + 3) / 4 * 4;
   const int64_t n = v->pitch * v->ny * v->nz_alloc;
+  v->packed = p->layout == TSDF_LAYOUT_PACKED || (p->layout == TSDF_LAYOUT_AUTO && packable);
+  v->p.layout = v->packed ? TSDF_LAYOUT_PACKED : TSDF_LAYOUT_F32W;
+  v->kmax = v->packed ? (unsigned)ceilf(p->max_weight) : 0u;
 
   int rc = TSDF_HIP_OK;
   auto bail = [&](int code) {
@@ -231,8 +244,9 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     if (_e != hipSuccess) return bail(tsdf_hip_fail(_e, #expr, __FILE__, __LINE__)); \
   } while (0)
   TRY_OR_BAIL(hipMalloc(&v->d, n * sizeof(float)));
-  TRY_OR_BAIL(hipMalloc(&v->w, n * sizeof(float)));
+  if (!v->packed) TRY_OR_BAIL(hipMalloc(&v->w, n * sizeof(float)));
   if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
+  if (v->packed && !p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->k8, n));
   for (int a = 0; a < 3; ++a) {
     build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
@@ -265,8 +279,9 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
   memcpy(&bits, &minus_one, 4);
   int rc = fill_u32(h, h->d, bits, n);
   if (rc) return rc;
-  rc = fill_u32(h, h->w, 0u, n);
+  if (h->w) rc = fill_u32(h, h->w, 0u, n);
   if (rc) return rc;
+  if (h->k8) TSDF_HIP_TRY(hipMemsetAsync(h->k8, 0, (size_t)n, h->stream));
   if (h->rgb) rc = fill_u32(h, h->rgb, 0u, n);
   if (rc) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -298,6 +313,10 @@ extern "C" int tsdf_hip_centers(tsdf_handle h, int axis, float *out) {
   if (!h || axis < 0 || axis > 2 || !out) return TSDF_HIP_E_INVALID;
   memcpy(out, h->h_ctr[axis].data(), h->h_ctr[axis].size() * sizeof(float));
   return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_layout(tsdf_handle h) {
+  return !h ? -1 : (h->packed ? TSDF_LAYOUT_PACKED : TSDF_LAYOUT_F32W);
 }
 
 extern "C" int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,
@@ -338,6 +357,36 @@ k_block_f32(BlockArgs a, float *__restrict__ vol, float *__restrict__ blk) {
   }
 }
 
+// Weights as floats, whatever the layout.  Storing into a PACKED volume fails (bad[0]++) for a weight that
+// no observation count represents; the voxel is then left unchanged.
+template <bool TO_BLOCK>
+static __global__ void __launch_bounds__(256)
+k_block_w(BlockArgs a, PlaneView pv, float *__restrict__ blk, unsigned *__restrict__ bad) {
+  const int64_t n = (int64_t)a.bx * a.by * a.bz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.bx);
+    const int64_t r = i / a.bx;
+    const int y = (int)(r % a.by);
+    const int z = (int)(r / a.by);
+    const int64_t vi = ((int64_t)(a.zl0 + z) * a.ny + (a.y0 + y)) * a.pitch + (a.x0 + x);
+    if (TO_BLOCK) {
+      blk[i] = tsdf_load_w(pv, vi);
+    } else if (!pv.packed) {
+      const_cast<float *>(pv.w)[vi] = blk[i];
+    } else {
+      unsigned k;
+      if (!tsdf_encode_w(blk[i], pv.wmax, pv.kmax, k)) {
+        atomicAdd(bad, 1u);
+      } else if (pv.rgb) {
+        uint32_t *c = const_cast<uint32_t *>(pv.rgb) + vi;
+        *c = (*c & 0xffffffu) | (k << 24);
+      } else {
+        const_cast<uint8_t *>(pv.k8)[vi] = (uint8_t)k;
+      }
+    }
+  }
+}
+
 template <bool TO_BLOCK>
 static __global__ void __launch_bounds__(256)
 k_block_rgb(BlockArgs a, uint32_t *__restrict__ vol, uint8_t *__restrict__ blk) {
@@ -354,7 +403,9 @@ k_block_rgb(BlockArgs a, uint32_t *__restrict__ vol, uint8_t *__restrict__ blk) 
       blk[3 * i + 1] = (uint8_t)((c >> 8) & 255u);
       blk[3 * i + 2] = (uint8_t)((c >> 16) & 255u);
     } else {
-      vol[vi] = (uint32_t)blk[3 * i] | ((uint32_t)blk[3 * i + 1] << 8) | ((uint32_t)blk[3 * i + 2] << 16);
+      // byte 3 (the observation count of the PACKED layout, else zero) is preserved
+      vol[vi] = (vol[vi] & 0xff000000u) | (uint32_t)blk[3 * i] | ((uint32_t)blk[3 * i + 1] << 8) |
+                ((uint32_t)blk[3 * i + 2] << 16);
     }
   }
 }
@@ -388,23 +439,39 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
     const int64_t n = plane * bz;
     BlockArgs a{x0, y0, z0 + zc - h->z_first, nx, ny, bz, h->ny, h->pitch};
     unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
-    float *planes[2] = {h->d, h->w};
+    const PlaneView pv = tsdf_plane_view(h);
     float *hosts[2] = {d, w};
     for (int k = 0; k < 2; ++k) {
       if (!hosts[k]) continue;
       float *hp = hosts[k] + (int64_t)zc * plane;
+      float *dev = (float *)h->scratch;
       if (DOWN) {
-        hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k],
-                           (float *)h->scratch);
+        if (k == 0)
+          hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, h->d, dev);
+        else
+          hipLaunchKernelGGL(k_block_w<true>, dim3(blocks), dim3(256), 0, h->stream, a, pv, dev, (unsigned *)h->counter);
         TSDF_HIP_TRY(hipGetLastError());
-        TSDF_HIP_TRY(hipMemcpyAsync(hp, h->scratch, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        TSDF_HIP_TRY(hipMemcpyAsync(hp, dev, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
       } else {
-        TSDF_HIP_TRY(hipMemcpyAsync(h->scratch, hp, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_block_f32<false>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k],
-                           (float *)h->scratch);
-        TSDF_HIP_TRY(hipGetLastError());
-        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+        TSDF_HIP_TRY(hipMemcpyAsync(dev, hp, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (k == 0) {
+          hipLaunchKernelGGL(k_block_f32<false>, dim3(blocks), dim3(256), 0, h->stream, a, h->d, dev);
+          TSDF_HIP_TRY(hipGetLastError());
+          TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+        } else {
+          unsigned bad = 0;
+          TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(unsigned), h->stream));
+          hipLaunchKernelGGL(k_block_w<false>, dim3(blocks), dim3(256), 0, h->stream, a, pv, dev, (unsigned *)h->counter);
+          TSDF_HIP_TRY(hipGetLastError());
+          TSDF_HIP_TRY(hipMemcpyAsync(&bad, h->counter, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+          TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+          if (bad) {
+            tsdf_set_error(std::to_string(bad) + " weights are not of the form min(k, max_weight): this volume "
+                           "needs the F32W layout (tsdf_params.layout)");
+            return TSDF_HIP_E_UNSUPPORTED;
+          }
+        }
       }
     }
     if (rgb) {
@@ -458,6 +525,49 @@ k_planes_u32(uint32_t *__restrict__ vol, uint32_t *__restrict__ packed, int nx, 
   }
 }
 
+// Weight planes as floats / colour planes as r|g<<8|b<<16 for any layout (the exchanged buffers keep the
+// documented format; a PACKED volume converts on the fly).  Planes coming from a peer slab of the same
+// volume are always representable, so an unrepresentable weight is stored as count 0 and flagged.
+template <bool TO_PACKED>
+static __global__ void __launch_bounds__(256)
+k_planes_w(PlaneView pv, float *__restrict__ packed, int nx, int ny, int nz, int zl0, int64_t pitch,
+           unsigned *__restrict__ bad) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx);
+    const int64_t r = i / nx;
+    const int64_t vi = ((int64_t)zl0 * ny + r) * pitch + x;
+    if (TO_PACKED) {
+      packed[i] = tsdf_load_w(pv, vi);
+    } else {
+      unsigned k;
+      if (!tsdf_encode_w(packed[i], pv.wmax, pv.kmax, k)) atomicAdd(bad, 1u);
+      if (pv.rgb) {
+        uint32_t *c = const_cast<uint32_t *>(pv.rgb) + vi;
+        *c = (*c & 0xffffffu) | (k << 24);
+      } else {
+        const_cast<uint8_t *>(pv.k8)[vi] = (uint8_t)k;
+      }
+    }
+  }
+}
+
+template <bool TO_PACKED>
+static __global__ void __launch_bounds__(256)
+k_planes_rgb(uint32_t *__restrict__ vol, uint32_t *__restrict__ packed, int nx, int ny, int nz, int zl0,
+             int64_t pitch) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx);
+    const int64_t r = i / nx;
+    const int64_t vi = ((int64_t)zl0 * ny + r) * pitch + x;
+    if (TO_PACKED)
+      packed[i] = vol[vi] & 0xffffffu;
+    else
+      vol[vi] = (vol[vi] & 0xff000000u) | (packed[i] & 0xffffffu);
+  }
+}
+
 template <bool TO_PACKED>
 static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *rgb) {
   if (!h || nz <= 0 || z0 < h->z_first || z0 + nz > h->z_first + h->nz_alloc) {
@@ -471,12 +581,25 @@ static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *
   TSDF_HIP_TRY(hipSetDevice(h->device));
   const int64_t n = (int64_t)h->nx * h->ny * nz;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
-  void *vols[3] = {h->d, h->w, h->rgb};
-  void *bufs[3] = {d, w, rgb};
-  for (int k = 0; k < 3; ++k) {
-    if (!bufs[k]) continue;
-    hipLaunchKernelGGL(k_planes_u32<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, (uint32_t *)vols[k],
-                       (uint32_t *)bufs[k], h->nx, h->ny, nz, z0 - h->z_first, h->pitch);
+  const int zl0 = z0 - h->z_first;
+  if (d) {
+    hipLaunchKernelGGL(k_planes_u32<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, (uint32_t *)h->d,
+                       (uint32_t *)d, h->nx, h->ny, nz, zl0, h->pitch);
+    TSDF_HIP_TRY(hipGetLastError());
+  }
+  if (w) {
+    if (!h->packed) {
+      hipLaunchKernelGGL(k_planes_u32<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, (uint32_t *)h->w,
+                         (uint32_t *)w, h->nx, h->ny, nz, zl0, h->pitch);
+    } else {
+      hipLaunchKernelGGL(k_planes_w<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, tsdf_plane_view(h),
+                         (float *)w, h->nx, h->ny, nz, zl0, h->pitch, (unsigned *)(h->counter + 1023));
+    }
+    TSDF_HIP_TRY(hipGetLastError());
+  }
+  if (rgb) {
+    hipLaunchKernelGGL(k_planes_rgb<TO_PACKED>, dim3(blocks), dim3(256), 0, h->stream, h->rgb, (uint32_t *)rgb,
+                       h->nx, h->ny, nz, zl0, h->pitch);
     TSDF_HIP_TRY(hipGetLastError());
   }
   return TSDF_HIP_OK;

@@ -28,6 +28,8 @@ struct IntegrateArgs {
   float band_u, band_v;      // half-width of the "too close to an integer to trust fp32" zone, in pixels
   float hb_u, hb_v;          // 1/2 - band
   int neg_in_window;         // max_dist_pos/neg inside the scale-free divider's window
+  unsigned kmax;             // PACKED layout: saturation count ceil(max_weight)
+  int wmax_is_int;           // PACKED layout: max_weight is an integer (then every stored weight is)
   float zmin, zmax;   // min/max_sensor_dist_
   float pos, neg;     // max_dist_pos_/neg_
   float wmax;         // max_weight_
@@ -175,10 +177,13 @@ static __device__ __forceinline__ void st_plane(V *p, V v, bool nt) {
 // NaN beyond nx, which fails the range test, so a partial last quad needs no extra predicate.
 // Planes whose four values did not change are not written back (free space: d stays at the hinge value;
 // after weight saturation nothing changes).
-template <int ORDER, bool COLOR, bool FASTPROJ>
+// PACKED: the weight is the observation count k in byte 3 of the colour word (COLOR) or in the uint8 plane
+// K8 (no colour); w = min(k, max_weight), k' = min(k + 1, kmax).  A thread then moves 8 (5) bytes per voxel
+// each way instead of 12 (8).
+template <int ORDER, bool COLOR, bool FASTPROJ, bool PACKED>
 static __device__ __forceinline__ unsigned
 integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, const Rcp32 &rneg,
-               float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+               float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB, uint8_t *__restrict__ K8,
                const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
                const float *__restrict__ ctrx) {
   // ---- pcl::transformPoint (hpp:145) + reprojectPoint (.cpp:611-617), voxel by voxel ------------------
@@ -259,6 +264,10 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
   }
   if (!any) return 0;
   if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
+    // An fdiv is ONE cheap-looking IR instruction, so LLVM would if-convert this rare block into the hot path
+    // (and the backend then expands every division into ~10 VALU ops there); the empty volatile asm keeps
+    // the block from being speculated.
+    asm volatile("");
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (act[j] && !(obs[j].z - obs[j].gz > a.pos)) dn[j] = (obs[j].z - obs[j].gz) / a.neg;
@@ -268,17 +277,33 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const bool nt = a.nontemporal != 0;
   const f4 d4 = ld_plane(reinterpret_cast<const f4 *>(D + idx), nt);
-  const f4 w4 = ld_plane(reinterpret_cast<const f4 *>(Wt + idx), nt);
+  f4 w4 = {0.f, 0.f, 0.f, 0.f};
   u4 c4 = {0u, 0u, 0u, 0u};
+  uint32_t k4 = 0u;
+  if (!PACKED) w4 = ld_plane(reinterpret_cast<const f4 *>(Wt + idx), nt);
   if (COLOR) c4 = ld_plane(reinterpret_cast<const u4 *>(RGB + idx), nt);
+  if (PACKED && !COLOR) k4 = ld_plane(reinterpret_cast<const uint32_t *>(K8 + idx), nt);
   const float d0[4] = {d4.x, d4.y, d4.z, d4.w};
-  const float w0[4] = {w4.x, w4.y, w4.z, w4.w};
   const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
+  float w0[4] = {w4.x, w4.y, w4.z, w4.w};
+  unsigned k0[4] = {0u, 0u, 0u, 0u};
+  if (PACKED) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k0[j] = COLOR ? (c0[j] >> 24) : ((k4 >> (8 * j)) & 255u);
+      w0[j] = tsdf_decode_w(k0[j], a.wmax);
+    }
+  }
   float dv[4], wv[4];
   uint32_t cv[4];
   bool safe = true;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) safe &= !act[j] || update_is_safe(d0[j], w0[j], dn[j]);
+  for (int j = 0; j < 4; ++j) {
+    // PACKED: the weight is an integer <= 255 unless it sits at a non-integer max_weight
+    const bool ok = PACKED ? ((a.wmax_is_int || k0[j] < a.kmax) && numerator_ok(d0[j] * w0[j] + dn[j]))
+                           : update_is_safe(d0[j], w0[j], dn[j]);
+    safe &= !act[j] || ok;
+  }
   if (safe) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -288,18 +313,28 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
       add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
     }
   } else {
+    asm volatile("");  // keep the 16 IEEE divisions of this rare block out of the hot path (see above)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dv[j] = d0[j];
       wv[j] = w0[j];
-      cv[j] = c0[j];
+      cv[j] = c0[j] & 0xffffffu;
       add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
     }
   }
   bool chg_d = false, chg_w = false, chg_c = false;
   unsigned cnt = 0;
+  uint32_t k4n = 0u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (PACKED) {
+      const unsigned k1 = k0[j] + 1u < a.kmax ? k0[j] + 1u : a.kmax;  // count after this observation
+      const unsigned kn = act[j] ? k1 : k0[j];
+      if (COLOR)
+        cv[j] |= kn << 24;  // both add_observation flavours return a 24-bit colour
+      else
+        k4n |= kn << (8 * j);
+    }
     dv[j] = act[j] ? dv[j] : d0[j];
     wv[j] = act[j] ? wv[j] : w0[j];
     cv[j] = act[j] ? cv[j] : c0[j];
@@ -309,17 +344,19 @@ integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, 
     cnt += act[j] ? 1u : 0u;
   }
   if (chg_d) st_plane(reinterpret_cast<f4 *>(D + idx), (f4){dv[0], dv[1], dv[2], dv[3]}, nt);
-  if (chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
+  if (!PACKED && chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
   if (COLOR && chg_c) st_plane(reinterpret_cast<u4 *>(RGB + idx), (u4){cv[0], cv[1], cv[2], cv[3]}, nt);
+  if (PACKED && !COLOR && k4n != k4) st_plane(reinterpret_cast<uint32_t *>(K8 + idx), k4n, nt);
   return cnt;
 }
 
 // Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
 // blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
 // COUNT = accumulate the observed-voxel counter.
-template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT>
+template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
 static __global__ void __launch_bounds__(256)
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+            uint8_t *__restrict__ K8,
             const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
             unsigned long long *__restrict__ n_obs) {
@@ -339,8 +376,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const int y = y0 + r * a.TY;
       if (y >= a.ny) break;
       const int64_t idx = (plane_base + y) * a.pitch + x4;
-      cnt += integrate_quad<ORDER, COLOR, FASTPROJ>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, depth, bgra,
-                                                          ctrx);
+      cnt += integrate_quad<ORDER, COLOR, FASTPROJ, PACKED>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, K8, depth,
+                                                            bgra, ctrx);
     }
   }
   if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host)
@@ -392,6 +429,8 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   a.pos = p.max_dist_pos;
   a.neg = p.max_dist_neg;
   a.wmax = p.max_weight;
+  a.kmax = h->kmax;
+  a.wmax_is_int = p.max_weight == floorf(p.max_weight);
   a.pos_over_neg = p.max_dist_pos / p.max_dist_neg;
   a.neg_in_window = p.max_dist_neg >= 0x1p-20f && p.max_dist_neg <= 0x1p20f && p.max_dist_pos <= 0x1p20f;
   a.W = p.image_width;
@@ -447,15 +486,22 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   const bool fastproj = fast_projection_ok(a, p.integrate_color != 0);
   if (pose_ok) {
     const dim3 grid(gx, gy, gz), block(256);
-#define LAUNCH(ORDER, COLOR, FP, COUNT)                                                                 \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT>), grid, block, 0, h->stream, a, h->d, h->w, \
-                     h->rgb, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+#define LAUNCH(ORDER, COLOR, FP, COUNT, PK)                                                                  \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, h->d, h->w, \
+                     h->rgb, h->k8, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+#define L5(ORDER, COLOR, FP, COUNT) \
+  do {                              \
+    if (h->packed)                  \
+      LAUNCH(ORDER, COLOR, FP, COUNT, true);  \
+    else                            \
+      LAUNCH(ORDER, COLOR, FP, COUNT, false); \
+  } while (0)
 #define L4(ORDER, COLOR, FP) \
   do {                       \
     if (count)               \
-      LAUNCH(ORDER, COLOR, FP, true);  \
+      L5(ORDER, COLOR, FP, true);  \
     else                     \
-      LAUNCH(ORDER, COLOR, FP, false); \
+      L5(ORDER, COLOR, FP, false); \
   } while (0)
 #define L2(ORDER, COLOR) \
   do {                   \
@@ -477,6 +523,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     }
 #undef L2
 #undef L4
+#undef L5
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
   }
@@ -567,25 +614,32 @@ extern "C" int tsdf_hip_selftest_div_f64(const double *a, const double *b, doubl
 // planes * voxels * 4 B read and the same written (MI355X_MICROARCH.md: calibrate FETCH_SIZE /
 // WRITE_SIZE on a known byte count in your own access pattern).
 static __global__ void __launch_bounds__(256)
-k_calib_rmw(float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB, int64_t first4,
-            int64_t n4, float addv /* 0 at run time */, uint32_t xorv /* 0 at run time */) {
+k_calib_rmw(float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB, uint8_t *__restrict__ K8,
+            int64_t first4, int64_t n4, float addv /* 0 at run time */, uint32_t xorv /* 0 at run time */) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 *pd = reinterpret_cast<float4 *>(D) + first4 + i;
-    float4 *pw = reinterpret_cast<float4 *>(Wt) + first4 + i;
-    float4 d4 = *pd, w4 = *pw;
     // run-time zeros keep the stores alive without changing any value
+    float4 *pd = reinterpret_cast<float4 *>(D) + first4 + i;
+    float4 d4 = *pd;
     d4.x += addv;
     d4.y += addv;
-    w4.x += addv;
-    w4.y += addv;
     *pd = d4;
-    *pw = w4;
+    if (Wt) {
+      float4 *pw = reinterpret_cast<float4 *>(Wt) + first4 + i;
+      float4 w4 = *pw;
+      w4.x += addv;
+      w4.y += addv;
+      *pw = w4;
+    }
     if (RGB) {
       uint4 *pc = reinterpret_cast<uint4 *>(RGB) + first4 + i;
       uint4 c4 = *pc;
       c4.x ^= xorv;
       c4.y ^= xorv;
       *pc = c4;
+    }
+    if (K8) {
+      uint32_t *pk = reinterpret_cast<uint32_t *>(K8) + first4 + i;
+      *pk = *pk ^ xorv;
     }
   }
 }
@@ -597,12 +651,12 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
   const int64_t first4 = (int64_t)(h->z_begin - h->z_first) * plane / 4;
   const int64_t n4 = (int64_t)(h->z_end - h->z_begin) * plane / 4;
   const unsigned grid = 256u * (unsigned)tsdf_tuning().blocks_per_cu;
-  hipLaunchKernelGGL(k_calib_rmw, dim3(grid), dim3(256), 0, h->stream, h->d, h->w, h->rgb, first4, n4, 0.f, 0u);
+  hipLaunchKernelGGL(k_calib_rmw, dim3(grid), dim3(256), 0, h->stream, h->d, h->w, h->rgb, h->k8, first4, n4, 0.f, 0u);
   TSDF_HIP_TRY(hipGetLastError());
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  const uint64_t planes = h->rgb ? 3 : 2;
-  if (bytes_read) *bytes_read = planes * (uint64_t)n4 * 16u;
-  if (bytes_written) *bytes_written = planes * (uint64_t)n4 * 16u;
+  const uint64_t bytes_per_quad = 16u + (h->w ? 16u : 0u) + (h->rgb ? 16u : 0u) + (h->k8 ? 4u : 0u);
+  if (bytes_read) *bytes_read = bytes_per_quad * (uint64_t)n4;
+  if (bytes_written) *bytes_written = bytes_per_quad * (uint64_t)n4;
   return TSDF_HIP_OK;
 }
 

@@ -29,8 +29,8 @@ struct McArgs {
   int z_first;            // global index of allocated plane 0
   int z_lo, z_hi;         // cells with z in [z_lo, z_hi)
   int64_t pitch;
-  const float *d, *w;
-  const uint32_t *rgb;
+  const float *d;
+  PlaneView pv;           // weights / colour through tsdf_load_w / tsdf_load_rgb (any layout)
   float w_min, neg;
   int color_mode;
   float lower[3], size_voxel[3];
@@ -40,7 +40,7 @@ struct McArgs {
 
 // getGridValue (:91-106): NaN if w < w_min or |d| >= 1, else d * max_dist_neg.
 static __device__ __forceinline__ float grid_value(const McArgs &a, int64_t vi) {
-  const float d = a.d[vi], w = a.w[vi];
+  const float d = a.d[vi], w = tsdf_load_w(a.pv, vi);
   if (w < a.w_min || fabsf(d) >= 1.f) return NAN;
   return d * a.neg;
 }
@@ -82,17 +82,37 @@ static __device__ __forceinline__ float grid_value_reg(float d, float w, float w
   return (w < w_min || fabsf(d) >= 1.f) ? NAN : d * neg;
 }
 
-// Five x-consecutive grid values x4 .. x4+4 of one row (a float4 pair plus the first voxel of the next
-// quad; `tail` says whether that voxel exists in the row).
-static __device__ __forceinline__ void row_values(const McArgs &a, const float *__restrict__ drow,
-                                                  const float *__restrict__ wrow, bool tail, float v[5]) {
-  const float4 d4 = *reinterpret_cast<const float4 *>(drow);
-  const float4 w4 = *reinterpret_cast<const float4 *>(wrow);
-  v[0] = grid_value_reg(d4.x, w4.x, a.w_min, a.neg);
-  v[1] = grid_value_reg(d4.y, w4.y, a.w_min, a.neg);
-  v[2] = grid_value_reg(d4.z, w4.z, a.w_min, a.neg);
-  v[3] = grid_value_reg(d4.w, w4.w, a.w_min, a.neg);
-  v[4] = tail ? grid_value_reg(drow[4], wrow[4], a.w_min, a.neg) : NAN;
+// Weights of the quad starting at element o (16-byte aligned), per layout:
+// WL 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3 of the colour word), 2 = PACKED
+// without colour (uint8 count plane).
+template <int WL>
+static __device__ __forceinline__ void load_w4(const PlaneView &pv, int64_t o, float w[4]) {
+  if (WL == 0) {
+    const float4 w4 = *reinterpret_cast<const float4 *>(pv.w + o);
+    w[0] = w4.x, w[1] = w4.y, w[2] = w4.z, w[3] = w4.w;
+  } else if (WL == 1) {
+    const uint4 c4 = *reinterpret_cast<const uint4 *>(pv.rgb + o);
+    w[0] = tsdf_decode_w(c4.x >> 24, pv.wmax), w[1] = tsdf_decode_w(c4.y >> 24, pv.wmax);
+    w[2] = tsdf_decode_w(c4.z >> 24, pv.wmax), w[3] = tsdf_decode_w(c4.w >> 24, pv.wmax);
+  } else {
+    const uint32_t k4 = *reinterpret_cast<const uint32_t *>(pv.k8 + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = tsdf_decode_w((k4 >> (8 * j)) & 255u, pv.wmax);
+  }
+}
+
+// Five x-consecutive grid values x4 .. x4+4 of one row (a quad plus the first voxel of the next quad;
+// `tail` says whether that voxel exists in the row).
+template <int WL>
+static __device__ __forceinline__ void row_values(const McArgs &a, int64_t o, bool tail, float v[5]) {
+  const float4 d4 = *reinterpret_cast<const float4 *>(a.d + o);
+  float w[4];
+  load_w4<WL>(a.pv, o, w);
+  v[0] = grid_value_reg(d4.x, w[0], a.w_min, a.neg);
+  v[1] = grid_value_reg(d4.y, w[1], a.w_min, a.neg);
+  v[2] = grid_value_reg(d4.z, w[2], a.w_min, a.neg);
+  v[3] = grid_value_reg(d4.w, w[3], a.w_min, a.neg);
+  v[4] = tail ? grid_value_reg(a.d[o + 4], tsdf_load_w(a.pv, o + 4), a.w_min, a.neg) : NAN;
 }
 
 // Classify: a streaming pass over d and w.  A thread owns a quad of 4 x-consecutive base voxels (one
@@ -104,6 +124,7 @@ static __device__ __forceinline__ void row_values(const McArgs &a, const float *
 // global (Morton key, packed cell) arrays with ONE atomic per flush and coalesced stores.
 // counters[0] = active cells, counters[1] = triangles.
 #define MC_WAVE_BUF 512  // entries per wave; one append adds at most 256
+template <int WL>
 static __global__ void __launch_bounds__(256)
 k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, uint64_t capacity,
               unsigned long long *__restrict__ counters) {
@@ -119,8 +140,7 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
   const int x4 = xq * 4;
   const int z = a.z_lo + (int)blockIdx.z;
   const int64_t sz = (int64_t)a.ny * a.pitch;
-  const float *__restrict__ dz = a.d + (int64_t)(z - a.z_first) * sz;
-  const float *__restrict__ wz = a.w + (int64_t)(z - a.z_first) * sz;
+  const int64_t zbase = (int64_t)(z - a.z_first) * sz;
   const bool tail = x4 + 4 < (int)a.pitch;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   unsigned n_buf = 0;    // wave-uniform: entries waiting in buf
@@ -149,10 +169,11 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     if (y0 - ty + r * a.TY >= a.ny - 1) break;  // whole block past the last cell row (uniform)
     unsigned nt[4] = {0u, 0u, 0u, 0u};
     if (xq < a.qpr && y < a.ny - 1) {
-      const int64_t o = (int64_t)y * a.pitch + x4;
-      const float4 d4 = *reinterpret_cast<const float4 *>(dz + o);
-      const float4 w4 = *reinterpret_cast<const float4 *>(wz + o);
-      const float dq[4] = {d4.x, d4.y, d4.z, d4.w}, wq[4] = {w4.x, w4.y, w4.z, w4.w};
+      const int64_t o = zbase + (int64_t)y * a.pitch + x4;
+      const float4 d4 = *reinterpret_cast<const float4 *>(a.d + o);
+      const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
+      float wq[4];
+      load_w4<WL>(a.pv, o, wq);
       bool cand[4], any = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {  // :192 and :199-202 (base voxel strictly inside the grid)
@@ -163,10 +184,10 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
         float v00[5], v10[5], v01[5], v11[5];  // [dy][dz]
 #pragma unroll
         for (int j = 0; j < 4; ++j) v00[j] = grid_value_reg(dq[j], wq[j], a.w_min, a.neg);
-        v00[4] = tail ? grid_value_reg(dz[o + 4], wz[o + 4], a.w_min, a.neg) : NAN;
-        row_values(a, dz + o + a.pitch, wz + o + a.pitch, tail, v10);
-        row_values(a, dz + o + sz, wz + o + sz, tail, v01);
-        row_values(a, dz + o + sz + a.pitch, wz + o + sz + a.pitch, tail, v11);
+        v00[4] = tail ? grid_value_reg(a.d[o + 4], tsdf_load_w(a.pv, o + 4), a.w_min, a.neg) : NAN;
+        row_values<WL>(a, o + a.pitch, tail, v10);
+        row_values<WL>(a, o + sz, tail, v01);
+        row_values<WL>(a, o + sz + a.pitch, tail, v11);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1)
@@ -249,13 +270,13 @@ k_mc_emit(const McArgs a, const uint64_t *__restrict__ vals, const uint32_t *__r
   unsigned char col[3] = {0, 0, 0};
   const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
   if (a.color_mode == 2) {  // :217-224 colour by confidence, evaluated in double like the reference
-    const float std_dev = (float)((100. - (double)a.w[vi]) / 100.);
+    const float std_dev = (float)((100. - (double)tsdf_load_w(a.pv, vi)) / 100.);
     const double r = (double)(1 - std_dev) * 255., b = (double)std_dev * 255.;
     const double rmin = (255. < r) ? 255. : r, bmin = (255. < b) ? 255. : b;  // std::min(x, 255.)
     col[0] = (unsigned char)((0. < rmin) ? rmin : 0.);                        // std::max(0., x)
     col[2] = (unsigned char)((0. < bmin) ? bmin : 0.);
-  } else if (a.color_mode == 1 && a.rgb) {  // :226-231
-    const uint32_t c = a.rgb[vi];
+  } else if (a.color_mode == 1 && a.pv.rgb) {  // :226-231
+    const uint32_t c = tsdf_load_rgb(a.pv, vi);
     col[0] = (unsigned char)(c & 255u);
     col[1] = (unsigned char)((c >> 8) & 255u);
     col[2] = (unsigned char)((c >> 16) & 255u);
@@ -321,8 +342,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   a.z_first = h->z_first;
   a.pitch = h->pitch;
   a.d = h->d;
-  a.w = h->w;
-  a.rgb = h->rgb;
+  a.pv = tsdf_plane_view(h);
   a.w_min = w_min;
   a.neg = p.max_dist_neg;
   a.color_mode = color_mode;
@@ -361,7 +381,12 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t cap = h->mc_cells_cap;
     TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2 * sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(k_mc_classify, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+    if (!h->packed)
+      hipLaunchKernelGGL(k_mc_classify<0>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+    else if (h->rgb)
+      hipLaunchKernelGGL(k_mc_classify<1>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+    else
+      hipLaunchKernelGGL(k_mc_classify<2>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
     TSDF_HIP_TRY(hipGetLastError());
     TSDF_HIP_TRY(hipMemcpyAsync(counts, h->counter, sizeof counts, hipMemcpyDeviceToHost, h->stream));
     TSDF_HIP_TRY(hipStreamSynchronize(h->stream));

@@ -22,8 +22,8 @@ struct GridView {
   float size[3];
   float half[3];         // size/2 in float (root bounds test, octree.cpp:630)
   int64_t pitch;
-  const float *d, *w;
-  const uint32_t *rgb;
+  const float *d;
+  PlaneView pv;          // weights (and colour) through tsdf_load_w: layout-independent
   const float *ctr[3];   // octree node-centre tables
 };
 
@@ -42,8 +42,7 @@ static GridView make_view(const tsdf_hip_volume *v) {
   }
   g.pitch = v->pitch;
   g.d = v->d;
-  g.w = v->w;
-  g.rgb = v->rgb;
+  g.pv = tsdf_plane_view(v);
   return g;
 }
 
@@ -131,14 +130,14 @@ static __device__ float trilinear(const GridView &g, float x, float y, float z, 
   const int64_t sy = g.pitch, sz = (int64_t)g.ny * g.pitch;
   const int64_t ox = o + 1, oy = o + sy, oz = o + sz, oxy = o + sy + 1, oxz = o + sz + 1, oyz = o + sz + sy,
                 oxyz = o + sz + sy + 1;
-  valid = valid && (g.w[o] > 0);
-  valid = valid && (g.w[ox] > 0);
-  valid = valid && (g.w[oy] > 0);
-  valid = valid && (g.w[oz] > 0);
-  valid = valid && (g.w[oxy] > 0);
-  valid = valid && (g.w[oxz] > 0);
-  valid = valid && (g.w[oyz] > 0);
-  valid = valid && (g.w[oxyz] > 0);
+  valid = valid && (tsdf_load_w(g.pv, o) > 0);
+  valid = valid && (tsdf_load_w(g.pv, ox) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oy) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oz) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oxy) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oxz) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oyz) > 0);
+  valid = valid && (tsdf_load_w(g.pv, oxyz) > 0);
   return (g.d[o] * (1 - a) * (1 - b) * (1 - c) + g.d[oz] * (1 - a) * (1 - b) * (c) +
           g.d[oy] * (1 - a) * (b) * (1 - c) + g.d[oyz] * (1 - a) * (b) * (c) +
           g.d[ox] * (a) * (1 - b) * (1 - c) + g.d[oxz] * (a) * (1 - b) * (c) + g.d[oxy] * (a) * (b) * (1 - c) +
@@ -270,7 +269,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
       all_local = all_local && local;
       hit_voxel = true;
       dd = local ? g.d[vi] : -1.f;
-      ww = local ? g.w[vi] : 0.f;
+      ww = local ? tsdf_load_w(g.pv, vi) : 0.f;
       if (((dd < 0 && last_d > 0) || (dd > 0 && last_d < 0)) && last_w && ww) {
         found_crossing = true;
         const float old_t = t - step;
@@ -282,7 +281,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
           for (int k = 0; k < 3; ++k) pt[k] -= step * du[k];
           if (!containing(g, pt[0], pt[1], pt[2], vi, local, kz)) break;
           all_local = all_local && local;
-          const float new_d = local ? g.d[vi] : -1.f, new_w = local ? g.w[vi] : 0.f;
+          const float new_d = local ? g.d[vi] : -1.f, new_w = local ? tsdf_load_w(g.pv, vi) : 0.f;
           if ((last_d > 0 && new_d > 0) || (last_d < 0 && new_d < 0)) {
             last_d = new_d;
             last_w = new_w;

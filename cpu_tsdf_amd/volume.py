@@ -90,6 +90,14 @@ class TSDFVolumeOctree:
         """Not in the reference: which PCL ``transformPoint`` summation order to mirror."""
         self._p.xform_order = int(order)
 
+    def setLayout(self, layout):
+        """Not in the reference: capi.LAYOUT_AUTO / LAYOUT_F32W / LAYOUT_PACKED (include/tsdf_hip.h)."""
+        self._p.layout = int(layout)
+
+    def getLayout(self):
+        """What AUTO resolved to (needs reset())."""
+        return int(capi.load().tsdf_hip_layout(self._need()))
+
     def setZSlab(self, z_begin, z_end, halo=0, device=-1):
         """Not in the reference: own only planes [z_begin, z_end) (multi-GPU Z-slab partition)."""
         self._p.z_begin, self._p.z_end, self._p.halo, self._p.device = int(z_begin), int(z_end), int(halo), int(device)

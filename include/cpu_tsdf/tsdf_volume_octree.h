@@ -97,6 +97,8 @@ class TSDFVolumeOctree : public TSDFInterface {
   tsdf_handle handle() const { return h_; }
   void setTransformOrder(int order) { p_.xform_order = order; }
   void setDevice(int device) { p_.device = device; }
+  // TSDF_LAYOUT_* (include/tsdf_hip.h): how the weight is stored in HBM; default AUTO
+  void setLayout(int layout) { p_.layout = layout; }
 
   const float UNOBSERVED_VOXEL;
 

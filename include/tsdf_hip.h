@@ -12,8 +12,10 @@
  *
  * Volume storage: flat SoA planes in HBM, x fastest:
  *     d  [nz_local][ny][pitch]  float   truncation-normalised distance, init -1
- *     w  [nz_local][ny][pitch]  float   weight, init 0
- *     rgb[nz_local][ny][pitch]  uint32  r | g<<8 | b<<16 (only when integrate_color)
+ *     w  [nz_local][ny][pitch]  float   weight, init 0                     (F32W layout)
+ *     rgb[nz_local][ny][pitch]  uint32  r | g<<8 | b<<16 (only when integrate_color); in the PACKED layout
+ *                                       byte 3 holds the observation count k, w = min(k, max_weight)
+ *     k  [nz_local][ny][pitch]  uint8   the same count when PACKED without colour
  * pitch = nx rounded up to a multiple of 4.  A handle may own only a Z-slab
  * [z_begin, z_end) of the full grid (multi-GPU partitioning) plus `halo` extra planes on
  * each side that integrate never touches but raycast / marching cubes may read.
@@ -47,6 +49,15 @@ enum {
   TSDF_XFORM_LEFT_TO_RIGHT = 1 /* ((m0*x + m1*y) + m2*z) + m3    PCL scalar build / Eigen Affine3f * Vector3f */
 };
 
+/* How the weight is stored.  Every observation adds w_new = 1 and clamps at max_weight
+ * (src/lib/octree.cpp:156-158; the depth/variance weightings of hpp:200-204 have no setter), so
+ * w == min(k, max_weight) where k counts observations.  PACKED stores k in one byte -- byte 3 of the
+ * colour word, or a uint8 plane without colour -- and saves a third of the HBM traffic of integrateCloud;
+ * every entry point still speaks float weights.  It needs 0 <= max_weight <= 255 and weights of that form:
+ * tsdf_hip_upload refuses anything else with TSDF_HIP_E_UNSUPPORTED (load such a volume with F32W).
+ * AUTO = PACKED when max_weight allows it, else F32W. */
+enum { TSDF_LAYOUT_AUTO = 0, TSDF_LAYOUT_F32W = 1, TSDF_LAYOUT_PACKED = 2 };
+
 /* Everything TSDFVolumeOctree's setters configure before reset()
  * (src/lib/tsdf_volume_octree.cpp:54-85 defaults, :92-199 setters). */
 typedef struct tsdf_params {
@@ -65,6 +76,7 @@ typedef struct tsdf_params {
   int32_t z_begin, z_end;     /* Z-slab owned by this handle; 0,0 => whole grid          */
   int32_t halo;               /* extra planes kept below z_begin and above z_end         */
   int32_t device;             /* HIP ordinal, -1 => current device                       */
+  int32_t layout;             /* TSDF_LAYOUT_*                                           */
 } tsdf_params;
 
 /* Fill *p with the reference constructor defaults (tsdf_volume_octree.cpp:54-85). */
@@ -159,10 +171,14 @@ int tsdf_hip_get_planes_device(tsdf_handle h, int z0, int nz, float *d, float *w
 int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const float *d, const float *w,
                                const uint32_t *rgb);
 
-/* Raw device pointers of the SoA planes and their geometry (for RCCL halo exchange done by the
- * caller): element index of voxel (x,y,z_global) = ((z_global - z_first)*ny + y)*pitch + x. */
+/* Raw device pointers of the SoA planes and their geometry: element index of voxel (x,y,z_global) =
+ * ((z_global - z_first)*ny + y)*pitch + x.  In the PACKED layout *w is NULL (see tsdf_hip_layout) and the
+ * count sits in byte 3 of *rgb; without colour neither is exposed -- use the get/set_planes calls. */
 int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,
                            int32_t *z_first, int32_t *nz_alloc);
+
+/* TSDF_LAYOUT_F32W or TSDF_LAYOUT_PACKED: what AUTO resolved to for this handle. */
+int tsdf_hip_layout(tsdf_handle h);
 
 /* Voxel-centre tables actually used by the kernels: the reference's octree node centres
  * (src/lib/octree.cpp:244-266 split arithmetic) for each axis.  out has res[axis] floats. */
@@ -192,7 +208,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 1
+#define TSDF_HIP_ABI_VERSION 2
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
-    assert lib.tsdf_hip_abi_version() == 1
+    assert lib.tsdf_hip_abi_version() == 2
 
 
 def test_default_params_match_reference_constructor():
@@ -40,9 +40,19 @@ def test_default_params_match_reference_constructor():
     assert (p.image_width, p.image_height, p.integrate_color) == (640, 480, 0)
 
 
-def test_params_struct_layout_matches_header():
-    # 3*4 + 3*4 + 5*4 = 44 -> pad to 48, 4 doubles, 8 int32
-    assert C.sizeof(capi.TsdfParams) == 48 + 32 + 32
+def test_params_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of struct tsdf_params as gcc lays it out from include/tsdf_hip.h == the ctypes mirror."""
+    import subprocess
+    names = [n for n, _ in capi.TsdfParams._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tsdf_hip.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(tsdf_params));\n' +
+                   "".join(f'printf("%zu\\n", offsetof(tsdf_params, {n}));\n' for n in names) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == C.sizeof(capi.TsdfParams)
+    assert got[1:] == [getattr(capi.TsdfParams, n).offset for n in names]
 
 
 def test_no_device_is_reported_not_crashed():

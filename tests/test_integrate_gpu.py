@@ -6,7 +6,7 @@ observed-voxel counter exact."""
 import numpy as np
 import pytest
 
-from cpu_tsdf_amd import synth
+from cpu_tsdf_amd import capi, synth
 from oracle.oracle import OracleVolume
 from tests.common import assert_same_f32, frames, make_volume
 
@@ -142,6 +142,7 @@ def test_z_slabs_equal_whole_grid(gpu):
 
 def test_upload_download_roundtrip(gpu):
     vol, sc = make_volume(64, color=True, res3=(30, 20, 10), size3=(0.25, 0.25, 0.25))
+    vol.setLayout(capi.LAYOUT_F32W)  # arbitrary float weights need the float weight plane
     vol.reset()
     rng = np.random.RandomState(0)
     d = rng.randn(10, 20, 30).astype(np.float32)
@@ -152,6 +153,51 @@ def test_upload_download_roundtrip(gpu):
     assert np.array_equal(d, d2) and np.array_equal(w, w2) and np.array_equal(rgb, rgb2)
     d3, w3, _ = vol.download(x0=3, y0=2, z0=1, nx=7, ny=5, nz=4)
     assert np.array_equal(d3, d[1:5, 2:7, 3:10]) and np.array_equal(w3, w[1:5, 2:7, 3:10])
+
+
+@pytest.mark.parametrize("color", [False, True])
+@pytest.mark.parametrize("wmax", [100.0, 2.5, 0.0, 255.0])
+def test_packed_layout_roundtrip_and_refusal(gpu, color, wmax):
+    """PACKED stores the observation count k (w = min(k, max_weight)): every weight of that form survives
+    upload/download bit for bit next to arbitrary d and rgb; anything else is refused, not rounded."""
+    vol, sc = make_volume(64, color=color, res3=(30, 20, 10), size3=(0.25, 0.25, 0.25), max_weight=wmax)
+    vol.reset()
+    assert vol.getLayout() == capi.LAYOUT_PACKED
+    rng = np.random.RandomState(1)
+    d = rng.randn(10, 20, 30).astype(np.float32)
+    k = rng.randint(0, int(np.ceil(wmax)) + 1, (10, 20, 30))
+    w = np.minimum(k.astype(np.float32), np.float32(wmax))
+    rgb = rng.randint(0, 256, (10, 20, 30, 3)).astype(np.uint8) if color else None
+    vol.upload(d, w, rgb)
+    d2, w2, rgb2 = vol.download()
+    assert np.array_equal(d, d2) and np.array_equal(w, w2)
+    if color:
+        assert np.array_equal(rgb, rgb2)
+        vol.upload(None, w[::-1].copy(), None)  # the count shares a word with the colour: neither disturbs the other
+        assert np.array_equal(vol.download()[2], rgb) and np.array_equal(vol.download()[1], w[::-1])
+    bad = w.copy()
+    bad[3, 4, 5] = 0.5 if wmax != 0.5 else 0.25
+    with pytest.raises(capi.TsdfHipError):
+        vol.upload(None, bad, None)
+    big, _ = make_volume(64, max_weight=300.0)
+    big.reset()
+    assert big.getLayout() == capi.LAYOUT_F32W  # AUTO falls back when one byte cannot hold the count
+    big.setLayout(capi.LAYOUT_PACKED)
+    with pytest.raises(capi.TsdfHipError):
+        big.reset()
+
+
+@pytest.mark.parametrize("layout", [capi.LAYOUT_F32W, capi.LAYOUT_PACKED])
+@pytest.mark.parametrize("color", [False, True])
+@pytest.mark.parametrize("wmax", [100.0, 3.0, 2.5])
+def test_parity_both_layouts_through_weight_saturation(gpu, layout, color, wmax):
+    """Same frames through both HBM layouts vs the oracle, long enough for the weight to saturate (also at a
+    non-integer max_weight, where the saturated weight is not an integer)."""
+    vol, sc = make_volume(64, color=color, max_weight=wmax)
+    vol.setLayout(layout)
+    ov = run_pair(vol, sc, 6, total=8)
+    assert vol.getLayout() == layout
+    compare(vol, ov)
 
 
 def test_center_tables_match_oracle(gpu):
