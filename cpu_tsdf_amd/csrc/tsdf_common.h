@@ -29,7 +29,8 @@ struct tsdf_hip_volume {
   float *ctr[3] = {nullptr, nullptr, nullptr};  // device centre tables (full axis length)
   std::vector<float> h_ctr[3];
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
-  uint32_t *frame_bgra = nullptr;
+  uint32_t *frame_bgra = nullptr;  // = frame_depth + W*H (same allocation)
+  double *cam64 = nullptr;         // fx, fy, cx, cy on the device
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.)
   hipStream_t stream = nullptr;
   // marching-cubes result buffers (owned, reused between calls)

@@ -170,7 +170,7 @@ static void free_volume(tsdf_hip_volume *v) {
   for (int a = 0; a < 3; ++a)
     if (v->ctr[a]) (void)hipFree(v->ctr[a]);
   if (v->frame_depth) (void)hipFree(v->frame_depth);
-  if (v->frame_bgra) (void)hipFree(v->frame_bgra);
+  if (v->cam64) (void)hipFree(v->cam64);
   if (v->counter) (void)hipFree(v->counter);
   if (v->mc_verts) (void)hipFree(v->mc_verts);
   if (v->mc_rgb) (void)hipFree(v->mc_rgb);
@@ -257,8 +257,14 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     TRY_OR_BAIL(hipMemcpy(v->ctr[a], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   const size_t npx = (size_t)p->image_width * p->image_height;
-  TRY_OR_BAIL(hipMalloc(&v->frame_depth, npx * sizeof(float)));
-  TRY_OR_BAIL(hipMalloc(&v->frame_bgra, npx * sizeof(uint32_t)));
+  // one allocation [depth | bgra]: the integrate kernel addresses the frame through ONE buffer descriptor
+  TRY_OR_BAIL(hipMalloc(&v->frame_depth, 2 * npx * sizeof(float)));
+  v->frame_bgra = reinterpret_cast<uint32_t *>(v->frame_depth + npx);
+  {
+    const double cam[4] = {p->fx, p->fy, p->cx, p->cy};  // read by the rare exact-projection path only
+    TRY_OR_BAIL(hipMalloc(&v->cam64, sizeof cam));
+    TRY_OR_BAIL(hipMemcpy(v->cam64, cam, sizeof cam, hipMemcpyHostToDevice));
+  }
   TRY_OR_BAIL(hipMalloc(&v->counter, 1024 * sizeof(unsigned long long)));
   TRY_OR_BAIL(hipMemset(v->counter, 0, 1024 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL

@@ -23,9 +23,7 @@
 
 struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
-  double fx, fy, cx, cy;
   float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path)
-  float band_u, band_v;      // half-width of the "too close to an integer to trust fp32" zone, in pixels
   float hb_u, hb_v;          // 1/2 - band
   int neg_in_window;         // max_dist_pos/neg inside the scale-free divider's window
   unsigned kmax;             // PACKED layout: saturation count ceil(max_weight)
@@ -35,23 +33,14 @@ struct IntegrateArgs {
   float wmax;         // max_weight_
   float pos_over_neg; // max_dist_pos_ / max_dist_neg_ (IEEE fp32, host)
   int W, H;
-  int nx, ny;
+  int ny;
   int qpr;            // quads per row = ceil(nx/4)
-  int planes;         // planes to integrate
   int z_global0;      // global z of the first integrated plane
   int zl0;            // allocated-plane index of the first integrated plane
   int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
   int rpb;            // row groups (of TY rows) per block
-  int nontemporal;    // nt hint on the SoA plane loads/stores (streamed once per frame)
+  unsigned bgra_off;  // byte offset of the colour image from the depth image (same buffer descriptor)
   int64_t pitch;
-};
-
-// Per-voxel observation: which pixel the voxel projects to and what the sensor saw there.
-struct Obs {
-  int pix;     // v*W + u, or -1 if the voxel fails hpp:146 / reprojectPoint
-  float gz;    // camera-frame z of the voxel centre
-  float z;     // gathered depth
-  uint32_t c;  // gathered colour (PCL b,g,r,a bytes)
 };
 
 // reprojectPoint (tsdf_volume_octree.cpp:611-617), EXACT: u = (int)(x*fx/z + cx) evaluated in double,
@@ -59,10 +48,11 @@ struct Obs {
 // u and v divide by the same g.z, so the fp64 reciprocal is refined once (tsdf_div.h).
 // v_cvt_i32_f64 saturates where x86's cvttsd2si returns INT_MIN; both land outside [0, W), and NaN
 // cannot occur (the host rejects non-finite / absurd poses before launching).
-static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, float gx, float gy, float gz) {
+static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, const double *__restrict__ cam,
+                                                    float gx, float gy, float gz) {
   const Rcp64 rz = rcp64_prepare((double)gz);
-  const int u = (int)(div64((double)gx * a.fx, rz) + a.cx);
-  const int v = (int)(div64((double)gy * a.fy, rz) + a.cy);
+  const int u = (int)(div64((double)gx * cam[0], rz) + cam[2]);  // cam = fx, fy, cx, cy
+  const int v = (int)(div64((double)gy * cam[1], rz) + cam[3]);
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? v * a.W + u : -1;
 }
@@ -71,7 +61,8 @@ static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, floa
 // value R by less than `band` whenever R~ lies in [-1-band, W+band] (derivation in DESIGN.md: three
 // roundings of 2^-24, v_rcp_f32's 1 ulp taken as 2^-22, fx/cx conversion, the final add; host computes
 // band with a 1.5x margin).  Therefore:
-//   * trunc(R~) outside [-1, W]  =>  R~ outside that interval  =>  R is outside the image too;
+//   * R~ outside that interval  =>  R is outside the image too, and so is trunc(R~) (or the point is
+//     flagged below);
 //   * R~ farther than band from every integer (|fract(R~) - 1/2| < 1/2 - band)  =>  trunc(R~) == trunc(R).
 // Anything else (including a non-finite R~, whose fract is 0 or NaN) is flagged ambiguous and recomputed
 // by project_exact.  hb = 1/2 - band.
@@ -83,10 +74,10 @@ static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float
   const bool cert = fabsf(__builtin_amdgcn_fractf(ru) - 0.5f) < a.hb_u &&
                     fabsf(__builtin_amdgcn_fractf(rv) - 0.5f) < a.hb_v;  // false for NaN
   const int u = (int)ru, v = (int)rv;  // v_cvt_i32_f32: truncates, saturates, NaN -> 0
-  const bool near = (unsigned)u + 1u < (unsigned)a.W + 2u && (unsigned)v + 1u < (unsigned)a.H + 2u;
-  ambiguous = near && !cert;
+  // an uncertified point far outside the image is recomputed needlessly, never wrongly
+  ambiguous = !cert;
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
-  return in ? v * a.W + u : -1;
+  return in ? (int)__umul24((unsigned)v, (unsigned)a.W) + u : -1;  // W, H < 2^24 (checked on the host)
 }
 
 // Scale-free divider (LLVM's fp32 division ladder without v_div_scale / v_div_fixup) for a divisor
@@ -140,9 +131,8 @@ static __device__ __forceinline__ void add_observation_ieee(float &d, float &w, 
 //    on either side, the two roundings and y's error move it by < 256 * 2^-23 = 3.1e-5.
 template <bool COLOR>
 static __device__ __forceinline__ void add_observation_fast(float &d, float &w, uint32_t &rgb, float dn,
-                                                            uint32_t bgra, float wmax) {
-  const float wsum = w + 1.f;
-  const Rcp32 rs = rcp32_prepare(wsum);
+                                                            uint32_t bgra, float wmax, const Rcp32 &rs) {
+  const float wsum = w + 1.f;  // rs = rcp32_prepare(wsum) (nb and y are all that is used)
   if (COLOR) {
     const float hy = 0.5f * rs.y;
     const uint32_t q0 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
@@ -160,224 +150,266 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
   return w_ok && numerator_ok(d * w + dn);
 }
 
-template <typename V>
-static __device__ __forceinline__ V ld_plane(const V *p, bool nt) {
-  return nt ? __builtin_nontemporal_load(p) : *p;
-}
-template <typename V>
-static __device__ __forceinline__ void st_plane(V *p, V v, bool nt) {
-  if (nt)
-    __builtin_nontemporal_store(v, p);
-  else
-    *p = v;
-}
+// ---- memory access through buffer descriptors ----------------------------------------------------------
+// Every global access of the kernel goes through a 128-bit buffer resource built from wave-uniform values
+// (blockIdx-derived plane/row-group base, frame base): the per-lane part is a 32-bit byte offset, so the
+// row loop carries no 64-bit address arithmetic in the VALU, the per-row step is the instruction's scalar
+// offset, and out-of-range lanes (pixel -1, rows past the grid) are absorbed by the hardware bounds check
+// (loads return 0, stores are dropped) instead of by exec-mask branches.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-// One quad (4 x-consecutive voxels of one row).  FASTPROJ selects the certified fp32 projection with
-// exact fallback; otherwise every voxel goes through project_exact.  The x centre table is padded with
-// NaN beyond nx, which fails the range test, so a partial last quad needs no extra predicate.
-// Planes whose four values did not change are not written back (free space: d stays at the hinge value;
-// after weight saturation nothing changes).
-// PACKED: the weight is the observation count k in byte 3 of the colour word (COLOR) or in the uint8 plane
-// K8 (no colour); w = min(k, max_weight), k' = min(k + 1, kmax).  A thread then moves 8 (5) bytes per voxel
-// each way instead of 12 (8).
-template <int ORDER, bool COLOR, bool FASTPROJ, bool PACKED>
-static __device__ __forceinline__ unsigned
-integrate_quad(const IntegrateArgs &a, int x4, float cy, float cz, int64_t idx, const Rcp32 &rneg,
-               float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB, uint8_t *__restrict__ K8,
-               const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
-               const float *__restrict__ ctrx) {
-  // ---- pcl::transformPoint (hpp:145) + reprojectPoint (.cpp:611-617), voxel by voxel ------------------
-  const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
-  const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
-  float s[3], p1[3], p2[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    if (ORDER == TSDF_XFORM_PCL_SSE) {
-      s[r] = cy * a.m[4 * r + 1] + (cz * a.m[4 * r + 2] + a.m[4 * r + 3]);
-    } else {
-      p1[r] = a.m[4 * r + 1] * cy;
-      p2[r] = a.m[4 * r + 2] * cz;
-    }
-  }
-  auto transform = [&](float cx, int r) -> float {
-    if (ORDER == TSDF_XFORM_PCL_SSE) return cx * a.m[4 * r] + s[r];
-    return ((a.m[4 * r] * cx + p1[r]) + p2[r]) + a.m[4 * r + 3];
-  };
-  Obs obs[4];
-  unsigned amb_mask = 0;
-  bool any = false, lowz = false;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gx = transform(cxs[j], 0), gy = transform(cxs[j], 1), gz = transform(cxs[j], 2);
-    // hpp:146  if (v_g.z < min_sensor_dist_ || v_g.z > max_sensor_dist_) return 0;  .cpp:616  pt.z > 0
-    const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f;
-    obs[j].gz = gz;
-    lowz |= in && gz < 0x1p-14f;
-    int pix;
-    if (FASTPROJ) {
-      bool amb;
-      pix = project_fast(a, gx, gy, in ? gz : 1.f, amb);
-      if (amb && in) amb_mask |= 1u << j;
-    } else {
-      pix = project_exact(a, gx, gy, in ? gz : 1.f);
-    }
-    obs[j].pix = in ? pix : -1;
-    any |= in;
-  }
-  if (!any) return 0;
-  // Voxels whose fp32 projection could not be certified: redo them exactly, one at a time through a
-  // single copy of the fp64 code (rare: a fraction ~4*band of the voxels).
-  while (FASTPROJ && amb_mask) {
-    const int j = __builtin_ctz(amb_mask);
-    amb_mask &= amb_mask - 1;
-    const float cx = j == 0 ? cxs[0] : j == 1 ? cxs[1] : j == 2 ? cxs[2] : cxs[3];
-    const int pix = project_exact(a, transform(cx, 0), transform(cx, 1), transform(cx, 2));
-    if (j == 0) obs[0].pix = pix;
-    if (j == 1) obs[1].pix = pix;
-    if (j == 2) obs[2].pix = pix;
-    if (j == 3) obs[3].pix = pix;
-  }
-  // ---- gather the frame (L2-resident) ---------------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    obs[j].z = 0.f;
-    obs[j].c = 0u;
-    if (obs[j].pix >= 0) {
-      obs[j].z = depth[(unsigned)obs[j].pix];
-      if (COLOR) obs[j].c = bgra[(unsigned)obs[j].pix];
-    }
-  }
-  // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
-  // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
-  // at least 2^-39 in magnitude (difference of two floats one of which is >= 2^-14), and at most
-  // max(pos, neg); the host checks pos/neg against the window.
-  float dn[4];
-  bool act[4];
-  any = false;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float raw = obs[j].z - obs[j].gz;                            // hpp:159
-    act[j] = obs[j].pix >= 0 && !isnan(obs[j].z) && !(raw < -a.neg);   // hpp:152, :193-196
-    const bool clamped = raw > a.pos;                                  // hpp:189-192
-    dn[j] = clamped ? a.pos_over_neg : div32_fast(raw, rneg);          // hpp:198
-    any |= act[j];
-  }
-  if (!any) return 0;
-  if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
-    // An fdiv is ONE cheap-looking IR instruction, so LLVM would if-convert this rare block into the hot path
-    // (and the backend then expands every division into ~10 VALU ops there); the empty volatile asm keeps
-    // the block from being speculated.
-    asm volatile("");
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (act[j] && !(obs[j].z - obs[j].gz > a.pos)) dn[j] = (obs[j].z - obs[j].gz) / a.neg;
-  }
-  // ---- read-modify-write -------------------------------------------------------------------------------
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  const bool nt = a.nontemporal != 0;
-  const f4 d4 = ld_plane(reinterpret_cast<const f4 *>(D + idx), nt);
-  f4 w4 = {0.f, 0.f, 0.f, 0.f};
-  u4 c4 = {0u, 0u, 0u, 0u};
-  uint32_t k4 = 0u;
-  if (!PACKED) w4 = ld_plane(reinterpret_cast<const f4 *>(Wt + idx), nt);
-  if (COLOR) c4 = ld_plane(reinterpret_cast<const u4 *>(RGB + idx), nt);
-  if (PACKED && !COLOR) k4 = ld_plane(reinterpret_cast<const uint32_t *>(K8 + idx), nt);
-  const float d0[4] = {d4.x, d4.y, d4.z, d4.w};
-  const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
-  float w0[4] = {w4.x, w4.y, w4.z, w4.w};
-  unsigned k0[4] = {0u, 0u, 0u, 0u};
-  if (PACKED) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      k0[j] = COLOR ? (c0[j] >> 24) : ((k4 >> (8 * j)) & 255u);
-      w0[j] = tsdf_decode_w(k0[j], a.wmax);
-    }
-  }
-  float dv[4], wv[4];
-  uint32_t cv[4];
-  bool safe = true;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    // PACKED: the weight is an integer <= 255 unless it sits at a non-integer max_weight
-    const bool ok = PACKED ? ((a.wmax_is_int || k0[j] < a.kmax) && numerator_ok(d0[j] * w0[j] + dn[j]))
-                           : update_is_safe(d0[j], w0[j], dn[j]);
-    safe &= !act[j] || ok;
-  }
-  if (safe) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      dv[j] = d0[j];
-      wv[j] = w0[j];
-      cv[j] = c0[j];
-      add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
-    }
-  } else {
-    asm volatile("");  // keep the 16 IEEE divisions of this rare block out of the hot path (see above)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      dv[j] = d0[j];
-      wv[j] = w0[j];
-      cv[j] = c0[j] & 0xffffffu;
-      add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], obs[j].c, a.wmax);
-    }
-  }
-  bool chg_d = false, chg_w = false, chg_c = false;
-  unsigned cnt = 0;
-  uint32_t k4n = 0u;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (PACKED) {
-      const unsigned k1 = k0[j] + 1u < a.kmax ? k0[j] + 1u : a.kmax;  // count after this observation
-      const unsigned kn = act[j] ? k1 : k0[j];
-      if (COLOR)
-        cv[j] |= kn << 24;  // both add_observation flavours return a 24-bit colour
-      else
-        k4n |= kn << (8 * j);
-    }
-    dv[j] = act[j] ? dv[j] : d0[j];
-    wv[j] = act[j] ? wv[j] : w0[j];
-    cv[j] = act[j] ? cv[j] : c0[j];
-    chg_d |= __float_as_uint(dv[j]) != __float_as_uint(d0[j]);
-    chg_w |= __float_as_uint(wv[j]) != __float_as_uint(w0[j]);
-    chg_c |= cv[j] != c0[j];
-    cnt += act[j] ? 1u : 0u;
-  }
-  if (chg_d) st_plane(reinterpret_cast<f4 *>(D + idx), (f4){dv[0], dv[1], dv[2], dv[3]}, nt);
-  if (!PACKED && chg_w) st_plane(reinterpret_cast<f4 *>(Wt + idx), (f4){wv[0], wv[1], wv[2], wv[3]}, nt);
-  if (COLOR && chg_c) st_plane(reinterpret_cast<u4 *>(RGB + idx), (u4){cv[0], cv[1], cv[2], cv[3]}, nt);
-  if (PACKED && !COLOR && k4n != k4) st_plane(reinterpret_cast<uint32_t *>(K8 + idx), k4n, nt);
-  return cnt;
+static __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ uint32_t bload32(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ u4 bload128(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ void bstore32(rsrc_t r, unsigned voff, unsigned soff, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsigned soff, u4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 
 // Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
 // blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
+// A thread owns one quad column (4 x-consecutive voxels) and walks rpb rows of it.  Everything that depends
+// only on x -- the centre products c.x * m[r][0] -- is computed once; per row only the y/z part of the rigid
+// transform is redone.  FASTPROJ selects the certified fp32 projection with exact fallback; otherwise every
+// voxel goes through project_exact.  The x centre table is padded with NaN beyond nx, which fails the range
+// test, so a partial last quad needs no predicate.  Planes whose four values did not change are not written
+// back (free space: d stays at the hinge value; after weight saturation nothing changes).
+// PACKED: the weight is the observation count k in byte 3 of the colour word (COLOR) or in the uint8 plane
+// K8 (no colour); w = min(k, max_weight), k' = min(k + 1, kmax); a thread then moves 8 (5) bytes per voxel
+// each way instead of 12 (8), and 1/(k+1) comes from a 256-entry LDS table of refined reciprocals.
 // COUNT = accumulate the observed-voxel counter.
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
 static __global__ void __launch_bounds__(256)
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
-            uint8_t *__restrict__ K8,
-            const float *__restrict__ depth, const uint32_t *__restrict__ bgra,
+            uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
             unsigned long long *__restrict__ n_obs) {
   const unsigned tid = threadIdx.x;
+  __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
+  __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
+  if (PACKED) s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
+  {
+    const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
+    s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
+  }
+  __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
   const int xq = (int)blockIdx.x * a.TX + tx;
   const int zl = (int)blockIdx.z;
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0;
+  // wave-uniform bases
+  const int row0 = (int)blockIdx.y * a.rpb * a.TY;
+  const int rows = min(a.rpb * a.TY, a.ny - row0);
+  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.ny + row0) * a.pitch;
+  const unsigned span = (unsigned)rows * (unsigned)a.pitch;  // elements of this block's row group
+  const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
+  const rsrc_t rsW = make_rsrc(PACKED ? D : Wt + e0, PACKED ? 0u : span * 4u);
+  const rsrc_t rsC = make_rsrc(COLOR ? RGB + e0 : (uint32_t *)D, COLOR ? span * 4u : 0u);
+  const rsrc_t rsK = make_rsrc(PACKED && !COLOR ? K8 + e0 : (uint8_t *)D, PACKED && !COLOR ? span : 0u);
+  const unsigned npix = (unsigned)a.W * (unsigned)a.H;
+  const rsrc_t rsF = make_rsrc(depth, COLOR ? a.bgra_off + npix * 4u : npix * 4u);  // [depth ... bgra]
   if (xq < a.qpr) {
     const int x4 = xq * 4;
     const float cz = ctrz[a.z_global0 + zl];
-    const int64_t plane_base = (int64_t)(a.zl0 + zl) * a.ny;
-    const int y0 = (int)blockIdx.y * a.rpb * a.TY + ty;
+    const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
+    const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+    // ---- pcl::transformPoint (hpp:145): the x products and the z part, once per thread -------------------
+    float px[4][3], zt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) px[j][r] = cxs[j] * a.m[4 * r];  // == m * cx bit for bit
+      zt[r] = ORDER == TSDF_XFORM_PCL_SSE ? cz * a.m[4 * r + 2] + a.m[4 * r + 3] : a.m[4 * r + 2] * cz;
+    }
+    const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;  // byte offset inside the row group
+    const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
     for (int r = 0; r < a.rpb; ++r) {
-      const int y = y0 + r * a.TY;
+      const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
-      const int64_t idx = (plane_base + y) * a.pitch + x4;
-      cnt += integrate_quad<ORDER, COLOR, FASTPROJ, PACKED>(a, x4, ctry[y], cz, idx, rneg, D, Wt, RGB, K8, depth,
-                                                            bgra, ctrx);
+      const unsigned soff = (unsigned)r * row_step;
+      const float cy = s_cy[ty + r * a.TY];
+      float yt[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * a.m[4 * q + 1] + zt[q] : a.m[4 * q + 1] * cy;
+      auto transform = [&](int j, int q) -> float {
+        if (ORDER == TSDF_XFORM_PCL_SSE) return px[j][q] + yt[q];
+        return ((px[j][q] + yt[q]) + zt[q]) + a.m[4 * q + 3];
+      };
+      // ---- range test (hpp:146, .cpp:616) + reprojectPoint (.cpp:611-617), voxel by voxel ----------------
+      int pix[4];
+      float gzs[4];
+      unsigned amb_mask = 0;
+      bool any = false, lowz = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
+        const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f;
+        gzs[j] = gz;
+        lowz |= in && gz < 0x1p-14f;
+        int p;
+        if (FASTPROJ) {
+          bool amb;
+          p = project_fast(a, gx, gy, gz, amb);  // garbage in, garbage out: masked by `in` below
+          if (amb && in) amb_mask |= 1u << j;
+        } else {
+          p = project_exact(a, cam, gx, gy, in ? gz : 1.f);
+        }
+        pix[j] = in ? p : -1;
+        any |= in;
+      }
+      if (!any) continue;
+      // Voxels whose fp32 projection could not be certified: redo them exactly, one at a time through a
+      // single copy of the fp64 code (rare: a fraction ~4*band of the voxels).
+      while (FASTPROJ && amb_mask) {
+        const int j = __builtin_ctz(amb_mask);
+        amb_mask &= amb_mask - 1;
+        float g[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          g[q] = j == 0 ? transform(0, q) : j == 1 ? transform(1, q) : j == 2 ? transform(2, q) : transform(3, q);
+        const int p = project_exact(a, cam, g[0], g[1], g[2]);
+        if (j == 0) pix[0] = p;
+        if (j == 1) pix[1] = p;
+        if (j == 2) pix[2] = p;
+        if (j == 3) pix[3] = p;
+      }
+      // ---- gather the frame (L2-resident); pixel -1 is out of the descriptor's range and reads 0 ----------
+      float zs[4];
+      uint32_t cs[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // a valid pixel offset is < npix*4; -1 becomes 0xfffffffc, beyond the descriptor with or without the
+        // colour image's scalar offset
+        zs[j] = __uint_as_float(bload32(rsF, (unsigned)pix[j] << 2, 0u));
+        if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
+      }
+      // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
+      // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
+      // at least 2^-39 in magnitude (difference of two floats one of which is >= 2^-14), and at most
+      // max(pos, neg); the host checks pos/neg against the window.
+      float dn[4], raw[4];
+      bool act[4], clamped[4];
+      any = false;
+      bool any_div = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        raw[j] = zs[j] - gzs[j];                                        // hpp:159
+        act[j] = pix[j] >= 0 && !isnan(zs[j]) && !(raw[j] < -a.neg);    // hpp:152, :193-196
+        clamped[j] = raw[j] > a.pos;                                    // hpp:189-192
+        dn[j] = a.pos_over_neg;
+        any |= act[j];
+        any_div |= act[j] && !clamped[j];
+      }
+      if (!any) continue;
+      if (any_div) {  // free space (every observed voxel of the wave beyond the hinge) skips all four ladders
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dn[j] = clamped[j] ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
+      }
+      if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (act[j] && !clamped[j]) dn[j] = raw[j] / a.neg;
+      }
+      // ---- read-modify-write -----------------------------------------------------------------------------
+      const u4 d4 = bload128(rsD, voff, soff);
+      u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
+      uint32_t k4 = 0u;
+      if (!PACKED) w4 = bload128(rsW, voff, soff);
+      if (COLOR) c4 = bload128(rsC, voff, soff);
+      if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+      const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
+      const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
+      const uint32_t w0u[4] = {w4.x, w4.y, w4.z, w4.w};
+      float d0[4], w0[4];
+      uint32_t kw[4];  // PACKED: the count in byte 3 of a word (colour word, or the k8 byte moved there)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d0[j] = __uint_as_float(d0u[j]);
+        w0[j] = __uint_as_float(w0u[j]);
+        kw[j] = 0u;
+        if (PACKED) {
+          kw[j] = COLOR ? c0[j] : (k4 << (24 - 8 * j));
+          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);  // tsdf_decode_w (neither is NaN here)
+        }
+      }
+      float dv[4], wv[4];
+      uint32_t cv[4];
+      // F32W: the fast update is exact if update_is_safe().  PACKED: the divisor k + 1 is an integer in
+      // [1, 256] (unless the weight sits at a non-integer max_weight), for which the scale-free ladder is
+      // exact whenever its RESULT is a normal number (residuals of a normal numerator against an integer
+      // divisor are multiples of 2^-149, so they are exact; only a subnormal quotient can double-round); a
+      // result that is zero, subnormal or non-finite sends the quad to the IEEE path instead.
+      bool safe = true;
+      if (!PACKED) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) safe &= !act[j] || update_is_safe(d0[j], w0[j], dn[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && numerator_ok(d0[j] * w0[j] + dn[j]));
+      }
+      if (safe) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dv[j] = d0[j];
+          wv[j] = w0[j];
+          cv[j] = c0[j];
+          if (PACKED) {
+            Rcp32 rs;
+            rs.nb = -(w0[j] + 1.f);
+            rs.y = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
+            add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs);
+          } else {
+            add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rcp32_prepare(w0[j] + 1.f));
+          }
+        }
+      }
+      else {
+        asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dv[j] = d0[j];
+          wv[j] = w0[j];
+          cv[j] = c0[j] & 0xffffffu;
+          add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax);
+        }
+      }
+      uint32_t diff_d = 0u, diff_w = 0u, diff_c = 0u, k4n = 0u;
+      uint32_t dn_u[4], wn_u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (PACKED) {
+          // count after this observation: k' = min(k + 1, kmax), done on byte 3 in place
+          const uint32_t k1 = min((kw[j] & 0xff000000u) + 0x01000000u, a.kmax << 24);
+          if (COLOR)
+            cv[j] = (cv[j] & 0xffffffu) | k1;  // both add_observation flavours return a 24-bit colour
+          else
+            k4n |= (act[j] ? k1 : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
+        }
+        dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
+        wn_u[j] = act[j] ? __float_as_uint(wv[j]) : w0u[j];
+        cv[j] = act[j] ? cv[j] : c0[j];
+        diff_d |= dn_u[j] ^ d0u[j];
+        diff_w |= wn_u[j] ^ w0u[j];
+        diff_c |= cv[j] ^ c0[j];
+        cnt += act[j] ? 1u : 0u;
+      }
+      if (diff_d) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
+      if (!PACKED && diff_w) bstore128(rsW, voff, soff, (u4){wn_u[0], wn_u[1], wn_u[2], wn_u[3]});
+      if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
+      if (PACKED && !COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
     }
   }
   if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host)
@@ -398,14 +430,21 @@ static float f32_ulp(float v) {
   return nextafterf(a, INFINITY) - a;
 }
 
-static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
-  const tsdf_params &p = h->p;
+// Kernel arguments plus what only the host needs to decide the launch.
+struct IntegrateHost {
   IntegrateArgs a;
+  float band_u, band_v;  // half-width of the "too close to an integer to trust fp32" zone, in pixels
+  double fx, fy;
+  int planes;            // planes to integrate
+};
+
+static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
+  const tsdf_params &p = h->p;
+  IntegrateHost hh;
+  IntegrateArgs &a = hh.a;
   for (int i = 0; i < 12; ++i) a.m[i] = T[i];
-  a.fx = p.fx;
-  a.fy = p.fy;
-  a.cx = p.cx;
-  a.cy = p.cy;
+  hh.fx = p.fx;
+  hh.fy = p.fy;
   a.fxf = (float)p.fx;
   a.fyf = (float)p.fy;
   a.cxf = (float)p.cx;
@@ -419,10 +458,10 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
                        f32_ulp((float)c) + 1e-9;
       return (float)(1.5 * e);
     };
-    a.band_u = band(p.cx, p.image_width);
-    a.band_v = band(p.cy, p.image_height);
-    a.hb_u = nextafterf(0.5f - a.band_u, 0.f);  // rounded toward the conservative side
-    a.hb_v = nextafterf(0.5f - a.band_v, 0.f);
+    hh.band_u = band(p.cx, p.image_width);
+    hh.band_v = band(p.cy, p.image_height);
+    a.hb_u = nextafterf(0.5f - hh.band_u, 0.f);  // rounded toward the conservative side
+    a.hb_v = nextafterf(0.5f - hh.band_v, 0.f);
   }
   a.zmin = p.min_sensor_dist;
   a.zmax = p.max_sensor_dist;
@@ -435,10 +474,9 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   a.neg_in_window = p.max_dist_neg >= 0x1p-20f && p.max_dist_neg <= 0x1p20f && p.max_dist_pos <= 0x1p20f;
   a.W = p.image_width;
   a.H = p.image_height;
-  a.nx = h->nx;
   a.ny = h->ny;
   a.qpr = (h->nx + 3) / 4;
-  a.planes = h->z_end - h->z_begin;
+  hh.planes = h->z_end - h->z_begin;
   a.z_global0 = h->z_begin;
   a.zl0 = h->z_begin - h->z_first;
   int l2 = 0;
@@ -447,26 +485,27 @@ static IntegrateArgs make_args(tsdf_handle h, const float T[12]) {
   a.TX = 1 << l2;
   a.TY = 256 / a.TX;
   a.rpb = std::max(1, tsdf_tuning().rows_per_block / a.TY);
-  a.nontemporal = tsdf_tuning().nontemporal;
   a.pitch = h->pitch;
-  return a;
+  return hh;
 }
 
-static bool fast_projection_ok(const IntegrateArgs &a, bool color, bool force = false) {
+static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = false) {
   // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
   const int knob = tsdf_tuning().fast_projection;
   const bool want = force || knob > 0 || (knob < 0 && color);
   return want && std::isfinite(a.band_u) && std::isfinite(a.band_v) &&
-         a.band_u < 0.05f && a.band_v < 0.05f && fabs(a.fx) < 1e6 && fabs(a.fy) < 1e6;
+         a.band_u < 0.05f && a.band_v < 0.05f && fabs(a.fx) < 1e6 && fabs(a.fy) < 1e6 && a.a.W < (1 << 23) &&
+         a.a.H < (1 << 23);
 }
 
 static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
                             uint64_t *n_observed) {
   const tsdf_params &p = h->p;
-  const IntegrateArgs a = make_args(h, T);
+  const IntegrateHost hh = make_args(h, T);
+  IntegrateArgs a = hh.a;
   const unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
   const unsigned gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
-  const unsigned gz = (unsigned)a.planes;
+  const unsigned gz = (unsigned)hh.planes;
   if (gy > 65535u || gz > 65535u) {
     tsdf_set_error("grid too large for one launch");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -476,6 +515,24 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
   }
+  // The kernel reads the frame through ONE buffer descriptor based at the depth image, with the colour
+  // image at a 32-bit byte offset from it.  Caller buffers laid out otherwise are staged into the handle's
+  // [depth | bgra] allocation first (two device copies of 1.2 MB each at 640x480).
+  const size_t npx = (size_t)p.image_width * p.image_height;
+  a.bgra_off = 0;
+  if (color) {
+    const char *zd = (const char *)d_depth, *cb = (const char *)d_bgra;
+    if (cb >= zd + npx * 4 && (size_t)(cb - zd) + npx * 4 < (1ull << 31)) {
+      a.bgra_off = (unsigned)(cb - zd);
+    } else {
+      if (d_depth != h->frame_depth)
+        TSDF_HIP_TRY(hipMemcpyAsync(h->frame_depth, d_depth, npx * 4, hipMemcpyDeviceToDevice, h->stream));
+      if (d_bgra != h->frame_bgra)
+        TSDF_HIP_TRY(hipMemcpyAsync(h->frame_bgra, d_bgra, npx * 4, hipMemcpyDeviceToDevice, h->stream));
+      d_depth = h->frame_depth;
+      a.bgra_off = (unsigned)(npx * 4);
+    }
+  }
   const bool count = n_observed != nullptr;
   if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
@@ -483,12 +540,12 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
   bool pose_ok = true;
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
-  const bool fastproj = fast_projection_ok(a, p.integrate_color != 0);
+  const bool fastproj = fast_projection_ok(hh, p.integrate_color != 0);
   if (pose_ok) {
     const dim3 grid(gx, gy, gz), block(256);
 #define LAUNCH(ORDER, COLOR, FP, COUNT, PK)                                                                  \
   hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, h->d, h->w, \
-                     h->rgb, h->k8, d_depth, d_bgra, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+                     h->rgb, h->k8, d_depth, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
 #define L5(ORDER, COLOR, FP, COUNT) \
   do {                              \
     if (h->packed)                  \
@@ -662,14 +719,14 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
 
 // Test hook: the kernel's pixel projection (certified fp32 path and exact fp64 path) on arbitrary
 // camera-frame points g (n x 3), with this volume's intrinsics and image size.
-static __global__ void k_selftest_project(const IntegrateArgs a, const float *g, size_t n, int *pix_fast,
+static __global__ void k_selftest_project(const IntegrateArgs a, const double *cam, const float *g, size_t n, int *pix_fast,
                                           int *pix_exact, unsigned char *ambiguous) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
   bool amb = false;
   int pf = project_fast(a, gx, gy, gz, amb);
-  const int pe = project_exact(a, gx, gy, gz);
+  const int pe = project_exact(a, cam, gx, gy, gz);
   if (amb) pf = pe;  // what integrate_quad does
   pix_fast[i] = pf;
   pix_exact[i] = pe;
@@ -681,7 +738,7 @@ extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n
   if (!h || !g || !n || !pix_fast || !pix_exact || !ambiguous) return TSDF_HIP_E_INVALID;
   TSDF_HIP_TRY(hipSetDevice(h->device));
   const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  const IntegrateArgs a = make_args(h, ident);
+  const IntegrateHost a = make_args(h, ident);
   if (!fast_projection_ok(a, true, true)) {
     tsdf_set_error("fast projection disabled for this camera");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -694,7 +751,7 @@ extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n
   TSDF_HIP_TRY(hipMalloc(&dpe, n * 4));
   TSDF_HIP_TRY(hipMalloc(&da, n));
   TSDF_HIP_TRY(hipMemcpy(dg, g, n * 12, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_selftest_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, dg, n, dpf, dpe, da);
+  hipLaunchKernelGGL(k_selftest_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a.a, h->cam64, dg, n, dpf, dpe, da);
   TSDF_HIP_TRY(hipGetLastError());
   TSDF_HIP_TRY(hipMemcpy(pix_fast, dpf, n * 4, hipMemcpyDeviceToHost));
   TSDF_HIP_TRY(hipMemcpy(pix_exact, dpe, n * 4, hipMemcpyDeviceToHost));

@@ -134,6 +134,6 @@ def test_certified_fp32_projection_matches_double(gpu, W, H):
     bad = pf != want
     assert not bad.any(), (int(bad.sum()), g[bad][:4], pf[bad][:4], want[bad][:4], ru[bad][:4], rv[bad][:4])
     frac = amb.mean()
-    assert 0.0 < frac < 0.5  # boundary-engineered points are flagged, random ones almost never
+    assert 0.0 < frac < 0.55  # boundary-engineered points (half of them) are flagged, random ones almost never
     rnd = amb[2 * k + 8:]
     assert rnd.mean() < 0.01
