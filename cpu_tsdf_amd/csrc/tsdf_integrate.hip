@@ -188,7 +188,7 @@ static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsign
 // each way instead of 12 (8), and 1/(k+1) comes from a 256-entry LDS table of refined reciprocals.
 // COUNT = accumulate the observed-voxel counter.
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
-static __global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
