@@ -29,7 +29,7 @@ def main():
     cal_w = prof["sweep_bytes_written"] / (write["k_calib_rmw"]["WRITE_SIZE"] * 1024)
     rd = fetch["k_integrate"]["FETCH_SIZE"] * 1024 * round(cal_r)
     wr = write["k_integrate"]["WRITE_SIZE"] * 1024 * round(cal_w)
-    key = f"{prof['res']}x{prof['res']}x{prof['planes']}_c{prof['color']}"
+    key = f"{prof['res']}x{prof['res']}x{prof['planes']}_c{prof['color']}_{prof.get('layout', 'f32w')}"
     out_path = os.path.join(dst, "pmc_traffic.json")
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     out[key] = {
@@ -42,6 +42,7 @@ def main():
                         "known_written_bytes": prof["sweep_bytes_written"],
                         "WRITE_SIZE_KiB": write["k_calib_rmw"]["WRITE_SIZE"], "ratio_write": cal_w},
         "algorithmic_bytes_per_launch": prof["alg_bytes_per_launch"],
+        "layout_bytes_per_launch": prof.get("layout_bytes_per_launch"),
         "k_integrate_avg_ns_kernel_trace": trace["k_integrate"]["duration_ns"],
     }
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)

@@ -13,7 +13,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_integrate", "k_calib_rmw", "k_fill_u32", "k_raycast", "k_march", "k_sample"):
+    for key in ("k_integrate", "k_calib_rmw", "k_fill_u32", "k_raycast", "k_ray_begin", "k_mc_classify", "k_mc_emit",
+                "k_mc_counts", "k_sample", "k_block", "k_planes"):
         if key in name:
             return key
     return name[:48]

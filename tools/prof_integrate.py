@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--calib", type=int, default=2)
     ap.add_argument("--color", type=int, default=1)
+    ap.add_argument("--layout", choices=["auto", "f32w", "packed"], default="auto")
     ap.add_argument("--total", type=int, default=44, help="turntable length the frames are taken from")
     a = ap.parse_args()
     res = a.res
@@ -39,6 +40,7 @@ def main():
     v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
     v.setSensorDistanceBounds(0.0, 3 * sc.size)
     v.setIntegrateColor(bool(a.color))
+    v.setLayout({"auto": capi.LAYOUT_AUTO, "f32w": capi.LAYOUT_F32W, "packed": capi.LAYOUT_PACKED}[a.layout])
     if a.planes:
         zb = (res - a.planes) // 2
         v.setZSlab(zb, zb + a.planes)
@@ -62,8 +64,11 @@ def main():
             n_obs.append(n)
     W, H = sc.width, sc.height
     bpv, bpp = (24, 8) if a.color else (16, 4)
+    packed = v.getLayout() == capi.LAYOUT_PACKED
+    lbpv = (16 if a.color else 10) if packed else bpv
     print(json.dumps({
-        "res": res, "planes": a.planes or res, "color": a.color, "calib_launches": a.calib,
+        "res": res, "planes": a.planes or res, "color": a.color, "layout": "packed" if packed else "f32w",
+        "layout_bytes_per_launch": lbpv * float(np.mean(n_obs)) + bpp * W * H, "calib_launches": a.calib,
         "integrate_launches": a.warmup + a.steps,
         "sweep_bytes_read": br.value, "sweep_bytes_written": bw.value, "sweep_wall_ms": t_sweep * 1e3,
         "n_obs_mean": float(np.mean(n_obs)),

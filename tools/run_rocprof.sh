@@ -5,7 +5,7 @@
 #      which also launches k_calib_rmw sweeps of exactly known bytes for calibration.
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/pmc_reduce.py turns them into JSON summaries.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r01b}
 STEPS=${2:-20}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
