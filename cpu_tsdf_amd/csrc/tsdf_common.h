@@ -31,6 +31,8 @@ struct tsdf_hip_volume {
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
   uint32_t *frame_bgra = nullptr;  // = frame_depth + W*H (same allocation)
   double *cam64 = nullptr;         // fx, fy, cx, cy on the device
+  uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
+  size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.)
   hipStream_t stream = nullptr;
   // marching-cubes result buffers (owned, reused between calls)
@@ -59,7 +61,7 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
-// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT); read once.
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL); read once.
 struct TsdfTuning {
   int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
   int blocks_per_cu;   // grid-stride helper kernels: grid = 256 CUs x this
@@ -68,6 +70,7 @@ struct TsdfTuning {
                        // -1 auto (only with colour, where VALU load is highest; measured, profiles/)
   int nontemporal;     // nt hint on the voxel-plane loads/stores
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
+  int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
 };
 const TsdfTuning &tsdf_tuning();
 

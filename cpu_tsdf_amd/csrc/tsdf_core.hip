@@ -44,12 +44,36 @@ static int env_int(const char *name, int dflt) {
   return (e && *e) ? atoi(e) : dflt;
 }
 
-const TsdfTuning &tsdf_tuning() {
-  static const TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
-                               std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
-                               env_int("TSDF_HIP_SKIP_UNCHANGED", 1), env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_NONTEMPORAL", 0),
-                               env_int("TSDF_HIP_MC_FLUSH_AT", 256)};
+static TsdfTuning &tuning_storage() {
+  static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
+                         std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
+                         env_int("TSDF_HIP_SKIP_UNCHANGED", 1), env_int("TSDF_HIP_FAST_PROJECTION", -1),
+                         env_int("TSDF_HIP_NONTEMPORAL", 0), env_int("TSDF_HIP_MC_FLUSH_AT", 256),
+                         env_int("TSDF_HIP_CULL", 1)};
   return t;
+}
+
+const TsdfTuning &tsdf_tuning() { return tuning_storage(); }
+
+// Test / A-B hook: change a launch-shape knob at run time (same names as the TSDF_HIP_* variables, lower
+// case, without the prefix).  None of them may change results; the tests use this to prove it.
+extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
+  if (!name) return TSDF_HIP_E_INVALID;
+  TsdfTuning &t = tuning_storage();
+  const std::string n(name);
+  if (n == "rows_per_block")
+    t.rows_per_block = std::max(1, value);
+  else if (n == "blocks_per_cu")
+    t.blocks_per_cu = std::max(1, value);
+  else if (n == "fast_projection")
+    t.fast_projection = value;
+  else if (n == "mc_flush_at")
+    t.mc_flush_at = value;
+  else if (n == "cull")
+    t.cull = value;
+  else
+    return TSDF_HIP_E_INVALID;
+  return TSDF_HIP_OK;
 }
 
 extern "C" int tsdf_hip_abi_version(void) { return TSDF_HIP_ABI_VERSION; }
@@ -171,6 +195,7 @@ static void free_volume(tsdf_hip_volume *v) {
     if (v->ctr[a]) (void)hipFree(v->ctr[a]);
   if (v->frame_depth) (void)hipFree(v->frame_depth);
   if (v->cam64) (void)hipFree(v->cam64);
+  if (v->live) (void)hipFree(v->live);
   if (v->counter) (void)hipFree(v->counter);
   if (v->mc_verts) (void)hipFree(v->mc_verts);
   if (v->mc_rgb) (void)hipFree(v->mc_rgb);

@@ -192,7 +192,9 @@ static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
-            unsigned long long *__restrict__ n_obs) {
+            unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live) {
+  // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
+  if (live && !live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)]) return;
   const unsigned tid = threadIdx.x;
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
   __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
@@ -425,6 +427,71 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Brick-level frustum cull -- the dense counterpart of getFrustumCulledVoxels (tsdf_volume_octree.cpp:
+// 619-652), which lets the reference skip coarse octree cells outside a 1.1x FOV frustum.  Here the unit is
+// one k_integrate block (up to 1024 voxels of x by rpb*TY rows of one plane) and the test is CONSERVATIVE:
+// a block is dropped only if no voxel in it can pass updateVoxel's own tests (hpp:146 sensor range,
+// .cpp:616 pixel inside the image), so results are identical with and without it.  The block's rectangle
+// of voxel centres is transformed in double; the per-voxel float transform differs from that by at most
+// ~4 roundings of magnitude |m||c| + |t|, covered by eps (8x margin); a rectangle in front of the camera
+// projects to a convex quadrilateral, so the pixel extremes are at its corners, widened by the projection's
+// sensitivity to eps plus one pixel for the truncation toward zero.
+struct CullArgs {
+  double m[12], fx, fy, cx, cy;
+  double zlo, zmax;  // a voxel needs g.z >= zlo (= max(min_sensor_dist, 0), with g.z > 0) and g.z <= zmax
+  int W, H, nx, ny, z_global0;
+  int bx_vox, by_rows;  // voxels along x / rows along y per block
+  int gx, gy, gz;
+};
+
+static __host__ __device__ inline bool box_may_be_observed(const CullArgs &c, double x0, double x1, double y0, double y1,
+                                                           double z) {
+  double gz_min = 1e300, gz_max = -1e300, eps = 0, u_min = 1e300, u_max = -1e300, v_min = 1e300, v_max = -1e300;
+  double g[4][3];
+  for (int k = 0; k < 4; ++k) {
+    const double x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0;
+    for (int r = 0; r < 3; ++r) {
+      g[k][r] = c.m[4 * r] * x + c.m[4 * r + 1] * y + c.m[4 * r + 2] * z + c.m[4 * r + 3];
+      const double mag = fabs(c.m[4 * r] * x) + fabs(c.m[4 * r + 1] * y) + fabs(c.m[4 * r + 2] * z) + fabs(c.m[4 * r + 3]);
+      eps = fmax(eps, 8.0 * 4.0 * 5.97e-8 * mag);
+    }
+    gz_min = fmin(gz_min, g[k][2]);
+    gz_max = fmax(gz_max, g[k][2]);
+  }
+  if (!(eps < 1e300)) return true;                          // non-finite: no claim
+  if (gz_max + eps < c.zlo || gz_max + eps <= 0) return false;  // every voxel behind the near bound / camera
+  if (gz_min - eps > c.zmax) return false;                  // every voxel beyond the far bound
+  const double zc = gz_min - eps;
+  if (!(zc > 1e-6 * (fabs(c.m[11]) + fabs(x1 - x0) + fabs(y1 - y0) + 1e-30))) return true;  // touches the camera plane
+  double mu_u = 0, mu_v = 0;
+  for (int k = 0; k < 4; ++k) {
+    const double iz = 1.0 / g[k][2];
+    const double u = c.fx * g[k][0] * iz + c.cx, v = c.fy * g[k][1] * iz + c.cy;
+    u_min = fmin(u_min, u), u_max = fmax(u_max, u);
+    v_min = fmin(v_min, v), v_max = fmax(v_max, v);
+    mu_u = fmax(mu_u, fabs(c.fx) * eps * (1.0 + fabs(g[k][0]) / zc) / zc);
+    mu_v = fmax(mu_v, fabs(c.fy) * eps * (1.0 + fabs(g[k][1]) / zc) / zc);
+  }
+  mu_u = 1.0 + 2.0 * mu_u;
+  mu_v = 1.0 + 2.0 * mu_v;
+  if (u_max < -1.0 - mu_u || u_min > c.W + mu_u) return false;  // (int)R in [0, W) needs -1 < R < W
+  if (v_max < -1.0 - mu_v || v_min > c.H + mu_v) return false;
+  return true;
+}
+
+static __global__ void __launch_bounds__(256)
+k_cull(const CullArgs c, const float *__restrict__ ctrx, const float *__restrict__ ctry,
+       const float *__restrict__ ctrz, uint8_t *__restrict__ live) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (int64_t)c.gx * c.gy * c.gz) return;
+  const int bx = (int)(b % c.gx), by = (int)((b / c.gx) % c.gy), bz = (int)(b / ((int64_t)c.gx * c.gy));
+  const int xa = bx * c.bx_vox, xb = min(c.nx, xa + c.bx_vox) - 1;
+  const int ya = by * c.by_rows, yb = min(c.ny, ya + c.by_rows) - 1;
+  // the centre tables increase with the index, so the first and last voxel bound the block
+  live[b] = box_may_be_observed(c, ctrx[xa], ctrx[xb], ctry[ya], ctry[yb], ctrz[c.z_global0 + bz]) ? 1 : 0;
+}
+
 static float f32_ulp(float v) {
   const float a = fabsf(v);
   return nextafterf(a, INFINITY) - a;
@@ -533,6 +600,45 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
       a.bgra_off = (unsigned)(npx * 4);
     }
   }
+  // Brick cull (TSDF_HIP_CULL: 1 on when useful, 0 off, 2 always): skipped when the whole slab is provably
+  // inside the frustum and sensor range (convex frustum: test the slab's 8 corners), the turntable case.
+  const uint8_t *live = nullptr;
+  if (tsdf_tuning().cull) {
+    CullArgs c;
+    for (int i = 0; i < 12; ++i) c.m[i] = T[i];
+    c.fx = p.fx, c.fy = p.fy, c.cx = p.cx, c.cy = p.cy;
+    c.zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
+    c.zmax = p.max_sensor_dist;
+    c.W = p.image_width, c.H = p.image_height, c.nx = h->nx, c.ny = h->ny, c.z_global0 = h->z_begin;
+    c.bx_vox = a.TX * 4, c.by_rows = a.rpb * a.TY;
+    c.gx = (int)gx, c.gy = (int)gy, c.gz = (int)gz;
+    bool all_inside = tsdf_tuning().cull != 2;
+    for (int k = 0; k < 8 && all_inside; ++k) {
+      const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
+                   z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
+      double g[3];
+      for (int r = 0; r < 3; ++r) g[r] = c.m[4 * r] * x + c.m[4 * r + 1] * y + c.m[4 * r + 2] * z + c.m[4 * r + 3];
+      const double u = c.fx * g[0] / g[2] + c.cx, v = c.fy * g[1] / g[2] + c.cy;
+      all_inside = g[2] > c.zlo + 1e-3 && g[2] > 1e-3 && g[2] < c.zmax - 1e-3 && u > 1 && u < c.W - 2 && v > 1 && v < c.H - 2;
+    }
+    if (!all_inside) {
+      const size_t nb = (size_t)gx * gy * gz;
+      if (nb > h->live_cap) {
+        if (h->live) {
+          TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+          TSDF_HIP_TRY(hipFree(h->live));
+          h->live = nullptr;
+          h->live_cap = 0;
+        }
+        TSDF_HIP_TRY(hipMalloc(&h->live, nb));
+        h->live_cap = nb;
+      }
+      hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, h->ctr[0], h->ctr[1],
+                         h->ctr[2], h->live);
+      TSDF_HIP_TRY(hipGetLastError());
+      live = h->live;
+    }
+  }
   const bool count = n_observed != nullptr;
   if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
@@ -545,7 +651,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     const dim3 grid(gx, gy, gz), block(256);
 #define LAUNCH(ORDER, COLOR, FP, COUNT, PK)                                                                  \
   hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, h->d, h->w, \
-                     h->rgb, h->k8, d_depth, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter)
+                     h->rgb, h->k8, d_depth, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter, live)
 #define L5(ORDER, COLOR, FP, COUNT) \
   do {                              \
     if (h->packed)                  \

@@ -203,6 +203,10 @@ int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
 
+/* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
+ * "mc_flush_at", "cull" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
+int tsdf_hip_set_tuning(const char *name, int value);
+
 const char *tsdf_hip_error_string(int code);
 const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);

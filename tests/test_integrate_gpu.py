@@ -200,6 +200,64 @@ def test_parity_both_layouts_through_weight_saturation(gpu, layout, color, wmax)
     compare(vol, ov)
 
 
+def test_brick_cull_is_conservative_camera_inside_volume(gpu):
+    """The brick-level frustum cull (dense counterpart of getFrustumCulledVoxels) may only drop blocks no voxel
+    of which can be observed.  Camera INSIDE the volume with a short sensor range, as in the reference's README
+    use: vs the oracle, and cull forced on == cull off bit for bit, with the counter proving blocks were cut."""
+    sc = synth.scene_b(160, 120)
+    try:
+        outs = []
+        for cull in (2, 0):
+            capi.set_tuning("cull", cull)
+            vol, _ = make_volume(128, 160, 120, color=True, size=10.0, zmin=0.0, zmax=3.0)
+            vol.reset()
+            ov = OracleVolume(vol._p) if cull == 2 else None
+            tot = 0
+            for i in range(5):
+                tr = synth.scene_b_pose(i, 5)
+                dep, col = sc.depth(tr), sc.bgra(i)
+                n = vol.integrateCloud(dep, col, tr, count=True)
+                tot += n
+                if ov is not None:
+                    assert n == ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+            d, w, rgb = vol.download()
+            if ov is not None:
+                assert_same_f32(d, ov.d, "d")
+                assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+            outs.append((d, w, rgb, tot))
+            vol.close()
+        assert 0 < outs[0][3] == outs[1][3] < 0.1 * 128 ** 3 * 5  # a small part of the grid is ever observed
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    finally:
+        capi.set_tuning("cull", 1)
+
+
+def test_brick_cull_random_poses_equal_no_cull(gpu):
+    """Random poses (inside, outside, grazing, behind) on a non-cubic odd grid: forced cull == no cull."""
+    rng = np.random.RandomState(5)
+    sc = synth.Scene(1.0, 160, 120)
+    poses = []
+    for _ in range(12):
+        eye = rng.uniform(-1.2, 1.2, 3)
+        tgt = rng.uniform(-0.4, 0.4, 3)
+        poses.append(synth.look_at_pose(eye, target=tgt))
+    try:
+        res = []
+        for cull in (2, 0):
+            capi.set_tuning("cull", cull)
+            vol, _ = make_volume(64, 160, 120, res3=(70, 45, 33), size3=(1.0, 0.8, 0.6), zmin=0.05, zmax=0.9)
+            vol.reset()
+            counts = [vol.integrateCloud(sc.depth(tr), None, tr, count=True) for tr in poses]
+            res.append((vol.download()[:2], counts))
+            vol.close()
+        assert res[0][1] == res[1][1] and sum(res[0][1]) > 1000
+        assert np.array_equal(res[0][0][0].view(np.uint32), res[1][0][0].view(np.uint32))
+        assert np.array_equal(res[0][0][1], res[1][0][1])
+    finally:
+        capi.set_tuning("cull", 1)
+
+
 def test_center_tables_match_oracle(gpu):
     vol, sc = make_volume(64, size=3.3)  # non-dyadic size: octree-descent sums, not the closed form
     vol.reset()
