@@ -118,6 +118,69 @@ def extras(vol, pose, W, H):
     return out
 
 
+def scene_b_leg(res, color, cpu_seconds):
+    """Report-only honesty check (Scene B): the regime the reference's octree was built for --
+    camera inside a 10 m volume, sensor range 0..3 m, ~1 % of the voxels in the frustum.  GPU: brick cull +
+    k_integrate on a second res^3 grid (frames resident in HBM, HIP events); CPU: the reference itself on the
+    same poses, bounded to `cpu_seconds` of integrateCloud time."""
+    import torch
+    from cpu_tsdf_amd import capi, synth
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    out = {}
+    try:
+        sc = synth.scene_b()
+        v = TSDFVolumeOctree()
+        v.setResolution(res, res, res)
+        v.setGridSize(10.0, 10.0, 10.0)
+        v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        v.setSensorDistanceBounds(0.0, 3.0)
+        v.setIntegrateColor(bool(color))
+        stream = torch.cuda.current_stream()
+        v.setStream(stream.cuda_stream)
+        v.reset()
+        nf = 12
+        poses = [synth.scene_b_pose(i, nf) for i in range(nf)]
+        frame = torch.empty((nf, 2, sc.height, sc.width), dtype=torch.float32, device="cuda")  # [depth | bgra] per frame
+        for i, p in enumerate(poses):
+            frame[i, 0].copy_(torch.from_numpy(sc.depth(p)))
+            frame[i, 1].view(torch.uint8).view(sc.height, sc.width, 4).copy_(torch.from_numpy(sc.bgra(i)))
+        lib, h = capi.load(), v._need()
+
+        def run(i, count=None):
+            capi.check(lib.tsdf_hip_integrate_device(h, C.c_void_p(frame[i, 0].data_ptr()),
+                                                     C.c_void_p(frame[i, 1].data_ptr()) if color else None,
+                                                     capi.as_f32p(synth.cam_from_vol_f32(poses[i])), count), "scene_b")
+        c = C.c_uint64(0)
+        run(0, C.byref(c))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(nf):
+            run(i)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / nf
+        out.update({"grid": [res] * 3, "size_m": 10.0, "sensor_range_m": [0.0, 3.0], "observed_voxels_per_frame": int(c.value),
+                    "gpu_ms_per_frame": ms, "gpu_frames_per_s": 1e3 / ms})
+        v.close()
+        if cpu_seconds > 0:
+            from oracle import refbind
+            if refbind.available():
+                cores = os.cpu_count() or 1
+                os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+                rv = refbind.RefVolume(res, 10.0, sc.width, sc.height, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3.0, color=bool(color),
+                                       dense=False, max_cell=0.5)
+                spent, n = 0.0, 0
+                while spent < cpu_seconds and n < nf:
+                    spent += rv.integrate(sc.depth(poses[n]), sc.bgra(n) if color else None, poses[n])
+                    n += 1
+                rv.close()
+                out.update({"cpu_reference_frames_per_s": n / spent, "cpu_cores": cores, "cpu_frames_timed": n})
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
+
+
 def capi_mod():
     from cpu_tsdf_amd import capi
     return capi
@@ -341,6 +404,7 @@ def main():
         }
         if world == 1 and args.extras:
             out["extras"] = extras(vol, poses[-1], W, H)
+            out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -31,6 +31,7 @@ struct tsdf_hip_volume {
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
   uint32_t *frame_bgra = nullptr;  // = frame_depth + W*H (same allocation)
   double *cam64 = nullptr;         // fx, fy, cx, cy on the device
+  int frame_staged = 0;            // tsdf_hip_organize left a frame in [frame_depth | frame_bgra]
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.)

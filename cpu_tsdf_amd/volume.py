@@ -178,6 +178,40 @@ class TSDFVolumeOctree:
         self._is_empty = False
         return int(n.value) if count else True
 
+    def organize(self, xyz, bgra=None, cloud_units=1.0, zero_nans=False, world_to_cam=None, fetch=True):
+        """The `integrate` program's per-cloud preparation (src/prog/integrate.cpp:559-618) on the GPU: scale,
+        (0,0,0) -> NaN, optional world -> camera transform (4x4 = poses[i].inverse()), z-buffer reprojection
+        into an organised frame that stays staged in the volume for integrateStaged().  xyz (n, >=3) float32,
+        bgra (n, >=4) uint8 in PCL b,g,r,a order.  Returns (depth, bgra, n_valid) when `fetch`."""
+        h = self._need()
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
+        H, W = self._p.image_height, self._p.image_width
+        depth = np.empty((H, W), np.float32) if fetch else None
+        out_c = np.empty((H, W, 4), np.uint8) if fetch else None
+        nv = C.c_uint64(0)
+        tf = None
+        if world_to_cam is not None:
+            tf = np.ascontiguousarray(np.asarray(world_to_cam, dtype=np.float64)[:3, :4])
+        capi.check(capi.load().tsdf_hip_organize(
+            h, capi.as_f32p(xyz), stride, capi.as_u8p(col) if col is not None else None,
+            col.shape[1] if col is not None else 0, n, float(cloud_units), int(bool(zero_nans)),
+            tf.ctypes.data_as(C.POINTER(C.c_double)) if tf is not None else None,
+            capi.as_f32p(depth) if fetch else None, capi.as_u8p(out_c) if fetch else None,
+            C.byref(nv) if fetch else None), "organize")
+        return (depth, out_c, int(nv.value)) if fetch else None
+
+    def integrateStaged(self, trans=None, count=False):
+        """integrateCloud on the frame the last organize() left in the volume."""
+        trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
+        T = np.ascontiguousarray(cam_from_vol_f32(trans).reshape(12))
+        c = C.c_uint64(0)
+        capi.check(capi.load().tsdf_hip_integrate_staged(self._need(), capi.as_f32p(T), C.byref(c) if count else None),
+                   "integrate_staged")
+        self._is_empty = False
+        return int(c.value) if count else True
+
     def renderView(self, trans=None, downsampleBy=1, camera_frame=True):
         """tsdf_volume_octree.cpp:278-424.  Returns (H/ds, W/ds, 8) float32: xyz, normal, t*, iterations.
         With camera_frame (the reference's behaviour) xyz/normal are moved back by trans^-1 (:422)."""

@@ -105,6 +105,23 @@ int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
 int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
                               const float cam_from_vol[12], uint64_t *n_observed);
 
+/* The `integrate` program's per-cloud preparation -- src/prog/integrate.cpp:559-618 and reprojectPoint
+ * :201-207: scale by cloud_units, optionally turn (0,0,0) into NaN, optionally move the cloud by
+ * poses[i].inverse() (world_to_cam: the first three rows of that matrix, row-major doubles, computed by
+ * the caller's Eigen; NULL = clouds are already in the camera frame), then z-buffer the points into an
+ * image_height x image_width organised frame (smallest z wins, the earlier point among equals) using the
+ * volume's intrinsics AS FLOATS, as the program does.
+ *   xyz / bgra   n points: 3 floats every xyz_stride floats, 4 bytes (b,g,r,a) every bgra_stride bytes
+ *                (a PCL PointXYZRGBA array is xyz_stride 8, bgra at byte 16 with bgra_stride 32); bgra may be NULL.
+ *   depth_out / bgra_out / n_valid   optional host copies of the frame (NaN = empty pixel) and the number
+ *                of filled pixels; with all three NULL the call is asynchronous.
+ * The frame stays in the handle; tsdf_hip_integrate_staged integrates it (same as tsdf_hip_integrate_device
+ * on it). */
+int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, const uint8_t *bgra,
+                      size_t bgra_stride, size_t n, float cloud_units, int zero_nans,
+                      const double world_to_cam[12], float *depth_out, uint8_t *bgra_out, uint64_t *n_valid);
+int tsdf_hip_integrate_staged(tsdf_handle h, const float cam_from_vol[12], uint64_t *n_observed);
+
 /* renderView -- tsdf_volume_octree.cpp:278-421 (everything except the last line).
  *   rot        3x3 row-major float:  trans.rotation().cast<float>()      (:303)
  *   origin     3 floats:             trans.translation().cast<float>()   (:304)

@@ -51,6 +51,9 @@ def lib():
         L.oracle_raycast_advance.restype = C.c_int
         L.oracle_raycast_advance.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, C.POINTER(C.c_int),
                                              C.c_void_p, C.c_void_p]
+        L.oracle_organize.restype = C.c_uint64
+        L.oracle_organize.argtypes = [C.POINTER(OracleParams), _f, C.c_size_t, _u8, C.c_size_t, C.c_size_t, C.c_float,
+                                      C.c_int, C.POINTER(C.c_double), _f, _u8]
         L.oracle_sample_batch.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_size_t, _f, _f, _f, _u8]
         L.oracle_march.restype = C.c_uint64
         L.oracle_march.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, C.c_float, C.c_int, _f, _u8,
@@ -114,6 +117,21 @@ class OracleVolume:
         out = np.empty((nh, nw, 8), dtype=np.float32)
         lib().oracle_raycast(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, _fp(out))
         return out
+
+    def organize(self, xyz, bgra=None, units=1.0, zero_nans=False, world_to_cam=None):
+        """integrate.cpp:559-618 on an (n, >=3) float32 array (+ (n, 4) uint8 b,g,r,a); returns (depth, bgra, filled)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        H, W = self.p.image_height, self.p.image_width
+        depth = np.empty((H, W), np.float32)
+        out_c = np.empty((H, W, 4), np.uint8)
+        col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
+        tf = None
+        if world_to_cam is not None:
+            tf = np.ascontiguousarray(np.asarray(world_to_cam, np.float64)[:3, :4]).ctypes.data_as(C.POINTER(C.c_double))
+        filled = lib().oracle_organize(C.byref(self.p), _fp(xyz), stride, _bp(col), col.shape[1] if col is not None else 0,
+                                       n, units, int(zero_nans), tf, _fp(depth), _bp(out_c))
+        return depth, out_c, int(filled)
 
     RAY_REC = 24
 

@@ -483,6 +483,57 @@ int oracle_raycast_advance(const oracle_params *p, const float *d, const float *
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The `integrate` program's per-cloud preparation, src/prog/integrate.cpp:559-618, as the serial loop it
+ * is there: units (:559-568), zero -> NaN (:570-578), world -> camera by pcl::transformPointCloud with
+ * poses[i].inverse() (:580-581) [PCL-recall: Transformer<double>::se3 = x*c0 + (y*c1 + (z*c2 + c3)) in
+ * double, cast to float; non-finite points of a non-dense cloud are skipped], then the z-buffer
+ * reprojection into a width x height organised cloud (:583-617) with reprojectPoint (:201-207), whose
+ * intrinsics are FLOAT globals.  tf = first three rows of poses[i].inverse().matrix() or NULL.
+ * depth[v*W+u] = pt.z of the organised cloud (NaN where no point landed); bgra = its colour bytes
+ * (PointXYZRGBA default 0,0,0,255 where empty).  Returns the number of filled pixels. */
+static int cvtt_f(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : INT_MIN; } /* cvttss2si */
+
+uint64_t oracle_organize(const oracle_params *p, const float *xyz, size_t xyz_stride, const uint8_t *bgra,
+                         size_t bgra_stride, size_t n, float units, int zero_nans, const double *tf, float *depth,
+                         uint8_t *bgra_out) {
+  const int W = p->image_width, H = p->image_height;
+  const float fx = (float)p->fx, fy = (float)p->fy, cx = (float)p->cx, cy = (float)p->cy;
+  for (size_t j = 0; j < (size_t)W * H; ++j) {
+    depth[j] = NAN;
+    if (bgra_out) {
+      bgra_out[4 * j] = bgra_out[4 * j + 1] = bgra_out[4 * j + 2] = 0;
+      bgra_out[4 * j + 3] = 255;
+    }
+  }
+  uint64_t filled = 0;
+  for (size_t j = 0; j < n; ++j) {
+    float x = xyz[j * xyz_stride], y = xyz[j * xyz_stride + 1], z = xyz[j * xyz_stride + 2];
+    if (units != 1) {
+      x *= units;
+      y *= units;
+      z *= units;
+    }
+    if (zero_nans && x == 0 && y == 0 && z == 0) x = y = z = NAN;
+    if (tf && isfinite(x) && isfinite(y) && isfinite(z)) {
+      const double dx = x, dy = y, dz = z;
+      float o[3];
+      for (int r = 0; r < 3; ++r)
+        o[r] = (float)(dx * tf[4 * r] + (dy * tf[4 * r + 1] + (dz * tf[4 * r + 2] + tf[4 * r + 3])));
+      x = o[0], y = o[1], z = o[2];
+    }
+    const int u = cvtt_f((x * fx / z) + cx), v = cvtt_f((y * fy / z) + cy);
+    if (!(!isnan(z) && z > 0 && u >= 0 && u < W && v >= 0 && v < H)) continue;
+    const size_t px = (size_t)v * W + u;
+    if (isnan(depth[px]) || depth[px] > z) {
+      if (isnan(depth[px])) filled++;
+      depth[px] = z;
+      if (bgra_out && bgra) memcpy(bgra_out + 4 * px, bgra + j * bgra_stride, 4);
+    }
+  }
+  return filled;
+}
+
+/* ------------------------------------------------------------------------------------------
  * getNeighbors tsdf_volume_octree.cpp:796-828, getFxn :655-672, getGradient :681-700,
  * getHessian :703-726.  Order of the 8 neighbours: dx outer, dy, dz inner.  getFxn/getGradient use
  * the octree NODE centre (vox->getCenter), getHessian uses getVoxelCenter (`centers[i]`).
