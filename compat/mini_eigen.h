@@ -152,6 +152,22 @@ class Matrix {
   }
   void setIdentity() { *this = Identity(); }
 
+  // topRightCorner<BR, BC>(): a writable view, enough for `m.topRightCorner<3,1>() *= s` (one product
+  // per coefficient, as Eigen evaluates it)
+  template <int BR, int BC>
+  struct CornerRef {
+    Matrix &m;
+    CornerRef &operator*=(T s) {
+      for (int c = 0; c < BC; ++c)
+        for (int r = 0; r < BR; ++r) m(r, C - BC + c) = m(r, C - BC + c) * s;
+      return *this;
+    }
+  };
+  template <int BR, int BC>
+  CornerRef<BR, BC> topRightCorner() {
+    return CornerRef<BR, BC>{*this};
+  }
+
   template <typename U>
   Matrix<U, R, C> cast() const {
     Matrix<U, R, C> m;

@@ -311,6 +311,13 @@ class PointCloud {
   typename VectorType::const_iterator begin() const { return points.begin(); }
   typename VectorType::const_iterator end() const { return points.end(); }
   Ptr makeShared() const { return Ptr(new PointCloud<PointT>(*this)); }
+  PointCloud &operator+=(const PointCloud &rhs) {  // concatenation: the result is unorganised
+    points.insert(points.end(), rhs.points.begin(), rhs.points.end());
+    width = static_cast<std::uint32_t>(points.size());
+    height = 1;
+    is_dense = is_dense && rhs.is_dense;
+    return *this;
+  }
 
   PCLHeader header;
   VectorType points;
@@ -343,6 +350,8 @@ struct Vertices {
 };
 
 struct PolygonMesh {
+  typedef boost::shared_ptr<PolygonMesh> Ptr;
+  typedef boost::shared_ptr<const PolygonMesh> ConstPtr;
   PCLHeader header;
   PCLPointCloud2 cloud;
   std::vector<Vertices> polygons;
@@ -399,9 +408,24 @@ void fromPCLPointCloud2(const PCLPointCloud2 &msg, PointCloud<PointT> &cloud) {
   cloud.width = msg.width;
   cloud.height = msg.height;
   cloud.is_dense = msg.is_dense != 0;
-  cloud.points.resize((std::size_t)msg.width * msg.height);
-  if (msg.point_step == sizeof(PointT) && !msg.data.empty())
-    std::memcpy(cloud.points.data(), msg.data.data(), msg.data.size());
+  const std::size_t n = (std::size_t)msg.width * msg.height;
+  cloud.points.assign(n, PointT());
+  if (msg.data.empty()) return;
+  std::vector<PCLPointField> want;
+  detail::fields_of((const PointT *)nullptr, want);
+  // fields are matched by name ("rgb" and "rgba" are the same 4 bytes); anything the target lacks is dropped
+  for (const PCLPointField &w : want)
+    for (const PCLPointField &f : msg.fields) {
+      const bool colour = (w.name == "rgb" || w.name == "rgba") && (f.name == "rgb" || f.name == "rgba");
+      if (f.name != w.name && !colour) continue;
+      for (std::size_t i = 0; i < n; ++i)
+        std::memcpy(reinterpret_cast<unsigned char *>(&cloud.points[i]) + w.offset, msg.data.data() + i * msg.point_step + f.offset, 4);
+    }
+}
+
+template <typename PointT>
+void copyPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out) {
+  out = in;
 }
 
 // ---- pcl/common/transforms.h  [PCL-recall: detail::Transformer, SSE2 nesting] ---------------------------

@@ -19,6 +19,8 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(_HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libtsdf_hip.so")
 SHELL_LIB = os.path.join(LIBDIR, "libcpu_tsdf_hip.so")
+PROG = os.path.join(CSRC, "prog")
+BINDIR = os.path.join(_HERE, "bin")
 
 # -ffp-contract=off: the reference CPU build has no FMA (no -march in its CMakeLists.txt), and
 # per-voxel parity needs the same separate mul/add roundings on the GPU.
@@ -102,3 +104,23 @@ def build_shell(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return SHELL_LIB
+
+
+def build_programs(force=False, verbose=False):
+    """cpu_tsdf_amd/bin/{integrate,tsdf2mesh}: the reference's two programs (src/prog/) on the MI355X path."""
+    build_shell(force=False, verbose=verbose)
+    os.makedirs(BINDIR, exist_ok=True)
+    outs = []
+    for name in ("integrate", "tsdf2mesh"):
+        src, exe = os.path.join(PROG, name + ".cpp"), os.path.join(BINDIR, name)
+        deps = [src, SHELL_LIB] + glob.glob(os.path.join(PROG, "*.h")) + glob.glob(os.path.join(ROOT, "compat", "*.h")) + \
+            glob.glob(os.path.join(ROOT, "include", "cpu_tsdf", "*.h"))
+        if force or _stale(exe, deps):
+            cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-ffp-contract=off", "-Wall", "-Wno-unknown-pragmas"] + \
+                host_include_flags() + ["-I" + PROG, src, "-L" + LIBDIR, "-lcpu_tsdf_hip", "-ltsdf_hip",
+                                        "-Wl,-rpath,$ORIGIN/../lib", "-o", exe]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        outs.append(exe)
+    return outs

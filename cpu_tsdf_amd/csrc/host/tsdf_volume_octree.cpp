@@ -151,6 +151,40 @@ bool TSDFVolumeOctree::integratePlanar(const float *depth, const unsigned char *
   return true;
 }
 
+// reference: src/prog/integrate.cpp:559-618 (prepare) + :650,673 (integrate)
+bool TSDFVolumeOctree::integrateUnorganized(const pcl::PointCloud<pcl::PointXYZRGBA> &cloud, const Eigen::Affine3d &trans,
+                                            float cloud_units, bool zero_nans, const Eigen::Affine3d *world_to_cam,
+                                            size_t *n_valid_pixels) {
+  if (!ready("integrateUnorganized")) return false;
+  static_assert(sizeof(pcl::PointXYZRGBA) == 32, "PointXYZRGBA layout: xyz at 0, rgba at 16, 32 bytes");
+  double w2c[12];
+  if (world_to_cam)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) w2c[4 * r + c] = world_to_cam->matrix()(r, c);
+  const pcl::PointXYZRGBA *pts = cloud.points.empty() ? nullptr : &cloud.points[0];
+  uint64_t nv = 0;
+  int rc = tsdf_hip_organize(h_, pts ? &pts->x : nullptr, 8, pts ? reinterpret_cast<const uint8_t *>(&pts->rgba) : nullptr, 32,
+                             cloud.points.size(), cloud_units, zero_nans ? 1 : 0, world_to_cam ? w2c : nullptr, nullptr,
+                             nullptr, n_valid_pixels ? &nv : nullptr);
+  if (rc) {
+    report("integrateUnorganized", rc);
+    return false;
+  }
+  if (n_valid_pixels) *n_valid_pixels = (size_t)nv;
+  const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
+  float T[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) T[4 * r + c] = trans_inv.matrix()(r, c);
+  rc = tsdf_hip_integrate_staged(h_, T, nullptr);
+  if (rc) {
+    report("integrateUnorganized", rc);
+    return false;
+  }
+  rc = tsdf_hip_synchronize(h_);  // the caller may free `cloud` right away
+  is_empty_ = false;
+  return rc == 0;
+}
+
 // reference: src/lib/tsdf_volume_octree.cpp:278-424
 pcl::PointCloud<pcl::PointNormal>::Ptr TSDFVolumeOctree::renderView(const Eigen::Affine3d &trans,
                                                                    int downsampleBy) const {

@@ -91,6 +91,13 @@ class TSDFVolumeOctree : public TSDFInterface {
   // 4 bytes per pixel in PointXYZRGBA byte order or NULL.
   bool integratePlanar(const float *depth, const unsigned char *bgra, int width, int height,
                        const Eigen::Affine3d &trans);
+  // The `integrate` program's per-cloud preparation + integrateCloud in one call (src/prog/integrate.cpp:
+  // 559-618, 650, 673): an UNORGANISED cloud in sensor units is scaled by cloud_units, (0,0,0) becomes NaN if
+  // zero_nans, it is moved by *world_to_cam (= poses[i].inverse()) when given, z-buffered into the configured
+  // image on the GPU (tsdf_hip_organize) and integrated with pose `trans`.
+  bool integrateUnorganized(const pcl::PointCloud<pcl::PointXYZRGBA> &cloud, const Eigen::Affine3d &trans,
+                            float cloud_units = 1.f, bool zero_nans = false,
+                            const Eigen::Affine3d *world_to_cam = nullptr, size_t *n_valid_pixels = nullptr);
   // Raw voxel block readback ([z][y][x]); any pointer may be NULL; rgb is 3 bytes per voxel.
   bool downloadBlock(int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, unsigned char *rgb) const;
   // The C-ABI handle (NULL before reset()); used by MarchingCubesTSDFOctree.

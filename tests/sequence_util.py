@@ -1,0 +1,180 @@
+"""Test helper: write a synthetic `integrate` input directory -- PCD clouds (ascii / binary /
+binary_compressed) + pose files (.txt or .transform) -- and read back the PLY / run the programs."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+from cpu_tsdf_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_INTEGRATE = os.path.join(ROOT, "oracle", "_ref", "ref_integrate")
+REF_TSDF2MESH = os.path.join(ROOT, "oracle", "_ref", "ref_tsdf2mesh")
+OUR_INTEGRATE = os.path.join(ROOT, "cpu_tsdf_amd", "bin", "integrate")
+OUR_TSDF2MESH = os.path.join(ROOT, "cpu_tsdf_amd", "bin", "tsdf2mesh")
+
+
+def digit_free_dir(tag):
+    """A fresh scratch directory whose path has no digit: the program's name matching (getSharedPrefix,
+    src/prog/integrate.cpp:209-230) cuts the shared prefix at the FIRST digit of the whole path."""
+    import random
+    import shutil
+    import string
+    base = os.environ.get("TMPDIR", "/tmp")
+    if any(ch.isdigit() for ch in base):
+        base = "/tmp"
+    while True:
+        d = os.path.join(base, "tsdfseq_" + tag + "_" + "".join(random.choice(string.ascii_lowercase) for _ in range(8)))
+        if not os.path.exists(d):
+            os.makedirs(d)
+            return d
+
+
+def lzf_literal_stream(raw):
+    """A valid LZF stream made of literal runs only (what a decompressor accepts; no need to compress)."""
+    out = bytearray()
+    for i in range(0, len(raw), 32):
+        chunk = raw[i:i + 32]
+        out.append(len(chunk) - 1)
+        out += chunk
+    return bytes(out)
+
+
+def write_pcd(path, xyz, rgba, kind, width=None, height=1, rgb_as_float=False):
+    """xyz (n,3) float32, rgba (n,) uint32 (b | g<<8 | r<<16 | a<<24 as PCL packs it)."""
+    n = len(xyz)
+    width = n if width is None else width
+    field, typ = ("rgb", "F") if rgb_as_float else ("rgba", "U")
+    head = (f"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z {field}\nSIZE 4 4 4 4\nTYPE F F F {typ}\n"
+            f"COUNT 1 1 1 1\nWIDTH {width}\nHEIGHT {height}\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA {kind}\n").encode()
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    rgba = np.ascontiguousarray(rgba, np.uint32)
+    with open(path, "wb") as f:
+        f.write(head)
+        if kind == "ascii":
+            for p, c in zip(xyz, rgba):
+                f.write((" ".join("nan" if np.isnan(v) else repr(float(v)) for v in p) + f" {int(c)}\n").encode())
+        elif kind == "binary":
+            rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("c", "<u4")])
+            rec["x"], rec["y"], rec["z"], rec["c"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], rgba
+            f.write(rec.tobytes())
+        else:  # binary_compressed: field-major body, LZF
+            raw = xyz[:, 0].tobytes() + xyz[:, 1].tobytes() + xyz[:, 2].tobytes() + rgba.tobytes()
+            comp = lzf_literal_stream(raw)
+            f.write(struct.pack("<II", len(comp), len(raw)) + comp)
+
+
+def read_pcd(path):
+    """Independent (numpy) reader of the files write_pcd makes: -> xyz (n,3) float32, colour words (n,) uint32."""
+    data = open(path, "rb").read()
+    i = data.index(b"DATA ")
+    j = data.index(b"\n", i)
+    kind = data[i + 5:j].decode()
+    n = int([l for l in data[:j].decode().splitlines() if l.startswith("POINTS")][0].split()[1])
+    body = data[j + 1:]
+    if kind == "ascii":
+        rows = [r.split() for r in body.decode().strip().split("\n")] if n else []
+        return (np.array([[float(t) for t in r[:3]] for r in rows], np.float32).reshape(-1, 3),
+                np.array([int(r[3]) for r in rows], np.uint32))
+    if kind == "binary":
+        rec = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("c", "<u4")], count=n)
+        return np.stack([rec["x"], rec["y"], rec["z"]], 1), rec["c"].copy()
+    csize, usize = struct.unpack("<II", body[:8])
+    comp, raw, k = body[8:8 + csize], bytearray(), 0
+    while k < len(comp):  # literal runs only (lzf_literal_stream)
+        run_len = comp[k] + 1
+        raw += comp[k + 1:k + 1 + run_len]
+        k += 1 + run_len
+    raw = bytes(raw)
+    return (np.frombuffer(raw, np.float32, count=3 * n).reshape(3, n).T.copy(),
+            np.frombuffer(raw, np.uint32, count=n, offset=12 * n).copy())
+
+
+def read_pose(path, binary):
+    m = np.fromfile(path, np.float32, 12).reshape(3, 4) if binary else np.loadtxt(path, dtype=np.float32)[:3]
+    T = np.eye(4)
+    T[:3] = m.astype(np.float64)
+    return T
+
+
+def write_pose(path, pose, binary):
+    m = np.asarray(pose, np.float64)[:3, :4].astype(np.float32)
+    if binary:
+        m.tofile(path)
+    else:
+        with open(path, "w") as f:
+            for r in m:
+                f.write(" ".join(repr(float(v)) for v in r) + "\n")
+            f.write("0 0 0 1\n")
+
+
+def make_sequence(dirname, n_frames=4, width=160, height=120, binary_poses=False, world=False, units=1.0, organized=False,
+                  seed=0):
+    """Scene-B style sequence (camera inside the volume, which the program centres on the first camera)."""
+    os.makedirs(dirname, exist_ok=True)
+    sc = synth.scene_b(width, height)
+    rng = np.random.RandomState(seed)
+    kinds = ["binary", "ascii", "binary_compressed"]
+    for i in range(n_frames):
+        pose = synth.scene_b_pose(i, n_frames)
+        dep = sc.depth(pose).astype(np.float64)
+        col = sc.bgra(i).view(np.uint32)[..., 0]
+        if organized:
+            v, u = np.mgrid[0:height, 0:width]
+            z = dep
+            pts = np.stack([(u - sc.cx) / sc.fx * z, (v - sc.cy) / sc.fy * z, z], -1).reshape(-1, 3)
+            rgba = col.reshape(-1)
+            w, h = width, height
+        else:
+            v, u = np.nonzero(np.isfinite(dep))
+            z = dep[v, u]
+            uu, vv = u + rng.uniform(0.1, 0.9, u.size), v + rng.uniform(0.1, 0.9, v.size)
+            pts = np.stack([(uu - sc.cx) / sc.fx * z, (vv - sc.cy) / sc.fy * z, z], 1)
+            rgba = col[v, u]
+            hidden = rng.choice(len(pts), len(pts) // 4)            # farther points on the same rays
+            pts = np.concatenate([pts, pts[hidden] * rng.uniform(1.05, 1.4, (len(hidden), 1)), np.zeros((20, 3))])
+            rgba = np.concatenate([rgba, rng.randint(0, 2 ** 32, len(hidden), dtype=np.uint64).astype(np.uint32),
+                                   np.zeros(20, np.uint32)])
+            order = rng.permutation(len(pts))
+            pts, rgba = pts[order], rgba[order]
+            w, h = len(pts), 1
+        if world:
+            pts = pts @ pose[:3, :3].T + pose[:3, 3]
+        pts = pts / units
+        write_pcd(os.path.join(dirname, f"cloud_{i:04d}.pcd"), pts.astype(np.float32), rgba, kinds[i % 3], w, h,
+                  rgb_as_float=(i % 2 == 1 and kinds[i % 3] != "ascii"))
+        write_pose(os.path.join(dirname, f"cloud_{i:04d}" + (".transform" if binary_poses else ".txt")), pose, binary_poses)
+    return sc
+
+
+def read_ply(path):
+    """-> (vertices (n,3) float32, colours (n,3) uint8 or None, faces (m,3) int32) of a PCL-style binary/ascii PLY."""
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    header = data[:end].decode().splitlines()
+    nv = int([l for l in header if l.startswith("element vertex")][0].split()[-1])
+    nf = int([l for l in header if l.startswith("element face")][0].split()[-1])
+    has_rgb = any("red" in l for l in header)
+    has_alpha = any("alpha" in l for l in header)
+    if "binary" in header[1]:
+        vdt = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")] + ([("r", "u1"), ("g", "u1"), ("b", "u1")] if has_rgb else []) + \
+            ([("a", "u1")] if has_alpha else [])
+        v = np.frombuffer(data, dtype=vdt, count=nv, offset=end)
+        fdt = [("n", "u1"), ("i", "<i4", 3)]
+        fc = np.frombuffer(data, dtype=fdt, count=nf, offset=end + nv * np.dtype(vdt).itemsize)
+        verts = np.stack([v["x"], v["y"], v["z"]], 1)
+        cols = np.stack([v["r"], v["g"], v["b"]], 1) if has_rgb else None
+        return verts, cols, fc["i"].copy()
+    rows = data[end:].decode().split("\n")
+    vals = np.array([r.split() for r in rows[:nv]], dtype=np.float64) if nv else np.zeros((0, 3))
+    faces = np.array([r.split()[1:] for r in rows[nv:nv + nf]], dtype=np.int32) if nf else np.zeros((0, 3), np.int32)
+    return vals[:, :3].astype(np.float32), (vals[:, 3:6].astype(np.uint8) if has_rgb else None), faces
+
+
+def run(exe, args, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
+    return out.returncode, out.stdout + out.stderr
