@@ -59,7 +59,7 @@ def cpu_baseline(args, sc, res3, size3, budget_s):
     except ImportError:
         pass
     from cpu_tsdf_amd import capi
-    from oracle.oracle import OracleVolume
+    from oracle.oracle import OracleVolume, SlabOracle
     p = capi.default_params()
     planes = max(8, min(res3[2], (64 * 2048 * 2048) // (res3[0] * res3[1])))
     zb = (res3[2] - planes) // 2
@@ -184,37 +184,6 @@ def scene_b_leg(res, color, cpu_seconds):
 def capi_mod():
     from cpu_tsdf_amd import capi
     return capi
-
-
-class SlabOracle:
-    """Dense oracle restricted to planes [zb, ze): arrays hold only the slab."""
-
-    def __init__(self, p, zb, ze):
-        from oracle import oracle as O
-        self.O = O
-        self.p = O.params_from(p)
-        self.zb, self.ze = zb, ze
-        nx, ny, _ = p.res
-        n = ze - zb
-        self.d = np.full((n, ny, nx), -1, np.float32)
-        self.w = np.zeros((n, ny, nx), np.float32)
-        self.rgb = np.zeros((n, ny, nx, 3), np.uint8) if p.integrate_color else None
-
-    def integrate(self, depth, bgra, T):
-        O = self.O
-        nx, ny, _ = self.p.res
-        off = self.zb * ny * nx
-        # the oracle indexes [z][y][x] from plane 0: hand it pointers shifted back by zb planes
-        fp = C.POINTER(C.c_float)
-        d = C.cast(self.d.ctypes.data - 4 * off, fp)
-        w = C.cast(self.w.ctypes.data - 4 * off, fp)
-        rgb = C.cast(self.rgb.ctypes.data - 3 * off, C.POINTER(C.c_uint8)) if self.rgb is not None else None
-        depth = np.ascontiguousarray(depth, np.float32)
-        col = np.ascontiguousarray(bgra, np.uint8) if bgra is not None else None
-        T = np.ascontiguousarray(T, np.float32)
-        return O.lib().oracle_integrate(C.byref(self.p), d, w, rgb, depth.ctypes.data_as(fp),
-                                        col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None,
-                                        T.ctypes.data_as(fp), self.zb, self.ze)
 
 
 def main():
