@@ -244,34 +244,27 @@ def main():
     radius = 2.2 * max(size3) / S
     poses = [synth.turntable_pose(i, n_distinct, S, radius_factor=radius) for i in range(n_total)]
     T_all = [synth.cam_from_vol_f32(p) for p in poses]
-    depth_dev = torch.empty((n_total, H, W), dtype=torch.float32, device=dev)
-    bgra_dev = torch.empty((n_total, H, W, 4), dtype=torch.uint8, device=dev) if args.color else None
+    # one allocation per frame: [depth | bgra] back to back, which is what the kernel's single frame
+    # descriptor wants (no staging copy) and what ONE broadcast per frame can carry
+    planes = 2 if args.color else 1
+    frames_dev = torch.empty((n_total, planes, H, W), dtype=torch.float32, device=dev)
     if rank == 0:
         for i, p in enumerate(poses):
-            depth_dev[i].copy_(torch.from_numpy(sc.depth(p)))
+            frames_dev[i, 0].copy_(torch.from_numpy(sc.depth(p)))
             if args.color:
-                bgra_dev[i].copy_(torch.from_numpy(sc.bgra(i)))
-    if world > 1:
-        recv_depth = torch.empty((H, W), dtype=torch.float32, device=dev)
-        recv_bgra = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if args.color else None
+                frames_dev[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
+    recv = torch.empty((planes, H, W), dtype=torch.float32, device=dev) if world > 1 else None
     lib = capi.load()
     h = vol._need()
 
     def step(i, count=None):
         if world > 1:
-            # the frame arrives on rank 0; RCCL broadcast over xGMI to every slab owner
-            src_d = depth_dev[i] if rank == 0 else recv_depth
-            dist.broadcast(src_d, src=0)
-            dptr = src_d.data_ptr()
-            cptr = None
-            if args.color:
-                src_c = bgra_dev[i] if rank == 0 else recv_bgra
-                dist.broadcast(src_c, src=0)
-                cptr = src_c.data_ptr()
+            # the frame arrives on rank 0; one RCCL broadcast (depth + colour, 2.4 MB) to every slab owner
+            fr = frames_dev[i] if rank == 0 else recv
+            dist.broadcast(fr, src=0)
         else:
-            dptr = depth_dev[i].data_ptr()
-            cptr = bgra_dev[i].data_ptr() if args.color else None
-        rc = lib.tsdf_hip_integrate_device(h, C.c_void_p(dptr), C.c_void_p(cptr) if cptr else None,
+            fr = frames_dev[i]
+        rc = lib.tsdf_hip_integrate_device(h, C.c_void_p(fr[0].data_ptr()), C.c_void_p(fr[1].data_ptr()) if args.color else None,
                                            capi.as_f32p(T_all[i]), count)
         capi.check(rc, "integrate_device")
 

@@ -62,14 +62,12 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
-// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_SKIP_UNCHANGED, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL); read once.
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL); read once, changeable
+// through tsdf_hip_set_tuning.
 struct TsdfTuning {
   int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
   int blocks_per_cu;   // grid-stride helper kernels: grid = 256 CUs x this
-  int skip_unchanged;  // do not write back SoA planes whose values did not change
-  int fast_projection; // certified fp32 pixel projection with exact fp64 fallback: 1 on, 0 off,
-                       // -1 auto (only with colour, where VALU load is highest; measured, profiles/)
-  int nontemporal;     // nt hint on the voxel-plane loads/stores
+  int fast_projection; // certified fp32 pixel projection with exact fp64 fallback: 0 off, anything else on
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
   int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
 };

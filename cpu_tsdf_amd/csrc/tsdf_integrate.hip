@@ -559,7 +559,8 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
 static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = false) {
   // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
   const int knob = tsdf_tuning().fast_projection;
-  const bool want = force || knob > 0 || (knob < 0 && color);
+  (void)color;
+  const bool want = force || knob != 0;  // auto (-1) = on: since v9 it wins with and without colour (tools/tune_sweep.sh)
   return want && std::isfinite(a.band_u) && std::isfinite(a.band_v) &&
          a.band_u < 0.05f && a.band_v < 0.05f && fabs(a.fx) < 1e6 && fabs(a.fy) < 1e6 && a.a.W < (1 << 23) &&
          a.a.H < (1 << 23);

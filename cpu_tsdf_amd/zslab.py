@@ -77,9 +77,12 @@ class HipSlab:
         self.vol.reset()
 
     def frame_buffers(self):
+        """Depth and colour images of the incoming frame as views of ONE allocation ([depth | bgra]): the
+        integrate kernel then needs no staging copy and the frame travels in one broadcast."""
         W, H = self.vol.getImageSize()
-        depth = torch.empty((H, W), dtype=torch.float32, device=self.device)
-        bgra = torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) if self.color else None
+        self.frame_packed = torch.empty((2 if self.color else 1, H, W), dtype=torch.float32, device=self.device)
+        depth = self.frame_packed[0]
+        bgra = self.frame_packed[1].view(torch.uint8).view(H, W, 4) if self.color else None
         return depth, bgra
 
     def integrate_tensor(self, depth, bgra, trans):
@@ -198,9 +201,13 @@ class ZSlabVolume:
             if fc is not None:
                 fc.copy_(torch.as_tensor(bgra).reshape(fc.shape))
         if self.world > 1:
-            dist.broadcast(fd, src=src, group=self.group)
-            if fc is not None:
-                dist.broadcast(fc, src=src, group=self.group)
+            packed = getattr(self.slab, "frame_packed", None)
+            if packed is not None:  # depth + colour in one collective
+                dist.broadcast(packed, src=src, group=self.group)
+            else:
+                dist.broadcast(fd, src=src, group=self.group)
+                if fc is not None:
+                    dist.broadcast(fc, src=src, group=self.group)
         self.slab.integrate_tensor(fd, fc, np.asarray(trans, dtype=np.float64))
         return True
 

@@ -1,15 +1,11 @@
+#!/bin/bash
+# Launch-shape sweep of k_integrate at the headline size (run via gpurun from the repo root).
+# Appends "<settings> -> ms_per_step frac frac_layout" lines to gpurun_out/tune_sweep.log.
 mkdir -p gpurun_out
-run() { echo "$1" >> gpurun_out/t5_bench.log; env $1 timeout 300 python bench.py --steps 40 --warmup 4 --cpu-baseline 0 --color $2 2>&1 | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['roofline']['frac'], j['value'])" >> gpurun_out/t5_bench.log; }
+run() { printf "%s color=%s layout=%s -> " "$1" "$2" "$3" >> gpurun_out/tune_sweep.log; env $1 timeout 300 python bench.py --steps 30 --warmup 4 --cpu-baseline 0 --extras 0 --color $2 --layout $3 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_step'],3), round(j['roofline']['frac'],3), round(j['roofline']['frac_layout'],3))" >> gpurun_out/tune_sweep.log; }
 for C in 1 0; do
- echo "== COLOR $C" >> gpurun_out/t5_bench.log
- for rep in 1 2; do
-  run "TSDF_HIP_ROWS_PER_BLOCK=8" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=16" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=32" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=64" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=32 TSDF_HIP_NONTEMPORAL=1" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=32 TSDF_HIP_FAST_PROJECTION=0" $C
-  run "TSDF_HIP_ROWS_PER_BLOCK=32 TSDF_HIP_SKIP_UNCHANGED=0" $C
- done
+  for R in 8 16 32 64 128; do run "TSDF_HIP_ROWS_PER_BLOCK=$R" $C packed; done
+  run "TSDF_HIP_FAST_PROJECTION=0" $C packed
+  run "TSDF_HIP_FAST_PROJECTION=1" $C packed
 done
-cat gpurun_out/t5_bench.log
+cat gpurun_out/tune_sweep.log
