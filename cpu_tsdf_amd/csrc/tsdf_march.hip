@@ -118,7 +118,7 @@ static __device__ __forceinline__ void row_values(const McArgs &a, int64_t o, bo
 // Classify: a streaming pass over d and w.  A thread owns a quad of 4 x-consecutive base voxels (one
 // 16-byte load per plane) and walks `rpb` rows; a wave touches 1 KiB contiguous per plane, like
 // k_integrate.  Quads with no candidate voxel (:192: w >= w_min && |d| < 1) -- almost all of the grid --
-// cost exactly those two loads.  A quad with a candidate fetches the other three rows of its 2x2 row
+// cost one load of d (the weight plane is only touched where |d| < 1).  A quad with a candidate fetches the other three rows of its 2x2 row
 // bundle (L1/L2 hits: the neighbouring thread / the block one plane up streams them anyway), builds the
 // case index of its up to 4 cells and appends the active ones to a wave-private LDS list, flushed to the
 // global (Morton key, packed cell) arrays with ONE atomic per flush and coalesced stores.
@@ -164,21 +164,32 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
   };
 
   const int y0 = 1 + (int)blockIdx.y * a.rpb * a.TY + ty;
-  for (int r = 0; r < a.rpb; ++r) {
+  // One row of this thread's quad column; d4 was loaded by the caller (4 rows are in flight at a time: a
+  // quad that fails the distance test costs nothing but that load, so the loop is pure memory latency
+  // unless several loads overlap).
+  auto row = [&](int r, const float4 d4) {
     const int y = y0 + r * a.TY;
-    if (y0 - ty + r * a.TY >= a.ny - 1) break;  // whole block past the last cell row (uniform)
     unsigned nt[4] = {0u, 0u, 0u, 0u};
     if (xq < a.qpr && y < a.ny - 1) {
       const int64_t o = zbase + (int64_t)y * a.pitch + x4;
-      const float4 d4 = *reinterpret_cast<const float4 *>(a.d + o);
       const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
-      float wq[4];
-      load_w4<WL>(a.pv, o, wq);
+      // :192 and :199-202 (base voxel strictly inside the grid).  The distance test goes first: free space
+      // (d at the hinge) and unobserved voxels (d = -1) fail it, so most of the grid never loads its weights.
       bool cand[4], any = false;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // :192 and :199-202 (base voxel strictly inside the grid)
-        cand[j] = wq[j] >= a.w_min && fabsf(dq[j]) < 1.f && x4 + j >= 1 && x4 + j < a.nx - 1;
+      for (int j = 0; j < 4; ++j) {
+        cand[j] = fabsf(dq[j]) < 1.f && x4 + j >= 1 && x4 + j < a.nx - 1;
         any |= cand[j];
+      }
+      float wq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (any) {
+        load_w4<WL>(a.pv, o, wq);
+        any = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cand[j] = cand[j] && wq[j] >= a.w_min;
+          any |= cand[j];
+        }
       }
       if (any) {
         float v00[5], v10[5], v01[5], v11[5];  // [dy][dz]
@@ -201,7 +212,7 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     }
     const unsigned cnt = (nt[0] > 0) + (nt[1] > 0) + (nt[2] > 0) + (nt[3] > 0);
     const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
-    if ((b0 | b1 | b2) == 0) continue;
+    if ((b0 | b1 | b2) == 0) return;
     unsigned pos = n_buf + (unsigned)__popcll(b0 & lanes_below) + 2u * (unsigned)__popcll(b1 & lanes_below) +
                    4u * (unsigned)__popcll(b2 & lanes_below);
     n_buf += (unsigned)__popcll(b0) + 2u * (unsigned)__popcll(b1) + 4u * (unsigned)__popcll(b2);
@@ -213,6 +224,21 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if ((int)n_buf > a.flush_at) flush();
+  };
+  const bool col_ok = xq < a.qpr;
+  for (int rg = 0; rg < a.rpb; rg += 4) {
+    if (y0 - ty + rg * a.TY >= a.ny - 1) break;  // whole block past the last cell row (uniform)
+    float4 d4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int y = y0 + (rg + u) * a.TY;
+      d4[u] = make_float4(1.f, 1.f, 1.f, 1.f);  // |d| >= 1: no candidate
+      if (col_ok && rg + u < a.rpb && y < a.ny - 1)
+        d4[u] = *reinterpret_cast<const float4 *>(a.d + zbase + (int64_t)y * a.pitch + x4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (rg + u < a.rpb) row(rg + u, d4[u]);
   }
   if (n_buf) flush();
   if (__ballot(tri_sum > 0)) {
