@@ -88,6 +88,7 @@ SIGNATURES = {
     "tsdf_hip_selftest_div_f32": (C.c_int, [_f32p, _f32p, _f32p, C.c_size_t]),
     "tsdf_hip_selftest_div_f64": (C.c_int, [_f64p, _f64p, _f64p, C.c_size_t]),
     "tsdf_hip_selftest_project": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]),
+    "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "tsdf_hip_error_string": (C.c_char_p, [C.c_int]),

@@ -215,6 +215,10 @@ int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, siz
 int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
                               int32_t *pix_exact, uint8_t *ambiguous);
 
+/* Test hook: the voxel Octree::getContainingVoxel (src/lib/octree.cpp:112-133,628-643) returns for n points,
+ * as the raycast kernel computes it: idx = i, j, k per point, or -1, -1, -1 where the reference returns NULL. */
+int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx);
+
 /* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */

@@ -44,6 +44,64 @@ def test_raycast_matches_oracle(fused64, view, ds):
     assert_same_f32(got, want, "renderView xyz/normal/t/iterations")
 
 
+@pytest.mark.parametrize("size3,res3", [((0.25, 0.25, 0.25), (64, 64, 64)), ((3.3, 3.3, 3.3), (128, 128, 128)),
+                                         ((3.0, 12.0, 0.7), (256, 64, 32)), ((1.0, 1.0, 1.0), (50, 37, 41))])
+def test_containing_voxel_lookup_equals_octree_descent(gpu, size3, res3):
+    """The raycast kernel's cell lookup == OctreeNode::getContainingVoxel's level-by-level walk (oracle
+    restatement, octree.cpp:112-121) on random points, on every node centre and its float neighbours (the strict
+    `(x - c) > 0` tie rule), on the volume's faces, and on NaN / infinities.  Includes non-dyadic sizes, whose
+    centres carry rounding, and non-power-of-two grids (closed-form fallback)."""
+    import ctypes as C
+    from cpu_tsdf_amd import capi
+    from oracle import oracle as O
+    vol, _ = make_volume(64, res3=res3, size3=size3)
+    vol.reset()
+    p = O.params_from(vol._p)
+    rng = np.random.RandomState(3)
+    pts = [rng.uniform(-0.55, 0.55, (200000, 3)) * np.array(size3)]
+    for a in range(3):  # every centre of every level (they are the decision boundaries) +- 1, 2 ulp
+        dyadic = [k * size3[a] / 2 ** l - size3[a] / 2 for l in range(1, 9) for k in range(2 ** l + 1)]
+        c = np.unique(np.concatenate([vol.centers(a), np.array(dyadic, np.float32)]).astype(np.float32))
+        near = np.concatenate([c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf)),
+                               np.nextafter(np.nextafter(c, np.float32(np.inf)), np.float32(np.inf)),
+                               np.float32(size3[a] / 2) * np.array([1, -1], np.float32)])
+        q = rng.uniform(-0.5, 0.5, (len(near), 3)) * np.array(size3)
+        q[:, a] = near
+        pts.append(q)
+    pts.append(np.array([[np.nan, 0, 0], [0, np.nan, 0], [0, 0, np.nan], [np.inf, 0, 0], [0, -np.inf, 0], [0, 0, 0],
+                         [-0.0, 0.0, -0.0]]))
+    xyz = np.ascontiguousarray(np.concatenate(pts), dtype=np.float32)
+    n = len(xyz)
+    got = np.empty((n, 3), np.int32)
+    capi.check(capi.load().tsdf_hip_selftest_containing(vol._need(), capi.as_f32p(xyz), n,
+                                                        got.ctypes.data_as(C.POINTER(C.c_int32))), "selftest_containing")
+    want = np.full((n, 3), -1, np.int32)
+    idx = (C.c_int * 3)()
+    L = O.lib()
+    for t in range(n):
+        if L.oracle_containing(C.byref(p), float(xyz[t, 0]), float(xyz[t, 1]), float(xyz[t, 2]), idx):
+            want[t] = idx[0], idx[1], idx[2]
+    bad = (got != want).any(1)
+    assert not bad.any(), (int(bad.sum()), xyz[bad][:5], got[bad][:5], want[bad][:5])
+    assert (want >= 0).all(1).mean() > 0.7
+    vol.close()
+
+
+def test_raycast_non_dyadic_volume(gpu):
+    """renderView on a 3.3 m volume (octree centres are rounded sums, not exact dyadics)."""
+    vol, sc = make_volume(64, color=True, size=3.3, zmax=12.0, trunc=(0.2, 0.2))
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i, tr, dep, col in frames(sc, 4, 8):
+        vol.integrateCloud(dep, col, tr)
+        ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+    for tr in (synth.turntable_pose(1, 8, sc.size), synth.look_at_pose((0.5, 0.2, -3.0)), synth.look_at_pose((0.0, 0.0, -0.6))):
+        got = vol.renderView(tr, 1, camera_frame=False)
+        want = ov.raycast(tr, 1)
+        assert_same_f32(got, want, "renderView, 3.3 m volume")
+        assert np.isfinite(want[..., 0]).sum() > 300
+
+
 def test_raycast_camera_frame_and_misses(fused64):
     vol, ov, sc = fused64
     tr = synth.turntable_pose(2, 8, sc.size)
