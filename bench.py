@@ -102,6 +102,7 @@ def extras(vol, pose, W, H):
         out["renderView_rays_per_s"] = W * H / dt
         out["renderView_hits"] = int(np.isfinite(img[..., 0]).sum())
         out["renderView_mean_steps"] = float(img[..., 7].mean())
+        out["renderView_steps_per_s"] = float(img[..., 7].sum()) / dt
         lib = capi_mod().load()
         n = C.c_uint64(0)
         lib.tsdf_hip_march(vol._need(), C.c_float(1.0), 1, C.byref(n))  # warm-up (buffer growth)
@@ -113,6 +114,9 @@ def extras(vol, pose, W, H):
             out["reconstruct_ms"] = dt * 1e3
             out["reconstruct_triangles"] = int(n.value)
             out["reconstruct_Mvoxels_per_s"] = rx * ry * float(rz) / dt / 1e6
+            # 8 B (12 B colour) per voxel + 36 B (+9 B colour) per triangle, whole call (classify + sort + emit)
+            color = bool(vol._p.integrate_color)
+            out["reconstruct_algorithmic_GBps"] = ((12 if color else 8) * rx * ry * float(rz) + (45 if color else 36) * n.value) / dt / 1e9
     except Exception as e:  # never let a report-only leg break the bench line
         out["error"] = repr(e)
     return out

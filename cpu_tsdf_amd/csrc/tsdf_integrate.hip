@@ -551,7 +551,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.log2TX = l2;
   a.TX = 1 << l2;
   a.TY = 256 / a.TX;
-  a.rpb = std::max(1, tsdf_tuning().rows_per_block / a.TY);
+  a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);  // rpb * TY <= 256: the block's row centres sit in LDS
   a.pitch = h->pitch;
   return hh;
 }

@@ -249,11 +249,15 @@ class ZSlabVolume:
         if recv_dn is not None:
             self.slab.set_planes(self.z_begin - recv_dn[0].shape[0], *recv_dn)
 
-    def reconstruct(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0):
+    def reconstruct(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0, gather=True):
         """MarchingCubesTSDFOctree::reconstruct over all slabs.  Returns the merged mesh on rank `dst`
-        (vertices (3n,3) float32, polygons, rgb, cells) in the reference's triangle order; None elsewhere."""
+        (vertices (3n,3) float32, polygons, rgb, cells) in the reference's triangle order; None elsewhere.
+        gather=False: every rank keeps the triangles of its own slab (already in Morton order within the
+        slab) -- the scalable form for meshes too large to collect on one rank."""
         self.exchange_halo()
         part = self.slab.march(w_min, color_by_rgb, color_by_confidence)
+        if not gather:
+            return part
         if self.world == 1:
             parts = [part]
         else:
