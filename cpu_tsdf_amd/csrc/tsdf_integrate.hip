@@ -188,7 +188,7 @@ static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsign
 // each way instead of 12 (8), and 1/(k+1) comes from a 256-entry LDS table of refined reciprocals.
 // COUNT = accumulate the observed-voxel counter.
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED || !COLOR) ? 7 : 6, 8)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
@@ -302,27 +302,30 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // at least 2^-39 in magnitude (difference of two floats one of which is >= 2^-14), and at most
       // max(pos, neg); the host checks pos/neg against the window.
       float dn[4], raw[4];
-      bool act[4], clamped[4];
+      bool act[4];
       any = false;
       bool any_div = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         raw[j] = zs[j] - gzs[j];                                        // hpp:159
         act[j] = pix[j] >= 0 && !isnan(zs[j]) && !(raw[j] < -a.neg);    // hpp:152, :193-196
-        clamped[j] = raw[j] > a.pos;                                    // hpp:189-192
-        dn[j] = a.pos_over_neg;
+        dn[j] = a.pos_over_neg;                                         // hpp:189-192: raw > pos clamps
         any |= act[j];
-        any_div |= act[j] && !clamped[j];
+        any_div |= act[j] && !(raw[j] > a.pos);
       }
       if (!any) continue;
       if (any_div) {  // free space (every observed voxel of the wave beyond the hinge) skips all four ladders
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dn[j] = clamped[j] ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
+        for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
       }
       if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
+        // An fdiv is ONE cheap-looking IR instruction, so LLVM would if-convert this rare block into the hot path
+        // (and the backend then expands every division into ~10 VALU ops there); the empty volatile asm keeps
+        // the block from being speculated.
+        asm volatile("");
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (act[j] && !clamped[j]) dn[j] = raw[j] / a.neg;
+          if (act[j] && !(raw[j] > a.pos)) dn[j] = raw[j] / a.neg;
       }
       // ---- read-modify-write -----------------------------------------------------------------------------
       const u4 d4 = bload128(rsD, voff, soff);
