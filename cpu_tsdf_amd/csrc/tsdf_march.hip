@@ -77,11 +77,6 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
   return c;
 }
 
-// One value of the corner grid: getGridValue (:91-106) on registers.
-static __device__ __forceinline__ float grid_value_reg(float d, float w, float w_min, float neg) {
-  return (w < w_min || fabsf(d) >= 1.f) ? NAN : d * neg;
-}
-
 // Weights of the quad starting at element o (16-byte aligned), per layout:
 // WL 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3 of the colour word), 2 = PACKED
 // without colour (uint8 count plane).
@@ -101,26 +96,12 @@ static __device__ __forceinline__ void load_w4(const PlaneView &pv, int64_t o, f
   }
 }
 
-// Five x-consecutive grid values x4 .. x4+4 of one row (a quad plus the first voxel of the next quad;
-// `tail` says whether that voxel exists in the row).
-template <int WL>
-static __device__ __forceinline__ void row_values(const McArgs &a, int64_t o, bool tail, float v[5]) {
-  const float4 d4 = *reinterpret_cast<const float4 *>(a.d + o);
-  float w[4];
-  load_w4<WL>(a.pv, o, w);
-  v[0] = grid_value_reg(d4.x, w[0], a.w_min, a.neg);
-  v[1] = grid_value_reg(d4.y, w[1], a.w_min, a.neg);
-  v[2] = grid_value_reg(d4.z, w[2], a.w_min, a.neg);
-  v[3] = grid_value_reg(d4.w, w[3], a.w_min, a.neg);
-  v[4] = tail ? grid_value_reg(a.d[o + 4], tsdf_load_w(a.pv, o + 4), a.w_min, a.neg) : NAN;
-}
-
 // Classify: a streaming pass over d and w.  A thread owns a quad of 4 x-consecutive base voxels (one
 // 16-byte load per plane) and walks `rpb` rows; a wave touches 1 KiB contiguous per plane, like
 // k_integrate.  Quads with no candidate voxel (:192: w >= w_min && |d| < 1) -- almost all of the grid --
-// cost one load of d (the weight plane is only touched where |d| < 1).  A quad with a candidate fetches the other three rows of its 2x2 row
-// bundle (L1/L2 hits: the neighbouring thread / the block one plane up streams them anyway), builds the
-// case index of its up to 4 cells and appends the active ones to a wave-private LDS list, flushed to the
+// cost one load of d.  A quad with a candidate fetches the distances of the other three rows of its 2x2 row
+// bundle (L1/L2 hits: the neighbouring thread / the block one plane up streams them anyway), and its weights
+// only if one of its up to 4 cells has corners of both signs; active cells go to a wave-private LDS list, flushed to the
 // global (Morton key, packed cell) arrays with ONE atomic per flush and coalesced stores.
 // counters[0] = active cells, counters[1] = triangles.
 #define MC_WAVE_BUF 512  // entries per wave; one append adds at most 256
@@ -173,40 +154,66 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     if (xq < a.qpr && y < a.ny - 1) {
       const int64_t o = zbase + (int64_t)y * a.pitch + x4;
       const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
-      // :192 and :199-202 (base voxel strictly inside the grid).  The distance test goes first: free space
-      // (d at the hinge) and unobserved voxels (d = -1) fail it, so most of the grid never loads its weights.
+      // :192 and :199-202 (base voxel strictly inside the grid).  Three filters, cheapest first:
+      //  1. |d| < 1 at the base voxel: free space (d at the hinge) and unobserved voxels (d = -1) fail, so most of
+      //     the grid costs one load of d;
+      //  2. the SIGNS of the eight corner values d * max_dist_neg (:91-106 for valid corners): a cell whose
+      //     corners agree in sign has case 0 or 255 and emits nothing whatever its weights -- that is the whole
+      //     truncation band except the one or two cells the surface actually crosses -- so the band needs the
+      //     distances of its 2x2 row bundle but not the weights;
+      //  3. only cells with a mixed case load the bundle's weights: every corner must be valid
+      //     (w >= w_min && |d| < 1, :91-106,145-177), which includes the base voxel's own test (:192).
       bool cand[4], any = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         cand[j] = fabsf(dq[j]) < 1.f && x4 + j >= 1 && x4 + j < a.nx - 1;
         any |= cand[j];
       }
-      float wq[4] = {0.f, 0.f, 0.f, 0.f};
       if (any) {
-        load_w4<WL>(a.pv, o, wq);
+        const int64_t ro[4] = {o, o + a.pitch, o + sz, o + sz + a.pitch};  // rows (y,z) (y+1,z) (y,z+1) (y+1,z+1)
+        float dr[4][5];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float4 q = rr == 0 ? d4 : *reinterpret_cast<const float4 *>(a.d + ro[rr]);
+          dr[rr][0] = q.x, dr[rr][1] = q.y, dr[rr][2] = q.z, dr[rr][3] = q.w;
+          dr[rr][4] = tail ? a.d[ro[rr] + 4] : 1.f;
+        }
+        unsigned sg[4];  // bit x: value of voxel x4 + x in this row is negative
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          sg[rr] = 0u;
+#pragma unroll
+          for (int x = 0; x < 5; ++x) sg[rr] |= (dr[rr][x] * a.neg < 0.f ? 1u : 0u) << x;
+        }
+        // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1) as (dx,dy,dz)
+        auto corners = [](const unsigned m[4], int j) -> unsigned {
+          return ((m[0] >> j) & 1u) | (((m[0] >> (j + 1)) & 1u) << 1) | (((m[2] >> (j + 1)) & 1u) << 2) |
+                 (((m[2] >> j) & 1u) << 3) | (((m[1] >> j) & 1u) << 4) | (((m[1] >> (j + 1)) & 1u) << 5) |
+                 (((m[3] >> (j + 1)) & 1u) << 6) | (((m[3] >> j) & 1u) << 7);
+        };
+        unsigned ci[4];
         any = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          cand[j] = cand[j] && wq[j] >= a.w_min;
+          ci[j] = corners(sg, j);
+          cand[j] = cand[j] && ci[j] != 0u && ci[j] != 255u;
           any |= cand[j];
         }
-      }
-      if (any) {
-        float v00[5], v10[5], v01[5], v11[5];  // [dy][dz]
+        if (any) {
+          unsigned vm[4];  // bit x: voxel x4 + x of this row is a valid grid value
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v00[j] = grid_value_reg(dq[j], wq[j], a.w_min, a.neg);
-        v00[4] = tail ? grid_value_reg(a.d[o + 4], tsdf_load_w(a.pv, o + 4), a.w_min, a.neg) : NAN;
-        row_values<WL>(a, o + a.pitch, tail, v10);
-        row_values<WL>(a, o + sz, tail, v01);
-        row_values<WL>(a, o + sz + a.pitch, tail, v11);
+          for (int rr = 0; rr < 4; ++rr) {
+            float w[5];
+            load_w4<WL>(a.pv, ro[rr], w);
+            w[4] = tail ? tsdf_load_w(a.pv, ro[rr] + 4) : 0.f;
+            vm[rr] = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1)
-          const float leaf[8] = {v00[j], v00[j + 1], v01[j + 1], v01[j], v10[j], v10[j + 1], v11[j + 1], v11[j]};
-          bool ok = cand[j];
+            for (int x = 0; x < 5; ++x) vm[rr] |= (w[x] >= a.w_min && fabsf(dr[rr][x]) < 1.f ? 1u : 0u) << x;
+            if (!tail) vm[rr] &= 15u;
+          }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) ok = ok && !isnan(leaf[k]);
-          if (ok) nt[j] = s_ntri[cube_index(leaf)];
+          for (int j = 0; j < 4; ++j)
+            if (cand[j] && corners(vm, j) == 255u) nt[j] = s_ntri[ci[j]];
         }
       }
     }
@@ -432,12 +439,15 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     return TSDF_HIP_E_UNSUPPORTED;
   }
 
-  // sort (key, val) by Morton key -> reference triangle order
+  // sort (key, val) by Morton key -> reference triangle order; only the bits a coordinate can set take part
+  int coord_bits = 1;
+  while ((1 << coord_bits) < std::max(a.nx, std::max(a.ny, a.nz))) ++coord_bits;
+  const unsigned key_bits = 3u * (unsigned)coord_bits;
   uint64_t *keys_out = nullptr, *vals_out = nullptr;
   uint32_t *cnt = nullptr, *off = nullptr;
   size_t tmp_bytes_sort = 0, tmp_bytes_scan = 0;
   TSDF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
-                                         (size_t)n_cells, 0, 63, h->stream));
+                                         (size_t)n_cells, 0, key_bits, h->stream));
   TSDF_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
                                        rocprim::plus<uint32_t>(), h->stream));
   const size_t al = 256;
@@ -453,7 +463,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   off = (uint32_t *)(sp + 2 * b_keys + b_cnt);
   void *tmp = sp + 2 * b_keys + 2 * b_cnt;
   TSDF_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
-                                         (size_t)n_cells, 0, 63, h->stream));
+                                         (size_t)n_cells, 0, key_bits, h->stream));
   const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
   hipLaunchKernelGGL(k_mc_counts, dim3(cell_blocks), dim3(256), 0, h->stream, vals_out, cnt, n_cells);
   TSDF_HIP_TRY(hipGetLastError());
