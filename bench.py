@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--extras", type=int, default=1, help="also time renderView + marching cubes once (N=1, untimed region)")
+    ap.add_argument("--scene-b", type=int, default=1, help="with --extras: the Scene-B (camera inside the volume) leg; the "
+                    "rocprof run turns it off so that k_integrate's average is the headline workload's alone")
     return ap.parse_args()
 
 
@@ -370,7 +372,8 @@ def main():
         }
         if world == 1 and args.extras:
             out["extras"] = extras(vol, poses[-1], W, H)
-            out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
+            if args.scene_b:
+                out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)

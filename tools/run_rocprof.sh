@@ -5,7 +5,7 @@
 #      which also launches k_calib_rmw sweeps of exactly known bytes for calibration.
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/pmc_reduce.py turns them into JSON summaries.
 set -u
-TAG=${1:-r01b}
+TAG=${1:-r01c}
 STEPS=${2:-20}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
-  python $ROOT/bench.py --steps $STEPS --warmup 2 --cpu-baseline 0 > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
+  python $ROOT/bench.py --steps $STEPS --warmup 2 --cpu-baseline 0 --scene-b 0 > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$C -o pmc --output-format csv -- \
     python $ROOT/tools/prof_integrate.py --steps 4 --warmup 1 --calib 2 > $ROOT/$OUT/prof_$C.json 2> $ROOT/$OUT/prof_$C.err
