@@ -181,6 +181,32 @@ def test_marching_cubes_odd_resolutions(gpu):
             assert n > 1000
 
 
+def test_marching_cubes_wide_rows(gpu):
+    """Rows of >= 1024 voxels make a block one row high (TY = 1, several x-chunks per row), the shape of the
+    BASELINE grids.  Exact parity on such grids, including a row count that is not a multiple of 4 and nx that is
+    not a multiple of 1024.  (A variant that fetched the bundle rows of four consecutive cell rows together and
+    took x+1 neighbours from the next lane passed this test too but was slower -- 14.0 vs 12.0 ms at 2048^3, 128
+    VGPRs -- and was dropped.)"""
+    for res3, size3 in [((1024, 24, 12), (4.0, 0.09375, 0.046875)), ((1100, 10, 7), (1.1, 0.01, 0.007))]:
+        vol, sc = make_volume(64, 160, 120, color=True, res3=res3, size3=size3, zmax=30.0, trunc=(0.01, 0.01))
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        D = 1.2 * size3[0]  # far enough for the 62 deg FOV to span the slab's width
+        tr = synth.look_at_pose((0.0, 0.0, -D))
+        u = np.arange(160, dtype=np.float32)[None, :]
+        v = np.arange(120, dtype=np.float32)[:, None]
+        for k in range(3):  # a gently tilted, rippled sheet through the slab: a surface cell in every column
+            dep = (np.float32(D) + np.float32(0.00004 * (k + 1)) * (u - 80) + np.float32(0.0003) * np.sin(v * 0.7 + k))
+            dep = np.ascontiguousarray(np.broadcast_to(dep.astype(np.float32), (120, 160)))
+            col = sc.bgra(k)
+            vol.integrateCloud(dep, col, tr)
+            ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+        n = _mesh_vs_oracle(vol, ov, 0.0, 1)
+        assert n > 30000, n
+        _mesh_vs_oracle(vol, ov, 2.0, 0)
+        vol.close()
+
+
 def test_marching_cubes_wave_list_flush_paths():
     """The classify kernel's wave-private LDS list flushes mid-block only on dense surfaces; force a flush
     after every append (TSDF_HIP_MC_FLUSH_AT=0, read once per process) and compare with the oracle."""
