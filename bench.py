@@ -32,7 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--res", type=int, default=2048, help="x/y resolution and planes per GPU")
+    ap.add_argument("--res", type=int, default=2048, help="x/y resolution (and planes per GPU unless --planes)")
+    ap.add_argument("--planes", type=int, default=0, help="z planes per GPU (weak) / in total (strong); 0 = --res.  "
+                    "--res 4096 --planes 512 --width 1280 --height 960 at N=8 is BASELINE configs[4]")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--color", type=int, default=1)
@@ -216,13 +218,14 @@ def main():
 
     res = args.res
     voxel = 2.0 ** -8
+    planes = args.planes or res
     if args.scaling == "weak":
-        res3 = (res, res, res * world)
-        z_begin, z_end = rank * res, (rank + 1) * res
+        res3 = (res, res, planes * world)
+        z_begin, z_end = rank * planes, (rank + 1) * planes
     else:
-        res3 = (res, res, res)
-        per = res // world
-        z_begin, z_end = rank * per, (rank + 1) * per if rank < world - 1 else res
+        res3 = (res, res, planes)
+        per = planes // world
+        z_begin, z_end = rank * per, (rank + 1) * per if rank < world - 1 else planes
     size3 = tuple(r * voxel for r in res3)
     S = size3[0]
     W, H = args.width, args.height
@@ -252,14 +255,14 @@ def main():
     T_all = [synth.cam_from_vol_f32(p) for p in poses]
     # one allocation per frame: [depth | bgra] back to back, which is what the kernel's single frame
     # descriptor wants (no staging copy) and what ONE broadcast per frame can carry
-    planes = 2 if args.color else 1
-    frames_dev = torch.empty((n_total, planes, H, W), dtype=torch.float32, device=dev)
+    fplanes = 2 if args.color else 1
+    frames_dev = torch.empty((n_total, fplanes, H, W), dtype=torch.float32, device=dev)
     if rank == 0:
         for i, p in enumerate(poses):
             frames_dev[i, 0].copy_(torch.from_numpy(sc.depth(p)))
             if args.color:
                 frames_dev[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
-    recv = torch.empty((planes, H, W), dtype=torch.float32, device=dev) if world > 1 else None
+    recv = torch.empty((fplanes, H, W), dtype=torch.float32, device=dev) if world > 1 else None
     lib = capi.load()
     h = vol._need()
 
