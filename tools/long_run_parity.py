@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--color", type=int, default=1)
     ap.add_argument("--check-every", type=int, default=0, help="also compare after every K frames (0 = only at the end)")
+    ap.add_argument("--raycast-every", type=int, default=0, help="renderView from the current pose every K frames (configs[2])")
     a = ap.parse_args()
     res = a.res
     sc = synth.scene_a(res)
@@ -36,8 +37,9 @@ def main():
     v.reset()
     groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 300, res - 298)]
     oracles = [SlabOracle(v._p, zb, ze) for zb, ze in groups]
-    t_gpu = t_cpu = t_synth = 0.0
-    mismatches = 0
+    t_gpu = t_cpu = t_synth = t_ray = 0.0
+    mismatches = n_views = 0
+    ray_err = []
     for i in range(a.frames):
         t0 = time.perf_counter()
         tr = synth.turntable_pose(i, a.frames, sc.size, tilt=0.15 * np.sin(i * 0.05))
@@ -45,12 +47,22 @@ def main():
         t1 = time.perf_counter()
         v.integrateCloud(dep, col if a.color else None, tr)  # host entry point: upload + kernel + sync
         t2 = time.perf_counter()
+        t_gpu += t2 - t1
+        if a.raycast_every and (i + 1) % a.raycast_every == 0:
+            tq = time.perf_counter()
+            view = v.renderView(tr, 1)  # camera frame: z is directly comparable with the noise-free depth image
+            t_ray += time.perf_counter() - tq
+            n_views += 1
+            if i >= 8 and n_views % 10 == 0:
+                clean = sc.depth(tr)
+                both = np.isfinite(view[..., 2]) & np.isfinite(clean)
+                ray_err.append(float(np.median(np.abs(view[..., 2][both] - clean[both]))))
+            t2 = time.perf_counter()
         T = synth.cam_from_vol_f32(tr)
         for o in oracles:
             o.integrate(dep, col if a.color else None, T)
         t3 = time.perf_counter()
         t_synth += t1 - t0
-        t_gpu += t2 - t1
         t_cpu += t3 - t2
         if a.check_every and (i + 1) % a.check_every == 0:
             for (zb, ze), o in zip(groups, oracles):
@@ -81,7 +93,9 @@ def main():
         "ms_per_frame_incl_upload": t_gpu / a.frames * 1e3, "marching_cubes_s": t_mc, "triangles": int(n.value),
         "oracle_plane_groups": groups, "planes_bit_identical_to_oracle": planes_equal,
         "intermediate_mismatches": mismatches, "fraction_of_checked_voxels_at_max_weight": saturated,
-        "cpu_oracle_seconds_for_its_planes": t_cpu, "frame_synthesis_seconds": t_synth}))
+        "cpu_oracle_seconds_for_its_planes": t_cpu, "frame_synthesis_seconds": t_synth,
+        "renderView_calls": n_views, "renderView_ms_incl_download": (t_ray / n_views * 1e3) if n_views else None,
+        "renderView_median_abs_depth_error_m": (float(np.median(ray_err)) if ray_err else None)}))
     v.close()
     return 0 if planes_equal and not mismatches else 1
 
