@@ -371,6 +371,10 @@ def main():
                 "layout_bytes_per_launch": layout_bytes,
                 "frac_layout": layout_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "sweep_upper_bound_bytes": bpv * vox_total / world,
+                "note": ("achieved/frac use SURVEY 8d's algorithmic record (24 B per observed voxel with colour, 16 B without); "
+                         "the PACKED HBM layout only has to move layout_bytes_per_observed_voxel, so frac can approach or pass 1 "
+                         "while the memory system runs at frac_layout (nominal layout bytes) / traffic (measured, PMC)") if packed else
+                        "F32W layout: the algorithmic record is what the layout moves",
             },
         }
         if world == 1 and args.extras:
