@@ -65,6 +65,7 @@ SIGNATURES = {
     "tsdf_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tsdf_hip_synchronize": (C.c_int, [C.c_void_p]),
     "tsdf_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _u8p, _f32p, _u64p]),
+    "tsdf_hip_integrate_async": (C.c_int, [C.c_void_p, _f32p, _u8p, _f32p]),
     "tsdf_hip_integrate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_organize": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, C.c_float, C.c_int,
                                     _f64p, _f32p, _u8p, _u64p]),

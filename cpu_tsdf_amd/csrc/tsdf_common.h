@@ -9,6 +9,8 @@
 
 #include "tsdf_hip.h"
 
+struct tsdf_hip_pipeline;  // tsdf_integrate.hip: pinned staging ring of tsdf_hip_integrate_async
+
 struct tsdf_hip_volume {
   tsdf_params p;
   int device = 0;
@@ -31,6 +33,7 @@ struct tsdf_hip_volume {
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
   uint32_t *frame_bgra = nullptr;  // = frame_depth + W*H (same allocation)
   double *cam64 = nullptr;         // fx, fy, cx, cy on the device
+  tsdf_hip_pipeline *pipe = nullptr;
   int frame_staged = 0;            // tsdf_hip_organize left a frame in [frame_depth | frame_bgra]
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
@@ -60,6 +63,7 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
   } while (0)
 
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
+void tsdf_pipeline_destroy(tsdf_hip_volume *v);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
 // TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL); read once, changeable

@@ -186,6 +186,7 @@ int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes) {
 static void free_volume(tsdf_hip_volume *v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
+  tsdf_pipeline_destroy(v);
   if (v->d) (void)hipFree(v->d);
   if (v->w) (void)hipFree(v->w);
   if (v->rgb) (void)hipFree(v->rgb);

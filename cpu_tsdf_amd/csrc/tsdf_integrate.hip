@@ -14,6 +14,7 @@
 // addObservation, so algorithmic traffic is 16 B (24 B colour) per observed voxel plus the depth
 // gather, which is served by L2 (the 640x480 frame is 1.2 MB).  HBM-bound, no MFMA.
 #include <limits.h>
+#include <string.h>
 #include <math.h>
 
 #include <cmath>
@@ -729,6 +730,73 @@ extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8
   int rc = launch_integrate(h, h->frame_depth, color ? h->frame_bgra : nullptr, cam_from_vol, n_observed);
   if (rc) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}
+
+// Pipelined host entry point: the caller's frame is copied into one of two pinned staging slots and the call
+// returns; the host-to-device copy runs on a private copy stream while the previous frame's kernel is still
+// busy, and the kernel of this frame waits for the copy through an event.  A stream of host frames then runs
+// at the kernel's rate instead of kernel + upload + synchronise.  Results are identical to tsdf_hip_integrate;
+// every other entry point is ordered after it on the handle's stream; errors of the asynchronous part surface
+// at the next synchronising call (tsdf_hip_synchronize, download, march, ...).
+struct tsdf_hip_pipeline {
+  hipStream_t copy_stream = nullptr;
+  float *pinned[2] = {nullptr, nullptr};   // host, [depth | bgra]
+  float *device[2] = {nullptr, nullptr};   // device, [depth | bgra]
+  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  unsigned long long frames = 0;
+};
+
+void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
+  tsdf_hip_pipeline *p = v->pipe;
+  if (!p) return;
+  for (int i = 0; i < 2; ++i) {
+    if (p->consumed[i]) (void)hipEventSynchronize(p->consumed[i]);
+    if (p->pinned[i]) (void)hipHostFree(p->pinned[i]);
+    if (p->device[i]) (void)hipFree(p->device[i]);
+    if (p->copied[i]) (void)hipEventDestroy(p->copied[i]);
+    if (p->consumed[i]) (void)hipEventDestroy(p->consumed[i]);
+  }
+  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+  delete p;
+  v->pipe = nullptr;
+}
+
+extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
+                                        const float cam_from_vol[12]) {
+  if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const bool color = h->p.integrate_color != 0;
+  if (color && !bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
+  if (!h->pipe) {
+    tsdf_hip_pipeline *p = new tsdf_hip_pipeline;
+    h->pipe = p;
+    TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
+      TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
+      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
+      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
+    }
+  }
+  tsdf_hip_pipeline *p = h->pipe;
+  const int slot = (int)(p->frames & 1ull);
+  // the slot was last used two frames ago: its kernel must be done before the staging buffers are reused
+  if (p->frames >= 2) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot]));
+  memcpy(p->pinned[slot], depth, npx * 4);
+  if (color) memcpy(p->pinned[slot] + npx, bgra, npx * 4);
+  TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], p->pinned[slot], bytes, hipMemcpyHostToDevice, p->copy_stream));
+  TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
+  TSDF_HIP_TRY(hipStreamWaitEvent(h->stream, p->copied[slot], 0));
+  const int rc = launch_integrate(h, p->device[slot], color ? reinterpret_cast<const uint32_t *>(p->device[slot] + npx) : nullptr,
+                                  cam_from_vol, nullptr);
+  if (rc) return rc;
+  TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
+  p->frames++;
   return TSDF_HIP_OK;
 }
 

@@ -144,9 +144,11 @@ class TSDFVolumeOctree:
         capi.check(capi.load().tsdf_hip_synchronize(self._need()), "synchronize")
 
     # -- hot path ------------------------------------------------------------------------------------
-    def integrateCloud(self, depth, bgra=None, trans=None, count=False):
+    def integrateCloud(self, depth, bgra=None, trans=None, count=False, pipelined=False):
         """``integrateCloud(cloud, normals, trans)`` (impl/tsdf_volume_octree.hpp:48-103).  Returns True
-        (as the reference always does), or the number of observed voxels when ``count`` is set."""
+        (as the reference always does), or the number of observed voxels when ``count`` is set.
+        ``pipelined``: return as soon as the frame sits in pinned staging (tsdf_hip_integrate_async); the upload
+        overlaps the previous frame's kernel and every later call on this volume is ordered after it."""
         h = self._need()
         trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
         depth = capi.f32c(depth)
@@ -161,6 +163,11 @@ class TSDFVolumeOctree:
             col = np.ascontiguousarray(bgra, dtype=np.uint8)
             if col.shape != (self._p.image_height, self._p.image_width, 4):
                 raise ValueError("bgra image must be (image_height, image_width, 4)")
+        if pipelined and not count:
+            capi.check(capi.load().tsdf_hip_integrate_async(h, capi.as_f32p(depth), capi.as_u8p(col) if col is not None else None,
+                                                            capi.as_f32p(T)), "integrate_async")
+            self._is_empty = False
+            return True
         capi.check(
             capi.load().tsdf_hip_integrate(h, capi.as_f32p(depth), capi.as_u8p(col) if col is not None else None,
                                            capi.as_f32p(T), C.byref(n) if count else None), "integrate")

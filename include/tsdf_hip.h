@@ -104,6 +104,12 @@ int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
                        const float cam_from_vol[12], uint64_t *n_observed);
 int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
                               const float cam_from_vol[12], uint64_t *n_observed);
+/* Pipelined form of tsdf_hip_integrate for a stream of host frames: the frame is copied into a pinned
+ * two-slot ring and the call returns; the upload overlaps the previous frame's kernel, so frames flow at the
+ * kernel's rate.  The caller's buffers may be reused as soon as the call returns.  Same results; ordered
+ * before every later call on this handle; asynchronous errors surface at the next synchronising call. */
+int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
+                             const float cam_from_vol[12]);
 
 /* The `integrate` program's per-cloud preparation -- src/prog/integrate.cpp:559-618 and reprojectPoint
  * :201-207: scale by cloud_units, optionally turn (0,0,0) into NaN, optionally move the cloud by

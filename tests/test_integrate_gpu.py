@@ -258,6 +258,33 @@ def test_brick_cull_random_poses_equal_no_cull(gpu):
         capi.set_tuning("cull", 1)
 
 
+@pytest.mark.parametrize("color", [False, True])
+def test_pipelined_host_frames_equal_synchronous(gpu, color):
+    """tsdf_hip_integrate_async: frames handed over back to back from ONE reused host buffer (the call must have
+    copied it before returning), more frames than ring slots, a synchronous call and a download in between --
+    same volume as the oracle, bit for bit."""
+    vol, sc = make_volume(64, color=color)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    dep_buf = np.empty((sc.height, sc.width), np.float32)
+    col_buf = np.empty((sc.height, sc.width, 4), np.uint8)
+    for i in range(9):
+        tr = synth.turntable_pose(i, 12, sc.size)
+        dep_buf[...] = sc.depth(tr, noise_seed=7 + i)
+        col_buf[...] = sc.bgra(i)
+        ov.integrate(dep_buf, col_buf if color else None, synth.cam_from_vol_f32(tr))
+        if i == 4:
+            vol.integrateCloud(dep_buf, col_buf if color else None, tr)  # synchronous call in the middle of the stream
+        else:
+            vol.integrateCloud(dep_buf, col_buf if color else None, tr, pipelined=True)
+        dep_buf.fill(np.nan)  # the caller may scribble over its buffers at once
+        col_buf.fill(0)
+        if i == 6:
+            assert_same_f32(vol.download()[0], ov.d, "d after 7 frames")
+    compare(vol, ov)
+    vol.close()
+
+
 def test_center_tables_match_oracle(gpu):
     vol, sc = make_volume(64, size=3.3)  # non-dyadic size: octree-descent sums, not the closed form
     vol.reset()
