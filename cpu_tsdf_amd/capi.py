@@ -77,6 +77,7 @@ SIGNATURES = {
     "tsdf_hip_sample": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]),
     "tsdf_hip_march": (C.c_int, [C.c_void_p, C.c_float, C.c_int, _u64p]),
     "tsdf_hip_march_fetch": (C.c_int, [C.c_void_p, _f32p, _u8p, _u64p]),
+    "tsdf_hip_march_fetch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsdf_hip_download": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
     "tsdf_hip_upload": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
     "tsdf_hip_get_planes_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -513,3 +513,23 @@ extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, u
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }
+
+// The same mesh into DEVICE buffers owned by the caller (asynchronous on the handle's stream): what a rank of
+// a Z-slab job hands to RCCL when the per-slab meshes are merged on the GPU.
+extern "C" int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)h->mc_ntri;
+  if (!n) return TSDF_HIP_OK;
+  if (d_verts)
+    TSDF_HIP_TRY(hipMemcpyAsync(d_verts, h->mc_verts, n * 9 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (d_rgb) {
+    if (!h->mc_has_rgb) {
+      tsdf_set_error("the last tsdf_hip_march ran without a colour mode");
+      return TSDF_HIP_E_INVALID;
+    }
+    TSDF_HIP_TRY(hipMemcpyAsync(d_rgb, h->mc_rgb, n * 9, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (d_cell) TSDF_HIP_TRY(hipMemcpyAsync(d_cell, h->mc_cell, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream));
+  return TSDF_HIP_OK;
+}

@@ -59,6 +59,23 @@ def morton_x_major(cells):
     return (spread(x) << np.uint64(2)) | (spread(y) << np.uint64(1)) | spread(z)
 
 
+def morton_x_major_torch(cells):
+    """morton_x_major on a torch int64 tensor (any device).  21-bit coordinates interleave into 63 bits, so the
+    signed 64-bit order equals the unsigned one."""
+    m = 0x1FFFFF
+    x, y, z = (cells >> 42) & m, (cells >> 21) & m, cells & m
+
+    def spread(v):
+        v = (v | (v << 32)) & 0x1F00000000FFFF
+        v = (v | (v << 16)) & 0x1F0000FF0000FF
+        v = (v | (v << 8)) & 0x100F00F00F00F00F
+        v = (v | (v << 4)) & 0x10C30C30C30C30C3
+        v = (v | (v << 2)) & 0x1249249249249249
+        return v
+
+    return (spread(x) << 2) | (spread(y) << 1) | spread(z)
+
+
 class HipSlab:
     """Slab backend on one MI355X: a TSDFVolumeOctree restricted to [z_begin, z_end) (+ `halo` planes on each
     side: 1 for marching cubes / sampling, tsdf_hip_render_halo() for renderView), exchanging planes as
@@ -117,6 +134,23 @@ class HipSlab:
         mc.setColorByRGB(by_rgb)
         mc.setColorByConfidence(by_confidence)
         return mc.reconstruct(want_cells=True)
+
+    def march_tensors(self, w_min, by_rgb, by_confidence):
+        """Marching cubes of the slab, mesh left on the device: (verts (n,9) float32, rgb (n,9) uint8 or None,
+        cells (n,) int64 packed x<<42|y<<21|z) as torch CUDA tensors."""
+        lib = capi.load()
+        n = C.c_uint64(0)
+        mode = 2 if by_confidence else (1 if by_rgb else 0)
+        capi.check(lib.tsdf_hip_march(self.vol._need(), C.c_float(w_min), mode, C.byref(n)), "march")
+        n = int(n.value)
+        verts = torch.empty((n, 9), dtype=torch.float32, device=self.device)
+        rgb = torch.empty((n, 9), dtype=torch.uint8, device=self.device) if mode else None
+        cells = torch.empty((n,), dtype=torch.int64, device=self.device)
+        if n:
+            capi.check(lib.tsdf_hip_march_fetch_device(self.vol._need(), C.c_void_p(verts.data_ptr()),
+                                                       C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                                                       C.c_void_p(cells.data_ptr())), "march_fetch_device")
+        return verts, rgb, cells
 
     def sample(self, pts):
         return self.vol.sample(pts)
@@ -273,6 +307,56 @@ class ZSlabVolume:
         n = len(cells)
         return {"vertices": verts[order].reshape(-1, 3), "polygons": np.arange(3 * n, dtype=np.int32).reshape(n, 3),
                 "rgb": rgb, "cells": cells[order]}
+
+    def reconstruct_tensors(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0):
+        """reconstruct() with the per-slab meshes merged ON THE DEVICE: every rank keeps its triangles in HBM,
+        the counts are all-gathered, the triangle arrays go to rank `dst` point-to-point (RCCL send/recv of
+        exactly-sized tensors, no pickling, no host copy), and rank `dst` orders them by the reference's Morton
+        key with one device sort.  Returns tensors (verts (n,9) float32, rgb (n,9) uint8 or None, cells (n,)
+        int64) on rank `dst`, None elsewhere."""
+        self.exchange_halo()
+        verts, rgb, cells = self.slab.march_tensors(w_min, color_by_rgb, color_by_confidence)
+        if self.world == 1:
+            return verts, rgb, cells
+        dev = verts.device
+        counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        counts[self.rank] = verts.shape[0]
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        counts = [int(c) for c in counts.tolist()]
+        has_rgb = rgb is not None
+        ops = []
+        if self.rank == dst:
+            total = sum(counts)
+            all_v = torch.empty((total, 9), dtype=torch.float32, device=dev)
+            all_c = torch.empty((total, 9), dtype=torch.uint8, device=dev) if has_rgb else None
+            all_k = torch.empty((total,), dtype=torch.int64, device=dev)
+            off = 0
+            for r, n in enumerate(counts):
+                sl = slice(off, off + n)
+                off += n
+                if n == 0:
+                    continue
+                if r == dst:
+                    all_v[sl], all_k[sl] = verts, cells
+                    if has_rgb:
+                        all_c[sl] = rgb
+                else:
+                    ops.append(dist.P2POp(dist.irecv, all_v[sl], r, self.group))
+                    ops.append(dist.P2POp(dist.irecv, all_k[sl], r, self.group))
+                    if has_rgb:
+                        ops.append(dist.P2POp(dist.irecv, all_c[sl], r, self.group))
+        elif counts[self.rank]:
+            ops.append(dist.P2POp(dist.isend, verts, dst, self.group))
+            ops.append(dist.P2POp(dist.isend, cells, dst, self.group))
+            if has_rgb:
+                ops.append(dist.P2POp(dist.isend, rgb, dst, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.rank != dst:
+            return None
+        order = torch.argsort(morton_x_major_torch(all_k), stable=True)
+        return all_v[order], (all_c[order] if has_rgb else None), all_k[order]
 
     # -- getFxn / getGradient / getHessian -------------------------------------------------------------------
     def sample(self, pts, dst=0):

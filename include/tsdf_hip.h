@@ -178,6 +178,9 @@ int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float
  * out in the reference's order (octree pre-order = Morton order with x as the high bit). */
 int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri);
 int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell);
+/* The same copies into DEVICE buffers of the caller, asynchronous on the handle's stream (multi-GPU mesh merge:
+ * the buffers go straight to RCCL). */
+int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell);
 
 /* Block transfer of raw voxels (parity tests, save/load, halo exchange).  Coordinates are global
  * grid indices; the block must lie inside the handle's slab + halo.  Any pointer may be NULL.

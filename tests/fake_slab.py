@@ -93,6 +93,13 @@ class OracleSlab:
         k3 = np.repeat(keep, 3)
         return {"vertices": verts[k3], "rgb": rgb[k3] if mode else None, "cells": cells[keep]}
 
+    def march_tensors(self, w_min, by_rgb, by_confidence):
+        part = self.march(w_min, by_rgb, by_confidence)
+        n = len(part["cells"])
+        rgb = torch.from_numpy(np.ascontiguousarray(part["rgb"].reshape(n, 9))) if part["rgb"] is not None else None
+        return (torch.from_numpy(np.ascontiguousarray(part["vertices"].reshape(n, 9))), rgb,
+                torch.from_numpy(part["cells"].astype(np.int64)))
+
     def sample(self, pts):
         ok, val, grad, hess = self.ov.sample(pts)
         # only answer for points whose lower-corner plane is ours (the HIP slab cannot see the others)

@@ -7,6 +7,7 @@ import socket
 
 import numpy as np
 import pytest
+import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -54,6 +55,21 @@ def _worker(rank, world, port, out_path):
         else:
             vol.integrateCloud(None, None, tr, src=src)
     mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    merged = vol.reconstruct_tensors(w_min=1.0, color_by_rgb=True, dst=world - 1)  # device-style merge, other root
+    if rank == world - 1:
+        tv, tc, tk = merged
+        dist.send(torch.tensor([tv.shape[0]]), 0)
+        dist.send(tv.contiguous(), 0)
+        dist.send(tc.contiguous(), 0)
+        dist.send(tk.contiguous(), 0)
+    if rank == 0:
+        n = torch.zeros(1, dtype=torch.int64)
+        dist.recv(n, world - 1)
+        n = int(n)
+        tv, tc, tk = torch.empty((n, 9)), torch.empty((n, 9), dtype=torch.uint8), torch.empty((n,), dtype=torch.int64)
+        dist.recv(tv, world - 1)
+        dist.recv(tc, world - 1)
+        dist.recv(tk, world - 1)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     samp = vol.sample(pts)
     renders, rounds = [], []
@@ -68,6 +84,7 @@ def _worker(rank, world, port, out_path):
         np.savez(out_path, verts=mesh["vertices"], rgb=mesh["rgb"], cells=mesh["cells"], ok=samp[0], val=samp[1],
                  grad=samp[2], d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
                  bounds=np.array([[g[0], g[1]] for g in gathered]), rounds=np.array(rounds),
+                 tverts=tv.numpy(), trgb=tc.numpy(), tcells=tk.numpy(),
                  **{f"view{k}": r for k, r in enumerate(renders)})
     dist.barrier()
     dist.destroy_process_group()
@@ -106,6 +123,9 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     assert len(cells) > 1000
     assert np.array_equal(got["cells"], cells), "merged triangle order"
     assert np.array_equal(got["verts"], verts) and np.array_equal(got["rgb"], rgb)
+    # the tensor merge (send/recv of exactly-sized arrays + one sort by the Morton key) gives the same mesh
+    assert np.array_equal(got["tcells"].astype(np.uint64), cells)
+    assert np.array_equal(got["tverts"].reshape(-1, 3), verts) and np.array_equal(got["trgb"].reshape(-1, 3), rgb)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, grad, _ = ov.sample(pts)
     assert np.array_equal(got["ok"], ok)

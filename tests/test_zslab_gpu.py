@@ -152,6 +152,10 @@ def test_zslab_volume_world1_end_to_end(gpu):
     v2, c2, cells2 = ov.march(1.0, 2)
     assert np.array_equal(mesh["cells"], cells2) and np.array_equal(mesh["rgb"], c2)
     assert_same_f32(mesh["vertices"], v2, "mesh")
+    tv, tc, tk = vol.reconstruct_tensors(w_min=1.0, color_by_confidence=True)  # mesh kept in HBM
+    assert tv.is_cuda and np.array_equal(tk.cpu().numpy().astype(np.uint64), cells2)
+    assert_same_f32(tv.cpu().numpy().reshape(-1, 3), v2, "device mesh")
+    assert np.array_equal(tc.cpu().numpy().reshape(-1, 3), c2)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, _, _ = vol.sample(pts)
     ok2, val2, _, _ = ov.sample(pts)
