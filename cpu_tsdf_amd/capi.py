@@ -71,6 +71,7 @@ SIGNATURES = {
                                     _f64p, _f32p, _u8p, _u64p]),
     "tsdf_hip_integrate_staged": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
+    "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),
     "tsdf_hip_raycast_begin": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_void_p]),
     "tsdf_hip_raycast_advance": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "tsdf_hip_render_halo": (C.c_int, [C.POINTER(TsdfParams)]),

@@ -163,6 +163,8 @@ struct RayArgs {
   float min_step;     // max_dist_neg_ * 3/4.           (:289)
   float refine_step;  // (zsize_/zres_)/2.              (:329)
   float leaf;         // finest leaf size_ (size_x halved L times; getMinSize/getSize, octree.cpp:58-78)
+  int to_camera;      // apply the final transformPointCloudWithNormals(trans^-1) (:422) in the kernel
+  double inv[12];     // rows of trans.inverse().matrix(), computed by the caller's Eigen
 };
 
 // Ray hand-off between Z-slab handles (multi-GPU renderView).  A ray's step sequence depends on the last
@@ -369,11 +371,24 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
       }
     }
   }
+  // :422 pcl::transformPointCloudWithNormals(*cloud, *cloud, trans.inverse()) [PCL-recall: Transformer<double>,
+  // se3 for the point, so3 for the normal, each x*c0 + (y*c1 + (z*c2 (+ c3))) in double, cast to float; the cloud
+  // is not dense, so points with a non-finite coordinate are left untouched]
+  if (!RESUMABLE && a.to_camera && isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2])) {
+    const double px = o[0], py = o[1], pz = o[2], nx = o[3], ny = o[4], nz = o[5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[r] = (float)(px * a.inv[4 * r] + (py * a.inv[4 * r + 1] + (pz * a.inv[4 * r + 2] + a.inv[4 * r + 3])));
+      o[3 + r] = (float)(nx * a.inv[4 * r] + (ny * a.inv[4 * r + 1] + nz * a.inv[4 * r + 2]));
+    }
+  }
   if (!all_local) atomicAdd(incomplete, 1u);
 }
 
 static int make_ray_args(tsdf_handle h, const float rot[9], const float origin[3], int downsample, RayArgs &a) {
   const tsdf_params &p = h->p;
+  a.to_camera = 0;
+  for (int i = 0; i < 12; ++i) a.inv[i] = 0;
   for (int i = 0; i < 9; ++i) a.rot[i] = rot[i];
   for (int i = 0; i < 3; ++i) a.org[i] = origin[i];
   a.nw = p.image_width / downsample;
@@ -398,12 +413,16 @@ static int make_ray_args(tsdf_handle h, const float rot[9], const float origin[3
   return (int64_t)a.nw * a.nh > 0 ? TSDF_HIP_OK : TSDF_HIP_E_INVALID;
 }
 
-extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
-                                float *out) {
+static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv,
+                        float *out) {
   if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
   TSDF_HIP_TRY(hipSetDevice(h->device));
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  if (inv) {
+    a.to_camera = 1;
+    for (int i = 0; i < 12; ++i) a.inv[i] = inv[i];
+  }
   const int64_t n = (int64_t)a.nw * a.nh;
   int rc = tsdf_ensure_scratch(h, (size_t)n * 8 * sizeof(float) + 16);
   if (rc) return rc;
@@ -423,6 +442,17 @@ extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float o
     return TSDF_HIP_E_UNSUPPORTED;
   }
   return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                float *out) {
+  return raycast_impl(h, rot, origin, downsample, nullptr, out);
+}
+
+extern "C" int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                       const double cam_from_vol[12], float *out) {
+  if (!cam_from_vol) return TSDF_HIP_E_INVALID;
+  return raycast_impl(h, rot, origin, downsample, cam_from_vol, out);
 }
 
 // Multi-slab renderView: ray records on the DEVICE (see RaySlab).  begin fills the start state of every

@@ -229,10 +229,14 @@ class TSDFVolumeOctree:
         out = np.empty((nh, nw, 8), dtype=np.float32)
         rot = np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9))
         org = np.ascontiguousarray(trans[:3, 3].astype(np.float32))
-        capi.check(capi.load().tsdf_hip_raycast(h, capi.as_f32p(rot), capi.as_f32p(org), ds, capi.as_f32p(out)),
-                   "raycast")
-        if camera_frame:
-            out = transform_cloud_with_normals(out, eigen_affine_inverse(trans))
+        if camera_frame:  # the final transformPointCloudWithNormals(trans^-1) (:422) runs in the kernel
+            inv = np.ascontiguousarray(eigen_affine_inverse(trans)[:3, :4], dtype=np.float64)
+            capi.check(capi.load().tsdf_hip_raycast_camera(h, capi.as_f32p(rot), capi.as_f32p(org), ds,
+                                                           inv.ctypes.data_as(C.POINTER(C.c_double)), capi.as_f32p(out)),
+                       "raycast_camera")
+        else:
+            capi.check(capi.load().tsdf_hip_raycast(h, capi.as_f32p(rot), capi.as_f32p(org), ds, capi.as_f32p(out)),
+                       "raycast")
         return out
 
     def getFxn(self, pts):

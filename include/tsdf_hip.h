@@ -140,6 +140,11 @@ int tsdf_hip_integrate_staged(tsdf_handle h, const float cam_from_vol[12], uint6
  *              A miss has NaN x,y,z and a zero normal (PointNormal's default constructor). */
 int tsdf_hip_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
                      float *out);
+/* The same with the reference's last line (:422) done in the kernel: cam_from_vol = the first three rows of
+ * trans.inverse().matrix() (row-major doubles, from the caller's Eigen); points and normals come back in the
+ * CAMERA frame, as renderView returns them.  For callers without PCL (the Python binding). */
+int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                            const double cam_from_vol[12], float *out);
 
 /* renderView across Z-slab handles (one handle per GPU): ray hand-off.  The reference's ray loop
  * (tsdf_volume_octree.cpp:313-369) chooses each step from the voxel it last visited, so the loop state of a
