@@ -5,14 +5,15 @@
 // The arithmetic below follows the reference line by line in fp32 with NO fused multiply-add
 // (the reference's CMake build has no -march flag, so x86-64 emits separate mul/add) and IEEE
 // division; this file is compiled with -ffp-contract=off.  What has no dense counterpart (octree
-// split hpp:161-187, prune :122-142, return codes :209-214, the surface pre-split pass :56-90,
-// coarse frustum cull :93-94) is dropped: on a dense grid every voxel is a finest leaf and the
-// per-voxel tests of updateVoxel imply the cull.
+// split hpp:161-187, prune :122-142, return codes :209-214, the surface pre-split pass :56-90) is
+// dropped: on a dense grid every voxel is a finest leaf.  The coarse frustum cull (:93-94,
+// getFrustumCulledVoxels) becomes k_cull, a conservative per-block pre-pass that never changes results.
 //
-// Memory behaviour: a thread owns 4 x-consecutive voxels (16 B of d, 16 B of w); a wave touches
-// 1 KiB contiguous per plane.  d/w(/rgb) are read only if at least one of the four voxels reaches
-// addObservation, so algorithmic traffic is 16 B (24 B colour) per observed voxel plus the depth
-// gather, which is served by L2 (the 640x480 frame is 1.2 MB).  HBM-bound, no MFMA.
+// Memory behaviour: a thread owns 4 x-consecutive voxels (one 16-byte vector per plane); a wave touches
+// 1 KiB contiguous per plane.  The planes are read only if at least one of the four voxels reaches
+// addObservation and written back only if a word changed; SURVEY's algorithmic traffic is 16 B (24 B colour)
+// per observed voxel plus the frame gather, which is served by L2 (the 640x480 frame is 2.4 MB); the PACKED
+// layout (tsdf_common.h) moves 10 B (16 B).  Co-limited by VALU issue and HBM; no MFMA.
 #include <limits.h>
 #include <string.h>
 #include <math.h>
