@@ -232,6 +232,9 @@ pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr TSDFVolumeOctree::renderColoredView
       new pcl::PointCloud<pcl::PointXYZRGBNormal>(grayscale->width, grayscale->height));
   colored->is_dense = false;
   const Eigen::Affine3f tf = trans.cast<float>();
+  // hits back in the volume frame (trans.cast<float>() * point, :441), then ONE batched lookup on the device
+  std::vector<float> query;
+  std::vector<size_t> who;
   for (size_t i = 0; i < colored->size(); ++i) {
     pcl::PointXYZRGBNormal &pt = colored->points[i];
     const pcl::PointNormal &g = grayscale->points[i];
@@ -243,16 +246,30 @@ pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr TSDFVolumeOctree::renderColoredView
     pt.normal_z = g.normal_z;
     if (std::isnan(pt.z) || !h_) continue;
     const Eigen::Vector3f v_t = tf * Eigen::Vector3f(pt.x, pt.y, pt.z);
-    int xi, yi, zi;
-    // nearest voxel by index (the octree lookup of the reference agrees except exactly on cell faces)
-    if (!getVoxelIndex(v_t(0), v_t(1), v_t(2), xi, yi, zi)) continue;
-    unsigned char rgb[3] = {127, 127, 127};
-    if (p_.integrate_color && tsdf_hip_download(h_, xi, yi, zi, 1, 1, 1, nullptr, nullptr, rgb) == 0) {
-      pt.r = rgb[0];
-      pt.g = rgb[1];
-      pt.b = rgb[2];
-    } else {
-      pt.r = pt.g = pt.b = 127;  // OctreeNode::getRGB default (src/lib/octree.cpp:172-177)
+    query.push_back(v_t(0));
+    query.push_back(v_t(1));
+    query.push_back(v_t(2));
+    who.push_back(i);
+  }
+  if (!who.empty()) {
+    std::vector<unsigned char> rgb(3 * who.size()), found(who.size());
+    const int rc = tsdf_hip_lookup_rgb(h_, query.data(), who.size(), rgb.data(), found.data());
+    if (rc) {
+      report("renderColoredView", rc);
+      return colored;
+    }
+    for (size_t k = 0; k < who.size(); ++k) {
+      if (!found[k]) continue;  // getContainingVoxel returned NULL: the point keeps its default colour (:445-446)
+      pcl::PointXYZRGBNormal &pt = colored->points[who[k]];
+      if (p_.integrate_color) {
+        pt.r = rgb[3 * k];
+        pt.g = rgb[3 * k + 1];
+        pt.b = rgb[3 * k + 2];
+      } else {
+        // without integrate_color_ the reference builds a "NOCOLOR" octree (.cpp:205-208) whose nodes answer
+        // OctreeNode::getRGB's 127,127,127 (octree.cpp:172-177)
+        pt.r = pt.g = pt.b = 127;
+      }
     }
   }
   return colored;

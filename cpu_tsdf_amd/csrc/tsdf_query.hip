@@ -511,6 +511,42 @@ extern "C" int tsdf_hip_render_halo(const tsdf_params *p) {
   return (int)ceil(step / vs) + 4;
 }
 
+// renderColoredView's per-hit lookup (tsdf_volume_octree.cpp:443-448): octree_->getContainingVoxel(v) then
+// voxel->getRGB, batched.  found[i] = 0 where the reference gets NULL (or the plane is not held by this handle).
+static __global__ void __launch_bounds__(256)
+k_lookup_rgb(const GridView g, const float *__restrict__ xyz, size_t n, unsigned char *__restrict__ rgb,
+             unsigned char *__restrict__ found) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int64_t vi;
+  bool local;
+  int k;
+  const bool hit = containing(g, xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], vi, local, k) && local;
+  uint32_t c = 0u;
+  if (hit && g.pv.rgb) c = tsdf_load_rgb(g.pv, vi);
+  rgb[3 * t] = (unsigned char)(c & 255u);
+  rgb[3 * t + 1] = (unsigned char)((c >> 8) & 255u);
+  rgb[3 * t + 2] = (unsigned char)((c >> 16) & 255u);
+  found[t] = hit ? 1 : 0;
+}
+
+extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
+  if (!h || !xyz || !n || !rgb || !found) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  int rc = tsdf_ensure_scratch(h, n * 16);
+  if (rc) return rc;
+  float *d_xyz = (float *)h->scratch;
+  unsigned char *d_rgb = (unsigned char *)(d_xyz + 3 * n), *d_found = d_rgb + 3 * n;
+  TSDF_HIP_TRY(hipMemcpyAsync(d_xyz, xyz, n * 12, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_lookup_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), d_xyz, n, d_rgb,
+                     d_found);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpyAsync(rgb, d_rgb, n * 3, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipMemcpyAsync(found, d_found, n, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  return TSDF_HIP_OK;
+}
+
 // Test hook: Octree::getContainingVoxel's voxel index for arbitrary points (idx = i, j, k or -1, -1, -1 for NULL).
 // (Measured alternatives to the level-by-level walk -- a boundary-table search and, on dyadic grids, computed
 // boundaries -- were slower inside k_raycast: 1.78 and 2.40 ms vs 1.55 ms per 640x480 view at 2048^3; the

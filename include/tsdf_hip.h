@@ -175,6 +175,11 @@ int tsdf_hip_render_halo(const tsdf_params *p);
 int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad,
                     float *hess, uint8_t *ok);
 
+/* renderColoredView's colour lookup -- tsdf_volume_octree.cpp:443-448: for n points (volume frame) the voxel
+ * Octree::getContainingVoxel returns (src/lib/octree.cpp:112-133,628-643) and its RGBNode colour (r,g,b; zeros
+ * if the volume stores no colour).  found[i] = 0 where the reference gets NULL. */
+int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found);
+
 /* MarchingCubesTSDFOctree::reconstruct -- src/lib/marching_cubes_tsdf_octree.cpp:108-236
  * (+ pcl::MarchingCubes::createSurface).  color_mode: 0 none, 1 setColorByRGB, 2 setColorByConfidence.
  * tsdf_hip_march runs the kernels and reports the triangle count; tsdf_hip_march_fetch copies

@@ -118,6 +118,25 @@ double ct_render_view(void *h, const double *trans16, int ds, float *out) {
   return dt;
 }
 
+// renderColoredView (tsdf_volume_octree.cpp:426-450): out as ct_render_view, rgb = 3 bytes r,g,b per pixel.
+void ct_render_colored_view(void *h, const double *trans16, int ds, float *out, uint8_t *rgb) {
+  pcl::PointCloud<pcl::PointXYZRGBNormal>::Ptr cloud = V(h)->renderColoredView(to_affine(trans16), ds);
+  for (size_t i = 0; i < cloud->size(); ++i) {
+    const pcl::PointXYZRGBNormal &p = cloud->points[i];
+    float *o = out + 8 * i;
+    o[0] = p.x;
+    o[1] = p.y;
+    o[2] = p.z;
+    o[3] = p.normal_x;
+    o[4] = p.normal_y;
+    o[5] = p.normal_z;
+    o[6] = o[7] = 0.f;
+    rgb[3 * i] = p.r;
+    rgb[3 * i + 1] = p.g;
+    rgb[3 * i + 2] = p.b;
+  }
+}
+
 // getFxn / getGradient / getHessian per point (tsdf_volume_octree.cpp:655-726).
 void ct_sample(void *h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok) {
   for (size_t i = 0; i < n; ++i) {

@@ -74,6 +74,7 @@ def load(path=LIB):
     L.ct_integrate.argtypes = [C.c_void_p, _f, _u8, C.c_int, C.c_int, _d]
     L.ct_render_view.restype = C.c_double
     L.ct_render_view.argtypes = [C.c_void_p, _d, C.c_int, _f]
+    L.ct_render_colored_view.argtypes = [C.c_void_p, _d, C.c_int, _f, _u8]
     L.ct_sample.argtypes = [C.c_void_p, _f, C.c_size_t, _f, _f, _f, _u8]
     L.ct_march.restype = C.c_uint64
     L.ct_march.argtypes = [C.c_void_p, C.c_float, C.c_int, _d]
@@ -176,6 +177,13 @@ class RefVolume:
         out = np.empty((self.H // ds, self.W // ds, 8), np.float32)
         dt = self.L.ct_render_view(self.h, _dp(tr), ds, _fp(out))
         return out, dt
+
+    def render_colored_view(self, trans, ds=1):
+        tr = np.ascontiguousarray(trans, np.float64).reshape(16)
+        out = np.empty((self.H // ds, self.W // ds, 8), np.float32)
+        rgb = np.empty((self.H // ds, self.W // ds, 3), np.uint8)
+        self.L.ct_render_colored_view(self.h, _dp(tr), ds, _fp(out), rgb.ctypes.data_as(_u8))
+        return out, rgb
 
     def sample(self, pts):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)

@@ -69,6 +69,36 @@ def test_dropin_integrate_render_sample_mesh(dropin):
     dv.close()
 
 
+@pytest.mark.parametrize("color", [True, False])
+def test_dropin_render_colored_view_equals_reference(dropin, color):
+    """renderColoredView (tsdf_volume_octree.cpp:426-450): the drop-in's batched device lookup
+    (tsdf_hip_lookup_rgb = getContainingVoxel + getRGB per hit) vs the reference's own method on a dense octree
+    fed the same frames.  Without integrateColor the reference's octree is "NOCOLOR": every found voxel answers
+    127,127,127 (OctreeNode::getRGB)."""
+    if not refbind.available():
+        pytest.skip("oracle/_ref/libcpu_tsdf_ref.so not built")
+    res, W, H = 64, 160, 120
+    sc = synth.scene_a(res, W, H)
+    vols = [refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=color, lib_path=lp)
+            for lp in (dropin, refbind.LIB)]
+    for i in range(5):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        for v in vols:
+            v.integrate(sc.depth(tr), sc.bgra(i), tr)
+    for tr, ds in [(synth.turntable_pose(1, 8, sc.size), 1), (synth.look_at_pose((0.3, -0.2, -0.25)), 2)]:
+        (got, got_rgb), (want, want_rgb) = (v.render_colored_view(tr, ds) for v in vols)
+        hits = np.isfinite(want[..., 0])
+        assert hits.sum() > 100
+        assert_same_f32(got[..., :6], want[..., :6], "renderColoredView geometry")
+        assert np.array_equal(got_rgb[hits], want_rgb[hits]), "colour of the voxel containing each hit"
+        if color:
+            assert len(np.unique(want_rgb[hits], axis=0)) > 20
+        else:
+            assert set(np.unique(want_rgb[hits]).tolist()) <= {0, 127} and (want_rgb[hits] == 127).mean() > 0.9
+    for v in vols:
+        v.close()
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_dropin_save_load_interop_with_reference(dropin, tmp_path, color):
     """.vol files cross both ways: the drop-in's save() is readable by the reference's load(), and the
