@@ -239,6 +239,32 @@ class TSDFVolumeOctree:
                        "raycast")
         return out
 
+    def renderColoredView(self, trans=None, downsampleBy=1):
+        """tsdf_volume_octree.cpp:426-450: renderView plus, per hit, the colour of the voxel that contains it
+        (one batched device lookup).  Returns (cloud (H/ds, W/ds, 8) in the camera frame, rgb (H/ds, W/ds, 3) uint8);
+        misses keep 0,0,0; a volume without integrateColor answers 127,127,127 like the reference's NOCOLOR octree."""
+        trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
+        cloud = self.renderView(trans, downsampleBy, camera_frame=True)
+        rgb = np.zeros(cloud.shape[:2] + (3,), dtype=np.uint8)
+        hit = ~np.isnan(cloud[..., 2])
+        if hit.any():
+            # :441  v_t = trans.cast<float>() * point  (Eigen: each coefficient m0*x + (m1*y + m2*z) + t [Eigen-recall])
+            m = trans.astype(np.float32)
+            p = cloud[..., :3][hit]
+            q = np.empty_like(p)
+            for r in range(3):
+                q[:, r] = (m[r, 0] * p[:, 0] + (m[r, 1] * p[:, 1] + m[r, 2] * p[:, 2])) + m[r, 3]
+            q = np.ascontiguousarray(q, dtype=np.float32)
+            c = np.empty((len(q), 3), np.uint8)
+            found = np.empty(len(q), np.uint8)
+            capi.check(capi.load().tsdf_hip_lookup_rgb(self._need(), capi.as_f32p(q), len(q), capi.as_u8p(c), capi.as_u8p(found)),
+                       "lookup_rgb")
+            if not self._p.integrate_color:
+                c[:] = 127
+            c[found == 0] = 0
+            rgb[hit] = c
+        return cloud, rgb
+
     def getFxn(self, pts):
         """Batched ``getFxn`` (tsdf_volume_octree.cpp:655-672): returns (ok, val)."""
         ok, val, _, _ = self.sample(pts, want_grad=False, want_hess=False)

@@ -81,12 +81,19 @@ def test_dropin_render_colored_view_equals_reference(dropin, color):
     sc = synth.scene_a(res, W, H)
     vols = [refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=color, lib_path=lp)
             for lp in (dropin, refbind.LIB)]
+    from tests.common import make_volume
+    pyvol, _ = make_volume(res, W, H, color=color)  # the Python binding of the same C ABI
+    pyvol.reset()
     for i in range(5):
         tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
         for v in vols:
             v.integrate(sc.depth(tr), sc.bgra(i), tr)
+        pyvol.integrateCloud(sc.depth(tr), sc.bgra(i) if color else None, tr)
     for tr, ds in [(synth.turntable_pose(1, 8, sc.size), 1), (synth.look_at_pose((0.3, -0.2, -0.25)), 2)]:
         (got, got_rgb), (want, want_rgb) = (v.render_colored_view(tr, ds) for v in vols)
+        py_cloud, py_rgb = pyvol.renderColoredView(tr, ds)
+        assert_same_f32(py_cloud[..., :6], want[..., :6], "Python renderColoredView geometry")
+        assert np.array_equal(py_rgb[np.isfinite(want[..., 0])], want_rgb[np.isfinite(want[..., 0])])
         hits = np.isfinite(want[..., 0])
         assert hits.sum() > 100
         assert_same_f32(got[..., :6], want[..., :6], "renderColoredView geometry")
