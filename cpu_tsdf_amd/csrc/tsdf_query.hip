@@ -181,6 +181,7 @@ struct RayArgs {
 // outside the allocated planes sets `incomplete` (the caller then asks for a larger halo).
 struct RaySlab {
   int rank, world, z_begin, z_end;
+  int list_count;  // > 0: state/delta are ONE compact list of that many records, ray id in word 11, updated in place
 };
 #define RAY_REC TSDF_HIP_RAY_RECORD_INTS
 
@@ -217,7 +218,8 @@ static __global__ void __launch_bounds__(256) k_ray_begin(const RayArgs a, int *
   }
   r[8] = r[9] = 0;  // last_d, last_w = 0.f
   r[10] = __float_as_int(a.min_step);
-  for (int k = 11; k < RAY_REC; ++k) r[k] = 0;
+  r[11] = (int)i;  // the ray's pixel index: lets records travel in compact lists (tsdf_hip_raycast_advance_list)
+  for (int k = 12; k < RAY_REC; ++k) r[k] = 0;
 }
 
 // renderView, tsdf_volume_octree.cpp:290-421, one ray per thread.  The while loop runs until every lane
@@ -229,8 +231,13 @@ template <bool RESUMABLE>
 static __global__ void __launch_bounds__(256)
 k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *__restrict__ incomplete,
           const int *__restrict__ state, int *__restrict__ delta, const RaySlab rs) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)a.nw * a.nh) return;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // record (and, unless a list, pixel) index
+  int64_t i = slot;
+  if (RESUMABLE && rs.list_count > 0) {
+    if (slot >= rs.list_count) return;
+    i = state[RAY_REC * slot + 11];
+  }
+  if (i < 0 || i >= (int64_t)a.nw * a.nh) return;
   bool found_crossing = false, all_local = true;
   float du[3];
   ray_direction(a, i, du);
@@ -241,7 +248,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
   bool hit_voxel = false;
   int niter = 0;
   if (RESUMABLE) {
-    const int *r = state + RAY_REC * i;
+    const int *r = state + RAY_REC * slot;
     if (r[0] != 1) return;
     const int need_z = r[1];
     const bool mine = need_z < 0 ? (int)(i % rs.world) == rs.rank : (need_z >= rs.z_begin && need_z < rs.z_end);
@@ -311,7 +318,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     for (int k = 0; k < 3; ++k) pt[k] += step * du[k];
     niter++;
   }
-  int *rec = RESUMABLE ? delta + RAY_REC * i : nullptr;
+  int *rec = RESUMABLE ? delta + RAY_REC * slot : nullptr;
   if (RESUMABLE) {
     rec[1] = suspend_z;
     rec[2] = niter;
@@ -431,7 +438,7 @@ static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3]
   TSDF_HIP_TRY(hipMemsetAsync(d_inc, 0, sizeof(unsigned), h->stream));
   const GridView g = make_view(h);
   hipLaunchKernelGGL(k_raycast<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a, d_out, d_inc,
-                     (const int *)nullptr, (int *)nullptr, RaySlab{0, 1, 0, 0});
+                     (const int *)nullptr, (int *)nullptr, RaySlab{0, 1, 0, 0, 0});
   TSDF_HIP_TRY(hipGetLastError());
   unsigned inc = 0;
   TSDF_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -487,7 +494,38 @@ extern "C" int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const
   const GridView g = make_view(h);
   hipLaunchKernelGGL(k_raycast<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, a,
                      (float *)nullptr, d_inc, (const int *)d_state, (int *)d_delta,
-                     RaySlab{rank, world, h->z_begin, h->z_end});
+                     RaySlab{rank, world, h->z_begin, h->z_end, 0});
+  TSDF_HIP_TRY(hipGetLastError());
+  unsigned inc = 0;
+  TSDF_HIP_TRY(hipMemcpyAsync(&inc, d_inc, sizeof inc, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (inc) {
+    tsdf_set_error("ray hand-off: the refinement walk / trilinear samples left this handle's halo planes; "
+                   "create the slab with a larger halo (tsdf_hip_render_halo)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  return TSDF_HIP_OK;
+}
+
+// The same on a COMPACT list of `count` records (ray id in word 11), updated in place: the scalable form of the
+// hand-off, where a record travels point-to-point to the rank that owns its next voxel instead of every rank
+// holding every ray.  Records this handle is not responsible for are left untouched.
+extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                             int rank, int world, int32_t *d_records, size_t count) {
+  if (!h || !rot || !origin || downsample < 1 || world < 1 || rank < 0 || rank >= world || count >= (1ull << 31) ||
+      (count && !d_records))
+    return TSDF_HIP_E_INVALID;
+  if (!count) return TSDF_HIP_OK;
+  TSDF_HIP_TRY(hipSetDevice(h->device));
+  RayArgs a;
+  if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  int rc = tsdf_ensure_scratch(h, 16);
+  if (rc) return rc;
+  unsigned *d_inc = (unsigned *)h->scratch;
+  TSDF_HIP_TRY(hipMemsetAsync(d_inc, 0, sizeof(unsigned), h->stream));
+  hipLaunchKernelGGL(k_raycast<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, make_view(h), a,
+                     (float *)nullptr, d_inc, (const int *)d_records, (int *)d_records,
+                     RaySlab{rank, world, h->z_begin, h->z_end, (int)count});
   TSDF_HIP_TRY(hipGetLastError());
   unsigned inc = 0;
   TSDF_HIP_TRY(hipMemcpyAsync(&inc, d_inc, sizeof inc, hipMemcpyDeviceToHost, h->stream));

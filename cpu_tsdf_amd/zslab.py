@@ -18,7 +18,9 @@ independent during integration, so the grid is cut into contiguous Z-slabs and t
   (each ray is advanced by exactly one rank), and this repeats until no ray is suspended -- at most
   world + 1 rounds, since a ray crosses the slabs monotonically in z.  The refinement walk of a hit and
   its trilinear samples look back/around by up to ``render_halo`` planes, which every rank refreshes from
-  both neighbours before rendering.  Results are bit-identical to the single-GPU kernel.
+  both neighbours before rendering.  `exchange="p2p"` keeps only a compact record list per rank and moves each
+  suspended record point-to-point to its next owner (traffic ~ rays crossing a boundary).  Results are
+  bit-identical to the single-GPU kernel in both forms.
 
 The slab backend is injected (``slab_factory``) so the N > 1 logic is testable on CPU with gloo; the
 default backend is the HIP volume.  There is no CPU fallback in the product: the default factory raises
@@ -181,6 +183,15 @@ class HipSlab:
                                                         C.c_void_p(delta.data_ptr())), "raycast_advance")
         return delta
 
+    def ray_advance_list(self, trans, ds, records, rank, world):
+        """Advance a compact (k, 24) int32 list of ray records in place (tsdf_hip_raycast_advance_list)."""
+        records = records.contiguous()
+        rot, org = self._rot_org(trans)
+        capi.check(capi.load().tsdf_hip_raycast_advance_list(self.vol._need(), capi.as_f32p(rot), capi.as_f32p(org), ds,
+                                                             rank, world, C.c_void_p(records.data_ptr()), records.shape[0]),
+                   "raycast_advance_list")
+        return records
+
     def image_size(self):
         return self.vol.getImageSize()
 
@@ -189,6 +200,12 @@ class HipSlab:
 
     def close(self):
         self.vol.close()
+
+
+def out_sum(out, group):
+    """Every ray finished on exactly one rank (zeros elsewhere): an integer SUM all-reduce assembles the image."""
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
 
 
 def _default_factory(configure, z_begin, z_end, nz, rank, halo=1):
@@ -376,9 +393,13 @@ class ZSlabVolume:
             ok |= o
         return ok, val, grad, hess
 
-    def renderView(self, trans, downsampleBy=1, camera_frame=True):
+    def renderView(self, trans, downsampleBy=1, camera_frame=True, exchange="allreduce"):
         """TSDFVolumeOctree::renderView over all slabs (ray hand-off, see the module docstring).  Collective;
-        every rank returns the full (H/ds, W/ds, 8) image."""
+        every rank returns the full (H/ds, W/ds, 8) image.
+        exchange="allreduce": every rank holds every ray's record, one integer SUM all-reduce of the image-sized
+        delta per round (simple; traffic ~ image x rounds).  exchange="p2p": every rank holds only the records it
+        is responsible for; after each round a suspended record travels point-to-point to the owner of its next
+        voxel (traffic ~ rays crossing a slab boundary), and the finished rays' outputs are summed once at the end."""
         if self.world == 1:
             return self.slab.render(trans, downsampleBy)
         from .volume import eigen_affine_inverse, transform_cloud_with_normals
@@ -387,20 +408,66 @@ class ZSlabVolume:
         self.exchange_halo(self.halo, both=True)
         state = self.slab.ray_begin(trans, ds)
         self.last_render_rounds = 0
-        for _ in range(2 * self.world + 4):
-            delta = self.slab.ray_advance(trans, ds, state, self.rank, self.world)
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
-            state = torch.where(delta[:, :1] != 0, delta, state)
-            self.last_render_rounds += 1
-            if int((state[:, 0] == 1).sum().item()) == 0:
-                break
-        else:
-            raise RuntimeError("ray hand-off did not converge")
         W, H = self.slab_image_size()
-        out = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(H // ds, W // ds, 8)
+        if exchange == "p2p":
+            out_words = self._render_p2p(trans, ds, state)
+        else:
+            for _ in range(2 * self.world + 4):
+                delta = self.slab.ray_advance(trans, ds, state, self.rank, self.world)
+                dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
+                state = torch.where(delta[:, :1] != 0, delta, state)
+                self.last_render_rounds += 1
+                if int((state[:, 0] == 1).sum().item()) == 0:
+                    break
+            else:
+                raise RuntimeError("ray hand-off did not converge")
+            out_words = state[:, 16:24]
+        out = out_words.contiguous().cpu().numpy().view(np.float32).reshape(H // ds, W // ds, 8)
         if camera_frame:
             out = transform_cloud_with_normals(out, eigen_affine_inverse(trans))
         return out
+
+    def _render_p2p(self, trans, ds, state):
+        dev, n = state.device, state.shape[0]
+        ids = torch.arange(n, device=dev)
+        mine = state[(ids % self.world) == self.rank].contiguous()  # before a ray needs a voxel: id mod world
+        out = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+        bounds = torch.tensor([slab_range(self.nz, self.world, r)[1] for r in range(self.world)], device=dev)
+        self.last_p2p_records = 0
+        for _ in range(2 * self.world + 4):
+            if mine.shape[0]:
+                mine = self.slab.ray_advance_list(trans, ds, mine, self.rank, self.world)
+            self.last_render_rounds += 1
+            done = mine[:, 0] == 2
+            fin = mine[done]
+            out[fin[:, 11].long()] = fin[:, 16:24]
+            sus = mine[~done]
+            dest = torch.bucketize(sus[:, 1].long(), bounds, right=True)  # owner of plane z: first rank with z_end > z
+            counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            if sus.shape[0]:
+                counts.scatter_add_(0, dest, torch.ones_like(dest))
+            table = [torch.zeros_like(counts) for _ in range(self.world)]
+            dist.all_gather(table, counts, group=self.group)
+            table = torch.stack(table).tolist()  # table[src][dst]
+            if sum(sum(row) for row in table) == 0:
+                return out_sum(out, self.group)
+            ops, parts = [], [sus[dest == self.rank]]
+            sends = []
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                if table[self.rank][r]:
+                    sends.append(sus[dest == r].contiguous())
+                    ops.append(dist.P2POp(dist.isend, sends[-1], r, self.group))
+                    self.last_p2p_records += int(table[self.rank][r])
+                if table[r][self.rank]:
+                    parts.append(torch.empty((int(table[r][self.rank]), state.shape[1]), dtype=torch.int32, device=dev))
+                    ops.append(dist.P2POp(dist.irecv, parts[-1], r, self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            mine = torch.cat(parts).contiguous()
+        raise RuntimeError("ray hand-off did not converge")
 
     def slab_image_size(self):
         return self.slab.image_size()

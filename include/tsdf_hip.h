@@ -152,7 +152,8 @@ int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const float origi
  * TSDF_HIP_RAY_RECORD_INTS 32-bit words per ray, in DEVICE memory, row-major like the image:
  *   [0] status (1 suspended, 2 finished; 0 = "not touched" in a delta buffer)   [1] global z plane of the
  *   voxel the ray needs next, -1 before it needed any   [2] iterations   [3] hit_voxel   [4] t   [5..7] pt
- *   [8] last_d   [9] last_w   [10] step   [11..15] zero   [16..23] the 8 output floats of tsdf_hip_raycast.
+ *   [8] last_d   [9] last_w   [10] step   [11] the ray's pixel index   [12..15] zero
+ *   [16..23] the 8 output floats of tsdf_hip_raycast.
  * tsdf_hip_raycast_begin   writes the start record of every ray (identical on every rank).
  * tsdf_hip_raycast_advance zero-fills d_delta, then resumes every suspended ray of d_state that this
  *   handle is responsible for (needed plane inside its OWNED slab; or ray index % world == rank while the
@@ -167,6 +168,12 @@ int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const float origin
                            int32_t *d_state);
 int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
                              int rank, int world, const int32_t *d_state, int32_t *d_delta);
+/* Scalable form: the caller keeps, per rank, a COMPACT list of the records it is responsible for (word 11 of a
+ * record is the ray's pixel index, set by tsdf_hip_raycast_begin) and advances it in place; suspended records then
+ * travel point-to-point to the owner of their next voxel, finished ones stay.  Traffic is proportional to the
+ * rays that cross a slab boundary instead of to the image. */
+int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
+                                  int rank, int world, int32_t *d_records, size_t count);
 int tsdf_hip_render_halo(const tsdf_params *p);
 
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.

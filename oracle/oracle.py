@@ -54,6 +54,9 @@ def lib():
         L.oracle_organize.restype = C.c_uint64
         L.oracle_organize.argtypes = [C.POINTER(OracleParams), _f, C.c_size_t, _u8, C.c_size_t, C.c_size_t, C.c_float,
                                       C.c_int, C.POINTER(C.c_double), _f, _u8]
+        L.oracle_raycast_advance_list.restype = C.c_int
+        L.oracle_raycast_advance_list.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, C.POINTER(C.c_int),
+                                                  C.c_void_p, C.c_int]
         L.oracle_sample_batch.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_size_t, _f, _f, _f, _u8]
         L.oracle_march.restype = C.c_uint64
         L.oracle_march.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, C.c_float, C.c_int, _f, _u8,
@@ -157,6 +160,14 @@ class OracleVolume:
         bad = lib().oracle_raycast_advance(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, slab,
                                            state.ctypes.data_as(C.c_void_p), delta.ctypes.data_as(C.c_void_p))
         return delta, int(bad)
+
+    def raycast_advance_list(self, trans, ds, records, rank, world, z_begin, z_end, alloc_lo, alloc_hi):
+        """Compact-list form (tsdf_hip_raycast_advance_list): `records` (k, 24) int32 updated in place."""
+        rot, org = self._rot_org(trans)
+        assert records.dtype == np.int32 and records.flags.c_contiguous
+        slab = (C.c_int * 6)(rank, world, z_begin, z_end, alloc_lo, alloc_hi)
+        return int(lib().oracle_raycast_advance_list(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(rot), _fp(org), ds, slab,
+                                                     records.ctypes.data_as(C.c_void_p), len(records)))
 
     def sample(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)

@@ -294,6 +294,9 @@ static void ray_direction(const oracle_params *p, const float rot[9], int ds, in
 static void ray_one(const oracle_params *p, const float *d, const float *w, const float rot[9],
                     const float org[3], int ds, int64_t i, float *o, const int32_t *st, int32_t *dl,
                     const int *slab /* rank, world, z_begin, z_end */) {
+  /* list mode (slab[6] > 0): i is the position in a compact list, the ray's pixel index is word 11 */
+  const int64_t slot = i;
+  if (st && slab[6] > 0) i = st[RAY_REC * slot + 11];
   const int nx = p->res[0], ny = p->res[1];
   const float min_step = p->max_dist_neg * 3 / 4.; /* :289 */
   /* leaf->getMinSize() is size_ = size_x for every axis (octree.h:63-66) */
@@ -307,7 +310,7 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
   float step = min_step;
   int hit_voxel = 0, niter = 0;
   if (st) {
-    const int32_t *r = st + RAY_REC * i;
+    const int32_t *r = st + RAY_REC * slot;
     if (r[0] != 1) return;
     const int mine = r[1] < 0 ? (int)(i % slab[1]) == slab[0] : (r[1] >= slab[2] && r[1] < slab[3]);
     if (!mine) return;
@@ -375,7 +378,7 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
     niter++;
   }
   if (st) {
-    int32_t *r = dl + RAY_REC * i;
+    int32_t *r = dl + RAY_REC * slot;
     r[0] = suspend_z >= 0 ? 1 : 2;
     r[1] = suspend_z;
     r[2] = niter;
@@ -461,7 +464,26 @@ void oracle_raycast_begin(const oracle_params *p, const float rot[9], const floa
       r[5 + k] = f2i(pt);
     }
     r[10] = f2i(p->max_dist_neg * 3 / 4.);
+    r[11] = (int32_t)i;
   }
+}
+
+/* The compact-list form (tsdf_hip_raycast_advance_list): `count` records updated in place. */
+int oracle_raycast_advance_list(const oracle_params *p, const float *d, const float *w, const float rot[9],
+                                const float org[3], int ds, const int *slab6, int32_t *records, int count) {
+  int bad = 0;
+  int slab[7];
+  memcpy(slab, slab6, 6 * sizeof(int));
+  slab[6] = count;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
+  for (int64_t i = 0; i < (int64_t)count; ++i) {
+    tl_zlo = slab[4];
+    tl_zhi = slab[5];
+    tl_bad = 0;
+    ray_one(p, d, w, rot, org, ds, i, NULL, records, records, slab);
+    bad += tl_bad;
+  }
+  return bad;
 }
 
 /* One hand-off round of one slab.  slab = {rank, world, z_begin, z_end, alloc_lo, alloc_hi}; returns the
@@ -470,13 +492,16 @@ int oracle_raycast_advance(const oracle_params *p, const float *d, const float *
                            const float org[3], int ds, const int *slab, const int32_t *state, int32_t *delta) {
   const int nw = p->image_width / ds, nh = p->image_height / ds;
   int bad = 0;
+  int slab7[7];
+  memcpy(slab7, slab, 6 * sizeof(int));
+  slab7[6] = 0;
   memset(delta, 0, (size_t)nw * nh * RAY_REC * sizeof(int32_t));
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
   for (int64_t i = 0; i < (int64_t)nw * nh; ++i) {
     tl_zlo = slab[4];
     tl_zhi = slab[5];
     tl_bad = 0;
-    ray_one(p, d, w, rot, org, ds, i, NULL, state, delta, slab);
+    ray_one(p, d, w, rot, org, ds, i, NULL, state, delta, slab7);
     bad += tl_bad;
   }
   return bad;

@@ -127,6 +127,14 @@ class OracleSlab:
             raise RuntimeError(f"ray hand-off: {bad} rays read planes outside the slab's halo [{lo}, {hi})")
         return torch.from_numpy(delta)
 
+    def ray_advance_list(self, trans, ds, records, rank, world):
+        lo, hi = max(0, self.z_begin - self.halo), min(self.nz, self.z_end + self.halo)
+        rec = np.ascontiguousarray(records.numpy())
+        bad = self.ov.raycast_advance_list(trans, ds, rec, rank, world, self.z_begin, self.z_end, lo, hi) if len(rec) else 0
+        if bad:
+            raise RuntimeError(f"ray hand-off: {bad} rays read planes outside the slab's halo [{lo}, {hi})")
+        return torch.from_numpy(rec)
+
     def synchronize(self):
         pass
 

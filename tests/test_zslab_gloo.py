@@ -73,9 +73,14 @@ def _worker(rank, world, port, out_path):
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     samp = vol.sample(pts)
     renders, rounds = [], []
+    p2p_records = []
     for k, tr in enumerate(views(sc.size)):
         renders.append(vol.renderView(tr, 1 + (k == 1)))
         rounds.append(vol.last_render_rounds)
+        again = vol.renderView(tr, 1 + (k == 1), exchange="p2p")  # records travel only to the next owner
+        assert np.array_equal(again.view(np.uint32), renders[-1].view(np.uint32)), f"p2p hand-off differs, view {k}"
+        p2p_records.append(vol.last_p2p_records)
+    assert max(p2p_records) < 0.8 * renders[0].shape[0] * renders[0].shape[1] * world
     zb, ze = vol.z_begin, vol.z_end
     d, w = vol.slab.ov.d[zb:ze].copy(), vol.slab.ov.w[zb:ze].copy()
     gathered = [None] * world if rank == 0 else None

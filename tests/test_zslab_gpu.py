@@ -111,6 +111,36 @@ def test_ray_handoff_between_slab_handles_equals_one_volume(gpu, world):
         total_rounds += rounds
         have = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(want.shape)
         assert_same_f32(have, want, f"view {k} world {world}")
+        # the compact-list form (what exchange="p2p" runs on every rank): each slab advances only the records
+        # routed to it; finished records leave their outputs, suspended ones move to the owner of their next plane
+        state = slabs[0].ray_begin(tr, ds)
+        n = state.shape[0]
+        ids = torch.arange(n, device=state.device)
+        lists = [state[(ids % world) == r].contiguous() for r in range(world)]
+        out = torch.zeros((n, 8), dtype=torch.int32, device=state.device)
+        ends = torch.tensor([ze for _, ze in cuts], device=state.device)
+        moved = 0
+        for _ in range(2 * world + 5):
+            nxt = [[] for _ in range(world)]
+            for r, s in enumerate(slabs):
+                if not lists[r].shape[0]:
+                    continue
+                rec = s.ray_advance_list(tr, ds, lists[r], r, world)
+                fin = rec[rec[:, 0] == 2]
+                out[fin[:, 11].long()] = fin[:, 16:24]
+                sus = rec[rec[:, 0] == 1]
+                dest = torch.bucketize(sus[:, 1].long(), ends, right=True)
+                assert not bool((dest == r).any())
+                for q in range(world):
+                    if bool((dest == q).any()):
+                        nxt[q].append(sus[dest == q])
+                        moved += int((dest == q).sum())
+            lists = [torch.cat(p).contiguous() if p else state[:0] for p in nxt]
+            if not any(l.shape[0] for l in lists):
+                break
+        assert not any(l.shape[0] for l in lists)
+        assert_same_f32(out.cpu().numpy().view(np.float32).reshape(want.shape), want, f"list hand-off, view {k} world {world}")
+        assert 0 < moved < n * world
     assert total_rounds > len(views(sc.size))  # rays really crossed slabs
     for s in slabs:
         s.close()
