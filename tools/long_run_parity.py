@@ -24,19 +24,30 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--color", type=int, default=1)
     ap.add_argument("--check-every", type=int, default=0, help="also compare after every K frames (0 = only at the end)")
+    ap.add_argument("--planes", type=int, default=0, help="integrate only a Z-slab of this many central planes (one rank's share)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--pipelined", type=int, default=0, help="hand frames over with tsdf_hip_integrate_async")
     ap.add_argument("--raycast-every", type=int, default=0, help="renderView from the current pose every K frames (configs[2])")
     a = ap.parse_args()
     res = a.res
-    sc = synth.scene_a(res)
+    sc = synth.scene_a(res, a.width, a.height)
     v = TSDFVolumeOctree()
     v.setResolution(res, res, res)
     v.setGridSize(sc.size, sc.size, sc.size)
+    v.setImageSize(a.width, a.height)
     v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
     v.setSensorDistanceBounds(0.0, 3 * sc.size)
     v.setIntegrateColor(bool(a.color))
+    slab0, slab1 = 0, res
+    if a.planes:
+        slab0 = (res - a.planes) // 2
+        slab1 = slab0 + a.planes
+        v.setZSlab(slab0, slab1)
     v.reset()
     groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 300, res - 298)]
+    if a.planes:
+        groups = [(slab0, slab0 + 2), ((slab0 + slab1) // 2, (slab0 + slab1) // 2 + 2), (slab1 - 2, slab1)]
     oracles = [SlabOracle(v._p, zb, ze) for zb, ze in groups]
     t_gpu = t_cpu = t_synth = t_ray = 0.0
     mismatches = n_views = 0
@@ -88,11 +99,13 @@ def main():
     lib = capi.load()
     import ctypes as C
     n = C.c_uint64(0)
-    capi.check(lib.tsdf_hip_march(v._need(), C.c_float(2.0), 1 if a.color else 0, C.byref(n)), "march")
+    if not a.planes:  # a slab without its +z halo plane cannot mesh its last cell row; the multi-GPU layer does that
+        capi.check(lib.tsdf_hip_march(v._need(), C.c_float(2.0), 1 if a.color else 0, C.byref(n)), "march")
     t_mc = time.perf_counter() - t0
     print(json.dumps({
-        "workload": f"{res}^3 grid, integrateColor={bool(a.color)}, {a.frames} distinct noisy 640x480 frames through the host entry "
-                    "point (" + ("pinned two-slot ring, upload overlapped with the previous kernel" if a.pipelined else "PCIe upload + sync per frame") + "), then marching cubes",
+        "workload": f"{res}^3 grid" + (f" (Z-slab [{slab0},{slab1}): one rank's share)" if a.planes else "") +
+                    f", integrateColor={bool(a.color)}, {a.frames} distinct noisy {a.width}x{a.height} frames through the host entry "
+                    "point (" + ("pinned two-slot ring, upload overlapped with the previous kernel" if a.pipelined else "PCIe upload + sync per frame") + ")" + ("" if a.planes else ", then marching cubes"),
         "frames": a.frames, "gpu_seconds_incl_upload": t_gpu, "frames_per_s_incl_upload": a.frames / t_gpu,
         "ms_per_frame_incl_upload": t_gpu / a.frames * 1e3, "marching_cubes_s": t_mc, "triangles": int(n.value),
         "oracle_plane_groups": groups, "planes_bit_identical_to_oracle": planes_equal,
