@@ -110,12 +110,12 @@ def write_pose(path, pose, binary):
 
 
 def make_sequence(dirname, n_frames=4, width=160, height=120, binary_poses=False, world=False, units=1.0, organized=False,
-                  seed=0):
+                  seed=0, kinds=("binary", "ascii", "binary_compressed")):
     """Scene-B style sequence (camera inside the volume, which the program centres on the first camera)."""
     os.makedirs(dirname, exist_ok=True)
     sc = synth.scene_b(width, height)
     rng = np.random.RandomState(seed)
-    kinds = ["binary", "ascii", "binary_compressed"]
+    kinds = list(kinds)
     for i in range(n_frames):
         pose = synth.scene_b_pose(i, n_frames)
         dep = sc.depth(pose).astype(np.float64)
@@ -142,8 +142,8 @@ def make_sequence(dirname, n_frames=4, width=160, height=120, binary_poses=False
         if world:
             pts = pts @ pose[:3, :3].T + pose[:3, 3]
         pts = pts / units
-        write_pcd(os.path.join(dirname, f"cloud_{i:04d}.pcd"), pts.astype(np.float32), rgba, kinds[i % 3], w, h,
-                  rgb_as_float=(i % 2 == 1 and kinds[i % 3] != "ascii"))
+        write_pcd(os.path.join(dirname, f"cloud_{i:04d}.pcd"), pts.astype(np.float32), rgba, kinds[i % len(kinds)], w, h,
+                  rgb_as_float=(i % 2 == 1 and kinds[i % len(kinds)] != "ascii"))
         write_pose(os.path.join(dirname, f"cloud_{i:04d}" + (".transform" if binary_poses else ".txt")), pose, binary_poses)
     return sc
 
@@ -175,6 +175,6 @@ def read_ply(path):
 
 def run(exe, args, timeout=600):
     env = dict(os.environ)
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", "8")  # callers that time the reference set it themselves
     out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
     return out.returncode, out.stdout + out.stderr
