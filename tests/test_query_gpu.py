@@ -210,25 +210,24 @@ def test_marching_cubes_wide_rows(gpu):
         vol.close()
 
 
-def test_marching_cubes_wave_list_flush_paths():
-    """The classify kernel's wave-private LDS list flushes mid-block only on dense surfaces; force a flush
-    after every append (TSDF_HIP_MC_FLUSH_AT=0, read once per process) and compare with the oracle."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import numpy as np\n"
-            "from tests.test_query_gpu import _mesh_vs_oracle\n"
-            "from tests.common import make_volume, frames\n"
-            "from cpu_tsdf_amd import synth\n"
-            "from oracle.oracle import OracleVolume\n"
-            "vol, sc = make_volume(64, color=True); vol.reset(); ov = OracleVolume(vol._p)\n"
-            "for i, tr, dep, col in frames(sc, 4, 8, noise=True):\n"
-            "    vol.integrateCloud(dep, col, tr); ov.integrate(dep, col, synth.cam_from_vol_f32(tr))\n"
-            "print('NVERT', _mesh_vs_oracle(vol, ov, 0.0, 1), _mesh_vs_oracle(vol, ov, 2.0, 0))\n")
-    env = dict(os.environ, TSDF_HIP_MC_FLUSH_AT="0", TSDF_HIP_ROWS_PER_BLOCK="64")
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "NVERT" in out.stdout and int(out.stdout.split("NVERT")[1].split()[0]) > 30000
+def test_marching_cubes_wave_list_flush_paths(gpu):
+    """The classify kernel's wave-private LDS list flushes mid-block only on dense surfaces; force a flush after
+    every append (tuning knob mc_flush_at = 0) and taller blocks, and compare with the oracle."""
+    from cpu_tsdf_amd import capi
+    try:
+        capi.set_tuning("mc_flush_at", 0)
+        capi.set_tuning("rows_per_block", 64)
+        vol, sc = make_volume(64, color=True)
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        for i, tr, dep, col in frames(sc, 4, 8, noise=True):
+            vol.integrateCloud(dep, col, tr)
+            ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+        assert _mesh_vs_oracle(vol, ov, 0.0, 1) > 30000
+        _mesh_vs_oracle(vol, ov, 2.0, 0)
+    finally:
+        capi.set_tuning("mc_flush_at", 256)
+        capi.set_tuning("rows_per_block", 32)
 
 
 def test_marching_cubes_empty_and_global_transform(gpu):
