@@ -6,6 +6,7 @@
 #include <pcl/console/print.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -406,62 +407,78 @@ void TSDFVolumeOctree::save(const std::string &filename) const {
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) hd.global_transform[4 * r + c] = global_transform_.matrix()(r, c);
   hd.color = p_.integrate_color != 0;
-  const size_t n = (size_t)p_.res[0] * p_.res[1] * p_.res[2];
-  std::vector<float> d(n), w(n);
-  std::vector<unsigned char> rgb(hd.color ? 3 * n : 0);
-  if (!downloadBlock(0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(), hd.color ? rgb.data() : nullptr))
-    return;
+  // streamed in blocks (vol_format.h): host memory stays at one block whatever the resolution
   std::string err;
-  if (!vol_write(filename, hd, d.data(), w.data(), hd.color ? rgb.data() : nullptr, &err))
-    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::save] %s\n", err.c_str());
+  const bool ok = vol_write_stream(
+      filename, hd, volChunk(),
+      [this](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
+        return downloadBlock(x0, y0, z0, c, c, c, d, w, rgb);
+      },
+      &err);
+  if (!ok) PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::save] %s\n", err.c_str());
+}
+
+// block edge for save / load; CPU_TSDF_VOL_CHUNK overrides (tests use small blocks on small grids)
+int TSDFVolumeOctree::volChunk() {
+  const char *e = std::getenv("CPU_TSDF_VOL_CHUNK");
+  const int v = e ? std::atoi(e) : 0;
+  return v > 0 ? v : 256;
 }
 
 void TSDFVolumeOctree::load(const std::string &filename) {
-  VolHeader hd;
-  std::vector<float> d, w;
-  std::vector<unsigned char> rgb;
-  std::string err;
-  if (!vol_read(filename, hd, d, w, rgb, &err)) {
-    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::load] %s\n", err.c_str());
+  // Blocks go to the device as they are read.  A file whose weights are not min(k, max_weight) (written with
+  // other weighting) cannot live in the packed layout: the upload says so and the file is read again into
+  // a float weight plane.
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    VolHeader hd;
+    std::string err;
+    int rc = TSDF_HIP_OK;
+    const bool ok = vol_read_stream(
+        filename, hd, volChunk(),
+        [this, attempt](const VolHeader &hd) {
+          for (int k = 0; k < 3; ++k) {
+            p_.res[k] = hd.res[k];
+            p_.size[k] = hd.size[k];
+            max_cell_size_[k] = hd.max_cell[k];
+          }
+          p_.max_dist_pos = hd.max_dist_pos;
+          p_.max_dist_neg = hd.max_dist_neg;
+          p_.max_weight = hd.max_weight;
+          p_.min_sensor_dist = hd.min_sensor_dist;
+          p_.max_sensor_dist = hd.max_sensor_dist;
+          p_.fx = hd.fx;
+          p_.fy = hd.fy;
+          p_.cx = hd.cx;
+          p_.cy = hd.cy;
+          p_.image_width = hd.image_width;
+          p_.image_height = hd.image_height;
+          weight_by_depth_ = hd.weight_by_depth;
+          weight_by_variance_ = hd.weight_by_variance;
+          Eigen::Matrix4d m;
+          for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) m(r, c) = hd.global_transform[4 * r + c];
+          global_transform_ = m;
+          p_.integrate_color = hd.color ? 1 : 0;
+          if (attempt) p_.layout = TSDF_LAYOUT_F32W;
+          reset();
+          return h_ != nullptr;
+        },
+        [this, &rc](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
+          rc = tsdf_hip_upload(h_, x0, y0, z0, c, c, c, d, w, rgb);
+          return rc == TSDF_HIP_OK;
+        },
+        &err);
+    if (ok) {
+      is_empty_ = hd.is_empty;
+      return;
+    }
+    if (rc == TSDF_HIP_E_UNSUPPORTED && attempt == 0 && h_ && tsdf_hip_layout(h_) == TSDF_LAYOUT_PACKED) continue;
+    if (rc)
+      report("load", rc);
+    else
+      PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::load] %s\n", err.c_str());
     return;
   }
-  for (int k = 0; k < 3; ++k) {
-    p_.res[k] = hd.res[k];
-    p_.size[k] = hd.size[k];
-    max_cell_size_[k] = hd.max_cell[k];
-  }
-  p_.max_dist_pos = hd.max_dist_pos;
-  p_.max_dist_neg = hd.max_dist_neg;
-  p_.max_weight = hd.max_weight;
-  p_.min_sensor_dist = hd.min_sensor_dist;
-  p_.max_sensor_dist = hd.max_sensor_dist;
-  p_.fx = hd.fx;
-  p_.fy = hd.fy;
-  p_.cx = hd.cx;
-  p_.cy = hd.cy;
-  p_.image_width = hd.image_width;
-  p_.image_height = hd.image_height;
-  weight_by_depth_ = hd.weight_by_depth;
-  weight_by_variance_ = hd.weight_by_variance;
-  Eigen::Matrix4d m;
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) m(r, c) = hd.global_transform[4 * r + c];
-  global_transform_ = m;
-  p_.integrate_color = hd.color ? 1 : 0;
-  reset();
-  if (!h_) return;
-  int rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
-                           hd.color ? rgb.data() : nullptr);
-  if (rc == TSDF_HIP_E_UNSUPPORTED && tsdf_hip_layout(h_) == TSDF_LAYOUT_PACKED) {
-    // weights that are not min(k, max_weight) (a file written with other weighting): float weight plane
-    p_.layout = TSDF_LAYOUT_F32W;
-    reset();
-    if (!h_) return;
-    rc = tsdf_hip_upload(h_, 0, 0, 0, p_.res[0], p_.res[1], p_.res[2], d.data(), w.data(),
-                         hd.color ? rgb.data() : nullptr);
-  }
-  if (rc) report("load", rc);
-  is_empty_ = hd.is_empty;
 }
 
 // reference: src/lib/tsdf_interface.cpp:44-51

@@ -15,12 +15,19 @@
 // reference does); M_ and nsample_ -- only used by the reference's unreachable variance weighting -- are
 // written as 0.  Reading rasterises every leaf over the voxels it covers.  Needs a cubic power-of-two
 // grid (the only kind the reference's octree represents faithfully).
+//
+// Both directions stream: the grid is visited in cubic chunks (edge `chunk`, a power of two) through a
+// fetch / store callback, so a 2048^3 volume (94 GB of voxels) is saved and loaded with a few hundred MB
+// of host memory.  The writer makes two passes -- one that classifies every chunk as uniform or not (the
+// top of the tree is built from that table), one that emits nodes in pre-order and re-fetches only the
+// non-uniform chunks -- and produces byte for byte the file the whole-grid writer would.
 #pragma once
 
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <sstream>
 #include <string>
@@ -56,6 +63,9 @@ struct Grid {
   // uniform[l][node] for levels 0..L-1 (level l has (2^l)^3 nodes); a node is uniform when all voxels
   // below it are bit-identical
   std::vector<std::vector<unsigned char> > uniform;
+  // optional, one flag per voxel of this grid: "the finer data this voxel stands for is uniform" (the
+  // streaming writer's chunk table); a node over a voxel with flag 0 is never uniform
+  const std::vector<unsigned char> *leaf_ok = nullptr;
   size_t vox(int x, int y, int z) const { return ((size_t)z * n + y) * n + x; }
   bool same(size_t a, size_t b) const {
     return std::memcmp(d + a, d + b, 4) == 0 && std::memcmp(w + a, w + b, 4) == 0 &&
@@ -80,6 +90,7 @@ inline void build_pyramid(Grid &g) {
           for (int c = 0; c < 8 && u; ++c) {
             const int cx = 2 * kx + ((c >> 2) & 1), cy = 2 * ky + ((c >> 1) & 1), cz = 2 * kz + (c & 1);
             if (below) u = (*below)[((size_t)cz * 2 * m + cy) * 2 * m + cx] != 0;
+            else if (g.leaf_ok) u = (*g.leaf_ok)[g.vox(cx, cy, cz)] != 0;
             if (u) u = g.same(ref, g.vox(cx * half, cy * half, cz * half));
           }
           g.uniform[l][((size_t)kz * m + ky) * m + kx] = u ? 1 : 0;
@@ -92,27 +103,51 @@ inline void put(std::ostream &f, const T &v) {
   f.write(reinterpret_cast<const char *>(&v), sizeof(T));
 }
 
-inline void write_node(std::ostream &f, const Grid &g, int level, int kx, int ky, int kz, float cx, float cy,
+// Node records are 40 / 43 bytes and a big volume has hundreds of millions of them: they are gathered
+// into a 4 MB block before they reach the stream.
+struct NodeSink {
+  std::ostream &f;
+  std::vector<char> buf;
+  size_t n;
+  explicit NodeSink(std::ostream &s) : f(s), buf(4u << 20), n(0) {}
+  void flush() {
+    if (n) f.write(buf.data(), (std::streamsize)n);
+    n = 0;
+  }
+  char *room(size_t bytes) {
+    if (n + bytes > buf.size()) flush();
+    char *p = buf.data() + n;
+    n += bytes;
+    return p;
+  }
+};
+
+inline void put_node(NodeSink &f, bool color, const unsigned char *rgb, float d, float w, float cx, float cy,
+                     float cz, float size, bool leaf) {
+  char *p = f.room(color ? 43 : 40);
+  if (color) {
+    const unsigned char zero[3] = {0, 0, 0};
+    std::memcpy(p, leaf ? rgb : zero, 3);
+    p += 3;
+  }
+  if (!leaf) {
+    d = -1.f;
+    w = 0.f;
+  }
+  const float rec[7] = {d, w, cx, cy, cz, size, 0.f};  // ..., M
+  const int32_t nsample = 0;
+  const size_t nchild = leaf ? 0 : 8;
+  std::memcpy(p, rec, 28);
+  std::memcpy(p + 28, &nsample, 4);
+  std::memcpy(p + 32, &nchild, 8);
+}
+
+inline void write_node(NodeSink &f, const Grid &g, int level, int kx, int ky, int kz, float cx, float cy,
                        float cz, float size) {
   const int span = g.n >> level;
   const bool leaf = level == g.L || g.uniform[level][((size_t)kz * (1 << level) + ky) * (1 << level) + kx];
   const size_t v0 = g.vox(kx * span, ky * span, kz * span);
-  if (g.rgb) {
-    const unsigned char zero[3] = {0, 0, 0};
-    f.write(reinterpret_cast<const char *>(leaf ? g.rgb + 3 * v0 : zero), 3);
-  }
-  const float d = leaf ? g.d[v0] : -1.f, w = leaf ? g.w[v0] : 0.f, M = 0.f;
-  const int32_t nsample = 0;
-  const size_t nchild = leaf ? 0 : 8;
-  put(f, d);
-  put(f, w);
-  put(f, cx);
-  put(f, cy);
-  put(f, cz);
-  put(f, size);
-  put(f, M);
-  put(f, nsample);
-  put(f, nchild);
+  put_node(f, g.rgb != nullptr, g.rgb ? g.rgb + 3 * v0 : nullptr, g.d[v0], g.w[v0], cx, cy, cz, size, leaf);
   if (leaf) return;
   const float off = size / 4, ns = size / 2;
   for (int c = 0; c < 8; ++c) {
@@ -147,57 +182,203 @@ inline bool get(std::istream &f, T &v) {
   return (bool)f;
 }
 
+struct NodeSource {  // the reading counterpart of NodeSink
+  std::istream &f;
+  std::vector<char> buf;
+  size_t pos, end;
+  explicit NodeSource(std::istream &s) : f(s), buf(4u << 20), pos(0), end(0) {}
+  const char *take(size_t bytes) {  // null at end of file
+    if (end - pos < bytes) {
+      std::memmove(buf.data(), buf.data() + pos, end - pos);
+      end -= pos;
+      pos = 0;
+      f.read(buf.data() + end, (std::streamsize)(buf.size() - end));
+      end += (size_t)f.gcount();
+      if (end < bytes) return nullptr;
+    }
+    const char *p = buf.data() + pos;
+    pos += bytes;
+    return p;
+  }
+};
+
+// One cubic block of voxels, edge c, origin (x0,y0,z0): d, w [c^3] and rgb [3 c^3] (null without colour),
+// x fastest.  fetch fills the buffers from the volume, store writes them into it; both return false on error.
+typedef std::function<bool(int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb)> BlockFn;
+
 struct ReadCtx {
-  int n;
+  int n, C, Lc;  // grid edge, chunk edge, tree level whose nodes are chunks
   float vs, half;
   bool color;
-  float *d, *w;
-  unsigned char *rgb;
+  std::vector<float> d, w;  // the chunk being assembled
+  std::vector<unsigned char> rgb;
+  int ox, oy, oz;  // its origin; ox < 0: none open
+  BlockFn store;
   std::string err;
 };
 
-inline bool read_node(std::istream &f, ReadCtx &c, int depth) {
+inline bool node_box(const ReadCtx &c, float cx, float cy, float cz, float size, int &x0, int &y0, int &z0, int &span) {
+  span = std::max(1, (int)std::lround(size / c.vs));
+  x0 = (int)std::lround((cx - size / 2 + c.half) / c.vs);
+  y0 = (int)std::lround((cy - size / 2 + c.half) / c.vs);
+  z0 = (int)std::lround((cz - size / 2 + c.half) / c.vs);
+  return x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + span <= c.n && y0 + span <= c.n && z0 + span <= c.n;
+}
+
+inline void fill_chunk(ReadCtx &c, int x0, int y0, int z0, int span, float d, float w, const unsigned char *col) {
+  for (int z = z0; z < z0 + span; ++z)
+    for (int y = y0; y < y0 + span; ++y) {
+      const size_t row = ((size_t)z * c.C + y) * c.C + x0;
+      for (int x = 0; x < span; ++x) {
+        c.d[row + x] = d;
+        c.w[row + x] = w;
+      }
+      if (c.color)
+        for (int x = 0; x < span; ++x) std::memcpy(&c.rgb[3 * (row + x)], col, 3);
+    }
+}
+
+inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
   unsigned char col[3] = {0, 0, 0};
-  if (c.color) f.read(reinterpret_cast<char *>(col), 3);
-  float d, w, cx, cy, cz, size, M;
-  int32_t nsample;
-  size_t nchild;
-  if (!(get(f, d) && get(f, w) && get(f, cx) && get(f, cy) && get(f, cz) && get(f, size) && get(f, M) &&
-        get(f, nsample) && get(f, nchild))) {
+  const char *p = f.take(c.color ? 43 : 40);
+  if (!p) {
     c.err = "truncated octree";
     return false;
   }
+  if (c.color) {
+    std::memcpy(col, p, 3);
+    p += 3;
+  }
+  float rec[6];  // d, w, centre, size (then M and nsample, unused)
+  size_t nchild;
+  std::memcpy(rec, p, 24);
+  std::memcpy(&nchild, p + 32, 8);
+  const float d = rec[0], w = rec[1], cx = rec[2], cy = rec[3], cz = rec[4], size = rec[5];
+  int x0, y0, z0, span;
   if (nchild == 0) {  // leaf: fill the voxels it covers
-    const int span = std::max(1, (int)std::lround(size / c.vs));
-    const int x0 = (int)std::lround((cx - size / 2 + c.half) / c.vs), y0 = (int)std::lround((cy - size / 2 + c.half) / c.vs),
-              z0 = (int)std::lround((cz - size / 2 + c.half) / c.vs);
-    if (x0 < 0 || y0 < 0 || z0 < 0 || x0 + span > c.n || y0 + span > c.n || z0 + span > c.n) {
+    if (!node_box(c, cx, cy, cz, size, x0, y0, z0, span)) {
       c.err = "leaf outside the grid";
       return false;
     }
-    for (int z = z0; z < z0 + span; ++z)
-      for (int y = y0; y < y0 + span; ++y)
-        for (int x = x0; x < x0 + span; ++x) {
-          const size_t v = ((size_t)z * c.n + y) * c.n + x;
-          c.d[v] = d;
-          c.w[v] = w;
-          if (c.color) std::memcpy(c.rgb + 3 * v, col, 3);
-        }
+    if (c.ox >= 0) {  // inside the open chunk
+      if (x0 < c.ox || y0 < c.oy || z0 < c.oz || x0 + span > c.ox + c.C || y0 + span > c.oy + c.C ||
+          z0 + span > c.oz + c.C) {
+        c.err = "leaf outside its parent node";
+        return false;
+      }
+      fill_chunk(c, x0 - c.ox, y0 - c.oy, z0 - c.oz, span, d, w, col);
+      return true;
+    }
+    if (span < c.C || x0 % c.C || y0 % c.C || z0 % c.C || span % c.C) {
+      c.err = "octree nodes are not aligned with their depth";
+      return false;
+    }
+    fill_chunk(c, 0, 0, 0, c.C, d, w, col);  // one constant chunk, stored over every chunk the leaf covers
+    for (int z = z0; z < z0 + span; z += c.C)
+      for (int y = y0; y < y0 + span; y += c.C)
+        for (int x = x0; x < x0 + span; x += c.C)
+          if (!c.store(x, y, z, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr)) {
+            c.err = "storing a block failed";
+            return false;
+          }
     return true;
   }
   if (nchild != 8 || depth > 24) {
     c.err = "malformed octree node";
     return false;
   }
+  const bool opens = c.ox < 0 && depth == c.Lc;
+  if (opens) {
+    if (!node_box(c, cx, cy, cz, size, x0, y0, z0, span) || span != c.C || x0 % c.C || y0 % c.C || z0 % c.C) {
+      c.err = "octree nodes are not aligned with their depth";
+      return false;
+    }
+    c.ox = x0;
+    c.oy = y0;
+    c.oz = z0;
+    fill_chunk(c, 0, 0, 0, c.C, -1.f, 0.f, col);  // (the eight children overwrite all of it)
+  } else if (c.ox < 0 && depth > c.Lc) {
+    c.err = "octree deeper than the grid";
+    return false;
+  }
   for (int k = 0; k < 8; ++k)
     if (!read_node(f, c, depth + 1)) return false;
+  if (opens) {
+    const bool ok = c.store(c.ox, c.oy, c.oz, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr);
+    c.ox = -1;
+    if (!ok) {
+      c.err = "storing a block failed";
+      return false;
+    }
+  }
   return true;
+}
+
+// largest power of two <= want that divides n (n a power of two)
+inline int chunk_edge(int n, int want) {
+  int c = 1;
+  while (2 * c <= want && 2 * c <= n) c *= 2;
+  return c;
+}
+
+struct WriteCtx {
+  NodeSink *f;
+  bool color;
+  int C, Lc, LC;  // chunk edge, chunk level, log2(C)
+  Grid top;       // one voxel per chunk (its first voxel) + the chunk-uniform table
+  std::vector<float> d, w;
+  std::vector<unsigned char> rgb;
+  BlockFn fetch;
+  std::string err;
+};
+
+inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, float cy, float cz, float size) {
+  const int m = 1 << level;
+  const int span = c.top.n >> level;  // chunks per node edge
+  const size_t v0 = c.top.vox(kx * span, ky * span, kz * span);
+  const bool leaf = level == c.Lc ? (*c.top.leaf_ok)[v0] != 0 : c.top.uniform[level][((size_t)kz * m + ky) * m + kx] != 0;
+  if (leaf || level < c.Lc) {
+    put_node(*c.f, c.color, c.color ? c.top.rgb + 3 * v0 : nullptr, c.top.d[v0], c.top.w[v0], cx, cy, cz, size, leaf);
+    if (leaf) return true;
+    const float off = size / 4, ns = size / 2;
+    for (int k = 0; k < 8; ++k) {
+      const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+      if (!write_top(c, level + 1, 2 * kx + bx, 2 * ky + by, 2 * kz + bz, bx ? cx + off : cx - off,
+                     by ? cy + off : cy - off, bz ? cz + off : cz - off, ns))
+        return false;
+    }
+    return true;
+  }
+  // a non-uniform chunk: fetch it again and write its subtree
+  if (!c.fetch(kx * c.C, ky * c.C, kz * c.C, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr)) {
+    c.err = "fetching a block failed";
+    return false;
+  }
+  Grid g;
+  g.n = c.C;
+  g.L = c.LC;
+  g.d = c.d.data();
+  g.w = c.w.data();
+  g.rgb = c.color ? c.rgb.data() : nullptr;
+  build_pyramid(g);
+  write_node(*c.f, g, 0, 0, 0, 0, cx, cy, cz, size);
+  return true;
+}
+
+inline bool all_same(const Grid &g) {
+  const size_t n = (size_t)g.n * g.n * g.n;
+  int differ = 0;
+#pragma omp parallel for reduction(| : differ)
+  for (long long i = 1; i < (long long)n; ++i)
+    if (!g.same(0, (size_t)i)) differ |= 1;
+  return !differ;
 }
 
 }  // namespace volfmt
 
-inline bool vol_write(const std::string &filename, const VolHeader &h, const float *d, const float *w,
-                      const unsigned char *rgb, std::string *err) {
+// Writes the volume `fetch` serves into `filename`, visiting it in blocks of edge <= chunk.
+inline bool vol_write_stream(const std::string &filename, const VolHeader &h, int chunk, const volfmt::BlockFn &fetch,
+                             std::string *err) {
   const int L = volfmt::log2_exact(h.res[0]);
   if (L < 0 || h.res[1] != h.res[0] || h.res[2] != h.res[0]) {
     if (err) *err = "the .vol octree format needs a cubic power-of-two resolution";
@@ -236,14 +417,55 @@ inline bool vol_write(const std::string &filename, const VolHeader &h, const flo
   const size_t r3[3] = {(size_t)h.res[0], (size_t)h.res[1], (size_t)h.res[2]};
   for (int k = 0; k < 3; ++k) volfmt::put(f, r3[k]);
   for (int k = 0; k < 3; ++k) volfmt::put(f, h.size[k]);
-  volfmt::Grid g;
-  g.n = h.res[0];
-  g.L = L;
-  g.d = d;
-  g.w = w;
-  g.rgb = h.color ? rgb : nullptr;
-  volfmt::build_pyramid(g);
-  volfmt::write_node(f, g, 0, 0, 0, 0, 0.f, 0.f, 0.f, h.size[0]);
+
+  volfmt::NodeSink sink(f);
+  volfmt::WriteCtx c;
+  c.f = &sink;
+  c.color = h.color;
+  c.C = volfmt::chunk_edge(h.res[0], chunk);
+  c.LC = volfmt::log2_exact(c.C);
+  c.Lc = L - c.LC;
+  c.fetch = fetch;
+  const size_t cv = (size_t)c.C * c.C * c.C;
+  c.d.resize(cv);
+  c.w.resize(cv);
+  c.rgb.resize(h.color ? 3 * cv : 0);
+  // pass 1: one voxel and one "uniform" flag per chunk
+  const int m = 1 << c.Lc;
+  std::vector<float> td((size_t)m * m * m), tw((size_t)m * m * m);
+  std::vector<unsigned char> trgb(h.color ? 3 * td.size() : 0), tok(td.size());
+  volfmt::Grid blk;
+  blk.n = c.C;
+  blk.L = c.LC;
+  blk.d = c.d.data();
+  blk.w = c.w.data();
+  blk.rgb = h.color ? c.rgb.data() : nullptr;
+  for (int kz = 0; kz < m; ++kz)
+    for (int ky = 0; ky < m; ++ky)
+      for (int kx = 0; kx < m; ++kx) {
+        if (!fetch(kx * c.C, ky * c.C, kz * c.C, c.C, c.d.data(), c.w.data(), h.color ? c.rgb.data() : nullptr)) {
+          if (err) *err = "fetching a block failed";
+          return false;
+        }
+        const size_t t = ((size_t)kz * m + ky) * m + kx;
+        td[t] = c.d[0];
+        tw[t] = c.w[0];
+        if (h.color) std::memcpy(&trgb[3 * t], c.rgb.data(), 3);
+        tok[t] = volfmt::all_same(blk) ? 1 : 0;
+      }
+  c.top.n = m;
+  c.top.L = c.Lc;
+  c.top.d = td.data();
+  c.top.w = tw.data();
+  c.top.rgb = h.color ? trgb.data() : nullptr;
+  c.top.leaf_ok = &tok;
+  volfmt::build_pyramid(c.top);
+  // pass 2: nodes in pre-order
+  if (!volfmt::write_top(c, 0, 0, 0, 0, 0.f, 0.f, 0.f, h.size[0])) {
+    if (err) *err = c.err;
+    return false;
+  }
+  sink.flush();
   f.close();
   if (!f) {
     if (err) *err = "write error on " + filename;
@@ -252,8 +474,11 @@ inline bool vol_write(const std::string &filename, const VolHeader &h, const flo
   return true;
 }
 
-inline bool vol_read(const std::string &filename, VolHeader &h, std::vector<float> &d, std::vector<float> &w,
-                     std::vector<unsigned char> &rgb, std::string *err) {
+// Reads `filename`: the header first (on_header gets it and prepares the volume; false aborts), then the
+// voxels, handed to `store` in blocks of edge min(chunk, res).  Every voxel is stored exactly once.
+inline bool vol_read_stream(const std::string &filename, VolHeader &h, int chunk,
+                            const std::function<bool(const VolHeader &)> &on_header, const volfmt::BlockFn &store,
+                            std::string *err) {
   std::ifstream f(filename.c_str(), std::ios::binary);
   if (!f) {
     if (err) *err = "cannot open " + filename;
@@ -298,19 +523,25 @@ inline bool vol_read(const std::string &filename, VolHeader &h, std::vector<floa
     if (err) *err = "bad octree header (cubic power-of-two grids only)";
     return false;
   }
-  const size_t n = (size_t)h.res[0] * h.res[1] * h.res[2];
-  d.assign(n, -1.f);
-  w.assign(n, 0.f);
-  rgb.assign(h.color ? 3 * n : 0, 0);
+  if (!on_header(h)) {
+    if (err) *err = "the volume could not be prepared";
+    return false;
+  }
   volfmt::ReadCtx c;
   c.n = h.res[0];
+  c.C = volfmt::chunk_edge(c.n, chunk);
+  c.Lc = volfmt::log2_exact(c.n) - volfmt::log2_exact(c.C);
   c.vs = s3[0] / (float)h.res[0];
   c.half = s3[0] / 2;
   c.color = h.color;
-  c.d = d.data();
-  c.w = w.data();
-  c.rgb = h.color ? rgb.data() : nullptr;
-  if (!volfmt::read_node(f, c, 0)) {
+  const size_t cv = (size_t)c.C * c.C * c.C;
+  c.d.resize(cv);
+  c.w.resize(cv);
+  c.rgb.resize(h.color ? 3 * cv : 0);
+  c.ox = c.oy = c.oz = -1;
+  c.store = store;
+  volfmt::NodeSource src(f);
+  if (!volfmt::read_node(src, c, 0)) {
     if (err) *err = c.err;
     return false;
   }

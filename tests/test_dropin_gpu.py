@@ -106,12 +106,16 @@ def test_dropin_render_colored_view_equals_reference(dropin, color):
         v.close()
 
 
-@pytest.mark.parametrize("color", [False, True])
-def test_dropin_save_load_interop_with_reference(dropin, tmp_path, color):
+@pytest.mark.parametrize("color,chunk", [(False, None), (True, None), (True, "8"), (False, "4")])
+def test_dropin_save_load_interop_with_reference(dropin, tmp_path, monkeypatch, color, chunk):
     """.vol files cross both ways: the drop-in's save() is readable by the reference's load(), and the
-    reference's save() by the drop-in's load(); voxels survive bit for bit."""
+    reference's save() by the drop-in's load(); voxels survive bit for bit.  save / load stream the grid
+    through host memory in blocks; `chunk` forces blocks smaller than this small grid (tsdf_hip_download /
+    tsdf_hip_upload on sub-boxes)."""
     if not refbind.available():
         pytest.skip("oracle/_ref not built")
+    if chunk:
+        monkeypatch.setenv("CPU_TSDF_VOL_CHUNK", chunk)
     dv, ov, sc = make_pair(dropin, res=32, W=80, H=60, color=color, n_frames=3)
     ours = str(tmp_path / "dropin.vol")
     dv.save(ours)
@@ -147,3 +151,31 @@ def test_dropin_save_load_interop_with_reference(dropin, tmp_path, color):
         assert np.array_equal(rgb2, ov.rgb)
     for v in (dv, dv2, ref, ref2):
         v.close()
+
+
+def test_dropin_load_of_a_file_with_other_weights_rereads_into_float_weights(dropin, tmp_path, monkeypatch):
+    """A .vol whose weights are not min(k, max_weight) (another weighting scheme wrote it) cannot live in the
+    packed layout.  The streamed load() finds out at the first such block -- here the last of 64 -- and reads
+    the file again into a float weight plane; every voxel must come back bit for bit."""
+    import subprocess
+    from tests.test_vol_stream import ROOT, RES, SIZE, grid, write_raw
+    exe = str(tmp_path / "vol_stream")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fopenmp", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc", "host"),
+                           os.path.join(ROOT, "tests", "harness", "vol_stream.cpp"), "-o", exe])
+    d, w, rgb = grid(True, seed=9)
+    w[RES - 1, RES - 1, RES - 1] = 2.5
+    d[RES - 1, RES - 1, RES - 1] = 0.125
+    raw, vol = str(tmp_path / "in.raw"), str(tmp_path / "odd.vol")
+    write_raw(raw, d, w, rgb, True)
+    subprocess.check_call([exe, "write", raw, str(RES), str(SIZE), "1", "32", vol], stdout=subprocess.DEVNULL)
+    monkeypatch.setenv("CPU_TSDF_VOL_CHUNK", "8")
+    dv = refbind.RefVolume(RES, SIZE, 640, 480, 525.0, 525.0, 319.5, 239.5, 0.0, 3.0, color=True, lib_path=dropin)
+    dv.load(vol)
+    d2, w2, rgb2 = dv.download()
+    assert_same_f32(d2, d, "d")
+    assert_same_f32(w2, w, "w")
+    assert np.array_equal(rgb2, rgb)
+    again = str(tmp_path / "again.vol")
+    dv.save(again)
+    assert open(again, "rb").read().split(b"#OCTREEBINARY")[1] == open(vol, "rb").read().split(b"#OCTREEBINARY")[1]
+    dv.close()

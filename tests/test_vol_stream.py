@@ -1,0 +1,129 @@
+"""CPU tier: the streaming .vol writer / reader (cpu_tsdf_amd/csrc/host/vol_format.h) behind
+TSDFVolumeOctree::save / load, driven from host arrays through tests/harness/vol_stream.cpp.
+
+The block size is an implementation detail: every block size must produce byte for byte the same file and
+read back the same voxels, and the files must cross with the reference's own save / load
+(src/lib/tsdf_volume_octree.cpp:222-275, src/lib/octree.cpp:289-304,360-367,645-656)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import refbind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = 32
+SIZE = 0.4
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("volstream") / "vol_stream")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fopenmp", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc", "host"),
+                           os.path.join(ROOT, "tests", "harness", "vol_stream.cpp"), "-o", exe])
+    return exe
+
+
+def grid(color, seed=0):
+    """A volume with structure at every octree level: unseen octants, free space, a noisy band."""
+    rng = np.random.RandomState(seed)
+    d = np.full((RES,) * 3, -1.0, np.float32)
+    w = np.zeros((RES,) * 3, np.float32)
+    rgb = np.zeros((RES,) * 3 + (3,), np.uint8)
+    d[:, :, 16:] = 1.0      # free space seen 3 times: collapses to 16^3 leaves
+    w[:, :, 16:] = 3.0
+    d[8:16, 8:24, 4:20] = rng.uniform(-1, 1, (8, 16, 16)).astype(np.float32)  # a surface band: single voxels
+    w[8:16, 8:24, 4:20] = rng.randint(1, 5, (8, 16, 16)).astype(np.float32)
+    d[24:28, 0:4, 0:4] = 0.25   # one uniform 4^3 node inside an otherwise unseen octant
+    w[24:28, 0:4, 0:4] = 1.0
+    if color:
+        rgb[w > 0] = (10, 20, 30)
+        rgb[8:16, 8:24, 4:20] = rng.randint(0, 256, (8, 16, 16, 3))
+    return d, w, rgb
+
+
+def write_raw(path, d, w, rgb, color):
+    with open(path, "wb") as f:
+        f.write(d.tobytes())
+        f.write(w.tobytes())
+        if color:
+            f.write(rgb.tobytes())
+
+
+def read_raw(path, n, color):
+    raw = np.fromfile(path, np.uint8)
+    nv = n ** 3
+    d = raw[:4 * nv].view(np.float32).reshape(n, n, n)
+    w = raw[4 * nv:8 * nv].view(np.float32).reshape(n, n, n)
+    rgb = raw[8 * nv:].reshape(n, n, n, 3) if color else None
+    return d, w, rgb
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_every_block_size_writes_the_same_file_and_reads_the_same_voxels(harness, tmp_path, color):
+    d, w, rgb = grid(color)
+    raw = str(tmp_path / "in.raw")
+    write_raw(raw, d, w, rgb, color)
+    files = {}
+    for chunk in (32, 16, 8, 4, 1):
+        out = str(tmp_path / f"c{chunk}.vol")
+        fetched = int(subprocess.check_output([harness, "write", raw, str(RES), str(SIZE), str(int(color)), str(chunk), out]))
+        files[chunk] = open(out, "rb").read()
+        m = (RES // chunk) ** 3
+        assert m <= fetched <= 2 * m       # pass 1 sees every block once, pass 2 only the non-uniform ones
+        if chunk == 16:
+            assert fetched == 8 + 5   # the band crosses four octants, the 4^3 node sits in a fifth
+    assert all(files[c] == files[32] for c in files), "block size changed the file"
+    node = 43 if color else 40
+    full = sum(8 ** l for l in range(6)) * node
+    assert len(files[32]) < 0.2 * full     # collapsed: far smaller than a fully refined tree
+    for chunk in (32, 8, 2):
+        back = str(tmp_path / f"back{chunk}.raw")
+        n, c, blocks = map(int, subprocess.check_output([harness, "read", str(tmp_path / "c32.vol"), str(chunk), back]).split())
+        assert (n, c) == (RES, int(color)) and blocks == (RES // chunk) ** 3   # each block stored exactly once
+        d2, w2, rgb2 = read_raw(back, RES, color)
+        assert np.array_equal(d2.view(np.uint32), d.view(np.uint32)) and np.array_equal(w2, w)
+        if color:
+            assert np.array_equal(rgb2, rgb)
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_streamed_files_cross_with_the_reference(harness, tmp_path, color):
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    d, w, rgb = grid(color, seed=3)
+    raw = str(tmp_path / "in.raw")
+    write_raw(raw, d, w, rgb, color)
+    ours = str(tmp_path / "ours.vol")
+    subprocess.check_call([harness, "write", raw, str(RES), str(SIZE), str(int(color)), "8", ours], stdout=subprocess.DEVNULL)
+    ref = refbind.RefVolume(RES, SIZE, 640, 480, 525.0, 525.0, 319.5, 239.5, 0.0, 3.0, color=color)
+    ref.load(ours)
+    rd, rw, rrgb, leaf, _ = ref.dump_dense()
+    assert np.array_equal(rd.view(np.uint32), d.view(np.uint32)) and np.array_equal(rw, w)
+    if color:
+        assert np.array_equal(rrgb, rgb)
+    assert leaf.max() >= 16 * leaf.min()            # coarse leaves survived the trip
+    theirs = str(tmp_path / "theirs.vol")
+    ref.save(theirs)                                # the reference's own writer, same tree
+    for chunk in (32, 4):
+        back = str(tmp_path / f"back{chunk}.raw")
+        subprocess.check_call([harness, "read", theirs, str(chunk), back], stdout=subprocess.DEVNULL)
+        d2, w2, rgb2 = read_raw(back, RES, color)
+        assert np.array_equal(d2.view(np.uint32), d.view(np.uint32)) and np.array_equal(w2, w)
+        if color:
+            assert np.array_equal(rgb2, rgb)
+    ref.close()
+
+
+def test_reader_rejects_damaged_files(harness, tmp_path):
+    d, w, rgb = grid(False)
+    raw = str(tmp_path / "in.raw")
+    write_raw(raw, d, w, rgb, False)
+    good = str(tmp_path / "good.vol")
+    subprocess.check_call([harness, "write", raw, str(RES), str(SIZE), "0", "8", good], stdout=subprocess.DEVNULL)
+    blob = open(good, "rb").read()
+    cut = str(tmp_path / "cut.vol")
+    open(cut, "wb").write(blob[:len(blob) - 100])
+    p = subprocess.run([harness, "read", cut, "8", str(tmp_path / "x.raw")], capture_output=True)
+    assert p.returncode == 1 and b"truncated" in p.stderr
