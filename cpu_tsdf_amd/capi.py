@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
 
-OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED = range(6)
+OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_IO = range(7)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
 LAYOUT_AUTO, LAYOUT_F32W, LAYOUT_PACKED = 0, 1, 2
 
@@ -39,6 +39,18 @@ class TsdfParams(C.Structure):
         ("halo", C.c_int32),
         ("device", C.c_int32),
         ("layout", C.c_int32),
+    ]
+
+
+class TsdfVolMeta(C.Structure):
+    """struct tsdf_vol_meta (include/tsdf_hip.h): what a .vol file carries beyond tsdf_params."""
+
+    _fields_ = [
+        ("max_cell_size", C.c_float * 3),
+        ("is_empty", C.c_int32),
+        ("weight_by_depth", C.c_int32),
+        ("weight_by_variance", C.c_int32),
+        ("global_transform", C.c_double * 16),
     ]
 
 
@@ -96,6 +108,9 @@ SIGNATURES = {
     "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "tsdf_hip_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(TsdfVolMeta)]),
+    "tsdf_hip_load": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), C.POINTER(C.c_void_p), C.POINTER(TsdfParams),
+                                C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_error_string": (C.c_char_p, [C.c_int]),
     "tsdf_hip_last_error": (C.c_char_p, []),
     "tsdf_hip_device_count": (C.c_int, []),

@@ -12,7 +12,6 @@
 #include <iostream>
 #include <limits>
 
-#include "vol_format.h"
 
 namespace cpu_tsdf {
 
@@ -382,103 +381,47 @@ bool TSDFVolumeOctree::getFxnGradientAndHessian(const pcl::PointXYZ &pt, float &
 }
 
 // ---- save / load: the reference's .vol format (src/lib/tsdf_volume_octree.cpp:222-275) -----------------------
+// The format and the block streaming live behind the C ABI (tsdf_hip_save / tsdf_hip_load); this class adds
+// what only it knows: max cell size, the empty flag, the weighting flags and the global transform.
 void TSDFVolumeOctree::save(const std::string &filename) const {
   if (!ready("save")) return;
-  VolHeader hd;
-  for (int k = 0; k < 3; ++k) {
-    hd.res[k] = p_.res[k];
-    hd.size[k] = p_.size[k];
-    hd.max_cell[k] = max_cell_size_[k];
-  }
-  hd.max_dist_pos = p_.max_dist_pos;
-  hd.max_dist_neg = p_.max_dist_neg;
-  hd.max_weight = p_.max_weight;
-  hd.min_sensor_dist = p_.min_sensor_dist;
-  hd.max_sensor_dist = p_.max_sensor_dist;
-  hd.fx = p_.fx;
-  hd.fy = p_.fy;
-  hd.cx = p_.cx;
-  hd.cy = p_.cy;
-  hd.image_width = p_.image_width;
-  hd.image_height = p_.image_height;
-  hd.is_empty = is_empty_;
-  hd.weight_by_depth = weight_by_depth_;
-  hd.weight_by_variance = weight_by_variance_;
+  tsdf_vol_meta m;
+  for (int k = 0; k < 3; ++k) m.max_cell_size[k] = max_cell_size_[k];
+  m.is_empty = is_empty_;
+  m.weight_by_depth = weight_by_depth_;
+  m.weight_by_variance = weight_by_variance_;
   for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) hd.global_transform[4 * r + c] = global_transform_.matrix()(r, c);
-  hd.color = p_.integrate_color != 0;
-  // streamed in blocks (vol_format.h): host memory stays at one block whatever the resolution
-  std::string err;
-  const bool ok = vol_write_stream(
-      filename, hd, volChunk(),
-      [this](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
-        return downloadBlock(x0, y0, z0, c, c, c, d, w, rgb);
-      },
-      &err);
-  if (!ok) PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::save] %s\n", err.c_str());
-}
-
-// block edge for save / load; CPU_TSDF_VOL_CHUNK overrides (tests use small blocks on small grids)
-int TSDFVolumeOctree::volChunk() {
-  const char *e = std::getenv("CPU_TSDF_VOL_CHUNK");
-  const int v = e ? std::atoi(e) : 0;
-  return v > 0 ? v : 256;
+    for (int c = 0; c < 4; ++c) m.global_transform[4 * r + c] = global_transform_.matrix()(r, c);
+  const int rc = tsdf_hip_save(h_, filename.c_str(), &m);
+  if (rc) report("save", rc);
 }
 
 void TSDFVolumeOctree::load(const std::string &filename) {
-  // Blocks go to the device as they are read.  A file whose weights are not min(k, max_weight) (written with
-  // other weighting) cannot live in the packed layout: the upload says so and the file is read again into
-  // a float weight plane.
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    VolHeader hd;
-    std::string err;
-    int rc = TSDF_HIP_OK;
-    const bool ok = vol_read_stream(
-        filename, hd, volChunk(),
-        [this, attempt](const VolHeader &hd) {
-          for (int k = 0; k < 3; ++k) {
-            p_.res[k] = hd.res[k];
-            p_.size[k] = hd.size[k];
-            max_cell_size_[k] = hd.max_cell[k];
-          }
-          p_.max_dist_pos = hd.max_dist_pos;
-          p_.max_dist_neg = hd.max_dist_neg;
-          p_.max_weight = hd.max_weight;
-          p_.min_sensor_dist = hd.min_sensor_dist;
-          p_.max_sensor_dist = hd.max_sensor_dist;
-          p_.fx = hd.fx;
-          p_.fy = hd.fy;
-          p_.cx = hd.cx;
-          p_.cy = hd.cy;
-          p_.image_width = hd.image_width;
-          p_.image_height = hd.image_height;
-          weight_by_depth_ = hd.weight_by_depth;
-          weight_by_variance_ = hd.weight_by_variance;
-          Eigen::Matrix4d m;
-          for (int r = 0; r < 4; ++r)
-            for (int c = 0; c < 4; ++c) m(r, c) = hd.global_transform[4 * r + c];
-          global_transform_ = m;
-          p_.integrate_color = hd.color ? 1 : 0;
-          if (attempt) p_.layout = TSDF_LAYOUT_F32W;
-          reset();
-          return h_ != nullptr;
-        },
-        [this, &rc](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
-          rc = tsdf_hip_upload(h_, x0, y0, z0, c, c, c, d, w, rgb);
-          return rc == TSDF_HIP_OK;
-        },
-        &err);
-    if (ok) {
-      is_empty_ = hd.is_empty;
-      return;
-    }
-    if (rc == TSDF_HIP_E_UNSUPPORTED && attempt == 0 && h_ && tsdf_hip_layout(h_) == TSDF_LAYOUT_PACKED) continue;
-    if (rc)
-      report("load", rc);
-    else
-      PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::load] %s\n", err.c_str());
+  tsdf_handle h = nullptr;
+  tsdf_params p;
+  tsdf_vol_meta m;
+  tsdf_params defaults = p_;  // device, layout, transform order
+  defaults.z_begin = defaults.z_end = defaults.halo = 0;
+  const int rc = tsdf_hip_load(filename.c_str(), &defaults, &h, &p, &m);
+  if (rc) {
+    report("load", rc);
     return;
   }
+  if (h_) tsdf_hip_destroy(h_);
+  h_ = h;
+  const int layout = p_.layout;
+  p_ = p;
+  p_.layout = (layout == TSDF_LAYOUT_AUTO && p.layout == TSDF_LAYOUT_F32W && p.max_weight >= 0 && p.max_weight <= 255)
+                  ? TSDF_LAYOUT_F32W  // the file's weights needed the float plane: a later reset() keeps it
+                  : layout;
+  for (int k = 0; k < 3; ++k) max_cell_size_[k] = m.max_cell_size[k];
+  is_empty_ = m.is_empty != 0;
+  weight_by_depth_ = m.weight_by_depth != 0;
+  weight_by_variance_ = m.weight_by_variance != 0;
+  Eigen::Matrix4d g;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) g(r, c) = m.global_transform[4 * r + c];
+  global_transform_ = g;
 }
 
 // reference: src/lib/tsdf_interface.cpp:44-51

@@ -66,7 +66,7 @@ int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 void tsdf_pipeline_destroy(tsdf_hip_volume *v);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
-// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL); read once, changeable
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL, TSDF_HIP_VOL_CHUNK); read once, changeable
 // through tsdf_hip_set_tuning.
 struct TsdfTuning {
   int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
@@ -74,6 +74,7 @@ struct TsdfTuning {
   int fast_projection; // certified fp32 pixel projection with exact fp64 fallback: 0 off, anything else on
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
   int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
+  int vol_chunk;       // edge of the voxel blocks save / load stream through host memory
 };
 const TsdfTuning &tsdf_tuning();
 

@@ -35,6 +35,7 @@ extern "C" const char *tsdf_hip_error_string(int code) {
     case TSDF_HIP_E_HIP: return "HIP runtime error";
     case TSDF_HIP_E_NODEVICE: return "no HIP device";
     case TSDF_HIP_E_UNSUPPORTED: return "unsupported";
+    case TSDF_HIP_E_IO: return "file error";
   }
   return "unknown";
 }
@@ -48,7 +49,7 @@ static TsdfTuning &tuning_storage() {
   static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 256),
-                         env_int("TSDF_HIP_CULL", 1)};
+                         env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256))};
   return t;
 }
 
@@ -70,6 +71,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.mc_flush_at = value;
   else if (n == "cull")
     t.cull = value;
+  else if (n == "vol_chunk")
+    t.vol_chunk = std::max(1, value);
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;

@@ -29,8 +29,10 @@
 #include <fstream>
 #include <functional>
 #include <iomanip>
+#include <atomic>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace cpu_tsdf {
@@ -48,6 +50,25 @@ struct VolHeader {
 };
 
 namespace volfmt {
+
+// f(i) for i in [0, n) on up to 16 threads (plain std::thread: this header is compiled into libtsdf_hip.so,
+// which must not drag a second OpenMP runtime into the caller's process)
+template <class F>
+inline void par_for(int n, const F &f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int t = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+  if (n < 4 || t < 2) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int k = 0; k < std::min(t, n); ++k)
+    th.emplace_back([&]() {
+      for (int i; (i = next.fetch_add(1)) < n;) f(i);
+    });
+  for (auto &x : th) x.join();
+}
 
 inline int log2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -81,8 +102,7 @@ inline void build_pyramid(Grid &g) {
     const int half = span / 2;
     g.uniform[l].assign((size_t)m * m * m, 0);
     const std::vector<unsigned char> *below = (l + 1 < g.L) ? &g.uniform[l + 1] : nullptr;
-#pragma omp parallel for collapse(2)
-    for (int kz = 0; kz < m; ++kz)
+    auto plane = [&](int kz) {
       for (int ky = 0; ky < m; ++ky)
         for (int kx = 0; kx < m; ++kx) {
           bool u = true;
@@ -95,6 +115,11 @@ inline void build_pyramid(Grid &g) {
           }
           g.uniform[l][((size_t)kz * m + ky) * m + kx] = u ? 1 : 0;
         }
+    };
+    if (m >= 32)
+      par_for(m, plane);
+    else
+      for (int kz = 0; kz < m; ++kz) plane(kz);
   }
 }
 
@@ -366,12 +391,21 @@ inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, 
 }
 
 inline bool all_same(const Grid &g) {
-  const size_t n = (size_t)g.n * g.n * g.n;
-  int differ = 0;
-#pragma omp parallel for reduction(| : differ)
-  for (long long i = 1; i < (long long)n; ++i)
-    if (!g.same(0, (size_t)i)) differ |= 1;
-  return !differ;
+  std::atomic<int> differ(0);
+  auto plane = [&](int z) {
+    if (differ.load(std::memory_order_relaxed)) return;
+    const size_t a = (size_t)z * g.n * g.n, b = a + (size_t)g.n * g.n;
+    for (size_t i = a; i < b; ++i)
+      if (!g.same(0, i)) {
+        differ.store(1, std::memory_order_relaxed);
+        return;
+      }
+  };
+  if (g.n >= 32)
+    par_for(g.n, plane);
+  else
+    for (int z = 0; z < g.n; ++z) plane(z);
+  return !differ.load();
 }
 
 }  // namespace volfmt

@@ -317,6 +317,35 @@ class TSDFVolumeOctree:
                                         capi.as_u8p(rgb) if rgb is not None else None), "upload")
         self._is_empty = False
 
+    # -- save / load: tsdf_volume_octree.cpp:222-275 ---------------------------------------------------
+    def save(self, filename):
+        """The reference's .vol checkpoint (tsdf_hip_save); streamed, host memory stays at one 256^3 block."""
+        m = capi.TsdfVolMeta()
+        cell = getattr(self, "_max_cell", None) or tuple(self._p.size[k] / self._p.res[k] for k in range(3))
+        m.max_cell_size[:] = cell
+        m.is_empty = int(self._is_empty)
+        m.global_transform[:] = [float(v) for v in self._global_transform.reshape(16)]
+        capi.check(capi.load().tsdf_hip_save(self._need(), str(filename).encode(), C.byref(m)), "save")
+
+    def load(self, filename):
+        """Replace this volume by the one in `filename` (written by either side).  Device, layout and
+        transform order stay as set on this object."""
+        lib = capi.load()
+        h, p, m = C.c_void_p(), capi.TsdfParams(), capi.TsdfVolMeta()
+        defaults = capi.TsdfParams.from_buffer_copy(self._p)
+        defaults.z_begin = defaults.z_end = defaults.halo = 0
+        capi.check(lib.tsdf_hip_load(str(filename).encode(), C.byref(defaults), C.byref(h), C.byref(p), C.byref(m)), "load")
+        self.close()
+        asked = self._p.layout
+        self._h, self._p = h, p
+        if not (asked == capi.LAYOUT_AUTO and p.layout == capi.LAYOUT_F32W and 0 <= p.max_weight <= 255):
+            self._p.layout = asked
+        if self._stream is not None:
+            capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
+        self._max_cell = tuple(m.max_cell_size)
+        self._is_empty = bool(m.is_empty)
+        self._global_transform = np.array(list(m.global_transform), dtype=np.float64).reshape(4, 4)
+
     def centers(self, axis):
         out = np.empty(self._p.res[axis], dtype=np.float32)
         capi.check(capi.load().tsdf_hip_centers(self._need(), axis, capi.as_f32p(out)), "centers")

@@ -100,8 +100,6 @@ class TSDFVolumeOctree : public TSDFInterface {
                             const Eigen::Affine3d *world_to_cam = nullptr, size_t *n_valid_pixels = nullptr);
   // Raw voxel block readback ([z][y][x]); any pointer may be NULL; rgb is 3 bytes per voxel.
   bool downloadBlock(int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, unsigned char *rgb) const;
-  // Edge of the voxel blocks save() / load() stream through host memory (256; CPU_TSDF_VOL_CHUNK overrides).
-  static int volChunk();
   // The C-ABI handle (NULL before reset()); used by MarchingCubesTSDFOctree.
   tsdf_handle handle() const { return h_; }
   void setTransformOrder(int order) { p_.xform_order = order; }

@@ -38,7 +38,8 @@ enum {
   TSDF_HIP_E_NOMEM = 2,       /* hipMalloc failed */
   TSDF_HIP_E_HIP = 3,         /* any other HIP runtime error (see tsdf_hip_last_error) */
   TSDF_HIP_E_NODEVICE = 4,    /* no gfx950 device visible */
-  TSDF_HIP_E_UNSUPPORTED = 5
+  TSDF_HIP_E_UNSUPPORTED = 5,
+  TSDF_HIP_E_IO = 6           /* file missing, unreadable, unwritable or not a .vol (see tsdf_hip_last_error) */
 };
 
 /* Summation order of the rigid transform g = T * (c,1), which decides the last ulp of the
@@ -207,6 +208,28 @@ int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int
 int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
                     const float *w, const uint8_t *rgb);
 
+/* save / load -- src/lib/tsdf_volume_octree.cpp:222-275 (+ Octree::serialize / deserialize,
+ * src/lib/octree.cpp:289-304,360-367,645-678): the reference's .vol checkpoint, readable and writable by both
+ * sides.  The dense grid becomes an octree whose uniform subtrees are single leaves (lossless for every
+ * reader that looks voxels up by position); both directions stream the grid through host memory in cubic
+ * blocks (tuning "vol_chunk", 256), so host memory stays at one block whatever the resolution.  Needs a
+ * cubic power-of-two grid and a handle that owns all of it.
+ *   meta      what the file carries that a tsdf_params does not; NULL on save = max_cell_size of one voxel,
+ *             not empty, no depth/variance weighting, identity transform.
+ * tsdf_hip_load makes a NEW handle from the file's header; `defaults` supplies what the file does not hold
+ * (device, layout, xform_order; NULL = tsdf_hip_default_params).  With layout AUTO a file whose weights
+ * are not min(k, max_weight) is read again into the F32W layout; PACKED fails with E_UNSUPPORTED. */
+typedef struct tsdf_vol_meta {
+  float max_cell_size[3];      /* setMaxVoxelSize, tsdf_volume_octree.h:166 (unused by a dense grid) */
+  int32_t is_empty;            /* tsdf_volume_octree.h:286,356 */
+  int32_t weight_by_depth;     /* :358 */
+  int32_t weight_by_variance;
+  double global_transform[16]; /* setGlobalTransform :132, row-major */
+} tsdf_vol_meta;
+int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta);
+int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out, tsdf_params *params_out,
+                  tsdf_vol_meta *meta_out);
+
 /* Whole planes [z0, z0+nz) to / from packed DEVICE buffers ([nz][ny][nx]; rgb as uint32 r|g<<8|b<<16),
  * asynchronous on the handle's stream.  This is the halo-exchange primitive: the buffers are what the
  * caller hands to RCCL send/recv.  Planes may lie in the halo.  Any pointer may be NULL. */
@@ -251,7 +274,7 @@ int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int3
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
 
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
- * "mc_flush_at", "cull" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
+ * "mc_flush_at", "cull", "vol_chunk" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 
 const char *tsdf_hip_error_string(int code);
@@ -259,7 +282,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 2
+#define TSDF_HIP_ABI_VERSION 3
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
-    assert lib.tsdf_hip_abi_version() == 2
+    assert lib.tsdf_hip_abi_version() == 3
 
 
 def test_default_params_match_reference_constructor():
@@ -40,19 +40,30 @@ def test_default_params_match_reference_constructor():
     assert (p.image_width, p.image_height, p.integrate_color) == (640, 480, 0)
 
 
-def test_params_struct_layout_matches_header(tmp_path):
-    """sizeof / offsetof of struct tsdf_params as gcc lays it out from include/tsdf_hip.h == the ctypes mirror."""
+@pytest.mark.parametrize("cname,mirror", [("tsdf_params", "TsdfParams"), ("tsdf_vol_meta", "TsdfVolMeta")])
+def test_struct_layout_matches_header(tmp_path, cname, mirror):
+    """sizeof / offsetof of the ABI structs as gcc lays them out from include/tsdf_hip.h == the ctypes mirrors."""
     import subprocess
-    names = [n for n, _ in capi.TsdfParams._fields_]
+    cls = getattr(capi, mirror)
+    names = [n for n, _ in cls._fields_]
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tsdf_hip.h"\nint main(void){\n'
-                   'printf("%zu\\n", sizeof(tsdf_params));\n' +
-                   "".join(f'printf("%zu\\n", offsetof(tsdf_params, {n}));\n' for n in names) + "return 0;}\n")
+                   f'printf("%zu\\n", sizeof({cname}));\n' +
+                   "".join(f'printf("%zu\\n", offsetof({cname}, {n}));\n' for n in names) + "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert got[0] == C.sizeof(capi.TsdfParams)
-    assert got[1:] == [getattr(capi.TsdfParams, n).offset for n in names]
+    assert got[0] == C.sizeof(cls)
+    assert got[1:] == [getattr(cls, n).offset for n in names]
+
+
+def test_load_of_a_missing_file_is_an_io_error_before_any_device_is_touched(tmp_path):
+    lib = capi.load()
+    h = C.c_void_p()
+    rc = lib.tsdf_hip_load(str(tmp_path / "absent.vol").encode(), None, C.byref(h), None, None)
+    assert rc == capi.E_IO and not h.value
+    assert b"cannot open" in lib.tsdf_hip_last_error()
+    assert lib.tsdf_hip_save(None, b"x.vol", None) == capi.E_INVALID
 
 
 def test_no_device_is_reported_not_crashed():

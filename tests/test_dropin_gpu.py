@@ -106,8 +106,16 @@ def test_dropin_render_colored_view_equals_reference(dropin, color):
         v.close()
 
 
-@pytest.mark.parametrize("color,chunk", [(False, None), (True, None), (True, "8"), (False, "4")])
-def test_dropin_save_load_interop_with_reference(dropin, tmp_path, monkeypatch, color, chunk):
+@pytest.fixture
+def vol_chunk():
+    """Set the block edge save / load stream with (tsdf_hip_set_tuning "vol_chunk"); restored afterwards."""
+    from cpu_tsdf_amd import capi
+    yield lambda n: capi.set_tuning("vol_chunk", n)
+    capi.set_tuning("vol_chunk", 256)
+
+
+@pytest.mark.parametrize("color,chunk", [(False, None), (True, None), (True, 8), (False, 4)])
+def test_dropin_save_load_interop_with_reference(dropin, tmp_path, vol_chunk, color, chunk):
     """.vol files cross both ways: the drop-in's save() is readable by the reference's load(), and the
     reference's save() by the drop-in's load(); voxels survive bit for bit.  save / load stream the grid
     through host memory in blocks; `chunk` forces blocks smaller than this small grid (tsdf_hip_download /
@@ -115,7 +123,7 @@ def test_dropin_save_load_interop_with_reference(dropin, tmp_path, monkeypatch, 
     if not refbind.available():
         pytest.skip("oracle/_ref not built")
     if chunk:
-        monkeypatch.setenv("CPU_TSDF_VOL_CHUNK", chunk)
+        vol_chunk(chunk)
     dv, ov, sc = make_pair(dropin, res=32, W=80, H=60, color=color, n_frames=3)
     ours = str(tmp_path / "dropin.vol")
     dv.save(ours)
@@ -153,14 +161,14 @@ def test_dropin_save_load_interop_with_reference(dropin, tmp_path, monkeypatch, 
         v.close()
 
 
-def test_dropin_load_of_a_file_with_other_weights_rereads_into_float_weights(dropin, tmp_path, monkeypatch):
+def test_dropin_load_of_a_file_with_other_weights_rereads_into_float_weights(dropin, tmp_path, vol_chunk):
     """A .vol whose weights are not min(k, max_weight) (another weighting scheme wrote it) cannot live in the
     packed layout.  The streamed load() finds out at the first such block -- here the last of 64 -- and reads
     the file again into a float weight plane; every voxel must come back bit for bit."""
     import subprocess
     from tests.test_vol_stream import ROOT, RES, SIZE, grid, write_raw
     exe = str(tmp_path / "vol_stream")
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fopenmp", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc", "host"),
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc"),
                            os.path.join(ROOT, "tests", "harness", "vol_stream.cpp"), "-o", exe])
     d, w, rgb = grid(True, seed=9)
     w[RES - 1, RES - 1, RES - 1] = 2.5
@@ -168,7 +176,7 @@ def test_dropin_load_of_a_file_with_other_weights_rereads_into_float_weights(dro
     raw, vol = str(tmp_path / "in.raw"), str(tmp_path / "odd.vol")
     write_raw(raw, d, w, rgb, True)
     subprocess.check_call([exe, "write", raw, str(RES), str(SIZE), "1", "32", vol], stdout=subprocess.DEVNULL)
-    monkeypatch.setenv("CPU_TSDF_VOL_CHUNK", "8")
+    vol_chunk(8)
     dv = refbind.RefVolume(RES, SIZE, 640, 480, 525.0, 525.0, 319.5, 239.5, 0.0, 3.0, color=True, lib_path=dropin)
     dv.load(vol)
     d2, w2, rgb2 = dv.download()
@@ -179,3 +187,68 @@ def test_dropin_load_of_a_file_with_other_weights_rereads_into_float_weights(dro
     dv.save(again)
     assert open(again, "rb").read().split(b"#OCTREEBINARY")[1] == open(vol, "rb").read().split(b"#OCTREEBINARY")[1]
     dv.close()
+
+
+def test_python_save_load_over_the_c_abi(dropin, tmp_path, vol_chunk):
+    """tsdf_hip_save / tsdf_hip_load as every binding sees them (here ctypes): the file the Python class
+    writes is the file the C++ class writes, the reference reads it, and load() restores voxels and metadata."""
+    from cpu_tsdf_amd import capi
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    dv, ov, sc = make_pair(dropin, res=32, W=80, H=60, color=True, n_frames=3)
+    by_cpp = str(tmp_path / "cpp.vol")
+    dv.save(by_cpp)
+    pv = TSDFVolumeOctree()
+    pv.setResolution(32, 32, 32)
+    pv.setGridSize(sc.size, sc.size, sc.size)
+    pv.setImageSize(80, 60)
+    pv.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    pv.setSensorDistanceBounds(0.0, 3 * sc.size)
+    pv.setIntegrateColor(True)
+    pv.reset()
+    for i in range(3):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        pv.integrateCloud(sc.depth(tr), sc.bgra(i), tr)
+    G = synth.turntable_pose(2, 8, sc.size)
+    pv.setGlobalTransform(G)
+    vol_chunk(16)
+    by_py = str(tmp_path / "py.vol")
+    pv.save(by_py)
+    tree = lambda path: open(path, "rb").read().split(b"#OCTREEBINARY")[1]
+    assert tree(by_py) == tree(by_cpp)
+    if refbind.available():
+        ref = refbind.RefVolume(32, sc.size, 80, 60, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True)
+        ref.load(by_py)
+        d, w, rgb, _, _ = ref.dump_dense()
+        assert_same_f32(d, ov.d, "reference reading the Python class's file")
+        assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+        ref.close()
+    back = TSDFVolumeOctree()      # nothing configured: everything must come from the file
+    back.load(by_py)
+    assert back.getResolution() == (32, 32, 32) and back.getImageSize() == (80, 60) and not back.isEmpty()
+    assert back.getLayout() == capi.LAYOUT_PACKED
+    assert np.array_equal(back.getGlobalTransform(), G)
+    d, w, rgb = back.download()
+    assert_same_f32(d, ov.d, "d after load")
+    assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+    tr = synth.turntable_pose(3, 8, sc.size)     # and it keeps integrating like the original
+    back.integrateCloud(sc.depth(tr), sc.bgra(3), tr)
+    pv.integrateCloud(sc.depth(tr), sc.bgra(3), tr)
+    assert all(np.array_equal(a, b) for a, b in zip(back.download(), pv.download()))
+    # errors: a missing file, a file that is not a .vol, a Z-slab handle
+    with pytest.raises(capi.TsdfHipError) as e:
+        back.load(str(tmp_path / "nope.vol"))
+    assert e.value.code == capi.E_IO and back.getResolution() == (32, 32, 32)   # the old volume is untouched
+    junk = tmp_path / "junk.vol"
+    junk.write_bytes(b"not a volume\n" * 10)
+    with pytest.raises(capi.TsdfHipError) as e:
+        back.load(str(junk))
+    assert e.value.code == capi.E_IO
+    slab = TSDFVolumeOctree()
+    slab.setResolution(32, 32, 32)
+    slab.setZSlab(0, 16)
+    slab.reset()
+    with pytest.raises(capi.TsdfHipError) as e:
+        slab.save(str(tmp_path / "slab.vol"))
+    assert e.value.code == capi.E_UNSUPPORTED
+    for v in (pv, back, slab, dv):
+        v.close()

@@ -20,7 +20,7 @@ SIZE = 0.4
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("volstream") / "vol_stream")
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-fopenmp", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc", "host"),
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc"),
                            os.path.join(ROOT, "tests", "harness", "vol_stream.cpp"), "-o", exe])
     return exe
 

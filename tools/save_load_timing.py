@@ -41,7 +41,7 @@ def main():
         dv.integrate(sc.depth(tr), sc.bgra(i), tr)
     grid_mb = a.res ** 3 * (11 if a.color else 8) / 2 ** 20
     out = {"res": a.res, "frames": a.frames, "color": a.color, "grid_mb": grid_mb, "rss_before_mb": rss_mb(),
-           "chunk": int(os.environ.get("CPU_TSDF_VOL_CHUNK", 256))}
+           "chunk": int(os.environ.get("TSDF_HIP_VOL_CHUNK", 256))}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
         path = os.path.join(td, "big.vol")
         t0 = time.time()
