@@ -62,6 +62,28 @@ int tsdf_hip_fail(hipError_t e, const char *what, const char *file, int line);
     if (_e != hipSuccess) return tsdf_hip_fail(_e, #expr, __FILE__, __LINE__); \
   } while (0)
 
+// Every entry point works on its handle's device and leaves the caller's current device as it found it
+// (a process may hold handles on several GPUs, or share the thread with another HIP user such as torch).
+struct TsdfDeviceScope {
+  int prev = -1;
+  hipError_t err;
+  explicit TsdfDeviceScope(int dev) {
+    err = hipGetDevice(&prev);
+    if (err != hipSuccess || prev == dev)
+      prev = -1;  // nothing to restore
+    else
+      err = hipSetDevice(dev);
+  }
+  ~TsdfDeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  TsdfDeviceScope(const TsdfDeviceScope &) = delete;
+  TsdfDeviceScope &operator=(const TsdfDeviceScope &) = delete;
+};
+#define TSDF_ON_DEVICE(dev)          \
+  TsdfDeviceScope _device_scope(dev); \
+  TSDF_HIP_TRY(_device_scope.err)
+
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 void tsdf_pipeline_destroy(tsdf_hip_volume *v);
 

@@ -188,7 +188,7 @@ int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes) {
 
 static void free_volume(tsdf_hip_volume *v) {
   if (!v) return;
-  (void)hipSetDevice(v->device);
+  TsdfDeviceScope scope(v->device);
   tsdf_pipeline_destroy(v);
   if (v->d) (void)hipFree(v->d);
   if (v->w) (void)hipFree(v->w);
@@ -240,7 +240,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   }
   int dev = p->device;
   if (dev < 0) TSDF_HIP_TRY(hipGetDevice(&dev));
-  TSDF_HIP_TRY(hipSetDevice(dev));
+  TSDF_ON_DEVICE(dev);
 
   tsdf_hip_volume *v = new tsdf_hip_volume;
   v->p = *p;
@@ -306,7 +306,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
 // (octree.h:177-180).
 extern "C" int tsdf_hip_reset(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const int64_t n = h->pitch * h->ny * h->nz_alloc;
   const float minus_one = -1.f;
   uint32_t bits;
@@ -324,7 +324,7 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
 
 extern "C" int tsdf_hip_destroy(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
-  (void)hipSetDevice(h->device);
+  TsdfDeviceScope scope(h->device);
   (void)hipStreamSynchronize(h->stream);
   free_volume(h);
   return TSDF_HIP_OK;
@@ -338,7 +338,7 @@ extern "C" int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream) {
 
 extern "C" int tsdf_hip_synchronize(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }
@@ -462,7 +462,7 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
     tsdf_set_error("volume has no colour plane");
     return TSDF_HIP_E_INVALID;
   }
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const int64_t plane = (int64_t)nx * ny;
   int64_t max_planes = (int64_t)(64 << 20) / plane;  // <= 64 Mi voxels (256 MiB of floats) per chunk
   if (max_planes < 1) max_planes = 1;
@@ -612,7 +612,7 @@ static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *
     tsdf_set_error("volume has no colour plane");
     return TSDF_HIP_E_INVALID;
   }
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const int64_t n = (int64_t)h->nx * h->ny * nz;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
   const int zl0 = z0 - h->z_first;

@@ -95,7 +95,7 @@ extern "C" int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_str
                                  const double world_to_cam[12], float *depth_out, uint8_t *bgra_out,
                                  uint64_t *n_valid) {
   if (!h || (n && !xyz) || xyz_stride < 3 || (bgra && bgra_stride < 4) || n >= (1ull << 32)) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const tsdf_params &p = h->p;
   const size_t npx = (size_t)p.image_width * p.image_height;
   // scratch: zbuf[npx] u64 | points | colours

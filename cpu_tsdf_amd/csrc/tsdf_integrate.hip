@@ -710,14 +710,14 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
 extern "C" int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
                                          const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !d_depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   return launch_integrate(h, d_depth, d_bgra, cam_from_vol, n_observed);
 }
 
 extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
                                   const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   TSDF_HIP_TRY(hipMemcpyAsync(h->frame_depth, depth, npx * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const bool color = h->p.integrate_color != 0;
@@ -766,7 +766,7 @@ void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
 extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
                                         const float cam_from_vol[12]) {
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const bool color = h->p.integrate_color != 0;
   if (color && !bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
@@ -882,7 +882,7 @@ k_calib_rmw(float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict_
 
 extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written) {
   if (!h) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const int64_t plane = h->pitch * h->ny;
   const int64_t first4 = (int64_t)(h->z_begin - h->z_first) * plane / 4;
   const int64_t n4 = (int64_t)(h->z_end - h->z_begin) * plane / 4;
@@ -915,7 +915,7 @@ static __global__ void k_selftest_project(const IntegrateArgs a, const double *c
 extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
                                          int32_t *pix_exact, uint8_t *ambiguous) {
   if (!h || !g || !n || !pix_fast || !pix_exact || !ambiguous) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const IntegrateHost a = make_args(h, ident);
   if (!fast_projection_ok(a, true, true)) {

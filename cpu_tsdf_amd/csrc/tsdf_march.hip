@@ -365,7 +365,7 @@ static int ensure_buf(T **buf, size_t *cap_elems, size_t need, hipStream_t s) {
 
 extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
   if (!h || color_mode < 0 || color_mode > 2) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const tsdf_params &p = h->p;
   if (p.res[0] >= (1 << 20) || p.res[1] >= (1 << 20) || p.res[2] >= (1 << 20)) return TSDF_HIP_E_UNSUPPORTED;
   McArgs a;
@@ -498,7 +498,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
 
 extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell) {
   if (!h) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
   if (verts) TSDF_HIP_TRY(hipMemcpyAsync(verts, h->mc_verts, n * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -518,7 +518,7 @@ extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, u
 // a Z-slab job hands to RCCL when the per-slab meshes are merged on the GPU.
 extern "C" int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell) {
   if (!h) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
   if (d_verts)

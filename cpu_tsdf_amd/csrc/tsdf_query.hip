@@ -423,7 +423,7 @@ static int make_ray_args(tsdf_handle h, const float rot[9], const float origin[3
 static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv,
                         float *out) {
   if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   if (inv) {
@@ -469,7 +469,7 @@ extern "C" int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const 
 extern "C" int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
                                       int32_t *d_state) {
   if (!h || !rot || !origin || !d_state || downsample < 1) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   const int64_t n = (int64_t)a.nw * a.nh;
@@ -482,7 +482,7 @@ extern "C" int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const
                                         int rank, int world, const int32_t *d_state, int32_t *d_delta) {
   if (!h || !rot || !origin || !d_state || !d_delta || downsample < 1 || world < 1 || rank < 0 || rank >= world)
     return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   const int64_t n = (int64_t)a.nw * a.nh;
@@ -516,7 +516,7 @@ extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], 
       (count && !d_records))
     return TSDF_HIP_E_INVALID;
   if (!count) return TSDF_HIP_OK;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   int rc = tsdf_ensure_scratch(h, 16);
@@ -570,7 +570,7 @@ k_lookup_rgb(const GridView g, const float *__restrict__ xyz, size_t n, unsigned
 
 extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
   if (!h || !xyz || !n || !rgb || !found) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   int rc = tsdf_ensure_scratch(h, n * 16);
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
@@ -608,7 +608,7 @@ k_selftest_containing(const GridView g, const float *__restrict__ xyz, size_t n,
 
 extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx) {
   if (!h || !xyz || !n || !idx) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   int rc = tsdf_ensure_scratch(h, n * 24);
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
@@ -697,7 +697,7 @@ k_sample(const GridView g, const float *__restrict__ xyz, size_t n, float *__res
 extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess,
                                uint8_t *ok) {
   if (!h || !xyz || !n) return TSDF_HIP_E_INVALID;
-  TSDF_HIP_TRY(hipSetDevice(h->device));
+  TSDF_ON_DEVICE(h->device);
   // scratch layout: xyz[3n] val[n] grad[3n] hess[9n] floats, ok[n] bytes
   const size_t fl = 16 * n;
   int rc = tsdf_ensure_scratch(h, fl * sizeof(float) + n + 16);
