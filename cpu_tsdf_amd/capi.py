@@ -54,6 +54,12 @@ class TsdfVolMeta(C.Structure):
     ]
 
 
+# tsdf_block_fn / tsdf_header_fn (include/tsdf_hip.h): callbacks of tsdf_hip_save_blocks / tsdf_hip_load_blocks
+BLOCK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                       C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+HEADER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta))
+
+
 class TsdfHipError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -109,6 +115,8 @@ SIGNATURES = {
     "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "tsdf_hip_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(TsdfVolMeta)]),
+    "tsdf_hip_save_blocks": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta), C.c_char_p, BLOCK_FN, C.c_void_p]),
+    "tsdf_hip_load_blocks": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), HEADER_FN, BLOCK_FN, C.c_void_p]),
     "tsdf_hip_load": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), C.POINTER(C.c_void_p), C.POINTER(TsdfParams),
                                 C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_error_string": (C.c_char_p, [C.c_int]),

@@ -1,6 +1,7 @@
-// tsdf_hip_save / tsdf_hip_load: the reference's .vol checkpoint (src/lib/tsdf_volume_octree.cpp:222-275)
-// over the C ABI.  Host code only; the format lives in vol_format.h, the voxels move through
-// tsdf_hip_download / tsdf_hip_upload one cubic block at a time.
+// tsdf_hip_save / tsdf_hip_load (+ the callback forms): the reference's .vol checkpoint
+// (src/lib/tsdf_volume_octree.cpp:222-275) over the C ABI.  Host code only; the format lives in
+// vol_format.h, the voxels move one cubic block at a time through tsdf_hip_download / tsdf_hip_upload or
+// the caller's callbacks.
 #include "tsdf_common.h"
 #include "vol_format.h"
 
@@ -13,23 +14,7 @@ static void default_meta(const tsdf_params &p, tsdf_vol_meta *m) {
   for (int i = 0; i < 16; ++i) m->global_transform[i] = (i % 5 == 0) ? 1.0 : 0.0;
 }
 
-extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta) {
-  if (!h || !filename) return TSDF_HIP_E_INVALID;
-  const tsdf_params &p = h->p;
-  if (h->z_begin != 0 || h->z_end != p.res[2]) {
-    tsdf_set_error("save needs a handle that owns the whole grid (gather the Z-slabs first)");
-    return TSDF_HIP_E_UNSUPPORTED;
-  }
-  if (cpu_tsdf::volfmt::log2_exact(p.res[0]) < 0 || p.res[1] != p.res[0] || p.res[2] != p.res[0]) {
-    tsdf_set_error("the .vol octree format needs a cubic power-of-two resolution");
-    return TSDF_HIP_E_UNSUPPORTED;
-  }
-  tsdf_vol_meta m;
-  if (meta)
-    m = *meta;
-  else
-    default_meta(p, &m);
-  VolHeader hd;
+static void header_from(const tsdf_params &p, const tsdf_vol_meta &m, VolHeader &hd) {
   for (int k = 0; k < 3; ++k) {
     hd.res[k] = p.res[k];
     hd.size[k] = p.size[k];
@@ -51,86 +36,150 @@ extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol
   hd.weight_by_variance = m.weight_by_variance != 0;
   for (int i = 0; i < 16; ++i) hd.global_transform[i] = m.global_transform[i];
   hd.color = p.integrate_color != 0;
-  int rc = TSDF_HIP_OK;
+}
+
+static void header_to(const VolHeader &f, tsdf_params &p, tsdf_vol_meta &m) {
+  for (int k = 0; k < 3; ++k) {
+    p.res[k] = f.res[k];
+    p.size[k] = f.size[k];
+    m.max_cell_size[k] = f.max_cell[k];
+  }
+  p.max_dist_pos = f.max_dist_pos;
+  p.max_dist_neg = f.max_dist_neg;
+  p.max_weight = f.max_weight;
+  p.min_sensor_dist = f.min_sensor_dist;
+  p.max_sensor_dist = f.max_sensor_dist;
+  p.fx = f.fx;
+  p.fy = f.fy;
+  p.cx = f.cx;
+  p.cy = f.cy;
+  p.image_width = f.image_width;
+  p.image_height = f.image_height;
+  p.integrate_color = f.color ? 1 : 0;
+  p.z_begin = p.z_end = p.halo = 0;
+  m.is_empty = f.is_empty;
+  m.weight_by_depth = f.weight_by_depth;
+  m.weight_by_variance = f.weight_by_variance;
+  for (int i = 0; i < 16; ++i) m.global_transform[i] = f.global_transform[i];
+}
+
+extern "C" int tsdf_hip_save_blocks(const tsdf_params *p, const tsdf_vol_meta *meta, const char *filename,
+                                    tsdf_block_fn fetch, void *user) {
+  if (!p || !filename || !fetch) return TSDF_HIP_E_INVALID;
+  if (cpu_tsdf::volfmt::log2_exact(p->res[0]) < 0 || p->res[1] != p->res[0] || p->res[2] != p->res[0]) {
+    tsdf_set_error("the .vol octree format needs a cubic power-of-two resolution");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  tsdf_vol_meta m;
+  if (meta)
+    m = *meta;
+  else
+    default_meta(*p, &m);
+  VolHeader hd;
+  header_from(*p, m, hd);
+  int rc = 0;
   std::string err;
   const bool ok = cpu_tsdf::vol_write_stream(
       filename, hd, tsdf_tuning().vol_chunk,
       [&](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
-        rc = tsdf_hip_download(h, x0, y0, z0, c, c, c, d, w, rgb);
-        return rc == TSDF_HIP_OK;
+        rc = fetch(user, x0, y0, z0, c, d, w, rgb);
+        return rc == 0;
       },
       &err);
   if (ok) return TSDF_HIP_OK;
-  if (rc) return rc;  // (tsdf_hip_download has set the message)
+  if (rc) return rc;  // (the callback's own code; its message, if any, is already set)
   tsdf_set_error(err);
   return TSDF_HIP_E_IO;
 }
+
+extern "C" int tsdf_hip_load_blocks(const char *filename, const tsdf_params *defaults, tsdf_header_fn on_header,
+                                    tsdf_block_fn store, void *user) {
+  if (!filename || (!on_header && !store)) return TSDF_HIP_E_INVALID;
+  tsdf_params p;
+  if (defaults)
+    p = *defaults;
+  else
+    tsdf_hip_default_params(&p);
+  tsdf_vol_meta m;
+  VolHeader hd;
+  int rc = 0;
+  bool header_only = false;
+  std::string err;
+  const bool ok = cpu_tsdf::vol_read_stream(
+      filename, hd, tsdf_tuning().vol_chunk,
+      [&](const VolHeader &f) {
+        header_to(f, p, m);
+        if (on_header) rc = on_header(user, &p, &m);
+        header_only = rc == 0 && !store;
+        return rc == 0 && store != nullptr;
+      },
+      [&](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
+        rc = store(user, x0, y0, z0, c, d, w, rgb);
+        return rc == 0;
+      },
+      &err);
+  if (ok || header_only) return TSDF_HIP_OK;
+  if (rc) return rc;
+  tsdf_set_error(err);
+  return TSDF_HIP_E_IO;
+}
+
+// ---- one handle ---------------------------------------------------------------------------------------------
+static int fetch_from_handle(void *user, int x0, int y0, int z0, int c, float *d, float *w, uint8_t *rgb) {
+  return tsdf_hip_download((tsdf_handle)user, x0, y0, z0, c, c, c, d, w, rgb);
+}
+
+extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta) {
+  if (!h || !filename) return TSDF_HIP_E_INVALID;
+  if (h->z_begin != 0 || h->z_end != h->p.res[2]) {
+    tsdf_set_error("save needs a handle that owns the whole grid (Z-slabs: tsdf_hip_save_blocks)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  return tsdf_hip_save_blocks(&h->p, meta, filename, fetch_from_handle, h);
+}
+
+namespace {
+struct LoadState {
+  tsdf_handle h = nullptr;
+  tsdf_params p;
+  tsdf_vol_meta m;
+  bool force_f32w = false;
+};
+int load_header(void *user, const tsdf_params *p, const tsdf_vol_meta *m) {
+  LoadState *s = (LoadState *)user;
+  s->p = *p;
+  s->m = *m;
+  if (s->force_f32w) s->p.layout = TSDF_LAYOUT_F32W;
+  return tsdf_hip_create(&s->p, &s->h);
+}
+int load_store(void *user, int x0, int y0, int z0, int c, float *d, float *w, uint8_t *rgb) {
+  return tsdf_hip_upload(((LoadState *)user)->h, x0, y0, z0, c, c, c, d, w, rgb);
+}
+}  // namespace
 
 extern "C" int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out,
                              tsdf_params *params_out, tsdf_vol_meta *meta_out) {
   if (!filename || !out) return TSDF_HIP_E_INVALID;
   *out = nullptr;
-  tsdf_params base;
-  if (defaults)
-    base = *defaults;
-  else
-    tsdf_hip_default_params(&base);
+  const int asked = defaults ? defaults->layout : TSDF_LAYOUT_AUTO;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    tsdf_handle h = nullptr;
-    tsdf_params p = base;
-    VolHeader hd;
-    int rc = TSDF_HIP_OK;
-    std::string err;
-    const bool ok = cpu_tsdf::vol_read_stream(
-        filename, hd, tsdf_tuning().vol_chunk,
-        [&](const VolHeader &f) {
-          for (int k = 0; k < 3; ++k) {
-            p.res[k] = f.res[k];
-            p.size[k] = f.size[k];
-          }
-          p.max_dist_pos = f.max_dist_pos;
-          p.max_dist_neg = f.max_dist_neg;
-          p.max_weight = f.max_weight;
-          p.min_sensor_dist = f.min_sensor_dist;
-          p.max_sensor_dist = f.max_sensor_dist;
-          p.fx = f.fx;
-          p.fy = f.fy;
-          p.cx = f.cx;
-          p.cy = f.cy;
-          p.image_width = f.image_width;
-          p.image_height = f.image_height;
-          p.integrate_color = f.color ? 1 : 0;
-          p.z_begin = p.z_end = p.halo = 0;
-          if (attempt) p.layout = TSDF_LAYOUT_F32W;
-          rc = tsdf_hip_create(&p, &h);
-          return rc == TSDF_HIP_OK;
-        },
-        [&](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
-          rc = tsdf_hip_upload(h, x0, y0, z0, c, c, c, d, w, rgb);
-          return rc == TSDF_HIP_OK;
-        },
-        &err);
-    if (ok) {
-      *out = h;
+    LoadState s;
+    s.force_f32w = attempt == 1;
+    const int rc = tsdf_hip_load_blocks(filename, defaults, load_header, load_store, &s);
+    if (rc == TSDF_HIP_OK) {
+      *out = s.h;
       if (params_out) {
-        *params_out = p;
-        params_out->layout = tsdf_hip_layout(h);
+        *params_out = s.p;
+        params_out->layout = tsdf_hip_layout(s.h);
       }
-      if (meta_out) {
-        for (int k = 0; k < 3; ++k) meta_out->max_cell_size[k] = hd.max_cell[k];
-        meta_out->is_empty = hd.is_empty;
-        meta_out->weight_by_depth = hd.weight_by_depth;
-        meta_out->weight_by_variance = hd.weight_by_variance;
-        for (int i = 0; i < 16; ++i) meta_out->global_transform[i] = hd.global_transform[i];
-      }
+      if (meta_out) *meta_out = s.m;
       return TSDF_HIP_OK;
     }
-    const bool packed_misfit = rc == TSDF_HIP_E_UNSUPPORTED && h && tsdf_hip_layout(h) == TSDF_LAYOUT_PACKED;
-    if (h) tsdf_hip_destroy(h);
-    if (packed_misfit && attempt == 0 && base.layout == TSDF_LAYOUT_AUTO) continue;
-    if (rc) return rc;
-    tsdf_set_error(err);
-    return TSDF_HIP_E_IO;
+    // weights that are not min(k, max_weight) (a file written with other weighting) do not fit the packed
+    // layout: with AUTO the file is read again into a float weight plane
+    const bool packed_misfit = rc == TSDF_HIP_E_UNSUPPORTED && s.h && tsdf_hip_layout(s.h) == TSDF_LAYOUT_PACKED;
+    if (s.h) tsdf_hip_destroy(s.h);
+    if (!(packed_misfit && attempt == 0 && asked == TSDF_LAYOUT_AUTO)) return rc;
   }
   return TSDF_HIP_E_UNSUPPORTED;
 }

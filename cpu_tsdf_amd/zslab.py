@@ -22,6 +22,10 @@ independent during integration, so the grid is cut into contiguous Z-slabs and t
   suspended record point-to-point to its next owner (traffic ~ rays crossing a boundary).  Results are
   bit-identical to the single-GPU kernel in both forms.
 
+* ``save`` / ``ZSlabVolume.load``: the .vol checkpoint of the whole grid.  The root rank runs the streaming
+  writer / reader of the C ABI (``tsdf_hip_save_blocks`` / ``tsdf_hip_load_blocks``); each 256^3 block it
+  asks for is served by the one or two ranks whose slabs it crosses, point to point.
+
 The slab backend is injected (``slab_factory``) so the N > 1 logic is testable on CPU with gloo; the
 default backend is the HIP volume.  There is no CPU fallback in the product: the default factory raises
 without a GPU.
@@ -128,6 +132,19 @@ class HipSlab:
                                                           C.c_void_p(w.data_ptr()),
                                                           C.c_void_p(rgb.data_ptr()) if rgb is not None else None),
                    "set_planes_device")
+
+    def params(self):
+        """tsdf_params of the WHOLE grid (slab fields cleared)."""
+        p = capi.TsdfParams.from_buffer_copy(self.vol._p)
+        p.z_begin = p.z_end = p.halo = 0
+        return p
+
+    def get_block(self, x0, y0, z0, nx, ny, nz):
+        """Host copy of a box of voxels this slab holds: d, w float32 [nz, ny, nx], rgb uint8 [..., 3] or None."""
+        return self.vol.download(x0, y0, z0, nx, ny, nz)
+
+    def set_block(self, x0, y0, z0, d, w, rgb):
+        self.vol.upload(d, w, rgb, x0, y0, z0)
 
     def march(self, w_min, by_rgb, by_confidence):
         mc = MarchingCubesTSDFOctree()
@@ -241,6 +258,7 @@ class ZSlabVolume:
         self.slab = factory(configure, self.z_begin, self.z_end, self.nz, self.rank, halo=self.halo)
         self._frame = self.slab.frame_buffers()
         self.global_transform = np.eye(4)
+        self._is_empty = True
 
     # -- integrateCloud -------------------------------------------------------------------------------
     def integrateCloud(self, depth, bgra, trans, src=0):
@@ -260,6 +278,7 @@ class ZSlabVolume:
                 if fc is not None:
                     dist.broadcast(fc, src=src, group=self.group)
         self.slab.integrate_tensor(fd, fc, np.asarray(trans, dtype=np.float64))
+        self._is_empty = False
         return True
 
     # -- marching cubes ---------------------------------------------------------------------------------
@@ -468,6 +487,173 @@ class ZSlabVolume:
                     req.wait()
             mine = torch.cat(parts).contiguous()
         raise RuntimeError("ray hand-off did not converge")
+
+    # -- save / load: tsdf_volume_octree.cpp:222-275 -----------------------------------------------------
+    def _owners(self, z0, nz):
+        """(rank, first plane, plane count) of every slab the planes [z0, z0 + nz) cross."""
+        out = []
+        for r in range(self.world):
+            zb, ze = slab_range(self.nz, self.world, r)
+            lo, hi = max(z0, zb), min(z0 + nz, ze)
+            if lo < hi:
+                out.append((r, lo, hi - lo))
+        return out
+
+    def _block_bytes(self, c, n):
+        return n * c * c * (11 if self.slab.color else 8)
+
+    def _pack_block(self, d, w, rgb):
+        parts = [np.ascontiguousarray(d, np.float32).view(np.uint8).reshape(-1),
+                 np.ascontiguousarray(w, np.float32).view(np.uint8).reshape(-1)]
+        if self.slab.color:
+            parts.append(np.ascontiguousarray(rgb, np.uint8).reshape(-1))
+        return np.concatenate(parts)
+
+    def _unpack_block(self, buf, c, n):
+        v = n * c * c
+        d = buf[:4 * v].view(np.float32).reshape(n, c, c)
+        w = buf[4 * v:8 * v].view(np.float32).reshape(n, c, c)
+        rgb = buf[8 * v:11 * v].reshape(n, c, c, 3) if self.slab.color else None
+        return d, w, rgb
+
+    def _serve_fetch(self, root, x0, y0, z0, c, out=None):
+        """One block request of the writer: owners send their planes of the block to `root` (which copies its own);
+        on the root `out` = (d, w, rgb) numpy views of the writer's block buffers."""
+        dev = self._frame[0].device
+        for r, lo, n in self._owners(z0, c):
+            if self.rank == r:
+                part = self.slab.get_block(x0, y0, lo, c, c, n)
+                if r == root:
+                    got = part
+                else:
+                    dist.send(torch.from_numpy(self._pack_block(*part)).to(dev), root, group=self.group)
+                    continue
+            elif self.rank == root:
+                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device=dev)
+                dist.recv(buf, r, group=self.group)
+                got = self._unpack_block(buf.cpu().numpy(), c, n)
+            else:
+                continue
+            out[0][lo - z0:lo - z0 + n] = got[0]
+            out[1][lo - z0:lo - z0 + n] = got[1]
+            if self.slab.color:
+                out[2][lo - z0:lo - z0 + n] = got[2]
+
+    def _serve_store(self, root, x0, y0, z0, c, blk=None):
+        """One block of the reader: the root sends every owner its planes (and keeps its own)."""
+        dev = self._frame[0].device
+        for r, lo, n in self._owners(z0, c):
+            if self.rank == root:
+                part = (blk[0][lo - z0:lo - z0 + n], blk[1][lo - z0:lo - z0 + n],
+                        blk[2][lo - z0:lo - z0 + n] if self.slab.color else None)
+                if r == root:
+                    self.slab.set_block(x0, y0, lo, *part)
+                else:
+                    dist.send(torch.from_numpy(self._pack_block(*part)).to(dev), r, group=self.group)
+            elif self.rank == r:
+                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device=dev)
+                dist.recv(buf, root, group=self.group)
+                self.slab.set_block(x0, y0, lo, *self._unpack_block(buf.cpu().numpy(), c, n))
+
+    def _request(self, root, req=None):
+        """The root announces the next block (x0, y0, z0, edge), or edge <= 0 = done / failed; everyone gets it."""
+        t = torch.tensor(req if req is not None else [0, 0, 0, 0], dtype=torch.int64, device=self._frame[0].device)
+        if self.world > 1:
+            dist.broadcast(t, src=root, group=self.group)
+        return [int(v) for v in t.cpu()]
+
+    def _drive_blocks(self, root, run, serve):
+        """`run(callback)` on the root calls `callback(x0, y0, z0, c, d, w, rgb)` per block; the other ranks follow
+        the root's requests.  Returns the root's status on every rank."""
+        color = self.slab.color
+        if self.rank == root:
+            failure = []
+
+            def cb(_user, x0, y0, z0, c, d, w, rgb):
+                try:
+                    self._request(root, [x0, y0, z0, c])
+                    v = c * c * c
+                    blk = (np.ctypeslib.as_array(d, (v,)).reshape(c, c, c), np.ctypeslib.as_array(w, (v,)).reshape(c, c, c),
+                           np.ctypeslib.as_array(rgb, (3 * v,)).reshape(c, c, c, 3) if color else None)
+                    serve(root, x0, y0, z0, c, blk)
+                    return 0
+                except Exception as e:  # an exception must not unwind through the C caller
+                    failure.append(e)
+                    return capi.E_INVALID
+            rc = run(capi.BLOCK_FN(cb))
+            self._request(root, [0, 0, 0, -1 if rc else 0])
+            if failure:
+                raise failure[0]
+            capi.check(rc, "checkpoint")
+            return
+        while True:
+            x0, y0, z0, c = self._request(root)
+            if c <= 0:
+                if c < 0:
+                    raise RuntimeError(f"checkpoint failed on rank {root}")
+                return
+            serve(root, x0, y0, z0, c)
+
+    def save(self, filename, dst=0):
+        """Write the whole grid as one .vol file on rank `dst` (collective).  The file equals the one a single
+        handle holding the whole grid would write."""
+        lib = capi.load()
+        p = self.slab.params()
+        m = capi.TsdfVolMeta()
+        m.max_cell_size[:] = [p.size[k] / p.res[k] for k in range(3)]
+        m.is_empty = int(self._is_empty)
+        m.global_transform[:] = [float(v) for v in np.asarray(self.global_transform, np.float64).reshape(16)]
+        self.slab.synchronize()
+        self._drive_blocks(dst, lambda cb: lib.tsdf_hip_save_blocks(C.byref(p), C.byref(m), str(filename).encode(), cb, None),
+                           self._serve_fetch)
+
+    @classmethod
+    def load(cls, filename, group=None, slab_factory=None, halo=None, src=0, configure_more=None):
+        """Collective: rank `src` reads `filename` (written by either side); the volume is built from its header and
+        every block goes to the ranks that own its planes.  `configure_more(vol)` is applied after the file's
+        settings (device-side choices the file does not carry: setTransformOrder, setLayout)."""
+        lib = capi.load()
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        hdr = [None]
+        if rank == src:
+            p, m = capi.TsdfParams(), capi.TsdfVolMeta()
+
+            def on_header(_user, pp, mm):
+                C.memmove(C.byref(p), pp, C.sizeof(p))
+                C.memmove(C.byref(m), mm, C.sizeof(m))
+                return 0
+            rc = lib.tsdf_hip_load_blocks(str(filename).encode(), None, capi.HEADER_FN(on_header), capi.BLOCK_FN(), None)
+            hdr[0] = (rc, bytes(p), bytes(m), lib.tsdf_hip_last_error().decode())
+        if world > 1:
+            dist.broadcast_object_list(hdr, src=src, group=group)
+        rc, pb, mb, msg = hdr[0]
+        if rc:
+            raise capi.TsdfHipError(rc, "load", msg)
+        p, m = capi.TsdfParams.from_buffer_copy(pb), capi.TsdfVolMeta.from_buffer_copy(mb)
+
+        def configure(v):
+            v.setResolution(*p.res)
+            v.setGridSize(*p.size)
+            v.setImageSize(p.image_width, p.image_height)
+            v.setCameraIntrinsics(p.fx, p.fy, p.cx, p.cy)
+            v.setSensorDistanceBounds(p.min_sensor_dist, p.max_sensor_dist)
+            v.setDepthTruncationLimits(p.max_dist_pos, p.max_dist_neg)
+            v.setWeightTruncationLimit(p.max_weight)
+            v.setIntegrateColor(bool(p.integrate_color))
+            if configure_more is not None:
+                configure_more(v)
+        self = cls(configure, p.res[2], group=group, slab_factory=slab_factory, halo=halo)
+        self.global_transform = np.array(list(m.global_transform), dtype=np.float64).reshape(4, 4)
+        self._is_empty = bool(m.is_empty)
+        keep = []  # (the header callback object must outlive the call)
+
+        def run(cb):
+            keep.append(capi.HEADER_FN(lambda *_: 0))
+            return lib.tsdf_hip_load_blocks(str(filename).encode(), None, keep[0], cb, None)
+        self._drive_blocks(src, run, self._serve_store)
+        self.slab.synchronize()
+        return self
 
     def slab_image_size(self):
         return self.slab.image_size()

@@ -230,6 +230,22 @@ int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta
 int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out, tsdf_params *params_out,
                   tsdf_vol_meta *meta_out);
 
+/* The same writer and reader for a volume that is not one handle (Z-slabs on several GPUs): the voxels
+ * move through callbacks, one cubic block of `edge`^3 voxels at a time (d, w: edge^3 floats; rgb: 3 edge^3
+ * bytes, NULL without colour; x fastest).  A callback returns 0 to go on; anything else aborts the call,
+ * which then returns that value.  No device is touched by these two functions themselves.
+ *   tsdf_hip_save_blocks  p describes the whole grid (res, size, ... ; slab fields ignored).  `fetch` is
+ *                         called once per block and once more for each block that is not uniform.
+ *   tsdf_hip_load_blocks  `on_header` receives the file's parameters (fields the file does not carry are
+ *                         taken from `defaults`, NULL = tsdf_hip_default_params) before the first block;
+ *                         then `store` is called exactly once per block.  store == NULL reads the header only. */
+typedef int (*tsdf_block_fn)(void *user, int x0, int y0, int z0, int edge, float *d, float *w, uint8_t *rgb);
+typedef int (*tsdf_header_fn)(void *user, const tsdf_params *p, const tsdf_vol_meta *meta);
+int tsdf_hip_save_blocks(const tsdf_params *p, const tsdf_vol_meta *meta, const char *filename,
+                         tsdf_block_fn fetch, void *user);
+int tsdf_hip_load_blocks(const char *filename, const tsdf_params *defaults, tsdf_header_fn on_header,
+                         tsdf_block_fn store, void *user);
+
 /* Whole planes [z0, z0+nz) to / from packed DEVICE buffers ([nz][ny][nx]; rgb as uint32 r|g<<8|b<<16),
  * asynchronous on the handle's stream.  This is the halo-exchange primitive: the buffers are what the
  * caller hands to RCCL send/recv.  Planes may lie in the halo.  Any pointer may be NULL. */

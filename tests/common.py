@@ -45,3 +45,32 @@ def assert_same_f32(a, b, what):
         idx = np.argwhere(ne)[:5]
         raise AssertionError(f"{what}: {int(ne.sum())} of {a.size} differ; first {idx.tolist()} "
                              f"got {a[ne][:5]} want {b[ne][:5]}; max abs diff {np.nanmax(np.abs(a - b))}")
+
+
+def write_vol_from_arrays(path, params, d, w, rgb, global_transform=None, chunk=None):
+    """A .vol written by the product's streaming writer (tsdf_hip_save_blocks) from whole-grid host arrays."""
+    import ctypes as C
+
+    from cpu_tsdf_amd import capi
+    lib = capi.load()
+    color = bool(params.integrate_color)
+    m = capi.TsdfVolMeta()
+    m.max_cell_size[:] = [params.size[k] / params.res[k] for k in range(3)]
+    m.global_transform[:] = [float(v) for v in (np.eye(4) if global_transform is None else np.asarray(global_transform)).reshape(16)]
+
+    def fetch(_user, x0, y0, z0, c, pd, pw, prgb):
+        sl = (slice(z0, z0 + c), slice(y0, y0 + c), slice(x0, x0 + c))
+        v = c * c * c
+        np.ctypeslib.as_array(pd, (v,))[:] = d[sl].reshape(-1)
+        np.ctypeslib.as_array(pw, (v,))[:] = w[sl].reshape(-1)
+        if color:
+            np.ctypeslib.as_array(prgb, (3 * v,))[:] = rgb[sl].reshape(-1)
+        return 0
+    if chunk:
+        capi.set_tuning("vol_chunk", chunk)
+    try:
+        capi.check(lib.tsdf_hip_save_blocks(C.byref(params), C.byref(m), str(path).encode(), capi.BLOCK_FN(fetch), None),
+                   "save_blocks")
+    finally:
+        if chunk:
+            capi.set_tuning("vol_chunk", 256)

@@ -55,6 +55,23 @@ class OracleSlab:
         self.color = bool(self.p.integrate_color)
         self.res = tuple(self.p.res)
 
+    def params(self):
+        from cpu_tsdf_amd import capi
+        return capi.TsdfParams.from_buffer_copy(self.p)
+
+    def get_block(self, x0, y0, z0, nx, ny, nz):
+        assert self.z_begin - self.halo <= z0 and z0 + nz <= self.z_end + self.halo
+        sl = (slice(z0, z0 + nz), slice(y0, y0 + ny), slice(x0, x0 + nx))
+        return self.ov.d[sl].copy(), self.ov.w[sl].copy(), (self.ov.rgb[sl].copy() if self.color else None)
+
+    def set_block(self, x0, y0, z0, d, w, rgb):
+        nz, ny, nx = d.shape
+        assert self.z_begin <= z0 and z0 + nz <= self.z_end
+        sl = (slice(z0, z0 + nz), slice(y0, y0 + ny), slice(x0, x0 + nx))
+        self.ov.d[sl], self.ov.w[sl] = d, w
+        if self.color:
+            self.ov.rgb[sl] = rgb
+
     def frame_buffers(self):
         H, W = self.p.image_height, self.p.image_width
         return torch.empty((H, W), dtype=torch.float32), (torch.empty((H, W, 4), dtype=torch.uint8) if self.color else None)

@@ -82,6 +82,22 @@ def _worker(rank, world, port, out_path):
         p2p_records.append(vol.last_p2p_records)
     assert max(p2p_records) < 0.8 * renders[0].shape[0] * renders[0].shape[1] * world
     zb, ze = vol.z_begin, vol.z_end
+    # checkpoint: one .vol of the whole grid written on the LAST rank from blocks that straddle the slabs (16^3
+    # blocks, slabs of 21-22 planes), read back on rank 0 into a new set of slabs built from the file's header
+    from cpu_tsdf_amd import capi
+    capi.set_tuning("vol_chunk", 16)
+    vol_path = out_path + ".vol"
+    vol.global_transform = synth.turntable_pose(1, 8, sc.size)
+    vol.save(vol_path, dst=world - 1)
+    dist.barrier()
+    back = ZSlabVolume.load(vol_path, slab_factory=OracleSlab, src=0)
+    assert (back.z_begin, back.z_end) == (zb, ze) and back.slab.color and not back._is_empty
+    assert np.allclose(back.global_transform, vol.global_transform, rtol=1e-15, atol=1e-15)  # (the format keeps 16 digits)
+    for name in ("d", "w", "rgb"):
+        a, b = getattr(back.slab.ov, name)[zb:ze], getattr(vol.slab.ov, name)[zb:ze]
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{name} after load on rank {rank}"
+    with pytest.raises(Exception):   # every rank learns that the root could not read the file
+        ZSlabVolume.load(vol_path + ".absent", slab_factory=OracleSlab, src=0)
     d, w = vol.slab.ov.d[zb:ze].copy(), vol.slab.ov.w[zb:ze].copy()
     gathered = [None] * world if rank == 0 else None
     dist.gather_object((zb, ze, d, w), gathered, dst=0)
@@ -147,3 +163,8 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
         hits += int(np.isfinite(want[..., 0]).sum())
     assert hits > 2000
     assert got["rounds"].max() <= world + 1 and got["rounds"].max() >= 2
+    # the distributed checkpoint is byte for byte the file one writer produces from the whole grid
+    from tests.common import write_vol_from_arrays
+    one = str(tmp_path / "one.vol")
+    write_vol_from_arrays(one, cfg._p, ov.d, ov.w, ov.rgb, global_transform=synth.turntable_pose(1, 8, sc.size))
+    assert open(out + ".vol", "rb").read() == open(one, "rb").read()

@@ -169,7 +169,7 @@ def test_ray_handoff_refuses_a_halo_that_is_too_small(gpu):
         s.close()
 
 
-def test_zslab_volume_world1_end_to_end(gpu):
+def test_zslab_volume_world1_end_to_end(gpu, tmp_path):
     ov, sc = truth()
     vol = ZSlabVolume(configure, RES)
     for i in range(NF):
@@ -192,4 +192,22 @@ def test_zslab_volume_world1_end_to_end(gpu):
     assert np.array_equal(ok, ok2) and np.array_equal(val[ok], val2[ok])
     tr = synth.turntable_pose(1, 8, sc.size)
     assert np.isfinite(vol.renderView(tr)[..., 0]).sum() > 50
+    # checkpoint through the block callbacks (tsdf_hip_save_blocks / tsdf_hip_load_blocks) == the one-handle file
+    from cpu_tsdf_amd import capi
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    capi.set_tuning("vol_chunk", 16)
+    try:
+        path = str(tmp_path / "slabs.vol")
+        vol.save(path)
+        back = ZSlabVolume.load(path)
+        assert all(np.array_equal(a, b) for a, b in zip(back.download_local(), (ov.d, ov.w, ov.rgb)))
+        single = TSDFVolumeOctree()
+        single.load(path)
+        one = str(tmp_path / "one.vol")
+        single.save(one)
+        assert open(one, "rb").read() == open(path, "rb").read()
+        single.close()
+        back.close()
+    finally:
+        capi.set_tuning("vol_chunk", 256)
     vol.close()
