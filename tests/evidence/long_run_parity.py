@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpu_tsdf_amd import capi, synth  # noqa: E402
 from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree  # noqa: E402
 from oracle.oracle import SlabOracle  # noqa: E402

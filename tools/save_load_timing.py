@@ -3,7 +3,7 @@ host memory high-water mark (the point of streaming: it must stay near one block
 
     python tools/save_load_timing.py --res 1024 --frames 8 --out gpurun_out/save_load.json
 
-Uses oracle/refbind only as the ctypes binding to the drop-in's C driver (no reference code runs)."""
+Goes through the Python mirror of the class (tsdf_hip_save / tsdf_hip_load over ctypes)."""
 import argparse
 import json
 import os
@@ -16,7 +16,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpu_tsdf_amd import synth  # noqa: E402
-from oracle import refbind  # noqa: E402
+from cpu_tsdf_amd.volume import TSDFVolumeOctree  # noqa: E402
 
 
 def rss_mb():
@@ -31,14 +31,22 @@ def main():
     ap.add_argument("--verify", type=int, default=1)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    lib = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
     sc = synth.scene_a(a.res)
-    mk = lambda: refbind.RefVolume(a.res, sc.size, 640, 480, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size,
-                                   color=bool(a.color), lib_path=lib)
+
+    def mk():
+        v = TSDFVolumeOctree()
+        v.setResolution(a.res, a.res, a.res)
+        v.setGridSize(sc.size, sc.size, sc.size)
+        v.setImageSize(640, 480)
+        v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        v.setSensorDistanceBounds(0.0, 3 * sc.size)
+        v.setIntegrateColor(bool(a.color))
+        v.reset()
+        return v
     dv = mk()
     for i in range(a.frames):
         tr = synth.turntable_pose(i, a.frames, sc.size)
-        dv.integrate(sc.depth(tr), sc.bgra(i), tr)
+        dv.integrateCloud(sc.depth(tr), sc.bgra(i) if a.color else None, tr)
     grid_mb = a.res ** 3 * (11 if a.color else 8) / 2 ** 20
     out = {"res": a.res, "frames": a.frames, "color": a.color, "grid_mb": grid_mb, "rss_before_mb": rss_mb(),
            "chunk": int(os.environ.get("TSDF_HIP_VOL_CHUNK", 256))}
@@ -49,7 +57,7 @@ def main():
         out["save_s"] = time.time() - t0
         out["file_mb"] = os.path.getsize(path) / 2 ** 20
         out["rss_after_save_mb"] = rss_mb()
-        dv2 = mk()
+        dv2 = TSDFVolumeOctree()  # configured by the file
         t0 = time.time()
         dv2.load(path)
         out["load_s"] = time.time() - t0
