@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_IO = range(7)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
 LAYOUT_AUTO, LAYOUT_F32W, LAYOUT_PACKED = 0, 1, 2
+COLOR_RGB, COLOR_RGB_NORMALIZED = 0, 1
 
 
 class TsdfParams(C.Structure):
@@ -39,6 +40,7 @@ class TsdfParams(C.Structure):
         ("halo", C.c_int32),
         ("device", C.c_int32),
         ("layout", C.c_int32),
+        ("color_mode", C.c_int32),
     ]
 
 

@@ -93,12 +93,19 @@ void TSDFVolumeOctree::setMaxVoxelSize(float x, float y, float z) {
   max_cell_size_[2] = z;
 }
 void TSDFVolumeOctree::setIntegrateColor(bool integrate_color) { p_.integrate_color = integrate_color ? 1 : 0; }
+// reference: tsdf_volume_octree.h:290 -> OctreeNode::instantiateByTypeString (src/lib/octree.cpp:193-206)
 void TSDFVolumeOctree::setColorMode(const std::string &color_mode) {
-  if (color_mode != "RGB")
-    PCL_WARN("[cpu_tsdf::TSDFVolumeOctree::setColorMode] only \"RGB\" voxels exist in the HIP volume; ignoring %s\n",
-             color_mode.c_str());
-  else
-    color_mode_ = color_mode;
+  if (color_mode == "RGB") {
+    p_.color_mode = TSDF_COLOR_RGB;
+  } else if (color_mode == "RGBNormalized") {
+    p_.color_mode = TSDF_COLOR_RGB_NORMALIZED;
+  } else {
+    // "LAB" goes through std::pow (octree.cpp:437-560), whose last bit belongs to the host's libm
+    PCL_WARN("[cpu_tsdf::TSDFVolumeOctree::setColorMode] \"%s\" voxels do not exist in the HIP volume; keeping %s\n",
+             color_mode.c_str(), color_mode_.c_str());
+    return;
+  }
+  color_mode_ = color_mode;
 }
 void TSDFVolumeOctree::setSensorDistanceBounds(float min_sensor_dist, float max_sensor_dist) {
   p_.min_sensor_dist = min_sensor_dist;

@@ -26,6 +26,9 @@ struct tsdf_hip_volume {
   float *d = nullptr, *w = nullptr;
   uint32_t *rgb = nullptr;
   uint8_t *k8 = nullptr;
+  // TSDF_COLOR_RGB_NORMALIZED: running means r/i, g/i, b/i, i (RGBNormalized, octree.cpp:380-402); the rgb
+  // plane then caches getRGB() of that state for every reader (queries, marching cubes, downloads)
+  float *cn[4] = {nullptr, nullptr, nullptr, nullptr};
   int packed = 0;
   unsigned kmax = 0;
   float *ctr[3] = {nullptr, nullptr, nullptr};  // device centre tables (full axis length)

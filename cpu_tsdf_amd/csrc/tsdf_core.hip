@@ -111,6 +111,7 @@ extern "C" void tsdf_hip_default_params(tsdf_params *p) {
   p->halo = 0;
   p->device = -1;
   p->layout = TSDF_LAYOUT_AUTO;
+  p->color_mode = TSDF_COLOR_RGB;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,6 +195,8 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->w) (void)hipFree(v->w);
   if (v->rgb) (void)hipFree(v->rgb);
   if (v->k8) (void)hipFree(v->k8);
+  for (int c = 0; c < 4; ++c)
+    if (v->cn[c]) (void)hipFree(v->cn[c]);
   for (int a = 0; a < 3; ++a)
     if (v->ctr[a]) (void)hipFree(v->ctr[a]);
   if (v->frame_depth) (void)hipFree(v->frame_depth);
@@ -219,11 +222,17 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     }
   if (p->image_width <= 0 || p->image_height <= 0 || !(p->max_dist_neg > 0.f) || p->halo < 0 ||
       (p->xform_order != TSDF_XFORM_PCL_SSE && p->xform_order != TSDF_XFORM_LEFT_TO_RIGHT) ||
-      p->layout < TSDF_LAYOUT_AUTO || p->layout > TSDF_LAYOUT_PACKED) {
-    tsdf_set_error("bad image size / truncation / halo / xform_order / layout");
+      p->layout < TSDF_LAYOUT_AUTO || p->layout > TSDF_LAYOUT_PACKED ||
+      (p->color_mode != TSDF_COLOR_RGB && p->color_mode != TSDF_COLOR_RGB_NORMALIZED)) {
+    tsdf_set_error("bad image size / truncation / halo / xform_order / layout / color_mode");
     return TSDF_HIP_E_INVALID;
   }
-  const bool packable = p->max_weight >= 0.f && p->max_weight <= 255.f;  // false for NaN
+  const bool rgbn = p->integrate_color && p->color_mode == TSDF_COLOR_RGB_NORMALIZED;
+  if (rgbn && p->layout == TSDF_LAYOUT_PACKED) {
+    tsdf_set_error("RGB_NORMALIZED colour keeps float weights: no PACKED layout");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  const bool packable = !rgbn && p->max_weight >= 0.f && p->max_weight <= 255.f;  // false for NaN
   if (p->layout == TSDF_LAYOUT_PACKED && !packable) {
     tsdf_set_error("the PACKED layout needs 0 <= max_weight <= 255");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -275,6 +284,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (!v->packed) TRY_OR_BAIL(hipMalloc(&v->w, n * sizeof(float)));
   if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
   if (v->packed && !p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->k8, n));
+  if (rgbn)
+    for (int c = 0; c < 4; ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
   for (int a = 0; a < 3; ++a) {
     build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
@@ -317,6 +328,9 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
   if (rc) return rc;
   if (h->k8) TSDF_HIP_TRY(hipMemsetAsync(h->k8, 0, (size_t)n, h->stream));
   if (h->rgb) rc = fill_u32(h, h->rgb, 0u, n);
+  if (rc) return rc;
+  for (int c = 0; c < 4 && !rc; ++c)  // RGBNormalized starts at r_n = g_n = b_n = i = 0 (octree.h:217-222)
+    if (h->cn[c]) rc = fill_u32(h, h->cn[c], 0u, n);
   if (rc) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
@@ -461,6 +475,10 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
   if (rgb && !h->rgb) {
     tsdf_set_error("volume has no colour plane");
     return TSDF_HIP_E_INVALID;
+  }
+  if (!DOWN && rgb && h->cn[0]) {
+    tsdf_set_error("RGB_NORMALIZED colour state cannot be set from r,g,b bytes");
+    return TSDF_HIP_E_UNSUPPORTED;
   }
   TSDF_ON_DEVICE(h->device);
   const int64_t plane = (int64_t)nx * ny;

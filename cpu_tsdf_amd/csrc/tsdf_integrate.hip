@@ -561,6 +561,71 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   return hh;
 }
 
+// ---------------------------------------------------------------------------------------------
+// TSDF_COLOR_RGB_NORMALIZED: updateVoxel with RGBNormalized::addObservation (src/lib/octree.cpp:380-393).
+// A plain kernel -- one thread per voxel, exact fp64 projection, the compiler's IEEE divisions and square
+// root, every operation in the reference's order -- because this voxel class is a setter away from the
+// default and nothing in the reference's programs selects it.  It moves d, w, four float means and the
+// cached getRGB() bytes (octree.cpp:396-402) per observed voxel.
+template <int ORDER>
+static __global__ void __launch_bounds__(256)
+k_integrate_rgbn(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+                 float *__restrict__ RN, float *__restrict__ GN, float *__restrict__ BN, float *__restrict__ IN,
+                 const float *__restrict__ depth, const uint32_t *__restrict__ bgra, const double *__restrict__ cam,
+                 const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
+                 unsigned long long *__restrict__ n_obs) {
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int y = (int)blockIdx.y, zl = (int)blockIdx.z;
+  bool observed = false;
+  if (x < (int)a.pitch) {  // the x centre table is NaN beyond nx: those lanes fail the range test
+    const float cx = ctrx[x], cy = ctry[y], cz = ctrz[a.z_global0 + zl];
+    float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
+      g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
+                                         : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
+    if (pix >= 0) {
+      const float z = depth[pix];
+      float dn = z - g[2];  // hpp:159
+      if (!isnan(z) && !(dn < -a.neg)) {  // hpp:152, :193-196
+        dn = dn > a.pos ? a.pos_over_neg : dn / a.neg;  // hpp:189-198
+        const int64_t vi = ((int64_t)(a.zl0 + zl) * a.ny + y) * a.pitch + x;
+        const uint32_t c = bgra[pix];  // PCL memory order b, g, r, a
+        const float r = (float)((c >> 16) & 255u), gch = (float)((c >> 8) & 255u), b = (float)(c & 255u);
+        float w = Wt[vi], d = D[vi];
+        const float wn = 1.f;
+        const float wsum = w + wn;
+        const float i = sqrtf(r * r + gch * gch + b * b);  // octree.cpp:384 (products and sums are exact)
+        const float rf = r / i, gf = gch / i, bf = b / i;   // a black pixel makes these NaN, as in the reference
+        const float rn = (w * RN[vi] + wn * rf) / wsum;
+        const float gn = (w * GN[vi] + wn * gf) / wsum;
+        const float bn = (w * BN[vi] + wn * bf) / wsum;
+        const float im = (w * IN[vi] + wn * i) / wsum;
+        RN[vi] = rn;
+        GN[vi] = gn;
+        BN[vi] = bn;
+        IN[vi] = im;
+        // getRGB (octree.cpp:396-402): uint8_t = float, i.e. cvttss2si and the low byte (NaN -> 0)
+        RGB[vi] = ((uint32_t)(int)(rn * im) & 255u) | (((uint32_t)(int)(gn * im) & 255u) << 8) |
+                  (((uint32_t)(int)(bn * im) & 255u) << 16);
+        uint32_t unused = 0;
+        add_observation_ieee<false>(d, w, unused, dn, 0u, a.wmax);
+        D[vi] = d;
+        Wt[vi] = w;
+        observed = true;
+      }
+    }
+  }
+  if (n_obs) {
+    const unsigned long long m = __ballot(observed);
+    if ((threadIdx.x & 63u) == 0u && m)
+      atomicAdd(n_obs + ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 1023u),
+                (unsigned long long)__popcll(m));
+  }
+}
+
 static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = false) {
   // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
   const int knob = tsdf_tuning().fast_projection;
@@ -587,6 +652,38 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   if (color && !d_bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
+  }
+  if (h->cn[0]) {  // TSDF_COLOR_RGB_NORMALIZED: its own plain kernel
+    const bool count = n_observed != nullptr;
+    if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
+    bool pose_ok = true;
+    for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
+    if (pose_ok) {
+      const dim3 grid((unsigned)((h->pitch + 255) / 256), (unsigned)h->ny, gz), block(256);
+      if (grid.y > 65535u) {
+        tsdf_set_error("grid too large for one launch");
+        return TSDF_HIP_E_UNSUPPORTED;
+      }
+#define LAUNCH_RGBN(ORDER)                                                                                       \
+  hipLaunchKernelGGL((k_integrate_rgbn<ORDER>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->cn[0],      \
+                     h->cn[1], h->cn[2], h->cn[3], d_depth, d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], \
+                     count ? h->counter : nullptr)
+      if (p.xform_order == TSDF_XFORM_PCL_SSE)
+        LAUNCH_RGBN(TSDF_XFORM_PCL_SSE);
+      else
+        LAUNCH_RGBN(TSDF_XFORM_LEFT_TO_RIGHT);
+#undef LAUNCH_RGBN
+      TSDF_HIP_TRY(hipGetLastError());
+    }
+    if (n_observed) {
+      unsigned long long c[1024];
+      TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
+      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      unsigned long long sum = 0;
+      for (int i = 0; i < 1024; ++i) sum += c[i];
+      *n_observed = pose_ok ? sum : 0;
+    }
+    return TSDF_HIP_OK;
   }
   // The kernel reads the frame through ONE buffer descriptor based at the depth image, with the colour
   // image at a 32-bit byte offset from it.  Caller buffers laid out otherwise are staged into the handle's

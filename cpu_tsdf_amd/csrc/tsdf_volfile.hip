@@ -135,6 +135,11 @@ extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol
     tsdf_set_error("save needs a handle that owns the whole grid (Z-slabs: tsdf_hip_save_blocks)");
     return TSDF_HIP_E_UNSUPPORTED;
   }
+  if (h->cn[0]) {
+    tsdf_set_error("RGB_NORMALIZED volumes have no usable .vol form (the reference writes one byte of each float, "
+                   "octree.cpp:417-433)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
   return tsdf_hip_save_blocks(&h->p, meta, filename, fetch_from_handle, h);
 }
 

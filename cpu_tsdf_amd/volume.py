@@ -80,6 +80,13 @@ class TSDFVolumeOctree:
     def setIntegrateColor(self, flag):
         self._p.integrate_color = 1 if flag else 0
 
+    def setColorMode(self, color_mode):
+        """tsdf_volume_octree.h:290: "RGB" (default) or "RGBNormalized"; "LAB" is not offered (std::pow)."""
+        modes = {"RGB": capi.COLOR_RGB, "RGBNormalized": capi.COLOR_RGB_NORMALIZED}
+        if color_mode not in modes:
+            raise ValueError(f"colour mode {color_mode!r} does not exist in the HIP volume (have {sorted(modes)})")
+        self._p.color_mode = modes[color_mode]
+
     def setSensorDistanceBounds(self, min_sensor_dist, max_sensor_dist):
         self._p.min_sensor_dist, self._p.max_sensor_dist = float(min_sensor_dist), float(max_sensor_dist)
 

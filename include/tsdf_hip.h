@@ -59,6 +59,21 @@ enum {
  * AUTO = PACKED when max_weight allows it, else F32W. */
 enum { TSDF_LAYOUT_AUTO = 0, TSDF_LAYOUT_F32W = 1, TSDF_LAYOUT_PACKED = 2 };
 
+/* Which voxel class carries the colour (setColorMode, include/cpu_tsdf/tsdf_volume_octree.h:290 ->
+ * OctreeNode::instantiateByTypeString, src/lib/octree.cpp:193-206).  Only read when integrate_color is set.
+ *   RGB             RGBNode (octree.cpp:328-337): three truncated uint8 running means.  The default.
+ *   RGB_NORMALIZED  RGBNormalized (octree.cpp:380-402): running means of r/i, g/i, b/i and of the intensity
+ *                   i = sqrt(r^2+g^2+b^2) as four floats; the colour read back is (uint8)(r_n * i) etc.
+ *                   Four more float planes per voxel, float weights (no PACKED layout), a plain per-voxel
+ *                   kernel; tsdf_hip_upload of rgb and save/load are refused (the reference's own
+ *                   serialisation of this class writes one byte of each float, octree.cpp:417-433).
+ * "LAB" (octree.cpp:437-560) is not offered: it goes through std::pow, whose last bit belongs to the host's
+ * libm. */
+enum {
+  TSDF_COLOR_RGB = 0,
+  TSDF_COLOR_RGB_NORMALIZED = 1
+};
+
 /* Everything TSDFVolumeOctree's setters configure before reset()
  * (src/lib/tsdf_volume_octree.cpp:54-85 defaults, :92-199 setters). */
 typedef struct tsdf_params {
@@ -78,6 +93,7 @@ typedef struct tsdf_params {
   int32_t halo;               /* extra planes kept below z_begin and above z_end         */
   int32_t device;             /* HIP ordinal, -1 => current device                       */
   int32_t layout;             /* TSDF_LAYOUT_*                                           */
+  int32_t color_mode;         /* TSDF_COLOR_*: setColorMode, tsdf_volume_octree.h:290    */
 } tsdf_params;
 
 /* Fill *p with the reference constructor defaults (tsdf_volume_octree.cpp:54-85). */

@@ -46,6 +46,8 @@ def lib():
         L.oracle_centers.argtypes = [C.c_int, C.c_float, _f]
         L.oracle_integrate.restype = C.c_uint64
         L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
+        L.oracle_integrate_rgbn.restype = C.c_uint64
+        L.oracle_integrate_rgbn.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
         L.oracle_raycast.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, _f]
         L.oracle_raycast_begin.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_int, C.c_void_p]
         L.oracle_raycast_advance.restype = C.c_int
@@ -111,6 +113,17 @@ class OracleVolume:
         col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
         return int(lib().oracle_integrate(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), _fp(depth),
                                           _bp(col), _fp(T), z_begin, z_end))
+
+    def integrate_rgbn(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
+        """integrate with RGBNormalized voxels (setColorMode("RGBNormalized")); self.cn holds r_n, g_n, b_n, i and
+        self.rgb what getRGB() returns."""
+        if not hasattr(self, "cn"):
+            self.cn = np.zeros((4,) + self.d.shape, dtype=np.float32)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        T = np.ascontiguousarray(cam_from_vol, dtype=np.float32).reshape(12)
+        col = np.ascontiguousarray(bgra, dtype=np.uint8)
+        return int(lib().oracle_integrate_rgbn(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(self.cn), _bp(self.rgb),
+                                               _fp(depth), _bp(col), _fp(T), z_begin, z_end))
 
     def raycast(self, trans, ds=1):
         trans = np.asarray(trans, dtype=np.float64)

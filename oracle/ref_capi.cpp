@@ -58,6 +58,7 @@ void ct_set_trunc(void *h, float pos, float neg) { V(h)->setDepthTruncationLimit
 void ct_set_max_weight(void *h, float w) { V(h)->setWeightTruncationLimit(w); }
 void ct_set_max_voxel_size(void *h, float x, float y, float z) { V(h)->setMaxVoxelSize(x, y, z); }
 void ct_set_integrate_color(void *h, int f) { V(h)->setIntegrateColor(f != 0); }
+void ct_set_color_mode(void *h, const char *mode) { V(h)->setColorMode(mode); }
 void ct_set_num_random_splits(void *h, int n) { V(h)->setNumRandomSplts(n); }
 void ct_set_global_transform(void *h, const double *m16) { V(h)->setGlobalTransform(to_affine(m16)); }
 void ct_reset(void *h) { V(h)->reset(); }

@@ -62,6 +62,7 @@ def load(path=LIB):
         "ct_set_max_weight": [C.c_void_p, C.c_float],
         "ct_set_max_voxel_size": [C.c_void_p, C.c_float, C.c_float, C.c_float],
         "ct_set_integrate_color": [C.c_void_p, C.c_int],
+        "ct_set_color_mode": [C.c_void_p, C.c_char_p],
         "ct_set_num_random_splits": [C.c_void_p, C.c_int],
         "ct_set_global_transform": [C.c_void_p, _d],
         "ct_reset": [C.c_void_p],
@@ -110,7 +111,7 @@ class RefVolume:
     Octree::init pre-splits to full resolution (src/lib/octree.cpp:593-599), the mode used for parity."""
 
     def __init__(self, res, size, width, height, fx, fy, cx, cy, zmin, zmax, trunc=(0.03, 0.03), max_weight=100.0,
-                 color=False, dense=True, max_cell=0.5, lib_path=LIB):
+                 color=False, dense=True, max_cell=0.5, lib_path=LIB, color_mode=None):
         self.L = load(lib_path)
         self.h = C.c_void_p(self.L.ct_create())
         self.res, self.size, self.W, self.H, self.color = res, float(size), width, height, bool(color)
@@ -125,6 +126,8 @@ class RefVolume:
         cell = float(np.float32(size) / np.float32(res)) if dense else max_cell
         L.ct_set_max_voxel_size(h, cell, cell, cell)
         L.ct_set_integrate_color(h, int(color))
+        if color_mode is not None:
+            L.ct_set_color_mode(h, color_mode.encode())
         L.ct_set_num_random_splits(h, 1)
         L.ct_reset(h)
 

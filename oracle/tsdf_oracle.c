@@ -134,6 +134,36 @@ int oracle_containing(const oracle_params *p, float x, float y, float z, int idx
  * T = trans.inverse().cast<float>() (hpp:54), row-major 3x4.  depth = pt.z of cloud(u,v),
  * bgra = PCL PointXYZRGBA byte order.  rgb is 3 bytes per voxel.  Returns the number of voxels
  * that reached addObservation. */
+/* The leaf branch of updateVoxel up to the call of addObservation (hpp:143-198): 1 and (*dn, *pixel) if the
+ * voxel centre (x, y, z) is observed by this frame. */
+static int observe(const oracle_params *p, const float T[12], float x, float y, float z, const float *depth,
+                   float *dn_out, size_t *pixel) {
+  const int W = p->image_width, H = p->image_height;
+  float g[3];
+  for (int r = 0; r < 3; ++r) { /* pcl::transformPoint, hpp:145 [PCL-recall] */
+    const float *m = T + 4 * r;
+    if (p->xform_order == 0)
+      g[r] = x * m[0] + (y * m[1] + (z * m[2] + m[3]));
+    else
+      g[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+  }
+  if (g[2] < p->min_sensor_dist || g[2] > p->max_sensor_dist) return 0; /* hpp:146 */
+  const int u = cvtt((double)g[0] * p->fx / (double)g[2] + p->cx);      /* .cpp:614 */
+  const int v = cvtt((double)g[1] * p->fy / (double)g[2] + p->cy);      /* .cpp:615 */
+  if (!(g[2] > 0 && u >= 0 && u < W && v >= 0 && v < H)) return 0;       /* .cpp:616 */
+  const float zs = depth[(size_t)v * W + u];
+  if (isnan(zs)) return 0; /* hpp:152 */
+  float dn = zs - g[2];    /* hpp:159 */
+  if (dn > p->max_dist_pos)
+    dn = p->max_dist_pos; /* hpp:189-192 */
+  else if (dn < -p->max_dist_neg)
+    return 0;             /* hpp:193-196 */
+  dn /= p->max_dist_neg;  /* hpp:198 */
+  *dn_out = dn;
+  *pixel = (size_t)v * W + u;
+  return 1;
+}
+
 uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                           const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
   const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
@@ -144,36 +174,17 @@ uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *r
   oracle_centers(nz, p->size[2], cz);
   if (z_begin == 0 && z_end == 0) z_end = nz;
   uint64_t n_obs = 0;
-  const int W = p->image_width, H = p->image_height;
 #pragma omp parallel for schedule(static) reduction(+ : n_obs)
   for (int k = z_begin; k < z_end; ++k)
     for (int j = 0; j < ny; ++j)
       for (int i = 0; i < nx; ++i) {
-        const float x = cx[i], y = cy[j], z = cz[k];
-        float g[3];
-        for (int r = 0; r < 3; ++r) { /* pcl::transformPoint, hpp:145 [PCL-recall] */
-          const float *m = T + 4 * r;
-          if (p->xform_order == 0)
-            g[r] = x * m[0] + (y * m[1] + (z * m[2] + m[3]));
-          else
-            g[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
-        }
-        if (g[2] < p->min_sensor_dist || g[2] > p->max_sensor_dist) continue; /* hpp:146 */
-        const int u = cvtt((double)g[0] * p->fx / (double)g[2] + p->cx);      /* .cpp:614 */
-        const int v = cvtt((double)g[1] * p->fy / (double)g[2] + p->cy);      /* .cpp:615 */
-        if (!(g[2] > 0 && u >= 0 && u < W && v >= 0 && v < H)) continue;       /* .cpp:616 */
-        const float zs = depth[(size_t)v * W + u];
-        if (isnan(zs)) continue; /* hpp:152 */
-        float dn = zs - g[2];    /* hpp:159 */
-        if (dn > p->max_dist_pos)
-          dn = p->max_dist_pos; /* hpp:189-192 */
-        else if (dn < -p->max_dist_neg)
-          continue;             /* hpp:193-196 */
-        dn /= p->max_dist_neg;  /* hpp:198 */
+        float dn;
+        size_t pixel;
+        if (!observe(p, T, cx[i], cy[j], cz[k], depth, &dn, &pixel)) continue;
         const float wn = 1;     /* hpp:200-204: both weightings unreachable */
         const size_t vi = ((size_t)k * ny + j) * nx + i;
         if (p->integrate_color && rgb) { /* octree.cpp:331-335 (old w, truncation) */
-          const uint8_t *px = bgra + 4 * ((size_t)v * W + u);
+          const uint8_t *px = bgra + 4 * pixel;
           const float wsum = w[vi] + wn;
           rgb[3 * vi + 0] = (uint8_t)((w[vi] * rgb[3 * vi + 0] + wn * px[2]) / wsum);
           rgb[3 * vi + 1] = (uint8_t)((w[vi] * rgb[3 * vi + 1] + wn * px[1]) / wsum);
@@ -182,6 +193,54 @@ uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *r
         d[vi] = (d[vi] * w[vi] + dn * wn) / (w[vi] + wn); /* octree.cpp:156 */
         w[vi] += wn;                                       /* octree.cpp:157 */
         if (w[vi] > p->max_weight) w[vi] = p->max_weight;  /* octree.cpp:158-159 */
+        ++n_obs;
+      }
+  free(cx);
+  free(cy);
+  free(cz);
+  return n_obs;
+}
+
+/* The same with RGBNormalized voxels (setColorMode("RGBNormalized")): RGBNormalized::addObservation,
+ * octree.cpp:380-393, and getRGB, octree.cpp:396-402.  cn = four planes (r_n, g_n, b_n, i), each nz*ny*nx
+ * floats starting at 0 (octree.h:217-222); rgb receives what getRGB() returns for every voxel touched. */
+uint64_t oracle_integrate_rgbn(const oracle_params *p, float *d, float *w, float *cn, uint8_t *rgb,
+                               const float *depth, const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  const size_t n = (size_t)nx * ny * nz;
+  float *r_n = cn, *g_n = cn + n, *b_n = cn + 2 * n, *i_m = cn + 3 * n;
+  float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
+        *cz = (float *)malloc(sizeof(float) * nz);
+  oracle_centers(nx, p->size[0], cx);
+  oracle_centers(ny, p->size[1], cy);
+  oracle_centers(nz, p->size[2], cz);
+  if (z_begin == 0 && z_end == 0) z_end = nz;
+  uint64_t n_obs = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_obs)
+  for (int k = z_begin; k < z_end; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        float dn;
+        size_t pixel;
+        if (!observe(p, T, cx[i], cy[j], cz[k], depth, &dn, &pixel)) continue;
+        const float w_new = 1;
+        const size_t vi = ((size_t)k * ny + j) * nx + i;
+        const uint8_t *px = bgra + 4 * pixel;
+        const uint8_t r = px[2], g = px[1], b = px[0];
+        const float wsum = w[vi] + w_new;                                                           /* :383 */
+        const float in = sqrtf((float)r * (float)r + (float)g * (float)g + (float)b * (float)b);    /* :384 */
+        const float r_f = r / in, g_f = g / in, b_f = b / in;                                       /* :385-387 */
+        r_n[vi] = (w[vi] * r_n[vi] + w_new * r_f) / wsum;                                           /* :388 */
+        g_n[vi] = (w[vi] * g_n[vi] + w_new * g_f) / wsum;
+        b_n[vi] = (w[vi] * b_n[vi] + w_new * b_f) / wsum;
+        i_m[vi] = (w[vi] * i_m[vi] + w_new * in) / wsum;                                            /* :391 */
+        /* getRGB: `uint8_t r = r_n_ * i_` is cvttss2si + low byte on x86-64 (NaN -> 0x80000000 -> 0) */
+        rgb[3 * vi + 0] = (uint8_t)cvtt((double)(r_n[vi] * i_m[vi]));
+        rgb[3 * vi + 1] = (uint8_t)cvtt((double)(g_n[vi] * i_m[vi]));
+        rgb[3 * vi + 2] = (uint8_t)cvtt((double)(b_n[vi] * i_m[vi]));
+        d[vi] = (d[vi] * w[vi] + dn * w_new) / (w[vi] + w_new); /* octree.cpp:156 */
+        w[vi] += w_new;
+        if (w[vi] > p->max_weight) w[vi] = p->max_weight;
         ++n_obs;
       }
   free(cx);

@@ -252,3 +252,30 @@ def test_python_save_load_over_the_c_abi(dropin, tmp_path, vol_chunk):
     assert e.value.code == capi.E_UNSUPPORTED
     for v in (pv, back, slab, dv):
         v.close()
+
+
+def test_dropin_set_color_mode_rgb_normalized(dropin):
+    """setColorMode("RGBNormalized") through the C++ classes: the drop-in against the reference's own library,
+    driven by the same C driver (colours read back through getRGB / marching cubes)."""
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    res, W, H = 32, 80, 60
+    sc = synth.scene_a(res, W, H)
+    vols = [refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True,
+                              color_mode="RGBNormalized", lib_path=lib) for lib in (dropin, refbind.LIB)]
+    for i in range(4):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        col = sc.bgra(i).copy()
+        col[25:35, 30:50, :3] = 0
+        for v in vols:
+            v.integrate(sc.depth(tr), col, tr)
+    d, w, rgb = vols[0].download()
+    rd, rw, rrgb, _, _ = vols[1].dump_dense()
+    assert_same_f32(d, rd, "d")
+    assert np.array_equal(w, rw) and np.array_equal(rgb, rrgb) and rgb.max() > 30
+    meshes = [v.march(1.0, 1) for v in vols]
+    assert len(meshes[0][0]) > 500
+    assert_same_f32(meshes[0][0], meshes[1][0], "mesh")
+    assert np.array_equal(meshes[0][1], meshes[1][1])
+    for v in vols:
+        v.close()
