@@ -35,6 +35,12 @@ struct tsdf_hip_volume {
   std::vector<float> h_ctr[3];
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
   uint32_t *frame_bgra = nullptr;  // = frame_depth + W*H (same allocation)
+  // pinned two-slot bounce buffer every host<->device transfer of caller memory goes through (tsdf_to_host /
+  // tsdf_to_device in tsdf_core.hip)
+  char *bounce = nullptr;
+  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+  bool bounce_busy[2] = {false, false};
+  unsigned bounce_turn = 0;  // slot of the next chunk: consecutive small transfers alternate instead of queueing on one slot
   double *cam64 = nullptr;         // fx, fy, cx, cy on the device
   tsdf_hip_pipeline *pipe = nullptr;
   int frame_staged = 0;            // tsdf_hip_organize left a frame in [frame_depth | frame_bgra]
@@ -88,6 +94,12 @@ struct TsdfDeviceScope {
   TSDF_HIP_TRY(_device_scope.err)
 
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
+// Copies between DEVICE memory and the CALLER's host memory, through the handle's pinned bounce buffer in chunks
+// (two slots, the host memcpy of one chunk overlapping the DMA of the next).  tsdf_to_host returns with the
+// data in `dst` (everything queued on the stream before it has completed); tsdf_to_device returns as soon as
+// `src` has been consumed, the device copy being ordered on the handle's stream like any other work.
+int tsdf_to_host(tsdf_hip_volume *v, void *dst, const void *dev_src, size_t bytes);
+int tsdf_to_device(tsdf_hip_volume *v, void *dev_dst, const void *src, size_t bytes);
 void tsdf_pipeline_destroy(tsdf_hip_volume *v);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,

@@ -119,16 +119,16 @@ extern "C" int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_str
   TSDF_HIP_TRY(hipMemsetAsync(zbuf, 0xff, b_z, h->stream));
   TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
   if (n) {
-    TSDF_HIP_TRY(hipMemcpyAsync(sp + b_z, xyz, n * xyz_stride * 4, hipMemcpyHostToDevice, h->stream));
-    if (bgra) TSDF_HIP_TRY(hipMemcpyAsync(sp + b_z + b_xyz, bgra, b_c, hipMemcpyHostToDevice, h->stream));
+    if ((rc = tsdf_to_device(h, sp + b_z, xyz, n * xyz_stride * 4))) return rc;
+    if (bgra && (rc = tsdf_to_device(h, sp + b_z + b_xyz, bgra, b_c))) return rc;
     hipLaunchKernelGGL(k_ingest_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, zbuf);
     TSDF_HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k_ingest_resolve, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, h->stream, a, zbuf,
                      h->frame_depth, h->frame_bgra, h->counter);
   TSDF_HIP_TRY(hipGetLastError());
-  if (depth_out) TSDF_HIP_TRY(hipMemcpyAsync(depth_out, h->frame_depth, npx * 4, hipMemcpyDeviceToHost, h->stream));
-  if (bgra_out) TSDF_HIP_TRY(hipMemcpyAsync(bgra_out, h->frame_bgra, npx * 4, hipMemcpyDeviceToHost, h->stream));
+  if (depth_out && (rc = tsdf_to_host(h, depth_out, h->frame_depth, npx * 4))) return rc;
+  if (bgra_out && (rc = tsdf_to_host(h, bgra_out, h->frame_bgra, npx * 4))) return rc;
   unsigned long long nv = 0;
   if (n_valid) TSDF_HIP_TRY(hipMemcpyAsync(&nv, h->counter, sizeof nv, hipMemcpyDeviceToHost, h->stream));
   if (depth_out || bgra_out || n_valid) TSDF_HIP_TRY(hipStreamSynchronize(h->stream));

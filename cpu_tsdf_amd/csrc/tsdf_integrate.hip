@@ -816,16 +816,16 @@ extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
   TSDF_ON_DEVICE(h->device);
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
-  TSDF_HIP_TRY(hipMemcpyAsync(h->frame_depth, depth, npx * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const bool color = h->p.integrate_color != 0;
-  if (color) {
-    if (!bgra) {
-      tsdf_set_error("integrate_color is set but no colour image was given");
-      return TSDF_HIP_E_INVALID;
-    }
-    TSDF_HIP_TRY(hipMemcpyAsync(h->frame_bgra, bgra, npx * 4, hipMemcpyHostToDevice, h->stream));
+  if (color && !bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
   }
-  int rc = launch_integrate(h, h->frame_depth, color ? h->frame_bgra : nullptr, cam_from_vol, n_observed);
+  // through the pinned bounce buffer (tsdf_to_device): the same cost whatever memory the caller hands over
+  int rc = tsdf_to_device(h, h->frame_depth, depth, npx * sizeof(float));
+  if (rc) return rc;
+  if (color && (rc = tsdf_to_device(h, h->frame_bgra, bgra, npx * 4))) return rc;
+  rc = launch_integrate(h, h->frame_depth, color ? h->frame_bgra : nullptr, cam_from_vol, n_observed);
   if (rc) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;

@@ -501,15 +501,14 @@ extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, u
   TSDF_ON_DEVICE(h->device);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
-  if (verts) TSDF_HIP_TRY(hipMemcpyAsync(verts, h->mc_verts, n * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (rgb) {
-    if (!h->mc_has_rgb) {
-      tsdf_set_error("the last tsdf_hip_march ran without a colour mode");
-      return TSDF_HIP_E_INVALID;
-    }
-    TSDF_HIP_TRY(hipMemcpyAsync(rgb, h->mc_rgb, n * 9, hipMemcpyDeviceToHost, h->stream));
+  if (rgb && !h->mc_has_rgb) {
+    tsdf_set_error("the last tsdf_hip_march ran without a colour mode");
+    return TSDF_HIP_E_INVALID;
   }
-  if (cell) TSDF_HIP_TRY(hipMemcpyAsync(cell, h->mc_cell, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  int rc = TSDF_HIP_OK;
+  if (verts && (rc = tsdf_to_host(h, verts, h->mc_verts, n * 9 * sizeof(float)))) return rc;
+  if (rgb && (rc = tsdf_to_host(h, rgb, h->mc_rgb, n * 9))) return rc;
+  if (cell && (rc = tsdf_to_host(h, cell, h->mc_cell, n * sizeof(uint64_t)))) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }

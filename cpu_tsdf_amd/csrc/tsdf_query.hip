@@ -13,6 +13,8 @@
 
 #include <algorithm>
 
+#include <string.h>
+
 #include "tsdf_common.h"
 
 struct GridView {
@@ -441,9 +443,8 @@ static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3]
                      (const int *)nullptr, (int *)nullptr, RaySlab{0, 1, 0, 0, 0});
   TSDF_HIP_TRY(hipGetLastError());
   unsigned inc = 0;
-  TSDF_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   TSDF_HIP_TRY(hipMemcpyAsync(&inc, d_inc, sizeof inc, hipMemcpyDeviceToHost, h->stream));
-  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = tsdf_to_host(h, out, d_out, (size_t)n * 8 * sizeof(float)))) return rc;  // (synchronises the stream)
   if (inc) {
     tsdf_set_error("raycast touched planes outside this handle's Z-slab (+halo)");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -575,14 +576,12 @@ extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, ui
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
   unsigned char *d_rgb = (unsigned char *)(d_xyz + 3 * n), *d_found = d_rgb + 3 * n;
-  TSDF_HIP_TRY(hipMemcpyAsync(d_xyz, xyz, n * 12, hipMemcpyHostToDevice, h->stream));
+  if ((rc = tsdf_to_device(h, d_xyz, xyz, n * 12))) return rc;
   hipLaunchKernelGGL(k_lookup_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), d_xyz, n, d_rgb,
                      d_found);
   TSDF_HIP_TRY(hipGetLastError());
-  TSDF_HIP_TRY(hipMemcpyAsync(rgb, d_rgb, n * 3, hipMemcpyDeviceToHost, h->stream));
-  TSDF_HIP_TRY(hipMemcpyAsync(found, d_found, n, hipMemcpyDeviceToHost, h->stream));
-  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  return TSDF_HIP_OK;
+  if ((rc = tsdf_to_host(h, rgb, d_rgb, n * 3))) return rc;
+  return tsdf_to_host(h, found, d_found, n);
 }
 
 // Test hook: Octree::getContainingVoxel's voxel index for arbitrary points (idx = i, j, k or -1, -1, -1 for NULL).
@@ -613,13 +612,11 @@ extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, siz
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
   int *d_idx = (int *)(d_xyz + 3 * n);
-  TSDF_HIP_TRY(hipMemcpyAsync(d_xyz, xyz, n * 12, hipMemcpyHostToDevice, h->stream));
+  if ((rc = tsdf_to_device(h, d_xyz, xyz, n * 12))) return rc;
   hipLaunchKernelGGL(k_selftest_containing, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), d_xyz,
                      n, d_idx);
   TSDF_HIP_TRY(hipGetLastError());
-  TSDF_HIP_TRY(hipMemcpyAsync(idx, d_idx, n * 12, hipMemcpyDeviceToHost, h->stream));
-  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  return TSDF_HIP_OK;
+  return tsdf_to_host(h, idx, d_idx, n * 12);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,15 +701,15 @@ extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float 
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch, *d_val = d_xyz + 3 * n, *d_grad = d_val + n, *d_hess = d_grad + 3 * n;
   unsigned char *d_ok = (unsigned char *)(d_hess + 9 * n);
-  TSDF_HIP_TRY(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = tsdf_to_device(h, d_xyz, xyz, 3 * n * sizeof(float)))) return rc;
   const GridView g = make_view(h);
   hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, d_xyz, n, d_val,
                      d_grad, d_hess, d_ok);
   TSDF_HIP_TRY(hipGetLastError());
-  if (val) TSDF_HIP_TRY(hipMemcpyAsync(val, d_val, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (grad) TSDF_HIP_TRY(hipMemcpyAsync(grad, d_grad, 3 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (hess) TSDF_HIP_TRY(hipMemcpyAsync(hess, d_hess, 9 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (ok) TSDF_HIP_TRY(hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, h->stream));
+  if (val && (rc = tsdf_to_host(h, val, d_val, n * sizeof(float)))) return rc;
+  if (grad && (rc = tsdf_to_host(h, grad, d_grad, 3 * n * sizeof(float)))) return rc;
+  if (hess && (rc = tsdf_to_host(h, hess, d_hess, 9 * n * sizeof(float)))) return rc;
+  if (ok && (rc = tsdf_to_host(h, ok, d_ok, n))) return rc;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }

@@ -12,6 +12,9 @@ import time
 
 import numpy as np
 
+# The oracle's OpenMP team must sleep, not spin, between its parallel regions: spinning threads on every host
+# core delay the HIP runtime's completion signals and show up as "GPU time" of the next call.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpu_tsdf_amd import capi, synth  # noqa: E402
 from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree  # noqa: E402
@@ -52,6 +55,7 @@ def main():
     t_gpu = t_cpu = t_synth = t_ray = 0.0
     mismatches = n_views = 0
     ray_err = []
+    per_call = []
     for i in range(a.frames):
         t0 = time.perf_counter()
         tr = synth.turntable_pose(i, a.frames, sc.size, tilt=0.15 * np.sin(i * 0.05))
@@ -60,6 +64,7 @@ def main():
         v.integrateCloud(dep, col if a.color else None, tr, pipelined=bool(a.pipelined))  # host entry point
         t2 = time.perf_counter()
         t_gpu += t2 - t1
+        per_call.append((t2 - t1) * 1e3)
         if a.raycast_every and (i + 1) % a.raycast_every == 0:
             tq = time.perf_counter()
             view = v.renderView(tr, 1)  # camera frame: z is directly comparable with the noise-free depth image
@@ -111,6 +116,9 @@ def main():
         "oracle_plane_groups": groups, "planes_bit_identical_to_oracle": planes_equal,
         "intermediate_mismatches": mismatches, "fraction_of_checked_voxels_at_max_weight": saturated,
         "cpu_oracle_seconds_for_its_planes": t_cpu, "frame_synthesis_seconds": t_synth,
+        "integrate_ms_median": float(np.median(per_call)),
+        "integrate_ms_by_tenth_of_run": [round(float(np.median(c)), 2) for c in np.array_split(np.array(per_call), 10)],
+        "integrate_ms_calls_20_to_70": [round(t, 1) for t in per_call[20:70]],
         "renderView_calls": n_views, "renderView_ms_incl_download": (t_ray / n_views * 1e3) if n_views else None,
         "renderView_median_abs_depth_error_m": (float(np.median(ray_err)) if ray_err else None)}))
     v.close()
