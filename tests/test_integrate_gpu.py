@@ -155,6 +155,24 @@ def test_upload_download_roundtrip(gpu):
     assert np.array_equal(d3, d[1:5, 2:7, 3:10]) and np.array_equal(w3, w[1:5, 2:7, 3:10])
 
 
+def test_block_transfers_across_bounce_chunks(gpu):
+    """Host transfers move through a pinned two-slot bounce buffer in 8 MiB chunks (tsdf_to_host / tsdf_to_device):
+    blocks of 2.2 chunks, exactly 1 chunk, and a few bytes, back to back and in both directions, must arrive intact."""
+    vol, sc = make_volume(64, color=True, res3=(176, 168, 160), size3=(0.25, 0.25, 0.25))
+    vol.setLayout(capi.LAYOUT_F32W)
+    vol.reset()
+    rng = np.random.RandomState(3)
+    for (x0, y0, z0, nx, ny, nz) in [(5, 3, 1, 163, 161, 157), (0, 0, 0, 128, 128, 128), (7, 9, 11, 3, 1, 2), (0, 0, 0, 176, 168, 160)]:
+        d = rng.randn(nz, ny, nx).astype(np.float32)
+        w = rng.rand(nz, ny, nx).astype(np.float32)
+        rgb = rng.randint(0, 256, (nz, ny, nx, 3)).astype(np.uint8)
+        vol.upload(d, w, rgb, x0, y0, z0)
+        d2, w2, rgb2 = vol.download(x0, y0, z0, nx, ny, nz)
+        assert np.array_equal(d.view(np.uint32), d2.view(np.uint32)), (nx, ny, nz)
+        assert np.array_equal(w, w2) and np.array_equal(rgb, rgb2), (nx, ny, nz)
+    vol.close()
+
+
 @pytest.mark.parametrize("color", [False, True])
 @pytest.mark.parametrize("wmax", [100.0, 2.5, 0.0, 255.0])
 def test_packed_layout_roundtrip_and_refusal(gpu, color, wmax):
