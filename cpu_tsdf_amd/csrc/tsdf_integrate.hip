@@ -18,6 +18,7 @@
 #include <string.h>
 #include <math.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "tsdf_common.h"
@@ -35,8 +36,9 @@ struct IntegrateArgs {
   float wmax;         // max_weight_
   float pos_over_neg; // max_dist_pos_ / max_dist_neg_ (IEEE fp32, host)
   int W, H;
-  int ny;
-  int qpr;            // quads per row = ceil(nx/4)
+  int ny;             // rows this launch may touch (counted from the launch's first row)
+  int plane_rows;     // rows of a whole plane: the address stride between planes
+  int qpr;            // quads per row = ceil(nx/4) (counted from the launch's first quad)
   int z_global0;      // global z of the first integrated plane
   int zl0;            // allocated-plane index of the first integrated plane
   int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
@@ -215,7 +217,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   // wave-uniform bases
   const int row0 = (int)blockIdx.y * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
-  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.ny + row0) * a.pitch;
+  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
   const unsigned span = (unsigned)rows * (unsigned)a.pitch;  // elements of this block's row group
   const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
   const rsrc_t rsW = make_rsrc(PACKED ? D : Wt + e0, PACKED ? 0u : span * 4u);
@@ -547,6 +549,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.W = p.image_width;
   a.H = p.image_height;
   a.ny = h->ny;
+  a.plane_rows = h->ny;
   a.qpr = (h->nx + 3) / 4;
   hh.planes = h->z_end - h->z_begin;
   a.z_global0 = h->z_begin;
@@ -591,7 +594,7 @@ k_integrate_rgbn(const IntegrateArgs a, float *__restrict__ D, float *__restrict
       float dn = z - g[2];  // hpp:159
       if (!isnan(z) && !(dn < -a.neg)) {  // hpp:152, :193-196
         dn = dn > a.pos ? a.pos_over_neg : dn / a.neg;  // hpp:189-198
-        const int64_t vi = ((int64_t)(a.zl0 + zl) * a.ny + y) * a.pitch + x;
+        const int64_t vi = ((int64_t)(a.zl0 + zl) * a.plane_rows + y) * a.pitch + x;
         const uint32_t c = bgra[pix];  // PCL memory order b, g, r, a
         const float r = (float)((c >> 16) & 255u), gch = (float)((c >> 8) & 255u), b = (float)(c & 255u);
         float w = Wt[vi], d = D[vi];
@@ -636,14 +639,73 @@ static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = 
          a.a.H < (1 << 23);
 }
 
+// Index box of the voxels a frame can possibly observe.  updateVoxel only touches a voxel whose centre maps to
+// 0 < g.z <= max_sensor_dist with a pixel (int)(g.x*fx/g.z + cx) inside the image (hpp:146, .cpp:611-617), i.e.
+// a point of the pyramid spanned by the camera centre and the far corners of the (slightly widened) image --
+// a convex set, so its bounding box in the volume frame is the bounding box of those five points mapped back
+// by the inverse of cam_from_vol.  The box is widened by two voxels plus the float transform's error before it
+// is turned into index ranges [lo, hi] (inclusive) through the centre tables.  Returns false when no claim can
+// be made (singular pose, unbounded range, odd intrinsics); *empty when nothing can be observed at all.
+static bool observable_index_box(const tsdf_hip_volume *h, const float T[12], int lo[3], int hi[3], bool *empty) {
+  const tsdf_params &p = h->p;
+  *empty = false;
+  if (!(p.max_sensor_dist > 0.f)) {  // also NaN: g.z <= NaN never holds
+    *empty = true;
+    return true;
+  }
+  if (!std::isfinite(p.max_sensor_dist) || !(p.fx > 0) || !(p.fy > 0) || !std::isfinite(p.cx) || !std::isfinite(p.cy))
+    return false;
+  double A[9], t[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) A[3 * r + c] = T[4 * r + c];
+    t[r] = T[4 * r + 3];
+  }
+  const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+  double scale = 0;
+  for (int i = 0; i < 9; ++i) scale = std::max(scale, fabs(A[i]));
+  if (!std::isfinite(det) || !(fabs(det) > 1e-9 * scale * scale * scale)) return false;
+  const double inv[9] = {(A[4] * A[8] - A[5] * A[7]) / det, (A[2] * A[7] - A[1] * A[8]) / det, (A[1] * A[5] - A[2] * A[4]) / det,
+                         (A[5] * A[6] - A[3] * A[8]) / det, (A[0] * A[8] - A[2] * A[6]) / det, (A[2] * A[3] - A[0] * A[5]) / det,
+                         (A[3] * A[7] - A[4] * A[6]) / det, (A[1] * A[6] - A[0] * A[7]) / det, (A[0] * A[4] - A[1] * A[3]) / det};
+  const double zf = (double)p.max_sensor_dist * (1.0 + 1e-6) + 1e-9;
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, big = 0;
+  for (int k = 0; k < 5; ++k) {
+    double g[3] = {0, 0, 0};
+    if (k < 4) {  // trunc toward zero keeps a pixel coordinate in (-1, W): one more pixel of slack on each side
+      const double u = (k & 1) ? p.image_width + 1.0 : -2.0, v = (k & 2) ? p.image_height + 1.0 : -2.0;
+      g[0] = (u - p.cx) / p.fx * zf;
+      g[1] = (v - p.cy) / p.fy * zf;
+      g[2] = zf;
+    }
+    for (int r = 0; r < 3; ++r) {
+      const double c = inv[3 * r] * (g[0] - t[0]) + inv[3 * r + 1] * (g[1] - t[1]) + inv[3 * r + 2] * (g[2] - t[2]);
+      if (!std::isfinite(c)) return false;
+      mn[r] = std::min(mn[r], c);
+      mx[r] = std::max(mx[r], c);
+      big = std::max(big, fabs(c));
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    const std::vector<float> &ctr = h->h_ctr[a];
+    const int n = (int)ctr.size();
+    const double margin = 2.0 * (double)p.size[a] / (double)p.res[a] + 1e-5 * (big + fabs((double)p.size[a]));
+    lo[a] = (int)(std::lower_bound(ctr.begin(), ctr.end(), (float)(mn[a] - margin)) - ctr.begin());
+    hi[a] = (int)(std::upper_bound(ctr.begin(), ctr.end(), (float)(mx[a] + margin)) - ctr.begin()) - 1;
+    if (lo[a] > 0) --lo[a];  // (the float casts above may have rounded inwards)
+    if (hi[a] < n - 1) ++hi[a];
+    if (lo[a] > hi[a]) *empty = true;
+  }
+  return true;
+}
+
 static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
                             uint64_t *n_observed) {
   const tsdf_params &p = h->p;
   const IntegrateHost hh = make_args(h, T);
   IntegrateArgs a = hh.a;
-  const unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
-  const unsigned gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
-  const unsigned gz = (unsigned)hh.planes;
+  unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
+  unsigned gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
+  unsigned gz = (unsigned)hh.planes;
   if (gy > 65535u || gz > 65535u) {
     tsdf_set_error("grid too large for one launch");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -703,43 +765,84 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
       a.bgra_off = (unsigned)(npx * 4);
     }
   }
-  // Brick cull (TSDF_HIP_CULL: 1 on when useful, 0 off, 2 always): skipped when the whole slab is provably
-  // inside the frustum and sensor range (convex frustum: test the slab's 8 corners), the turntable case.
+  // Cull (TSDF_HIP_CULL: 1 on when useful, 0 off, 2 always): skipped when the whole slab is provably inside the
+  // frustum and sensor range (convex frustum: test the slab's 8 corners), the turntable case.  Otherwise
+  //  (1) the launch shrinks to the blocks that meet the index box of the observable pyramid
+  //      (observable_index_box; host only -- pointers, centre tables and limits are offset to the box's first
+  //      block, the kernel does not know), and
+  //  (2) k_cull flags, inside that box, the blocks none of whose voxels can be observed.
+  // Neither changes results: both are conservative.
   const uint8_t *live = nullptr;
+  float *D = h->d, *Wt = h->w;
+  uint32_t *RGB = h->rgb;
+  uint8_t *K8 = h->k8;
+  const float *ctrx = h->ctr[0], *ctry = h->ctr[1];
+  bool nothing_observable = false;
   if (tsdf_tuning().cull) {
-    CullArgs c;
-    for (int i = 0; i < 12; ++i) c.m[i] = T[i];
-    c.fx = p.fx, c.fy = p.fy, c.cx = p.cx, c.cy = p.cy;
-    c.zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
-    c.zmax = p.max_sensor_dist;
-    c.W = p.image_width, c.H = p.image_height, c.nx = h->nx, c.ny = h->ny, c.z_global0 = h->z_begin;
-    c.bx_vox = a.TX * 4, c.by_rows = a.rpb * a.TY;
-    c.gx = (int)gx, c.gy = (int)gy, c.gz = (int)gz;
     bool all_inside = tsdf_tuning().cull != 2;
     for (int k = 0; k < 8 && all_inside; ++k) {
       const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
                    z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
       double g[3];
-      for (int r = 0; r < 3; ++r) g[r] = c.m[4 * r] * x + c.m[4 * r + 1] * y + c.m[4 * r + 2] * z + c.m[4 * r + 3];
-      const double u = c.fx * g[0] / g[2] + c.cx, v = c.fy * g[1] / g[2] + c.cy;
-      all_inside = g[2] > c.zlo + 1e-3 && g[2] > 1e-3 && g[2] < c.zmax - 1e-3 && u > 1 && u < c.W - 2 && v > 1 && v < c.H - 2;
+      for (int r = 0; r < 3; ++r) g[r] = (double)T[4 * r] * x + (double)T[4 * r + 1] * y + (double)T[4 * r + 2] * z + (double)T[4 * r + 3];
+      const double u = p.fx * g[0] / g[2] + p.cx, v = p.fy * g[1] / g[2] + p.cy;
+      const double zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
+      all_inside = g[2] > zlo + 1e-3 && g[2] > 1e-3 && g[2] < p.max_sensor_dist - 1e-3 && u > 1 && u < p.image_width - 2 && v > 1 &&
+                   v < p.image_height - 2;
     }
     if (!all_inside) {
-      const size_t nb = (size_t)gx * gy * gz;
-      if (nb > h->live_cap) {
-        if (h->live) {
-          TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-          TSDF_HIP_TRY(hipFree(h->live));
-          h->live = nullptr;
-          h->live_cap = 0;
+      int lo[3], hi[3];
+      bool empty = false;
+      if (observable_index_box(h, T, lo, hi, &empty)) {
+        lo[2] = std::max(lo[2], h->z_begin);
+        hi[2] = std::min(hi[2], h->z_end - 1);
+        if (empty || lo[2] > hi[2]) {
+          nothing_observable = true;
+        } else {
+          const int bxv = a.TX * 4, byr = a.rpb * a.TY;  // voxels / rows per block
+          const int bx0 = lo[0] / bxv, bx1 = hi[0] / bxv, by0 = lo[1] / byr, by1 = hi[1] / byr;
+          const int x_off = bx0 * bxv, y_off = by0 * byr, z_off = lo[2] - h->z_begin;
+          const int64_t e_off = (int64_t)y_off * h->pitch + x_off;
+          D += e_off;
+          if (Wt) Wt += e_off;
+          if (RGB) RGB += e_off;
+          if (K8) K8 += e_off;
+          ctrx += x_off;
+          ctry += y_off;
+          a.qpr -= x_off / 4;
+          a.ny -= y_off;
+          a.z_global0 += z_off;
+          a.zl0 += z_off;
+          gx = (unsigned)(bx1 - bx0 + 1);
+          gy = (unsigned)(by1 - by0 + 1);
+          gz = (unsigned)(hi[2] - lo[2] + 1);
         }
-        TSDF_HIP_TRY(hipMalloc(&h->live, nb));
-        h->live_cap = nb;
       }
-      hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, h->ctr[0], h->ctr[1],
-                         h->ctr[2], h->live);
-      TSDF_HIP_TRY(hipGetLastError());
-      live = h->live;
+      if (!nothing_observable) {
+        CullArgs c;
+        for (int i = 0; i < 12; ++i) c.m[i] = T[i];
+        c.fx = p.fx, c.fy = p.fy, c.cx = p.cx, c.cy = p.cy;
+        c.zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
+        c.zmax = p.max_sensor_dist;
+        c.W = p.image_width, c.H = p.image_height;
+        c.nx = h->nx - (int)(ctrx - h->ctr[0]), c.ny = a.ny, c.z_global0 = a.z_global0;
+        c.bx_vox = a.TX * 4, c.by_rows = a.rpb * a.TY;
+        c.gx = (int)gx, c.gy = (int)gy, c.gz = (int)gz;
+        const size_t nb = (size_t)gx * gy * gz;
+        if (nb > h->live_cap) {
+          if (h->live) {
+            TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+            TSDF_HIP_TRY(hipFree(h->live));
+            h->live = nullptr;
+            h->live_cap = 0;
+          }
+          TSDF_HIP_TRY(hipMalloc(&h->live, nb));
+          h->live_cap = nb;
+        }
+        hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, ctrx, ctry, h->ctr[2], h->live);
+        TSDF_HIP_TRY(hipGetLastError());
+        live = h->live;
+      }
     }
   }
   const bool count = n_observed != nullptr;
@@ -750,11 +853,11 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   bool pose_ok = true;
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
   const bool fastproj = fast_projection_ok(hh, p.integrate_color != 0);
-  if (pose_ok) {
+  if (pose_ok && !nothing_observable) {
     const dim3 grid(gx, gy, gz), block(256);
 #define LAUNCH(ORDER, COLOR, FP, COUNT, PK)                                                                  \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, h->d, h->w, \
-                     h->rgb, h->k8, d_depth, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter, live)
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
+                     d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live)
 #define L5(ORDER, COLOR, FP, COUNT) \
   do {                              \
     if (h->packed)                  \

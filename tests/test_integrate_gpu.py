@@ -276,6 +276,47 @@ def test_brick_cull_random_poses_equal_no_cull(gpu):
         capi.set_tuning("cull", 1)
 
 
+@pytest.mark.parametrize("slab", [None, (7, 31)])
+def test_cull_sub_grid_offsets_on_a_wide_grid(gpu, slab):
+    """The launch shrinks to the index box of the observable pyramid (observable_index_box): pointers, centre tables
+    and limits are offset on the host.  A grid wide enough for several blocks along x (1024 voxels each) and y,
+    whole and as a Z-slab handle, with cameras inside / outside / grazing / looking away, a sheared (non-rigid)
+    pose and a short sensor range: forced cull == no cull, bit for bit, voxel counts included."""
+    rng = np.random.RandomState(17)
+    res3, size3 = (2304, 72, 40), (9.0, 0.3, 0.16)
+    sc = synth.Scene(1.0, 160, 120)
+    poses = []
+    for k in range(14):
+        eye = np.array([rng.uniform(-5.0, 5.0), rng.uniform(-0.3, 0.3), rng.uniform(-0.4, 0.4)])
+        tgt = np.array([rng.uniform(-4.5, 4.5), rng.uniform(-0.1, 0.1), rng.uniform(-0.05, 0.05)])
+        tr = synth.look_at_pose(eye, target=tgt)
+        if k == 5:   # a general affine pose: cam_from_vol is not a rotation
+            tr = tr.copy()
+            tr[:3, :3] = tr[:3, :3] @ np.array([[1.1, 0.05, 0.0], [0.0, 0.9, 0.02], [0.03, 0.0, 1.0]])
+        poses.append(tr)
+    poses.append(synth.look_at_pose((6.0, 0.0, 0.0), target=(12.0, 0.0, 0.0)))    # outside, looking away: nothing
+    poses.append(synth.look_at_pose((6.5, 0.01, 0.0), target=(0.0, 0.0, 0.0)))    # outside, grid beyond the sensor range
+    frames = [np.full((120, 160), d, np.float32) for d in rng.uniform(0.2, 1.4, len(poses))]
+    try:
+        res = []
+        for cull in (2, 0):
+            capi.set_tuning("cull", cull)
+            vol, _ = make_volume(64, 160, 120, color=True, res3=res3, size3=size3, zmin=0.05, zmax=1.5)
+            if slab:
+                vol.setZSlab(*slab)
+            vol.reset()
+            counts = [vol.integrateCloud(dep, sc.bgra(i), tr, count=True) for i, (tr, dep) in enumerate(zip(poses, frames))]
+            res.append((vol.download(), counts))
+            vol.close()
+        assert res[0][1] == res[1][1] and sum(res[0][1]) > 10000 and min(res[0][1]) == 0 < max(res[0][1])
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+        w = res[0][0][1]
+        assert 0.0 < (w > 0).mean() < 0.95   # the frames covered only part of the grid
+    finally:
+        capi.set_tuning("cull", 1)
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_pipelined_host_frames_equal_synchronous(gpu, color):
     """tsdf_hip_integrate_async: frames handed over back to back from ONE reused host buffer (the call must have
