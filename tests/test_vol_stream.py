@@ -127,3 +127,39 @@ def test_reader_rejects_damaged_files(harness, tmp_path):
     open(cut, "wb").write(blob[:len(blob) - 100])
     p = subprocess.run([harness, "read", cut, "8", str(tmp_path / "x.raw")], capture_output=True)
     assert p.returncode == 1 and b"truncated" in p.stderr
+
+
+def test_reader_survives_corrupted_files(tmp_path):
+    """load() parses files from anywhere: flipped bytes, truncations, corrupted header text and child counts must
+    end in an error (or a successful read of a still-consistent tree), never in a memory error -- the harness is
+    built with AddressSanitizer + UBSan for this test."""
+    exe = str(tmp_path / "vol_stream_asan")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-pthread", "-I", os.path.join(ROOT, "cpu_tsdf_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "harness", "vol_stream.cpp"), "-o", exe])
+    d, w, rgb = grid(True)
+    raw, vol = str(tmp_path / "in.raw"), str(tmp_path / "good.vol")
+    write_raw(raw, d, w, rgb, True)
+    subprocess.check_call([exe, "write", raw, str(RES), str(SIZE), "1", "8", vol], stdout=subprocess.DEVNULL)
+    blob = open(vol, "rb").read()
+    tree = blob.index(b"#OCTREEBINARY") + 14
+    rng = np.random.RandomState(0)
+    outcomes = set()
+    for it in range(90):
+        b = bytearray(blob)
+        mode = it % 4
+        if mode == 0:      # bytes of the binary tree
+            for _ in range(rng.randint(1, 6)):
+                b[rng.randint(tree, len(b))] = rng.randint(0, 256)
+        elif mode == 1:    # truncation
+            b = b[:rng.randint(10, len(b))]
+        elif mode == 2:    # the ASCII header
+            b[rng.randint(0, tree)] = rng.randint(32, 127)
+        else:              # resolution words / the root's child count
+            b[tree + rng.randint(0, 64)] = rng.randint(0, 256)
+        bad = str(tmp_path / "bad.vol")
+        open(bad, "wb").write(b)
+        p = subprocess.run([exe, "read", bad, str([8, 32, 4][it % 3]), str(tmp_path / "out.raw")], capture_output=True, timeout=120)
+        assert p.returncode in (0, 1, 4, 5), (it, mode, p.returncode, p.stderr[-600:])
+        outcomes.add(p.returncode)
+    assert 1 in outcomes      # errors were really provoked
