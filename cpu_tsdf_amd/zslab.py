@@ -412,15 +412,20 @@ class ZSlabVolume:
             ok |= o
         return ok, val, grad, hess
 
-    def renderView(self, trans, downsampleBy=1, camera_frame=True, exchange="allreduce"):
+    def renderView(self, trans, downsampleBy=1, camera_frame=True, exchange=None):
         """TSDFVolumeOctree::renderView over all slabs (ray hand-off, see the module docstring).  Collective;
         every rank returns the full (H/ds, W/ds, 8) image.
         exchange="allreduce": every rank holds every ray's record, one integer SUM all-reduce of the image-sized
         delta per round (simple; traffic ~ image x rounds).  exchange="p2p": every rank holds only the records it
         is responsible for; after each round a suspended record travels point-to-point to the owner of its next
-        voxel (traffic ~ rays crossing a slab boundary), and the finished rays' outputs are summed once at the end."""
+        voxel (traffic ~ rays crossing a slab boundary), and the finished rays' outputs are summed once at the end.
+        Default: "allreduce" for two ranks, "p2p" beyond (the all-reduce moves the whole image up to world + 1 times)."""
         if self.world == 1:
             return self.slab.render(trans, downsampleBy)
+        if exchange is None:
+            exchange = "allreduce" if self.world <= 2 else "p2p"
+        if exchange not in ("allreduce", "p2p"):
+            raise ValueError(f"exchange must be 'allreduce' or 'p2p', not {exchange!r}")
         from .volume import eigen_affine_inverse, transform_cloud_with_normals
         trans = np.asarray(trans, dtype=np.float64)
         ds = int(downsampleBy)

@@ -75,11 +75,13 @@ def _worker(rank, world, port, out_path):
     renders, rounds = [], []
     p2p_records = []
     for k, tr in enumerate(views(sc.size)):
-        renders.append(vol.renderView(tr, 1 + (k == 1)))
+        renders.append(vol.renderView(tr, 1 + (k == 1), exchange="allreduce"))
         rounds.append(vol.last_render_rounds)
         again = vol.renderView(tr, 1 + (k == 1), exchange="p2p")  # records travel only to the next owner
         assert np.array_equal(again.view(np.uint32), renders[-1].view(np.uint32)), f"p2p hand-off differs, view {k}"
         p2p_records.append(vol.last_p2p_records)
+        if k == 0:  # the default picks one of the two by world size; either way the same image
+            assert np.array_equal(vol.renderView(tr, 1).view(np.uint32), renders[-1].view(np.uint32))
     assert max(p2p_records) < 0.8 * renders[0].shape[0] * renders[0].shape[1] * world
     zb, ze = vol.z_begin, vol.z_end
     # checkpoint: one .vol of the whole grid written on the LAST rank from blocks that straddle the slabs (16^3
