@@ -8,7 +8,9 @@ independent during integration, so the grid is cut into contiguous Z-slabs and t
   (1.2 MB + 1.2 MB at 640x480) -- no voxel ever crosses a link;
 * ``reconstruct`` (marching cubes): a cell reads planes z and z+1, so every rank receives ONE plane
   (the first plane of the next slab: res^2 * 8..12 B) from its +z neighbour by point-to-point send/recv,
-  meshes its own cells, and the per-rank triangle lists are merged by the reference's Morton key;
+  meshes its own cells, and the per-rank triangle lists are merged by the reference's Morton key -- on one rank
+  (``reconstruct``, ``reconstruct_tensors``) or by a distributed sample sort that leaves every rank one contiguous
+  range of the global triangle order (``reconstruct_distributed``);
 * ``sample`` (getFxn...): a point is answered by the rank that owns the lower-corner plane.
 
 * ``renderView``: a ray's step sequence depends on the last voxel it visited (tsdf_volume_octree.cpp:360),
@@ -393,6 +395,84 @@ class ZSlabVolume:
             return None
         order = torch.argsort(morton_x_major_torch(all_k), stable=True)
         return all_v[order], (all_c[order] if has_rgb else None), all_k[order]
+
+    def reconstruct_distributed(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, samples=256):
+        """reconstruct() for meshes too large for one GPU: a distributed sample sort by the reference's Morton key.
+        Every rank ends up with one contiguous range of the GLOBAL triangle order -- rank 0 the first triangles,
+        rank world-1 the last -- so the ranks' results, concatenated in rank order, are the reference's mesh.
+        Returns (verts (n,9) float32, rgb (n,9) uint8 or None, cells (n,) int64, first) on every rank, `first` being
+        the global index of this rank's first triangle.
+
+        Each rank meshes its slab (sorted by key within the slab), `samples` evenly spaced keys per rank are
+        all-gathered and world-1 splitters picked from them, whole cells go to the rank that owns their key range
+        (point-to-point, exactly-sized tensors), and a stable local sort merges the received runs: triangles of
+        one cell come from one slab, so their emit order survives."""
+        self.exchange_halo()
+        verts, rgb, cells = self.slab.march_tensors(w_min, color_by_rgb, color_by_confidence)
+        if self.world == 1:
+            return verts, rgb, cells, 0
+        dev = verts.device
+        has_rgb = rgb is not None
+        keys = morton_x_major_torch(cells)
+        order = torch.argsort(keys, stable=True)  # (already sorted within a slab; cheap and makes no assumption)
+        keys, verts, cells = keys[order], verts[order], cells[order]
+        if has_rgb:
+            rgb = rgb[order]
+        n = keys.shape[0]
+        # splitters: the same on every rank
+        mine = torch.full((samples,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+        if n:
+            mine = keys[(torch.arange(samples, device=dev) * n) // samples]
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine, group=self.group)
+        pool = torch.sort(torch.cat(gathered)).values
+        pool = pool[pool != torch.iinfo(torch.int64).max]
+        if pool.numel() == 0:
+            return verts, rgb, cells, 0
+        split = pool[(torch.arange(1, self.world, device=dev) * pool.numel()) // self.world]
+        # my triangles with split[q-1] <= key < split[q] go to rank q (all triangles of a cell share the key)
+        cuts = torch.searchsorted(keys, split, right=False)
+        bounds = [0] + [int(c) for c in cuts.tolist()] + [n]
+        send_counts = torch.tensor([bounds[q + 1] - bounds[q] for q in range(self.world)], dtype=torch.int64, device=dev)
+        table = [torch.empty_like(send_counts) for _ in range(self.world)]
+        dist.all_gather(table, send_counts, group=self.group)
+        table = torch.stack(table).cpu()                       # table[src][dst]
+        recv_counts = [int(table[r][self.rank]) for r in range(self.world)]
+        total = sum(recv_counts)
+        out_v = torch.empty((total, 9), dtype=torch.float32, device=dev)
+        out_c = torch.empty((total, 9), dtype=torch.uint8, device=dev) if has_rgb else None
+        out_k = torch.empty((total,), dtype=torch.int64, device=dev)
+        ops, off = [], 0
+        for r in range(self.world):
+            m = recv_counts[r]
+            sl = slice(off, off + m)
+            off += m
+            if m == 0:
+                continue
+            if r == self.rank:
+                src = slice(bounds[r], bounds[r + 1])
+                out_v[sl], out_k[sl] = verts[src], cells[src]
+                if has_rgb:
+                    out_c[sl] = rgb[src]
+            else:
+                ops.append(dist.P2POp(dist.irecv, out_v[sl], r, self.group))
+                ops.append(dist.P2POp(dist.irecv, out_k[sl], r, self.group))
+                if has_rgb:
+                    ops.append(dist.P2POp(dist.irecv, out_c[sl], r, self.group))
+        for q in range(self.world):
+            src = slice(bounds[q], bounds[q + 1])
+            if q == self.rank or bounds[q + 1] == bounds[q]:
+                continue
+            ops.append(dist.P2POp(dist.isend, verts[src].contiguous(), q, self.group))
+            ops.append(dist.P2POp(dist.isend, cells[src].contiguous(), q, self.group))
+            if has_rgb:
+                ops.append(dist.P2POp(dist.isend, rgb[src].contiguous(), q, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        order = torch.argsort(morton_x_major_torch(out_k), stable=True)
+        first = int(table[:, :self.rank].sum())
+        return out_v[order], (out_c[order] if has_rgb else None), out_k[order], first
 
     # -- getFxn / getGradient / getHessian -------------------------------------------------------------------
     def sample(self, pts, dst=0):

@@ -70,6 +70,10 @@ def _worker(rank, world, port, out_path):
         dist.recv(tv, world - 1)
         dist.recv(tc, world - 1)
         dist.recv(tk, world - 1)
+    # distributed sample sort: every rank keeps one contiguous range of the GLOBAL triangle order
+    dv, dc, dk, first = vol.reconstruct_distributed(w_min=1.0, color_by_rgb=True, samples=64)
+    slices = [None] * world if rank == 0 else None
+    dist.gather_object((first, dv.numpy(), dc.numpy(), dk.numpy()), slices, dst=0)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     samp = vol.sample(pts)
     renders, rounds = [], []
@@ -108,6 +112,9 @@ def _worker(rank, world, port, out_path):
                  grad=samp[2], d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
                  bounds=np.array([[g[0], g[1]] for g in gathered]), rounds=np.array(rounds),
                  tverts=tv.numpy(), trgb=tc.numpy(), tcells=tk.numpy(),
+                 dfirst=np.array([s[0] for s in slices]), dcount=np.array([len(s[3]) for s in slices]),
+                 dverts=np.concatenate([s[1] for s in slices]), drgb=np.concatenate([s[2] for s in slices]),
+                 dcells=np.concatenate([s[3] for s in slices]),
                  **{f"view{k}": r for k, r in enumerate(renders)})
     dist.barrier()
     dist.destroy_process_group()
@@ -149,6 +156,11 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     # the tensor merge (send/recv of exactly-sized arrays + one sort by the Morton key) gives the same mesh
     assert np.array_equal(got["tcells"].astype(np.uint64), cells)
     assert np.array_equal(got["tverts"].reshape(-1, 3), verts) and np.array_equal(got["trgb"].reshape(-1, 3), rgb)
+    # the distributed sort: rank slices concatenated in rank order are the same mesh; offsets add up; balanced
+    assert np.array_equal(got["dcells"].astype(np.uint64), cells)
+    assert np.array_equal(got["dverts"].reshape(-1, 3), verts) and np.array_equal(got["drgb"].reshape(-1, 3), rgb)
+    assert got["dfirst"].tolist() == np.concatenate([[0], np.cumsum(got["dcount"])[:-1]]).tolist()
+    assert got["dcount"].min() > 0.4 * len(cells) / world and got["dcount"].max() < 2.0 * len(cells) / world
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, grad, _ = ov.sample(pts)
     assert np.array_equal(got["ok"], ok)

@@ -186,6 +186,9 @@ def test_zslab_volume_world1_end_to_end(gpu, tmp_path):
     assert tv.is_cuda and np.array_equal(tk.cpu().numpy().astype(np.uint64), cells2)
     assert_same_f32(tv.cpu().numpy().reshape(-1, 3), v2, "device mesh")
     assert np.array_equal(tc.cpu().numpy().reshape(-1, 3), c2)
+    dv, dc, dk, first = vol.reconstruct_distributed(w_min=1.0, color_by_confidence=True)
+    assert first == 0 and np.array_equal(dk.cpu().numpy().astype(np.uint64), cells2)
+    assert_same_f32(dv.cpu().numpy().reshape(-1, 3), v2, "distributed mesh (world 1)")
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, _, _ = vol.sample(pts)
     ok2, val2, _, _ = ov.sample(pts)
