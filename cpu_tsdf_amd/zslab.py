@@ -33,6 +33,7 @@ default backend is the HIP volume.  There is no CPU fallback in the product: the
 without a GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -473,6 +474,54 @@ class ZSlabVolume:
         order = torch.argsort(morton_x_major_torch(out_k), stable=True)
         first = int(table[:, :self.rank].sum())
         return out_v[order], (out_c[order] if has_rgb else None), out_k[order], first
+
+    def save_ply(self, filename, w_min=2.5, color_by_rgb=False, color_by_confidence=False):
+        """Mesh the whole grid and write ONE binary PLY in the layout pcl::io::savePLYFileBinary gives a
+        PolygonMesh (what the reference's `integrate` / `tsdf2mesh` programs write): after a distributed sort
+        every rank knows the global index of its first triangle, so each writes its own vertex and face records
+        at their byte offsets -- no rank ever holds the whole mesh.  Needs a file system all ranks share (one
+        node).  Vertices are moved by `global_transform` as marching_cubes_tsdf_octree.cpp:119-130 does.
+        Returns the total number of triangles."""
+        from .volume import transform_points_f64
+        verts, rgb, _cells, first = self.reconstruct_distributed(w_min, color_by_rgb, color_by_confidence)
+        n = int(verts.shape[0])
+        dev = verts.device
+        total_t = torch.tensor([n], dtype=torch.int64, device=dev)
+        if self.world > 1:
+            dist.all_reduce(total_t, op=dist.ReduceOp.SUM, group=self.group)
+        total = int(total_t.item())
+        has_rgb = rgb is not None
+        header = ("ply\nformat binary_little_endian 1.0\ncomment PCL generated\n"
+                  f"element vertex {3 * total}\nproperty float x\nproperty float y\nproperty float z\n" +
+                  ("property uchar red\nproperty uchar green\nproperty uchar blue\n" if has_rgb else "") +
+                  f"element face {total}\nproperty list uchar int vertex_indices\nend_header\n").encode()
+        vrec, frec = 12 + (3 if has_rgb else 0), 13
+        xyz = verts.cpu().numpy().reshape(-1, 3)
+        if not np.array_equal(self.global_transform, np.eye(4)):
+            xyz = transform_points_f64(xyz, np.asarray(self.global_transform, dtype=np.float64))
+        vbuf = np.zeros((3 * n, vrec), dtype=np.uint8)
+        vbuf[:, :12] = np.ascontiguousarray(xyz, dtype="<f4").view(np.uint8).reshape(-1, 12)
+        if has_rgb:
+            vbuf[:, 12:15] = rgb.cpu().numpy().reshape(-1, 3)
+        fbuf = np.zeros((n, frec), dtype=np.uint8)
+        fbuf[:, 0] = 3
+        idx = (3 * first + np.arange(3 * n, dtype=np.int64)).astype("<i4").reshape(n, 3)
+        fbuf[:, 1:] = idx.view(np.uint8).reshape(n, 12)
+        if self.rank == 0:  # header + file size first, then everyone writes its ranges
+            with open(filename, "wb") as f:
+                f.write(header)
+                f.truncate(len(header) + 3 * total * vrec + total * frec)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        fd = os.open(filename, os.O_WRONLY)
+        try:
+            os.pwrite(fd, vbuf.tobytes(), len(header) + 3 * first * vrec)
+            os.pwrite(fd, fbuf.tobytes(), len(header) + 3 * total * vrec + first * frec)
+        finally:
+            os.close(fd)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        return total
 
     # -- getFxn / getGradient / getHessian -------------------------------------------------------------------
     def sample(self, pts, dst=0):

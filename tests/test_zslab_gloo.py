@@ -74,6 +74,8 @@ def _worker(rank, world, port, out_path):
     dv, dc, dk, first = vol.reconstruct_distributed(w_min=1.0, color_by_rgb=True, samples=64)
     slices = [None] * world if rank == 0 else None
     dist.gather_object((first, dv.numpy(), dc.numpy(), dk.numpy()), slices, dst=0)
+    n_ply = vol.save_ply(out_path + ".ply", w_min=1.0, color_by_rgb=True)   # every rank writes its own byte ranges
+    assert n_ply == sum(s[3].shape[0] for s in slices) if rank == 0 else n_ply > 0
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     samp = vol.sample(pts)
     renders, rounds = [], []
@@ -161,6 +163,16 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     assert np.array_equal(got["dverts"].reshape(-1, 3), verts) and np.array_equal(got["drgb"].reshape(-1, 3), rgb)
     assert got["dfirst"].tolist() == np.concatenate([[0], np.cumsum(got["dcount"])[:-1]]).tolist()
     assert got["dcount"].min() > 0.4 * len(cells) / world and got["dcount"].max() < 2.0 * len(cells) / world
+    # the PLY the ranks wrote together: header, then 3n vertex records (xyz + rgb), then n faces (3, i, i+1, i+2)
+    blob = open(out + ".ply", "rb").read()
+    head, body = blob.split(b"end_header\n", 1)
+    n = len(cells)
+    assert f"element vertex {3 * n}\n".encode() in head and f"element face {n}\n".encode() in head and b"property uchar red" in head
+    assert len(body) == 3 * n * 15 + n * 13
+    vrec = np.frombuffer(body[:3 * n * 15], np.uint8).reshape(3 * n, 15)
+    assert np.array_equal(vrec[:, :12].copy().view(np.float32), verts) and np.array_equal(vrec[:, 12:], rgb)
+    frec = np.frombuffer(body[3 * n * 15:], np.uint8).reshape(n, 13)
+    assert (frec[:, 0] == 3).all() and np.array_equal(frec[:, 1:].copy().view(np.int32).ravel(), np.arange(3 * n, dtype=np.int32))
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, grad, _ = ov.sample(pts)
     assert np.array_equal(got["ok"], ok)

@@ -189,6 +189,11 @@ def test_zslab_volume_world1_end_to_end(gpu, tmp_path):
     dv, dc, dk, first = vol.reconstruct_distributed(w_min=1.0, color_by_confidence=True)
     assert first == 0 and np.array_equal(dk.cpu().numpy().astype(np.uint64), cells2)
     assert_same_f32(dv.cpu().numpy().reshape(-1, 3), v2, "distributed mesh (world 1)")
+    ply = str(tmp_path / "mesh.ply")
+    assert vol.save_ply(ply, w_min=1.0, color_by_confidence=True) == len(cells2)
+    body = open(ply, "rb").read().split(b"end_header\n", 1)[1]
+    vrec = np.frombuffer(body[:3 * len(cells2) * 15], np.uint8).reshape(-1, 15)
+    assert np.array_equal(vrec[:, :12].copy().view(np.float32), v2) and np.array_equal(vrec[:, 12:], c2)
     pts = np.random.RandomState(1).uniform(-0.06, 0.06, (300, 3)).astype(np.float32)
     ok, val, _, _ = vol.sample(pts)
     ok2, val2, _, _ = ov.sample(pts)
