@@ -277,6 +277,45 @@ class TSDFVolumeOctree:
         ok, val, _, _ = self.sample(pts, want_grad=False, want_hess=False)
         return ok, val
 
+    def getGradient(self, pts):
+        """Batched ``getGradient`` (tsdf_volume_octree.cpp:681-700): returns (ok, grad (n,3))."""
+        ok, _, grad, _ = self.sample(pts, want_hess=False)
+        return ok, grad
+
+    def getHessian(self, pts):
+        """Batched ``getHessian`` (:703-726): returns (ok, hessian (n,3,3))."""
+        ok, _, _, hess = self.sample(pts, want_grad=False)
+        return ok, hess
+
+    def getFxnAndGradient(self, pts):
+        """:728-738 -- (ok, val, grad)."""
+        ok, val, grad, _ = self.sample(pts, want_hess=False)
+        return ok, val, grad
+
+    def getFxnGradientAndHessian(self, pts):
+        """:740-752 -- (ok, val, grad, hessian)."""
+        return self.sample(pts)
+
+    def getVoxelCenter(self, x, y, z):
+        """tsdf_volume_octree.cpp:553-560: (i + 0.5) * size / (double)res - size/2 in double, stored as float
+        (the closed form; the integrate kernel uses the octree's node centres instead, see centers())."""
+        out = []
+        for i, a in zip((x, y, z), range(3)):
+            size = np.float32(self._p.size[a])
+            off = np.float32(np.float64(size) / 2.0)
+            out.append(np.float32((np.float64(i) + 0.5) * np.float64(size) / np.float64(self._p.res[a]) - np.float64(off)))
+        return tuple(out)
+
+    def getVoxelIndex(self, x, y, z):
+        """tsdf_volume_octree.cpp:562-574: (has_voxel, (ix, iy, iz)) with floor(((double)v + size/2) / size * res)."""
+        idx = []
+        for v, a in zip((x, y, z), range(3)):
+            size = np.float64(np.float32(self._p.size[a]))
+            q = np.floor((np.float64(np.float32(v)) + size / 2.0) / size * np.float64(self._p.res[a]))
+            idx.append(int(q) if np.isfinite(q) and abs(q) < 2 ** 31 else -2 ** 31)  # cvttsd2si on overflow / NaN
+        ok = all(0 <= i < r for i, r in zip(idx, self._p.res))
+        return ok, tuple(idx)
+
     def sample(self, pts, want_grad=True, want_hess=True):
         """getFxn / getGradient / getHessian (tsdf_volume_octree.cpp:655-828), batched."""
         h = self._need()

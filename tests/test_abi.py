@@ -109,3 +109,30 @@ def test_scene_depth_is_analytic():
     assert np.isnan(d[0, 0])
     # a ray that misses the sphere but enters the box hits the far face z = +0.47 S
     assert abs(d[cy, cx + 80] - (2.2 + 0.47) * sc.size) < 1e-5
+
+
+def test_python_mirror_voxel_center_and_index_equal_the_reference():
+    """getVoxelCenter / getVoxelIndex (tsdf_volume_octree.cpp:553-574) are host arithmetic in the Python mirror:
+    bit for bit the reference's, on a non-dyadic default-style grid (3 m / 512) and a dyadic one."""
+    from oracle import refbind
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    rng = np.random.RandomState(2)
+    for res, size in [(512, 3.0), (64, 0.25), (100, 1.7)]:
+        ref = refbind.RefVolume(res, size, 640, 480, 525.0, 525.0, 319.5, 239.5, 0.0, 3.0, dense=False)
+        v = TSDFVolumeOctree()
+        v.setResolution(res, res, res)
+        v.setGridSize(size, size, size)
+        out = np.empty(3, np.float32)
+        for i, j, k in rng.randint(0, res, (50, 3)):
+            ref.L.ct_voxel_center(ref.h, int(i), int(j), int(k), out.ctypes.data_as(C.POINTER(C.c_float)))
+            assert tuple(np.float32(c) for c in v.getVoxelCenter(i, j, k)) == tuple(out)
+        idx = (C.c_int * 3)()
+        pts = rng.uniform(-0.6 * size, 0.6 * size, (200, 3)).astype(np.float32)
+        pts[:3] = [[size / 2, 0, 0], [-size / 2, 0, 0], [np.float32(size / 2) - np.float32(1e-7), 0, 0]]
+        for x, y, z in pts:
+            inside = bool(ref.L.ct_voxel_index(ref.h, float(x), float(y), float(z), idx))
+            ok, mine = v.getVoxelIndex(x, y, z)
+            assert ok == inside and mine == tuple(idx), (x, y, z, mine, tuple(idx))
+        ref.close()
