@@ -193,7 +193,7 @@ int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes) {
 // (measured: every other integrateCloud taking 22 ms instead of 2.2 ms after a renderView into a fresh array).
 // Going through pinned memory costs one host memcpy (~10 GB/s, overlapped with the DMA chunk by chunk) and is
 // the same every time.
-static const size_t kBounceChunk = 8u << 20;
+static const size_t kBounceChunk = 2u << 20;
 
 static int bounce_ready(tsdf_hip_volume *v) {
   if (!v->bounce) {

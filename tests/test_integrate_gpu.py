@@ -156,8 +156,9 @@ def test_upload_download_roundtrip(gpu):
 
 
 def test_block_transfers_across_bounce_chunks(gpu):
-    """Host transfers move through a pinned two-slot bounce buffer in 8 MiB chunks (tsdf_to_host / tsdf_to_device):
-    blocks of 2.2 chunks, exactly 1 chunk, and a few bytes, back to back and in both directions, must arrive intact."""
+    """Host transfers move through a pinned two-slot bounce buffer in 2 MiB chunks (tsdf_to_host / tsdf_to_device):
+    blocks of 7.9 chunks, exactly 4 chunks, a few bytes and 14+ chunks, back to back and in both directions, must
+    arrive intact."""
     vol, sc = make_volume(64, color=True, res3=(176, 168, 160), size3=(0.25, 0.25, 0.25))
     vol.setLayout(capi.LAYOUT_F32W)
     vol.reset()
