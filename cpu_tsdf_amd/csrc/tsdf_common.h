@@ -93,6 +93,8 @@ struct TsdfDeviceScope {
   TsdfDeviceScope _device_scope(dev); \
   TSDF_HIP_TRY(_device_scope.err)
 
+// Per-axis voxel-centre table (tsdf_core.hip): the octree's node-centre recurrence, or the closed form.
+void tsdf_build_centers(int res, float size, std::vector<float> &out, int *levels);
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 // Copies between DEVICE memory and the CALLER's host memory, through the handle's pinned bounce buffer in chunks
 // (two slots, the host memcpy of one chunk overlapping the DMA of the next).  tsdf_to_host returns with the

@@ -132,7 +132,7 @@ static int ilog2_exact(int v) {
   return l;
 }
 
-static void build_centers(int res, float size, std::vector<float> &out, int *levels) {
+void tsdf_build_centers(int res, float size, std::vector<float> &out, int *levels) {
   out.resize(res);
   const int L = ilog2_exact(res);
   *levels = L;
@@ -360,7 +360,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (rgbn)
     for (int c = 0; c < 4; ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
   for (int a = 0; a < 3; ++a) {
-    build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
+    tsdf_build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
     // fails k_integrate's sensor-range test, so voxels of the pitch padding are never observed
     std::vector<float> padded(v->h_ctr[a]);

@@ -689,6 +689,7 @@ static bool observable_index_box(const tsdf_hip_volume *h, const float T[12], in
     const std::vector<float> &ctr = h->h_ctr[a];
     const int n = (int)ctr.size();
     const double margin = 2.0 * (double)p.size[a] / (double)p.res[a] + 1e-5 * (big + fabs((double)p.size[a]));
+    if (mx[a] + margin < (double)ctr.front() || mn[a] - margin > (double)ctr.back()) *empty = true;  // wholly beside the grid
     lo[a] = (int)(std::lower_bound(ctr.begin(), ctr.end(), (float)(mn[a] - margin)) - ctr.begin());
     hi[a] = (int)(std::upper_bound(ctr.begin(), ctr.end(), (float)(mx[a] + margin)) - ctr.begin()) - 1;
     if (lo[a] > 0) --lo[a];  // (the float casts above may have rounded inwards)
@@ -1078,6 +1079,30 @@ k_calib_rmw(float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict_
       *pk = *pk ^ xorv;
     }
   }
+}
+
+// Test hook, host only (no device needed): the index box launch_integrate would restrict a frame's launch to.
+// rc 0 and box = {lo x,y,z, hi x,y,z} (inclusive); *state = 0 box valid, 1 nothing observable, 2 no claim.
+extern "C" int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam_from_vol[12], int32_t box[6], int32_t *state) {
+  if (!p || !cam_from_vol || !box || !state) return TSDF_HIP_E_INVALID;
+  tsdf_hip_volume v;
+  v.p = *p;
+  for (int a = 0; a < 3; ++a) {
+    if (p->res[a] <= 0 || !(p->size[a] > 0.f)) return TSDF_HIP_E_INVALID;
+    tsdf_build_centers(p->res[a], p->size[a], v.h_ctr[a], &v.levels[a]);
+  }
+  int lo[3], hi[3];
+  bool empty = false;
+  if (!observable_index_box(&v, cam_from_vol, lo, hi, &empty)) {
+    *state = 2;
+    return TSDF_HIP_OK;
+  }
+  *state = empty ? 1 : 0;
+  for (int a = 0; a < 3; ++a) {
+    box[a] = lo[a];
+    box[3 + a] = hi[a];
+  }
+  return TSDF_HIP_OK;
 }
 
 extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written) {

@@ -299,6 +299,9 @@ int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *
 /* Test hook: the voxel Octree::getContainingVoxel (src/lib/octree.cpp:112-133,628-643) returns for n points,
  * as the raycast kernel computes it: idx = i, j, k per point, or -1, -1, -1 where the reference returns NULL. */
 int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx);
+/* Test hook, host only: the voxel index box {lo x,y,z, hi x,y,z} (inclusive) the integrate launch is restricted to for
+ * this pose; *state = 0 box valid, 1 nothing can be observed, 2 no claim (the launch then covers the whole slab). */
+int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam_from_vol[12], int32_t box[6], int32_t *state);
 
 /* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to

@@ -1,0 +1,75 @@
+"""CPU tier: the launch-shrinking index box of integrateCloud (observable_index_box, cpu_tsdf_amd/csrc/
+tsdf_integrate.hip) must contain every voxel the reference's updateVoxel can possibly observe -- otherwise results
+would silently change.  Property test on the host (tsdf_hip_selftest_index_box needs no device): random grids
+(non-cubic, dyadic and not), intrinsics, sensor ranges and poses (inside, outside, looking away, sheared); the
+oracle integrates a frame whose every pixel returns a far depth, so that EVERY voxel passing the range and
+image tests (hpp:146, .cpp:611-617) is observed, and the observed set is compared with the box."""
+import ctypes as C
+
+import numpy as np
+
+from cpu_tsdf_amd import capi, synth
+from oracle.oracle import OracleVolume
+
+
+def index_box(p, T):
+    box = (C.c_int32 * 6)()
+    state = C.c_int32(-1)
+    capi.check(capi.load().tsdf_hip_selftest_index_box(C.byref(p), capi.as_f32p(T), box, C.byref(state)), "index_box")
+    return int(state.value), np.array(box[:3]), np.array(box[3:])
+
+
+def test_index_box_contains_every_observable_voxel():
+    rng = np.random.RandomState(23)
+    tight = empty = whole = 0
+    for case in range(400):
+        p = capi.default_params()
+        res = [int(r) for r in rng.choice([16, 24, 32, 40, 56], 3)]
+        size = [float(s) for s in rng.uniform(0.5, 4.0, 3)]
+        p.res[:], p.size[:] = res, size
+        W, H = (64, 48) if case % 3 else (40, 56)
+        p.image_width, p.image_height = W, H
+        f = float(rng.uniform(25.0, 90.0))
+        p.fx, p.fy, p.cx, p.cy = f, f * float(rng.uniform(0.8, 1.2)), W / 2 - 0.5 + float(rng.uniform(-5, 5)), H / 2 - 0.5
+        p.min_sensor_dist = float(rng.choice([0.0, 0.2]))
+        p.max_sensor_dist = float(rng.uniform(0.3, 6.0))
+        p.max_dist_pos = p.max_dist_neg = 0.03
+        ext = max(size)
+        eye = rng.uniform(-1.2 * ext, 1.2 * ext, 3) * (1.0 if case % 4 else 0.3)
+        tgt = rng.uniform(-0.5 * ext, 0.5 * ext, 3) if case % 7 else eye + (eye - 0.0) + 1e-3   # sometimes looking away
+        tr = synth.look_at_pose(eye, target=tgt)
+        if case % 5 == 0:  # a sheared, scaled pose
+            tr = tr.copy()
+            tr[:3, :3] = tr[:3, :3] @ (np.eye(3) + rng.uniform(-0.15, 0.15, (3, 3)))
+        T = synth.cam_from_vol_f32(tr)
+        ov = OracleVolume(p)
+        n = ov.integrate(np.full((H, W), 1.0e6, np.float32), None, T)
+        state, lo, hi = index_box(p, np.ascontiguousarray(T, np.float32).reshape(12))
+        seen = np.argwhere(ov.w > 0)[:, ::-1]  # (x, y, z)
+        assert len(seen) == n
+        if state == 1:
+            assert n == 0, (case, n)
+            empty += 1
+        elif state == 0:
+            if n:
+                assert (seen >= lo).all() and (seen <= hi).all(), (case, lo, hi, seen.min(0), seen.max(0))
+                # and not absurdly loose: within a few voxels + the pyramid's own slack of the true bounding box
+            vol_box = np.prod(np.clip(hi, 0, np.array(res) - 1) - np.clip(lo, 0, np.array(res) - 1) + 1)
+            tight += vol_box < 0.5 * np.prod(res)
+        else:
+            whole += 1
+    assert tight > 60 and empty > 10 and whole == 0
+
+
+def test_index_box_gives_up_on_degenerate_input():
+    p = capi.default_params()
+    T = np.zeros(12, np.float32)              # singular pose
+    assert index_box(p, T)[0] == 2
+    T = synth.cam_from_vol_f32(np.eye(4)).reshape(12).astype(np.float32)
+    p.max_sensor_dist = float("inf")
+    assert index_box(p, T)[0] == 2            # unbounded range: no claim
+    p.max_sensor_dist = -1.0
+    assert index_box(p, T)[0] == 1            # nothing can have 0 < z <= -1
+    p.max_sensor_dist = 3.0
+    p.fx = 0.0
+    assert index_box(p, T)[0] == 2
