@@ -116,6 +116,7 @@ SIGNATURES = {
     "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "tsdf_hip_selftest_block_flags": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.c_int, C.c_int, _u8p]),
     "tsdf_hip_selftest_index_box": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdf_hip_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_save_blocks": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta), C.c_char_p, BLOCK_FN, C.c_void_p]),

@@ -1105,6 +1105,37 @@ extern "C" int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam
   return TSDF_HIP_OK;
 }
 
+// Test hook, host only: k_cull's predicate (box_may_be_observed) for every block of the WHOLE grid, blocks of
+// bx_vox voxels along x by by_rows rows of one plane; flags[(z * gy + by) * gx + bx] = 1 if the block may hold an
+// observable voxel.  gx = ceil(nx / bx_vox), gy = ceil(ny / by_rows).
+extern "C" int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol[12], int bx_vox, int by_rows,
+                                             uint8_t *flags) {
+  if (!p || !cam_from_vol || !flags || bx_vox < 1 || by_rows < 1) return TSDF_HIP_E_INVALID;
+  std::vector<float> ctr[3];
+  for (int a = 0; a < 3; ++a) {
+    int levels;
+    if (p->res[a] <= 0 || !(p->size[a] > 0.f)) return TSDF_HIP_E_INVALID;
+    tsdf_build_centers(p->res[a], p->size[a], ctr[a], &levels);
+  }
+  CullArgs c;
+  for (int i = 0; i < 12; ++i) c.m[i] = cam_from_vol[i];
+  c.fx = p->fx, c.fy = p->fy, c.cx = p->cx, c.cy = p->cy;
+  c.zlo = p->min_sensor_dist > 0 ? p->min_sensor_dist : 0;
+  c.zmax = p->max_sensor_dist;
+  c.W = p->image_width, c.H = p->image_height, c.nx = p->res[0], c.ny = p->res[1], c.z_global0 = 0;
+  c.bx_vox = bx_vox, c.by_rows = by_rows;
+  c.gx = (p->res[0] + bx_vox - 1) / bx_vox, c.gy = (p->res[1] + by_rows - 1) / by_rows, c.gz = p->res[2];
+  for (int bz = 0; bz < c.gz; ++bz)
+    for (int by = 0; by < c.gy; ++by)
+      for (int bx = 0; bx < c.gx; ++bx) {  // (the same index arithmetic as k_cull)
+        const int xa = bx * c.bx_vox, xb = std::min(c.nx, xa + c.bx_vox) - 1;
+        const int ya = by * c.by_rows, yb = std::min(c.ny, ya + c.by_rows) - 1;
+        flags[((size_t)bz * c.gy + by) * c.gx + bx] =
+            box_may_be_observed(c, ctr[0][xa], ctr[0][xb], ctr[1][ya], ctr[1][yb], ctr[2][bz]) ? 1 : 0;
+      }
+  return TSDF_HIP_OK;
+}
+
 extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_ON_DEVICE(h->device);

@@ -302,6 +302,10 @@ int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int3
 /* Test hook, host only: the voxel index box {lo x,y,z, hi x,y,z} (inclusive) the integrate launch is restricted to for
  * this pose; *state = 0 box valid, 1 nothing can be observed, 2 no claim (the launch then covers the whole slab). */
 int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam_from_vol[12], int32_t box[6], int32_t *state);
+/* Test hook, host only: the brick cull's per-block predicate over the whole grid (blocks of bx_vox voxels along x by
+ * by_rows rows of one plane); flags[(z * gy + by) * gx + bx] with gx = ceil(nx / bx_vox), gy = ceil(ny / by_rows). */
+int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol[12], int bx_vox, int by_rows,
+                                  uint8_t *flags);
 
 /* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to

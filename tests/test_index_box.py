@@ -61,6 +61,42 @@ def test_index_box_contains_every_observable_voxel():
     assert tight > 60 and empty > 10 and whole == 0
 
 
+def test_brick_cull_predicate_never_drops_an_observable_voxel():
+    """k_cull's per-block test (box_may_be_observed, evaluated here on the host for every block of the grid): a
+    block holding any voxel the oracle observes must be flagged live; and the flags do cut something."""
+    rng = np.random.RandomState(31)
+    dropped_total = live_total = 0
+    for case in range(150):
+        p = capi.default_params()
+        res = [int(r) for r in rng.choice([24, 33, 40, 64], 3)]
+        size = [float(s) for s in rng.uniform(0.5, 4.0, 3)]
+        p.res[:], p.size[:] = res, size
+        W, H = 64, 48
+        p.image_width, p.image_height = W, H
+        f = float(rng.uniform(25.0, 90.0))
+        p.fx, p.fy, p.cx, p.cy = f, f, W / 2 - 0.5, H / 2 - 0.5 + float(rng.uniform(-4, 4))
+        p.min_sensor_dist = float(rng.choice([0.0, 0.3]))
+        p.max_sensor_dist = float(rng.uniform(0.4, 5.0))
+        ext = max(size)
+        eye = rng.uniform(-1.1 * ext, 1.1 * ext, 3) * (1.0 if case % 3 else 0.3)
+        tr = synth.look_at_pose(eye, target=rng.uniform(-0.5 * ext, 0.5 * ext, 3))
+        if case % 6 == 0:
+            tr = tr.copy()
+            tr[:3, :3] = tr[:3, :3] @ (np.eye(3) + rng.uniform(-0.1, 0.1, (3, 3)))
+        T = np.ascontiguousarray(synth.cam_from_vol_f32(tr), np.float32).reshape(12)
+        bx, by = int(rng.choice([4, 8, 16])), int(rng.choice([1, 4, 8]))
+        gx, gy = -(-res[0] // bx), -(-res[1] // by)
+        flags = np.zeros((res[2], gy, gx), np.uint8)
+        capi.check(capi.load().tsdf_hip_selftest_block_flags(C.byref(p), capi.as_f32p(T), bx, by, capi.as_u8p(flags)), "flags")
+        ov = OracleVolume(p)
+        ov.integrate(np.full((H, W), 1.0e6, np.float32), None, T)
+        z, y, x = np.nonzero(ov.w > 0)
+        assert flags[z, y // by, x // bx].all(), (case, int((flags[z, y // by, x // bx] == 0).sum()))
+        live_total += int(flags.sum())
+        dropped_total += int(flags.size - flags.sum())
+    assert dropped_total > 0.2 * (live_total + dropped_total)
+
+
 def test_index_box_gives_up_on_degenerate_input():
     p = capi.default_params()
     T = np.zeros(12, np.float32)              # singular pose
