@@ -174,7 +174,8 @@ struct RayArgs {
 // record per ray, TSDF_HIP_RAY_RECORD_INTS 32-bit words:
 //   [0] status: 0 untouched (only in a delta buffer), 1 suspended, 2 finished
 //   [1] need_z: global plane of the voxel the main loop needs next (-1: none yet)
-//   [2] niter  [3] hit_voxel  [4] t  [5..7] pt  [8] last_d  [9] last_w  [10] step  [11..15] zero
+//   [2] niter  [3] hit_voxel  [4] t  [5..7] pt  [8] last_d  [9] last_w  [10] step  [11] pixel index
+//   [12] finish flag: the main loop is done, word 4 holds t_star, only the normal is left  [13..15] zero
 //   [16..23] the 8 output floats (valid when finished)
 // k_raycast<true> resumes every suspended ray this handle is responsible for -- need_z inside its OWNED
 // planes [z_begin, z_end), or ray index % world == rank while the ray has not needed a voxel yet -- and
@@ -240,7 +241,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     i = state[RAY_REC * slot + 11];
   }
   if (i < 0 || i >= (int64_t)a.nw * a.nh) return;
-  bool found_crossing = false, all_local = true;
+  bool found_crossing = false, all_local = true, finish_only = false;
   float du[3];
   ray_direction(a, i, du);
   float pt[3] = {a.org[0], a.org[1], a.org[2]};
@@ -263,12 +264,14 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     last_d = __int_as_float(r[8]);
     last_w = __int_as_float(r[9]);
     step = __int_as_float(r[10]);
+    finish_only = r[12] != 0;  // the main loop is done; only the normal at t_star (= t) is left, see below
+    found_crossing = finish_only;
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
   }
   int suspend_z = -1;
-  while (t < a.zmax) {
+  while (!finish_only && t < a.zmax) {
     int64_t vi;
     bool local;
     int kz;
@@ -331,6 +334,7 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     rec[8] = __float_as_int(last_d);
     rec[9] = __float_as_int(last_w);
     rec[10] = __float_as_int(step);
+    rec[12] = 0;
     rec[0] = suspend_z >= 0 ? 1 : 2;
     if (suspend_z >= 0) return;
   }
@@ -341,14 +345,17 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
   if (!found_crossing) {
     o[0] = o[1] = o[2] = NAN;
   } else {
-    bool has_data = true;
-    const float tcurr = t, tprev = t - step;
-    last_d = trilinear(g, a.org[0] + tprev * du[0], a.org[1] + tprev * du[1], a.org[2] + tprev * du[2], has_data,
-                       all_local);
-    dd = trilinear(g, a.org[0] + tcurr * du[0], a.org[1] + tcurr * du[1], a.org[2] + tcurr * du[2], has_data,
-                   all_local);
-    // :389  evaluated in double: unqualified fabs(float) is double fabs(double) under <cmath>
-    const float t_star = (float)((double)t + (double)step * (-1 + fabs((double)(last_d / (last_d - dd)))));
+    float t_star = t;  // finish_only: the record carries t_star in the t word
+    if (!finish_only) {
+      bool has_data = true;
+      const float tcurr = t, tprev = t - step;
+      last_d = trilinear(g, a.org[0] + tprev * du[0], a.org[1] + tprev * du[1], a.org[2] + tprev * du[2], has_data,
+                         all_local);
+      dd = trilinear(g, a.org[0] + tcurr * du[0], a.org[1] + tcurr * du[1], a.org[2] + tcurr * du[2], has_data,
+                     all_local);
+      // :389  evaluated in double: unqualified fabs(float) is double fabs(double) under <cmath>
+      t_star = (float)((double)t + (double)step * (-1 + fabs((double)(last_d / (last_d - dd)))));
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = a.org[k] + t_star * du[k];
     o[6] = t_star;
@@ -357,6 +364,18 @@ k_raycast(const GridView g, const RayArgs a, float *__restrict__ out, unsigned *
     int kz;
     if (!containing(g, o[0], o[1], o[2], vi, local, kz)) {
       o[3] = o[4] = o[5] = NAN;
+    } else if (RESUMABLE && !finish_only &&
+               ((kz - 2 < g.z_first && g.z_first > 0) || (kz + 2 >= g.z_first + g.nz_alloc && g.z_first + g.nz_alloc < g.nz))) {
+      // t_star extrapolates from two trilinear samples and can land ANY distance ahead when they are nearly equal,
+      // so the six samples of the normal (planes kz-2 .. kz+2) may not be held here.  The ray then travels once
+      // more: suspended for the owner of the hit point's plane with the finish flag and t_star in the t word; that
+      // rank recomputes o = org + t_star * du (the same arithmetic) and the normal.
+      rec[0] = 1;
+      rec[1] = kz;
+      rec[4] = __float_as_int(t_star);
+      rec[12] = 1;
+      if (!all_local) atomicAdd(incomplete, 1u);
+      return;
     } else {
       const float s = a.leaf;
       bool valid = true;

@@ -18,7 +18,8 @@ independent during integration, so the grid is cut into contiguous Z-slabs and t
   travels: every rank resumes the rays whose next voxel it owns until they finish or reach another slab
   (``tsdf_hip_raycast_advance``), the per-rank deltas are merged by ONE integer SUM all-reduce per round
   (each ray is advanced by exactly one rank), and this repeats until no ray is suspended -- at most
-  world + 1 rounds, since a ray crosses the slabs monotonically in z.  The refinement walk of a hit and
+  world + 2 rounds: a ray crosses the slabs monotonically in z, and a hit whose extrapolated point lies in
+  another slab travels once more to have its normal computed there.  The refinement walk of a hit and
   its trilinear samples look back/around by up to ``render_halo`` planes, which every rank refreshes from
   both neighbours before rendering.  `exchange="p2p"` keeps only a compact record list per rank and moves each
   suspended record point-to-point to its next owner (traffic ~ rays crossing a boundary).  Results are

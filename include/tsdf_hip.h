@@ -169,7 +169,8 @@ int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const float origi
  * TSDF_HIP_RAY_RECORD_INTS 32-bit words per ray, in DEVICE memory, row-major like the image:
  *   [0] status (1 suspended, 2 finished; 0 = "not touched" in a delta buffer)   [1] global z plane of the
  *   voxel the ray needs next, -1 before it needed any   [2] iterations   [3] hit_voxel   [4] t   [5..7] pt
- *   [8] last_d   [9] last_w   [10] step   [11] the ray's pixel index   [12..15] zero
+ *   [8] last_d   [9] last_w   [10] step   [11] the ray's pixel index   [12] finish flag (the march is done, [4]
+ *   holds t_star and only the normal is left: a hit whose extrapolated point lies in another slab)   [13..15] zero
  *   [16..23] the 8 output floats of tsdf_hip_raycast.
  * tsdf_hip_raycast_begin   writes the start record of every ray (identical on every rank).
  * tsdf_hip_raycast_advance zero-fills d_delta, then resumes every suspended ray of d_state that this
@@ -177,7 +178,7 @@ int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const float origi
  *   ray has not needed a voxel yet) until it finishes or needs another slab's voxel, and writes the new
  *   record to d_delta.  Exactly one rank touches a ray per round, so the caller merges with an integer
  *   SUM all-reduce of the deltas (RCCL) and overwrites the records whose status word is non-zero; it
- *   repeats until no record is suspended.  The refinement walk and the trilinear samples of a hit read up
+ *   repeats until no record is suspended (at most world + 2 rounds).  The refinement walk and the trilinear samples of a hit read up
  *   to tsdf_hip_render_halo(params) planes beyond the owned slab: create the handles with that halo and
  *   refresh it (tsdf_hip_get/set_planes_device) before rendering.  Synchronises the stream. */
 #define TSDF_HIP_RAY_RECORD_INTS 24

@@ -360,7 +360,7 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
   const float min_step = p->max_dist_neg * 3 / 4.; /* :289 */
   /* leaf->getMinSize() is size_ = size_x for every axis (octree.h:63-66) */
   const float lsz = leaf_size(p, 0);
-  int found_crossing = 0;
+  int found_crossing = 0, finish_only = 0;
   float du[3];
   ray_direction(p, rot, ds, i, du);
   float pt[3] = {org[0], org[1], org[2]};
@@ -380,11 +380,13 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
     last_d = i2f(r[8]);
     last_w = i2f(r[9]);
     step = i2f(r[10]);
+    finish_only = r[12] != 0; /* the main loop is done; only the normal at t_star = t is left (see below) */
   } else {
     for (int k = 0; k < 3; ++k) pt[k] += t * du[k];
   }
   int suspend_z = -1;
-  while (t < p->max_sensor_dist) {
+  if (finish_only) found_crossing = 1;
+  while (!finish_only && t < p->max_sensor_dist) {
     int id[3];
     if (oracle_containing(p, pt[0], pt[1], pt[2], id)) {
       if (st && (id[2] < slab[2] || id[2] >= slab[3])) {
@@ -447,6 +449,7 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
     r[8] = f2i(last_d);
     r[9] = f2i(last_w);
     r[10] = f2i(step);
+    r[12] = 0;
     if (suspend_z >= 0) return;
     o = (float *)(r + 16);
   }
@@ -457,19 +460,35 @@ static void ray_one(const oracle_params *p, const float *d, const float *w, cons
     o[0] = o[1] = o[2] = NAN;
     return;
   }
-  int has_data = 1;
-  const float tcurr = t, tprev = t - step;
-  last_d = trilinear(p, d, w, org[0] + tprev * du[0], org[1] + tprev * du[1], org[2] + tprev * du[2], &has_data);
-  dd = trilinear(p, d, w, org[0] + tcurr * du[0], org[1] + tcurr * du[1], org[2] + tcurr * du[2], &has_data);
-  /* :385-388 sets NaN but does not `continue`; :389-390 then overwrites xyz anyway */
-  /* unqualified fabs(float) resolves to double fabs(double) with <cmath> only (g++), so the
-   * update of t_star is evaluated in double */
-  const float t_star = t + step * (-1 + fabs(last_d / (last_d - dd)));
+  float t_star = t; /* finish_only: the record carries t_star in the t word */
+  if (!finish_only) {
+    int has_data = 1;
+    const float tcurr = t, tprev = t - step;
+    last_d = trilinear(p, d, w, org[0] + tprev * du[0], org[1] + tprev * du[1], org[2] + tprev * du[2], &has_data);
+    dd = trilinear(p, d, w, org[0] + tcurr * du[0], org[1] + tcurr * du[1], org[2] + tcurr * du[2], &has_data);
+    /* :385-388 sets NaN but does not `continue`; :389-390 then overwrites xyz anyway */
+    /* unqualified fabs(float) resolves to double fabs(double) with <cmath> only (g++), so the
+     * update of t_star is evaluated in double */
+    t_star = t + step * (-1 + fabs(last_d / (last_d - dd)));
+  }
   for (int k = 0; k < 3; ++k) o[k] = org[k] + t_star * du[k];
   o[6] = t_star;
   int id[3];
   if (!oracle_containing(p, o[0], o[1], o[2], id)) {
     o[3] = o[4] = o[5] = NAN;
+    return;
+  }
+  /* Slab hand-off only: t_star extrapolates from two trilinear samples and can land ANY distance ahead when they
+   * are nearly equal, so the six samples of the normal may need planes of another slab.  The ray then travels once
+   * more: suspended for the owner of the hit point's plane with the finish flag (word 12) and t_star in the t word;
+   * that rank recomputes o = org + t_star * du (same arithmetic) and the normal.  (Only when the planes the normal
+   * reads, id[2]-2 .. id[2]+2, are not all held here: slab[4..5] = the allocated range.) */
+  if (st && !finish_only && ((id[2] - 2 < slab[4] && slab[4] > 0) || (id[2] + 2 >= slab[5] && slab[5] < p->res[2]))) {
+    int32_t *r = dl + RAY_REC * slot;
+    r[0] = 1;
+    r[1] = id[2];
+    r[4] = f2i(t_star);
+    r[12] = 1;
     return;
   }
   const float xs = lsz, ys = lsz, zs = lsz; /* getSize returns size_ thrice (octree.cpp:58-64) */

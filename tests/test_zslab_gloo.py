@@ -188,7 +188,7 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
             np.array_equal(np.nan_to_num(have, nan=-7.0), np.nan_to_num(want, nan=-7.0)), f"view {k}"
         hits += int(np.isfinite(want[..., 0]).sum())
     assert hits > 2000
-    assert got["rounds"].max() <= world + 1 and got["rounds"].max() >= 2
+    assert got["rounds"].max() <= world + 2 and got["rounds"].max() >= 2   # + 1: a far-extrapolated hit finishes at its owner
     # the distributed checkpoint is byte for byte the file one writer produces from the whole grid
     from tests.common import write_vol_from_arrays
     one = str(tmp_path / "one.vol")

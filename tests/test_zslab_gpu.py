@@ -107,7 +107,7 @@ def test_ray_handoff_between_slab_handles_equals_one_volume(gpu, world):
             if int((state[:, 0] == 1).sum()) == 0:
                 break
         assert int((state[:, 0] == 2).sum()) == state.shape[0]
-        assert rounds <= world + 1
+        assert rounds <= world + 2   # + 1: a hit whose extrapolated point lies in another slab finishes at its owner
         total_rounds += rounds
         have = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(want.shape)
         assert_same_f32(have, want, f"view {k} world {world}")
@@ -142,6 +142,64 @@ def test_ray_handoff_between_slab_handles_equals_one_volume(gpu, world):
         assert_same_f32(out.cpu().numpy().view(np.float32).reshape(want.shape), want, f"list hand-off, view {k} world {world}")
         assert 0 < moved < n * world
     assert total_rounds > len(views(sc.size))  # rays really crossed slabs
+    for s in slabs:
+        s.close()
+    whole.close()
+
+
+def test_ray_handoff_finishes_far_extrapolated_hits_at_their_owner(gpu):
+    """t_star = t + step * (-1 + |d0 / (d0 - d1)|) (tsdf_volume_octree.cpp:389) lands arbitrarily far ahead when the two
+    trilinear samples are nearly equal; the normal's samples then need planes far outside the halo of the slab that
+    found the crossing.  This small configuration (32^3, two slabs of 16 planes, halo 12) has such a ray: its hit
+    point sits 12 planes past the first slab.  The record travels once more (finish flag) and the image still
+    equals the whole-volume kernel's bit for bit."""
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    res, w, h = 32, 80, 60
+    sc = synth.scene_a(res, w, h)
+
+    def conf(v):
+        v.setResolution(res, res, res)
+        v.setGridSize(sc.size, sc.size, sc.size)
+        v.setImageSize(w, h)
+        v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        v.setSensorDistanceBounds(0.0, 3 * sc.size)
+        v.setIntegrateColor(True)
+    halo = render_halo(conf)
+    whole = TSDFVolumeOctree()
+    conf(whole)
+    whole.reset()
+    cuts = [slab_range(res, 2, r) for r in range(2)]
+    slabs = [HipSlab(conf, zb, ze, res, 0, halo=halo) for zb, ze in cuts]
+    fd, fc = slabs[0].frame_buffers()
+    for i in range(3):
+        tr = synth.turntable_pose(i, 3, sc.size)
+        dep, col = sc.depth(tr), sc.bgra(i)
+        whole.integrateCloud(dep, col, tr)
+        fd.copy_(torch.from_numpy(dep))
+        fc.copy_(torch.from_numpy(col))
+        for s in slabs:
+            s.integrate_tensor(fd, fc, tr)
+    for r, s in enumerate(slabs):
+        nb = 1 - r
+        zb, ze = cuts[nb]
+        n = min(halo, ze - zb)
+        z0 = ze - n if nb < r else zb
+        planes = slabs[nb].get_planes(z0, n)
+        slabs[nb].synchronize()
+        s.set_planes(z0, *planes)
+    tr = synth.turntable_pose(0, 8, sc.size)
+    want = whole.renderView(tr, 1, camera_frame=False)
+    state = slabs[0].ray_begin(tr, 1)
+    finish_hops = 0
+    for rounds in range(1, 9):
+        delta = sum(s.ray_advance(tr, 1, state, r, 2) for r, s in enumerate(slabs))
+        finish_hops += int(((delta[:, 0] == 1) & (delta[:, 12] == 1)).sum())
+        state = torch.where(delta[:, :1] != 0, delta, state)
+        if int((state[:, 0] == 1).sum()) == 0:
+            break
+    assert int((state[:, 0] == 2).sum()) == state.shape[0] and finish_hops >= 1
+    have = state[:, 16:24].contiguous().cpu().numpy().view(np.float32).reshape(want.shape)
+    assert_same_f32(have, want, "far-extrapolated hit")
     for s in slabs:
         s.close()
     whole.close()
