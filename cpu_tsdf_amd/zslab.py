@@ -287,41 +287,42 @@ class ZSlabVolume:
 
     # -- marching cubes ---------------------------------------------------------------------------------
     def exchange_halo(self, planes=1, both=False):
-        """Every rank receives the first `planes` planes of its +z neighbour into its upper halo and, with
-        `both`, the last `planes` planes of its -z neighbour into its lower halo (point-to-point, one batch).
-        Slabs thinner than `planes` forward what they own; the rest of the halo then stays at its reset
-        value, and a ray that needs it fails loudly in tsdf_hip_raycast_advance."""
+        """Every rank fills the `planes` halo planes above its slab (and, with `both`, below it) with the planes their
+        owners hold -- point-to-point, one batch.  The owner is usually the adjacent rank; slabs thinner than
+        `planes` make the halo span several ranks, each of which sends what it owns of it."""
         if self.world == 1:
             return
         planes = min(int(planes), self.halo)
-        ops, recv_up, recv_dn = [], None, None
-        n_mine = min(planes, self.z_end - self.z_begin)
-        if self.rank > 0 and n_mine > 0:  # my first planes go down to rank - 1
-            send = self.slab.get_planes(self.z_begin, n_mine)
-            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self.group) for t in send if t is not None]
-        if both and self.rank < self.world - 1 and n_mine > 0:  # my last planes go up to rank + 1
-            send_up = self.slab.get_planes(self.z_end - n_mine, n_mine)
-            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self.group) for t in send_up if t is not None]
+        lo = max(0, self.z_begin - planes) if both else self.z_begin
+        hi = min(self.nz, self.z_end + planes)
+        want = [(lo, self.z_begin), (self.z_end, hi)]          # my halo ranges (below, above)
+        ops, recvs, keep = [], [], []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            zb, ze = slab_range(self.nz, self.world, r)
+            # what rank r wants of MY planes (the same arithmetic it does for itself)
+            rlo = max(0, zb - planes) if both else zb
+            rhi = min(self.nz, ze + planes)
+            for a, b in ((rlo, zb), (ze, rhi)):
+                s0, s1 = max(a, self.z_begin), min(b, self.z_end)
+                if s0 < s1:
+                    send = self.slab.get_planes(s0, s1 - s0)
+                    keep.append(send)
+                    ops += [dist.P2POp(dist.isend, t, r, self.group) for t in send if t is not None]
+            # what I want of rank r's planes
+            for a, b in want:
+                r0, r1 = max(a, zb), min(b, ze)
+                if r0 < r1:
+                    buf = self.slab.plane_buffers(r1 - r0)
+                    recvs.append((r0, buf))
+                    ops += [dist.P2POp(dist.irecv, t, r, self.group) for t in buf if t is not None]
         self.slab.synchronize()
-        if self.rank < self.world - 1:
-            nb = slab_range(self.nz, self.world, self.rank + 1)
-            n_up = min(planes, nb[1] - nb[0])
-            if n_up > 0:
-                recv_up = self.slab.plane_buffers(n_up)
-                ops += [dist.P2POp(dist.irecv, t, self.rank + 1, self.group) for t in recv_up if t is not None]
-        if both and self.rank > 0:
-            nb = slab_range(self.nz, self.world, self.rank - 1)
-            n_dn = min(planes, nb[1] - nb[0])
-            if n_dn > 0:
-                recv_dn = self.slab.plane_buffers(n_dn)
-                ops += [dist.P2POp(dist.irecv, t, self.rank - 1, self.group) for t in recv_dn if t is not None]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        if recv_up is not None:
-            self.slab.set_planes(self.z_end, *recv_up)
-        if recv_dn is not None:
-            self.slab.set_planes(self.z_begin - recv_dn[0].shape[0], *recv_dn)
+        for z0, buf in recvs:
+            self.slab.set_planes(z0, *buf)
 
     def reconstruct(self, w_min=2.5, color_by_rgb=False, color_by_confidence=False, dst=0, gather=True):
         """MarchingCubesTSDFOctree::reconstruct over all slabs.  Returns the merged mesh on rank `dst`

@@ -194,3 +194,65 @@ def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     one = str(tmp_path / "one.vol")
     write_vol_from_arrays(one, cfg._p, ov.d, ov.w, ov.rgb, global_transform=synth.turntable_pose(1, 8, sc.size))
     assert open(out + ".vol", "rb").read() == open(one, "rb").read()
+
+
+def _thin_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.fake_slab import OracleSlab
+    res, w, h = 32, 64, 48
+    sc = synth.scene_a(res, w, h)
+
+    def conf(v):
+        v.setResolution(res, res, res)
+        v.setGridSize(sc.size, sc.size, sc.size)
+        v.setImageSize(w, h)
+        v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        v.setSensorDistanceBounds(0.0, 3 * sc.size)
+        v.setIntegrateColor(True)
+    vol = ZSlabVolume(conf, res, slab_factory=OracleSlab)
+    assert vol.halo > vol.z_end - vol.z_begin          # the halo spans more than one neighbour
+    for i in range(3):
+        tr = synth.turntable_pose(i, 3, sc.size)
+        vol.integrateCloud(sc.depth(tr) if rank == 0 else None, sc.bgra(i) if rank == 0 else None, tr)
+    views = [synth.turntable_pose(0, 8, sc.size), synth.look_at_pose((0.1, -0.05, 0.2))]
+    imgs = [vol.renderView(tr, 1, exchange=ex) for tr in views for ex in ("allreduce", "p2p")]
+    mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    if rank == 0:
+        np.savez(out_path, cells=mesh["cells"], verts=mesh["vertices"], **{f"img{k}": im for k, im in enumerate(imgs)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slabs_thinner_than_the_render_halo(tmp_path):
+    """Five slabs of 6-7 planes under a 12-plane render halo: every rank's halo is filled by SEVERAL owners, rays cross
+    up to five slabs and hit points extrapolate into far slabs; images and mesh still equal one volume's."""
+    from cpu_tsdf_amd.volume import eigen_affine_inverse, transform_cloud_with_normals
+    from oracle.oracle import OracleVolume
+    from tests.fake_slab import _Cfg
+    out = str(tmp_path / "thin.npz")
+    mp.spawn(_thin_worker, args=(5, _free_port(), out), nprocs=5, join=True)
+    got = np.load(out)
+    res, w, h = 32, 64, 48
+    sc = synth.scene_a(res, w, h)
+    cfg = _Cfg()
+    cfg.setResolution(res, res, res)
+    cfg.setGridSize(sc.size, sc.size, sc.size)
+    cfg.setImageSize(w, h)
+    cfg.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    cfg.setSensorDistanceBounds(0.0, 3 * sc.size)
+    cfg.setIntegrateColor(True)
+    ov = OracleVolume(cfg._p)
+    for i in range(3):
+        tr = synth.turntable_pose(i, 3, sc.size)
+        ov.integrate(sc.depth(tr), sc.bgra(i), synth.cam_from_vol_f32(tr))
+    views = [synth.turntable_pose(0, 8, sc.size), synth.look_at_pose((0.1, -0.05, 0.2))]
+    k = 0
+    for tr in views:
+        want = transform_cloud_with_normals(ov.raycast(tr, 1), eigen_affine_inverse(tr))
+        for _ in range(2):
+            have = got[f"img{k}"]
+            k += 1
+            assert np.array_equal(np.nan_to_num(have, nan=-7.0), np.nan_to_num(want, nan=-7.0))
+    verts, rgb, cells = ov.march(1.0, 1)
+    assert len(cells) > 300 and np.array_equal(got["cells"], cells) and np.array_equal(got["verts"], verts)
