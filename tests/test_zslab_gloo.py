@@ -218,8 +218,20 @@ def _thin_worker(rank, world, port, out_path):
     views = [synth.turntable_pose(0, 8, sc.size), synth.look_at_pose((0.1, -0.05, 0.2))]
     imgs = [vol.renderView(tr, 1, exchange=ex) for tr in views for ex in ("allreduce", "p2p")]
     mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    # checkpoint with 16^3 blocks, each crossing three of the thin slabs; and getFxn routed to the owners
+    from cpu_tsdf_amd import capi
+    capi.set_tuning("vol_chunk", 16)
+    vol.save(out_path + ".vol", dst=2)
+    dist.barrier()
+    back = ZSlabVolume.load(out_path + ".vol", slab_factory=OracleSlab, src=1)
+    zb, ze = vol.z_begin, vol.z_end
+    for name in ("d", "w", "rgb"):
+        assert np.array_equal(getattr(back.slab.ov, name)[zb:ze].view(np.uint8), getattr(vol.slab.ov, name)[zb:ze].view(np.uint8))
+    pts = np.random.RandomState(3).uniform(-0.05, 0.05, (200, 3)).astype(np.float32)
+    samp = vol.sample(pts)
     if rank == 0:
-        np.savez(out_path, cells=mesh["cells"], verts=mesh["vertices"], **{f"img{k}": im for k, im in enumerate(imgs)})
+        np.savez(out_path, cells=mesh["cells"], verts=mesh["vertices"], ok=samp[0], val=samp[1],
+                 **{f"img{k}": im for k, im in enumerate(imgs)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -256,3 +268,5 @@ def test_slabs_thinner_than_the_render_halo(tmp_path):
             assert np.array_equal(np.nan_to_num(have, nan=-7.0), np.nan_to_num(want, nan=-7.0))
     verts, rgb, cells = ov.march(1.0, 1)
     assert len(cells) > 300 and np.array_equal(got["cells"], cells) and np.array_equal(got["verts"], verts)
+    ok, val, _, _ = ov.sample(np.random.RandomState(3).uniform(-0.05, 0.05, (200, 3)).astype(np.float32))
+    assert np.array_equal(got["ok"], ok) and ok.sum() > 20 and np.array_equal(got["val"][ok], val[ok])
