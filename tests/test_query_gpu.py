@@ -319,3 +319,34 @@ def test_raycast_and_mesh_at_512_properties(gpu):
     r = np.linalg.norm(v, axis=1)
     on_sphere = np.abs(r - sc.r) < 3 * sc.size / 256
     assert on_sphere.sum() > 10000
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_marching_cubes_on_a_random_volume(gpu, color):
+    """Every cube configuration: random distances (3 % beyond +-1), random weights (some zero or under the threshold)
+    and colours uploaded into the HIP volume; mesh == the oracle's (which tests/test_oracle_golden.py pins to the
+    reference on the same kind of volume), triangle for triangle."""
+    res = 48
+    vol, sc = make_volume(res, 80, 60, color=color)
+    vol.reset()
+    rng = np.random.RandomState(40 + color)
+    ov = OracleVolume(vol._p)
+    ov.d[:] = rng.uniform(-1.03, 1.03, ov.d.shape).astype(np.float32)
+    ov.w[:] = np.where(rng.rand(*ov.w.shape) < 0.04, rng.randint(0, 2, ov.w.shape), rng.randint(2, 4, ov.w.shape)).astype(np.float32)
+    if color:
+        ov.rgb[:] = rng.randint(0, 256, ov.rgb.shape)
+    vol.upload(ov.d, ov.w, ov.rgb if color else None)
+    for w_min, mode in [(1.5, 1 if color else 0), (0.5, 2)]:
+        mc = MarchingCubesTSDFOctree()
+        mc.setInputTSDF(vol)
+        mc.setMinWeight(w_min)
+        mc.setColorByRGB(mode == 1)
+        mc.setColorByConfidence(mode == 2)
+        mesh = mc.reconstruct(want_cells=True)
+        v, c, cells = ov.march(w_min, mode)
+        assert len(cells) > 20000
+        assert np.array_equal(mesh["cells"], cells)
+        assert_same_f32(mesh["vertices"], v, f"random volume, w_min {w_min}")
+        if mode:
+            assert np.array_equal(mesh["rgb"], c)
+    vol.close()
