@@ -350,3 +350,35 @@ def test_marching_cubes_on_a_random_volume(gpu, color):
         if mode:
             assert np.array_equal(mesh["rgb"], c)
     vol.close()
+
+
+def test_raycast_and_sampling_on_a_random_volume(gpu):
+    """k_raycast / k_sample on a volume of random distances and weights (uploaded): erratic steps, sign changes
+    everywhere, refinement walks, t_star extrapolation on nearly equal samples, mostly invalid normals -- == the oracle
+    (pinned to the reference on the same kind of volume in tests/test_oracle_golden.py), float for float."""
+    res, W, H = 32, 80, 60
+    vol, sc = make_volume(res, W, H)
+    vol.reset()
+    rng = np.random.RandomState(99)
+    ov = OracleVolume(vol._p)
+    z, y, x = np.meshgrid(*[np.linspace(-1, 1, res)] * 3, indexing="ij")
+    ov.d[:] = np.clip(0.9 * np.sin(3 * x + 1) * np.cos(2 * y) + 0.5 * z + rng.normal(0, 0.15, ov.d.shape), -1, 1).astype(np.float32)
+    ov.w[:] = np.where(rng.rand(*ov.w.shape) < 0.1, 0, rng.randint(1, 5, ov.w.shape)).astype(np.float32)
+    vol.upload(ov.d, ov.w)
+    hits = 0
+    for k in range(6):
+        eye = rng.uniform(-2.2, 2.2, 3) * sc.size * (1.0 if k % 3 else 0.25)
+        tr = synth.look_at_pose(eye, target=rng.uniform(-0.2, 0.2, 3) * sc.size)
+        ds = 1 + (k == 4)
+        got = vol.renderView(tr, ds, camera_frame=False)
+        assert_same_f32(got, ov.raycast(tr, ds), f"renderView pose {k}")
+        hits += int(np.isfinite(got[..., 0]).sum())
+    assert hits > 3000
+    pts = rng.uniform(-0.07, 0.07, (2000, 3)).astype(np.float32)
+    ok, val, grad, hess = vol.sample(pts)
+    ok2, val2, grad2, hess2 = ov.sample(pts)
+    assert np.array_equal(ok, ok2) and ok.sum() > 200
+    assert_same_f32(val[ok], val2[ok], "getFxn")
+    assert_same_f32(grad[ok], grad2[ok], "getGradient")
+    assert_same_f32(hess[ok], hess2[ok], "getHessian")
+    vol.close()
