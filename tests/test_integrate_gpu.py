@@ -371,3 +371,50 @@ def test_linearity_property_512(gpu):
     assert np.array_equal(w4[obs], np.full(n1, 4, np.float32)) and (w4[~obs] == 0).all()
     assert np.max(np.abs(d4[obs] - d1[obs])) <= 2e-7  # (d*w + d)/(w+1) re-rounds in fp32
     assert (d4[~obs] == -1).all()
+
+
+def test_integrate_fuzz_equals_the_oracle(gpu):
+    """The HIP path on the adversarial inputs of tests/test_oracle_golden.py::test_integrate_fuzz_equals_compiled_reference
+    (where the oracle is pinned to the reference): random non-dyadic grid sizes, intrinsics, sensor bounds, asymmetric
+    truncation, small weight limits, cameras anywhere incl. sheared poses, depth images with NaN / inf / 0 / negative /
+    huge values -- d, w, rgb and the observed-voxel counts equal the oracle's, in both layouts."""
+    rng = np.random.RandomState(2024)
+    for case in range(24):
+        res = int(rng.choice([16, 32]))
+        size = float(rng.choice([0.125, 0.3, 1.0, 3.0]))
+        W, H = (48, 36) if case % 2 else (64, 48)
+        f = float(rng.uniform(20.0, 80.0))
+        fx, fy, cx, cy = f, f * float(rng.uniform(0.9, 1.1)), W / 2 - 0.5 + float(rng.uniform(-3, 3)), H / 2 - 0.5
+        zmin, zmax = float(rng.choice([0.0, 0.05 * size])), float(rng.uniform(0.8, 3.5)) * size
+        pos, neg = float(rng.uniform(0.02, 0.3)) * size, float(rng.uniform(0.02, 0.3)) * size
+        wmax = float(rng.choice([100.0, 2.0, 3.5]))
+        color = bool(case % 3)
+        vol, _ = make_volume(res, W, H, color=color, size=size, zmin=zmin, zmax=zmax, trunc=(pos, neg), max_weight=wmax)
+        vol.setCameraIntrinsics(fx, fy, cx, cy)
+        if case % 4 == 3:
+            vol.setLayout(capi.LAYOUT_F32W)
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        for i in range(5):
+            eye = rng.uniform(-1.6, 1.6, 3) * size * (1.0 if rng.rand() < 0.7 else 0.2)
+            tr = synth.look_at_pose(eye, target=rng.uniform(-0.3, 0.3, 3) * size)
+            if rng.rand() < 0.25:
+                tr = tr.copy()
+                tr[:3, :3] = tr[:3, :3] @ (np.eye(3) + rng.uniform(-0.2, 0.2, (3, 3)))
+            dep = (rng.uniform(0.2, 2.5, (H, W)) * size).astype(np.float32)
+            junk = rng.rand(H, W)
+            dep[junk < 0.05] = np.nan
+            dep[(junk >= 0.05) & (junk < 0.07)] = np.inf
+            dep[(junk >= 0.07) & (junk < 0.09)] = 0.0
+            dep[(junk >= 0.09) & (junk < 0.10)] = -1.0
+            dep[(junk >= 0.10) & (junk < 0.11)] = 3.0e38
+            col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
+            n_gpu = vol.integrateCloud(dep, col if color else None, tr, count=True)
+            n_cpu = ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+            assert n_gpu == n_cpu, (case, i, n_gpu, n_cpu)
+        d, w, rgb = vol.download()
+        assert_same_f32(d, ov.d, f"case {case}: d")
+        assert_same_f32(w, ov.w, f"case {case}: w")
+        if color:
+            assert np.array_equal(rgb, ov.rgb), f"case {case}: rgb"
+        vol.close()
