@@ -134,7 +134,7 @@ def test_slab_range_and_morton_key():
     assert morton_x_major(cells).tolist() == [4, 2, 1, 7, 8]
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_two_and_three_slabs_equal_one_volume(world, tmp_path):
     out = str(tmp_path / "out.npz")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
