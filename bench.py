@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- integrateCloud throughput on MI355X (BASELINE.json metric).
 
-One "step" = one integrateCloud pass of one synthetic 640x480 depth(+colour) frame over the whole
-voxel grid.  N=1 workload = BASELINE.json configs[3]: 2048^3 grid (8 m, voxel 2^-8 m),
-integrateColor=true, Scene A turntable frames.  Frames are resident in HBM before
-the timed region.  For N>1 (one process per GPU, torch.distributed/RCCL) the grid is Z-slab
-partitioned: weak scaling extends the grid along z by 2048 planes per GPU (default) -- every rank
-integrates its own 2048-plane slab after an RCCL broadcast of the frame from rank 0.
+One "step" = one integrateCloud pass of one synthetic 640x480 depth(+colour) frame over the whole voxel grid.
+Workload = BASELINE.json configs[3]'s integrate leg, the configuration `metric` is quoted on: 2048^3 grid (8 m,
+voxel 2^-8 m), integrateColor=true, Scene A turntable frames, frames resident in HBM before the
+timed region.
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement), with `roofline` for the
-dominant kernel (k_integrate; HBM-bound) and `cpu_baseline` (the reference CPU path, timed on this
-host on a bounded sample).
+N > 1 (one process per GPU, torch.distributed / RCCL): the SAME 2048^3 grid, Z-slab partitioned (strong scaling,
+2048/N planes per GPU: the metric is "@2048^3 ... 1/2/4/8 GPUs").  The frame lives on rank 0; every step is one
+RCCL broadcast of it (depth + colour in one 2.4 MB buffer) and one k_integrate launch per rank on its slab.  The
+broadcast of frame i+1 is issued before the kernel of frame i is launched and lands in the other half of a
+two-slot receive buffer, so it runs on RCCL's stream under that kernel.  `--config 4` is BASELINE configs[4]
+(4096^3, 1280x960 frames, needs >= 4 GPUs); `--scaling weak` keeps --planes planes per GPU instead.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+(k_integrate, HBM-bound) and `cpu_baseline` (the reference CPU path timed on this host on a bounded sample).
+
+roofline.achieved uses the ALGORITHMIC bytes of the shipped HBM layout, measured per frame by the kernel's counting
+instance: bytes of the voxel words an observed voxel must read (PACKED colour: d + colour|count word = 8 B) + bytes
+of the words whose value changed (tsdf_hip_last_count_detail) + the frame.  SURVEY 8d's figure for the reference's
+own (d, w, rgb) record, 24 B per observed voxel, stays as a labelled side note (`reference_record_*`): the PACKED
+layout moves fewer bytes than that record holds, so a fraction computed from it can exceed 1 and means nothing.
+roofline.traffic is the PMC measurement (rocprofv3 FETCH_SIZE / WRITE_SIZE over THIS command's timed launches,
+tools/run_rocprof.sh -> profiles/pmc_traffic.json), reported only while the profile's kernel-source hash matches the
+tree that is running.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+KERNEL_SOURCES = ("tsdf_integrate.hip", "tsdf_div.h", "tsdf_buffer.h", "tsdf_common.h")
+
+
+def kernel_sha16():
+    """Hash of the sources k_integrate is compiled from: stamps profiles so that a stale one is never quoted."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cpu_tsdf_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -32,22 +56,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--res", type=int, default=2048, help="x/y resolution (and planes per GPU unless --planes)")
-    ap.add_argument("--planes", type=int, default=0, help="z planes per GPU (weak) / in total (strong); 0 = --res.  "
-                    "--res 4096 --planes 512 --width 1280 --height 960 at N=8 is BASELINE configs[4]")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+                    help="BASELINE.json configs[k]: 3 = 2048^3, 640x480 (default); 4 = 4096^3, 1280x960, Z-slabs over >= 4 GPUs")
+    ap.add_argument("--res", type=int, default=0, help="x/y/z resolution (default: the config's)")
+    ap.add_argument("--planes", type=int, default=0, help="z planes in total (strong) / per GPU (weak); 0 = --res")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--color", type=int, default=1)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--layout", choices=["auto", "f32w", "packed"], default="auto",
                     help="HBM weight layout (include/tsdf_hip.h TSDF_LAYOUT_*); auto = packed when max_weight <= 255")
     ap.add_argument("--frames", type=int, default=0, help="distinct frames on the turntable (default steps+warmup)")
+    ap.add_argument("--overlap", type=int, default=1, help="N>1: broadcast frame i+1 under the kernel of frame i")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--extras", type=int, default=1, help="also time renderView + marching cubes once (N=1, untimed region)")
     ap.add_argument("--scene-b", type=int, default=1, help="with --extras: the Scene-B (camera inside the volume) leg; the "
                     "rocprof run turns it off so that k_integrate's average is the headline workload's alone")
-    return ap.parse_args()
+    ap.add_argument("--calib", type=int, default=0, help="run this many k_calib_rmw sweeps of exactly known bytes first "
+                    "(PMC passes: calibrates FETCH_SIZE / WRITE_SIZE in the same process)")
+    a = ap.parse_args()
+    if a.config == 4:
+        a.res, a.width, a.height = a.res or 4096, a.width or 1280, a.height or 960
+    else:
+        a.res, a.width, a.height = a.res or 2048, a.width or 640, a.height or 480
+    return a
 
 
 def cpu_baseline(args, sc, res3, size3, budget_s):
@@ -63,7 +96,7 @@ def cpu_baseline(args, sc, res3, size3, budget_s):
     except ImportError:
         pass
     from cpu_tsdf_amd import capi
-    from oracle.oracle import OracleVolume, SlabOracle
+    from oracle.oracle import SlabOracle
     p = capi.default_params()
     planes = max(8, min(res3[2], (64 * 2048 * 2048) // (res3[0] * res3[1])))
     zb = (res3[2] - planes) // 2
@@ -95,7 +128,7 @@ def cpu_baseline(args, sc, res3, size3, budget_s):
 def extras(vol, pose, W, H):
     """Report-only timings of the other two kernels of the path on the fused volume (outside the timed
     region; gather/latency-bound raycast, streaming marching cubes): not part of `value`."""
-    from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree
+    from cpu_tsdf_amd import capi
     out = {}
     try:
         vol.renderView(pose, 1, camera_frame=False)  # warm-up (scratch allocation)
@@ -107,7 +140,7 @@ def extras(vol, pose, W, H):
         out["renderView_hits"] = int(np.isfinite(img[..., 0]).sum())
         out["renderView_mean_steps"] = float(img[..., 7].mean())
         out["renderView_steps_per_s"] = float(img[..., 7].sum()) / dt
-        lib = capi_mod().load()
+        lib = capi.load()
         n = C.c_uint64(0)
         lib.tsdf_hip_march(vol._need(), C.c_float(1.0), 1, C.byref(n))  # warm-up (buffer growth)
         t0 = time.perf_counter()
@@ -115,12 +148,26 @@ def extras(vol, pose, W, H):
         dt = time.perf_counter() - t0
         if rc == 0:
             rx, ry, rz = vol.getResolution()
+            vox = rx * ry * float(rz)
+            ms = (C.c_float * 3)()
+            cells = C.c_uint64(0)
+            lib.tsdf_hip_march_timing(vol._need(), ms, C.byref(cells))
+            color = bool(vol._p.integrate_color)
             out["reconstruct_ms"] = dt * 1e3
             out["reconstruct_triangles"] = int(n.value)
-            out["reconstruct_Mvoxels_per_s"] = rx * ry * float(rz) / dt / 1e6
-            # 8 B (12 B colour) per voxel + 36 B (+9 B colour) per triangle, whole call (classify + sort + emit)
-            color = bool(vol._p.integrate_color)
-            out["reconstruct_algorithmic_GBps"] = ((12 if color else 8) * rx * ry * float(rz) + (45 if color else 36) * n.value) / dt / 1e9
+            out["reconstruct_active_cells"] = int(cells.value)
+            out["reconstruct_Mvoxels_per_s"] = vox / dt / 1e6
+            out["reconstruct_phase_ms"] = {"classify": ms[0], "sort_scan": ms[1], "emit": ms[2]}
+            # PHYSICAL bytes (what the kernels must move in the shipped layout), not SURVEY's 8/12 B record:
+            #  classify streams the distance plane once (4 B per voxel) and gathers 8 weight words per listed cell;
+            #  emit reads 8 corners (d + weight word) per active cell and writes 36 B of vertices + 9 B of colour +
+            #  8 B of cell key per triangle; 16 B (key, cell) per active cell go out of classify and through the sort.
+            classify_bytes = 4.0 * vox + (32.0 + 16.0) * cells.value
+            emit_bytes = 64.0 * cells.value + (36.0 + (9.0 if color else 0.0) + 8.0) * n.value
+            out["reconstruct_classify_bytes"] = classify_bytes
+            out["reconstruct_classify_GBps"] = classify_bytes / (ms[0] * 1e-3) / 1e9 if ms[0] > 0 else None
+            out["reconstruct_classify_frac_of_hbm_peak"] = (classify_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else None
+            out["reconstruct_emit_GBps"] = emit_bytes / (ms[2] * 1e-3) / 1e9 if ms[2] > 0 else None
     except Exception as e:  # never let a report-only leg break the bench line
         out["error"] = repr(e)
     return out
@@ -189,9 +236,19 @@ def scene_b_leg(res, color, cpu_seconds):
     return out
 
 
-def capi_mod():
-    from cpu_tsdf_amd import capi
-    return capi
+def pmc_traffic(key, sha):
+    """HBM bytes per timed k_integrate launch from the committed PMC profile of this very command -- only if the
+    profile was taken on the kernel sources that are running now."""
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        e = json.load(open(prof)).get(key)
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if not e:
+        return None, f"no PMC profile for {key}"
+    if e.get("kernel_sha16") != sha:
+        return None, f"PMC profile {e.get('tag')} was taken on other kernel sources ({e.get('kernel_sha16')} != {sha}): not quoted"
+    return e, None
 
 
 def main():
@@ -208,14 +265,22 @@ def main():
         args.gpus = world
     # Test hooks for boxes with ONE GPU (gpurun): TSDF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # TSDF_BENCH_BACKEND=gloo moves the collectives off RCCL (which refuses two ranks per device), so the N>1
-    # code path can be smoke-run there.  Numbers from such a run mean nothing; the driver never sets these.
+    # code path can be smoke-run there; TSDF_BENCH_FORCE_DIST=1 takes the collective path even at world size 1
+    # (one rank on RCCL: communicator init + device-tensor broadcast / all-reduce really run).  Numbers from such
+    # runs mean nothing; the driver never sets these.
     if os.environ.get("TSDF_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("TSDF_BENCH_BACKEND", "nccl")
+    use_dist = world > 1 or os.environ.get("TSDF_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -238,6 +303,10 @@ def main():
     size3 = tuple(r * voxel for r in res3)
     S = size3[0]
     W, H = args.width, args.height
+    slab_gb = (z_end - z_begin) * res * res * 8 / 2 ** 30
+    if slab_gb > 250:
+        raise SystemExit(f"a {z_end - z_begin}-plane slab of a {res}x{res} grid is {slab_gb:.0f} GiB: use more GPUs "
+                         f"(configs[4] needs >= 4)")
     sc = synth.Scene(S, W, H)  # sphere + far-face box scaled to the x/y extent
     if res3[2] != res3[0]:
         sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
@@ -255,6 +324,16 @@ def main():
     stream = torch.cuda.current_stream(dev)
     vol.setStream(stream.cuda_stream)
     vol.reset()
+    lib = capi.load()
+    h = vol._need()
+
+    calibration = None
+    if args.calib:
+        br, bw = C.c_uint64(), C.c_uint64()
+        for _ in range(args.calib):
+            capi.check(lib.tsdf_hip_selftest_sweep(h, C.byref(br), C.byref(bw)), "sweep")
+        calibration = {"kernel": "k_calib_rmw", "launches": args.calib, "known_read_bytes": br.value,
+                       "known_written_bytes": bw.value}
 
     # ---- synthetic frames, resident in HBM before the timed region ---------------------------------
     n_total = args.warmup + args.steps
@@ -265,25 +344,26 @@ def main():
     # one allocation per frame: [depth | bgra] back to back, which is what the kernel's single frame
     # descriptor wants (no staging copy) and what ONE broadcast per frame can carry
     fplanes = 2 if args.color else 1
-    frames_dev = torch.empty((n_total, fplanes, H, W), dtype=torch.float32, device=dev)
+    frames_dev = torch.empty((n_total if rank == 0 else 1, fplanes, H, W), dtype=torch.float32, device=dev)
     if rank == 0:
         for i, p in enumerate(poses):
             frames_dev[i, 0].copy_(torch.from_numpy(sc.depth(p)))
             if args.color:
                 frames_dev[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
-    recv = torch.empty((fplanes, H, W), dtype=torch.float32, device=dev) if world > 1 else None
-    lib = capi.load()
-    h = vol._need()
-
+    # two receive slots: the broadcast of frame i+1 fills one while k_integrate reads frame i from the other
+    recv = torch.empty((2, fplanes, H, W), dtype=torch.float32, device=dev) if use_dist else None
     pairs = []  # HIP event pairs around each timed launch, on the stream the kernel runs on
 
-    def step(i, count=None, timed=False):
-        if world > 1:
-            # the frame arrives on rank 0; one RCCL broadcast (depth + colour, 2.4 MB) to every slab owner
-            fr = frames_dev[i] if rank == 0 else recv
-            dist.broadcast(fr, src=0)
-        else:
-            fr = frames_dev[i]
+    def frame_buf(i):
+        return frames_dev[i] if rank == 0 else recv[i & 1]
+
+    def bcast(i, async_op):
+        # the frame arrives on rank 0; one RCCL broadcast (depth + colour, 2.4 MB) to every slab owner.  RCCL's
+        # stream first waits for what is queued on `stream` now, i.e. for the kernel that last read this slot.
+        return dist.broadcast(frame_buf(i), src=0, async_op=async_op)
+
+    def launch(i, count=None, timed=False):
+        fr = frame_buf(i)
         if timed:
             pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
             pairs[-1][0].record(stream)
@@ -293,20 +373,40 @@ def main():
         if timed:
             pairs[-1][1].record(stream)
 
+    counted = []  # (observed voxels, changed-word bytes) of every counted launch
+
+    def run(first, last, counting=False, timed=False):
+        """Frames [first, last): broadcast + integrate, the next frame's broadcast in flight under each kernel.
+        counting: through the counting instance of the kernel (synchronous), results appended to `counted`."""
+        pending = bcast(first, True) if (use_dist and args.overlap and first < last) else None
+        detail = (C.c_uint64 * 2)()
+        for i in range(first, last):
+            if use_dist:
+                if args.overlap:
+                    pending.wait()  # `stream` waits for frame i (the host does not)
+                    pending = bcast(i + 1, True) if i + 1 < last else None
+                else:
+                    bcast(i, False)
+            if counting:
+                c = C.c_uint64(0)
+                launch(i, C.byref(c), timed)
+                capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+                counted.append((int(detail[0]), int(detail[1])))
+            else:
+                launch(i, None, timed)
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     # Warm-up launches go through the COUNTING template instance of k_integrate (they integrate exactly the same
-    # way), so that in a `rocprofv3 --kernel-trace --stats` table of this command the non-counting instance holds
-    # the K timed launches and nothing else: its average there is directly comparable with roofline.kernel_ms.
-    for i in range(args.warmup):
-        step(i, C.byref(C.c_uint64(0)))
+    # way), so that in a `rocprofv3 --kernel-trace --stats` / --pmc table of this command the non-counting instance
+    # holds the K timed launches and nothing else: its averages there are directly comparable with roofline.*.
+    run(0, args.warmup, counting=True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
-        step(i, timed=True)
+    run(args.warmup, n_total, timed=True)
     barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
@@ -314,21 +414,37 @@ def main():
     # N > 1 this leaves the frame broadcast out of the kernel's roofline; `value` keeps it, via the wall clock)
     kern_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
 
-    # observed voxels of the timed frames (state-independent: depends on pose + depth only), counted
-    # outside the timed region by re-running the same frames with the counter read back
-    n_obs = 0
-    for i in range(args.warmup, n_total):
-        c = C.c_uint64(0)
-        step(i, C.byref(c))
-        n_obs += c.value
-    n_obs_rank = n_obs / args.steps
+    # Algorithmic bytes of the timed frames, counted outside the timed region by running the same frames once more
+    # through the counting instance: observed voxels (state-independent: pose + depth only) and the bytes of voxel
+    # words whose value changed (the state then holds `steps` more observations per voxel; which words change --
+    # the count byte until saturation, colour and distance inside the truncation band, nothing in free space at the
+    # hinge -- does not depend on that to first order).
+    del counted[:]
+    run(args.warmup, n_total, counting=True)
+    n_obs_rank = sum(c[0] for c in counted) / args.steps
+    chg_rank = sum(c[1] for c in counted) / args.steps
+    chg_per_obs = chg_rank / n_obs_rank if n_obs_rank else 0.0
 
-    t = torch.tensor([wall, kern_ms, n_obs_rank], dtype=torch.float64, device=dev)
-    if world > 1:
+    # isolated cost of one frame broadcast (report only)
+    bcast_ms = None
+    if use_dist:
+        barrier()
+        tb = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            bcast(i, False)
+        barrier()
+        bcast_ms = (time.perf_counter() - tb) / args.steps * 1e3
+
+    t = torch.tensor([wall, kern_ms, n_obs_rank, chg_rank], dtype=torch.float64, device=dev)
+    per_rank_kernel_ms = [kern_ms]
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        allk = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allk, t[1:2].clone())
+        per_rank_kernel_ms = [float(x) for x in allk]
         wall = float(tmax[0])
         n_obs_all = float(tsum[2])
     else:
@@ -337,26 +453,17 @@ def main():
     if rank == 0:
         vox_total = float(res3[0]) * res3[1] * res3[2]
         fps = args.steps / wall
-        bpv = 24 if args.color else 16
-        bpp = 8 if args.color else 4
-        alg_bytes = bpv * n_obs_rank + bpp * W * H  # rank 0's launch
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        # bytes the chosen HBM layout actually has to move per observed voxel (read + write back):
-        # F32W d,w(,rgb) = 16 (24); PACKED d + colour|count word = 16, d + count byte = 10
         packed = vol.getLayout() == capi.LAYOUT_PACKED
-        lbpv = (16 if args.color else 10) if packed else bpv
-        layout_bytes = lbpv * n_obs_rank + bpp * W * H
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                pj = json.load(open(prof))
-                key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
-                traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        bpp = 8 if args.color else 4                              # frame bytes per pixel (depth + bgra)
+        ref_bpv = 24 if args.color else 16                        # the reference's (d, w, rgb) record, read + write
+        read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))  # voxel words an observed voxel must read
+        alg_bytes = read_bpv * n_obs_rank + chg_rank + bpp * W * H  # rank 0's launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        sha = kernel_sha16()
+        key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
+        prof, why = pmc_traffic(key, sha)
         out = {
-            "metric": "integrateCloud throughput, Scene A turntable depth frames, 640x480 -> voxel grid",
+            "metric": f"integrateCloud throughput, Scene A turntable depth frames, {W}x{H} -> voxel grid",
             "value": vox_total * fps / 1e6,
             "unit": "Mvoxels/s",
             "frames_per_s": fps,
@@ -372,8 +479,9 @@ def main():
             "config": {
                 "workload": f"integrateCloud {res3[0]}x{res3[1]}x{res3[2]} grid (voxel 2^-8 m), "
                             f"integrateColor={'true' if args.color else 'false'}, {W}x{H} Scene-A turntable frames "
-                            f"resident in HBM" + (f", Z-slab {z_end - z_begin} planes/GPU, RCCL frame broadcast"
-                                                  if world > 1 else " (BASELINE configs[3] integrate leg)"),
+                            f"resident in HBM (BASELINE configs[{args.config}] integrate leg)" +
+                            (f", Z-slab {z_end - z_begin} planes/GPU, one RCCL frame broadcast per step"
+                             + (" overlapped with the previous kernel" if args.overlap else "") if use_dist else ""),
                 "grid": list(res3), "image": [W, H], "color": bool(args.color),
                 "layout": "packed" if packed else "f32w",
                 "observed_voxels_per_frame": n_obs_all,
@@ -381,20 +489,31 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_integrate", "kernel_ms": kern_ms,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                "kernel": "k_integrate", "kernel_ms": kern_ms, "kernel_sha16": sha,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_per_observed_voxel": bpv,
-                "layout_bytes_per_observed_voxel": lbpv,
-                "layout_bytes_per_launch": layout_bytes,
-                "frac_layout": layout_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "sweep_upper_bound_bytes": bpv * vox_total / world,
-                "note": ("achieved/frac use SURVEY 8d's algorithmic record (24 B per observed voxel with colour, 16 B without); "
-                         "the PACKED HBM layout only has to move layout_bytes_per_observed_voxel, so frac can approach or pass 1 "
-                         "while the memory system runs at frac_layout (nominal layout bytes) / traffic (measured, PMC)") if packed else
-                        "F32W layout: the algorithmic record is what the layout moves",
+                "algorithmic_bytes": {"read_per_observed_voxel": read_bpv, "observed_voxels": n_obs_rank,
+                                      "changed_word_bytes": chg_rank, "changed_bytes_per_observed_voxel": chg_per_obs,
+                                      "frame_bytes": bpp * W * H},
+                "traffic_profile": ({"tag": prof.get("tag"), "read_bytes": prof.get("read_bytes"),
+                                     "written_bytes": prof.get("written_bytes"),
+                                     "frac_of_peak_by_traffic": prof["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "kernel_ms_in_profile": prof.get("kernel_ms_in_profile")} if prof else why),
+                "reference_record_bytes_per_observed_voxel": ref_bpv,
+                "reference_record_bytes_per_launch": ref_bpv * n_obs_rank + bpp * W * H,
+                "sweep_upper_bound_bytes": ref_bpv * vox_total / world,
+                "note": "achieved/frac: algorithmic bytes of the shipped HBM layout (words an observed voxel must read + words whose "
+                        "value changed, counted by the kernel's counting instance + the frame) / kernel_ms; traffic: PMC FETCH_SIZE x2 + "
+                        "WRITE_SIZE over this command's timed launches; reference_record_*: SURVEY 8d's 24 B (16 B) record of the "
+                        "reference, a side note -- the PACKED layout moves fewer bytes than that record holds",
             },
         }
+        if use_dist:
+            out["multi_gpu"] = {"per_rank_kernel_ms": per_rank_kernel_ms, "frame_broadcast_ms_isolated": bcast_ms,
+                                "overlap": bool(args.overlap), "backend": backend, "planes_per_gpu": z_end - z_begin}
+        if calibration:
+            out["calibration"] = calibration
         if world == 1 and args.extras:
             out["extras"] = extras(vol, poses[-1], W, H)
             if args.scene_b:
@@ -404,7 +523,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     vol.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

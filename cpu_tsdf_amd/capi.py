@@ -90,6 +90,9 @@ SIGNATURES = {
     "tsdf_hip_organize": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, C.c_float, C.c_int,
                                     _f64p, _f32p, _u8p, _u64p]),
     "tsdf_hip_integrate_staged": (C.c_int, [C.c_void_p, _f32p, _u64p]),
+    "tsdf_hip_set_weighting": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
+    "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
     "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),
     "tsdf_hip_raycast_begin": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_void_p]),

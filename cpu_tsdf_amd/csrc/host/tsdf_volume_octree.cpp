@@ -129,7 +129,13 @@ void TSDFVolumeOctree::reset() {
     tsdf_hip_destroy(h_);
     h_ = nullptr;
   }
-  const int rc = tsdf_hip_create(&p_, &h_);
+  // weight_by_depth_ / weight_by_variance_ (set only by load(), as in the reference) survive a reset there too
+  if (weight_by_depth_ && p_.layout == TSDF_LAYOUT_AUTO) p_.layout = TSDF_LAYOUT_F32W;
+  int rc = tsdf_hip_create(&p_, &h_);
+  if (!rc && (weight_by_depth_ || weight_by_variance_)) {
+    rc = tsdf_hip_set_weighting(h_, weight_by_depth_, weight_by_variance_);
+    if (rc) tsdf_hip_destroy(h_);
+  }
   if (rc) {
     h_ = nullptr;
     report("reset", rc);

@@ -1,0 +1,34 @@
+// Buffer-descriptor memory access for the streaming kernels (device code only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- memory access through buffer descriptors ----------------------------------------------------------
+// Every global access of k_integrate (and of k_mc_classify) goes through a 128-bit buffer resource built from
+// wave-uniform values
+// (blockIdx-derived plane/row-group base, frame base): the per-lane part is a 32-bit byte offset, so the
+// row loop carries no 64-bit address arithmetic in the VALU, the per-row step is the instruction's scalar
+// offset, and out-of-range lanes (pixel -1, rows past the grid) are absorbed by the hardware bounds check
+// (loads return 0, stores are dropped) instead of by exec-mask branches.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ uint32_t bload32(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ u4 bload128(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ void bstore32(rsrc_t r, unsigned voff, unsigned soff, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ uint32_t bload8(rsrc_t r, unsigned voff, unsigned soff) {
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, 0) & 0xffu;
+}
+static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsigned soff, u4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}

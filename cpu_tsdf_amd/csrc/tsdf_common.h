@@ -31,6 +31,9 @@ struct tsdf_hip_volume {
   float *cn[4] = {nullptr, nullptr, nullptr, nullptr};
   int packed = 0;
   unsigned kmax = 0;
+  // hpp:200-204: weightings only a loaded .vol can switch on (tsdf_hip_set_weighting).  weight_by_depth integrates
+  // through the plain kernel (float weights); weight_by_variance makes integrate refuse (it needs M_ / nsample_).
+  int weight_by_depth = 0, weight_by_variance = 0;
   float *ctr[3] = {nullptr, nullptr, nullptr};  // device centre tables (full axis length)
   std::vector<float> h_ctr[3];
   float *frame_depth = nullptr;  // staging for the host-pointer entry points
@@ -46,7 +49,8 @@ struct tsdf_hip_volume {
   int frame_staged = 0;            // tsdf_hip_organize left a frame in [frame_depth | frame_bgra]
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
-  unsigned long long *counter = nullptr;  // device scratch (n_observed etc.)
+  unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
+  unsigned long long last_observed = 0, last_changed_bytes = 0;  // tsdf_hip_last_count_detail
   hipStream_t stream = nullptr;
   // marching-cubes result buffers (owned, reused between calls)
   float *mc_verts = nullptr;
@@ -57,6 +61,9 @@ struct tsdf_hip_volume {
   bool mc_has_rgb = false;
   uint64_t *mc_keys = nullptr, *mc_vals = nullptr;  // active-cell list (Morton key, packed cell)
   size_t mc_cells_cap = 0;
+  hipEvent_t mc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // tsdf_hip_march_timing
+  float mc_ms[3] = {0.f, 0.f, 0.f};                            // classify, sort + scan, emit of the last call
+  uint64_t mc_ncells = 0;
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
 };
@@ -114,6 +121,7 @@ struct TsdfTuning {
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
   int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
   int vol_chunk;       // edge of the voxel blocks save / load stream through host memory
+  int plain_kernel;    // F32W volumes integrate through the plain per-voxel kernel (the weight_by_depth one, w_new = 1)
 };
 const TsdfTuning &tsdf_tuning();
 

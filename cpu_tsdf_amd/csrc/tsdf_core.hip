@@ -49,7 +49,8 @@ static TsdfTuning &tuning_storage() {
   static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 256),
-                         env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256))};
+                         env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
+                         env_int("TSDF_HIP_PLAIN_KERNEL", 0)};
   return t;
 }
 
@@ -73,6 +74,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.cull = value;
   else if (n == "vol_chunk")
     t.vol_chunk = std::max(1, value);
+  else if (n == "plain_kernel")
+    t.plain_kernel = value;
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;
@@ -281,6 +284,8 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->mc_cell) (void)hipFree(v->mc_cell);
   if (v->mc_keys) (void)hipFree(v->mc_keys);
   if (v->mc_vals) (void)hipFree(v->mc_vals);
+  for (int i = 0; i < 4; ++i)
+    if (v->mc_ev[i]) (void)hipEventDestroy(v->mc_ev[i]);
   if (v->scratch) (void)hipFree(v->scratch);
   delete v;
 }
@@ -377,8 +382,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     TRY_OR_BAIL(hipMalloc(&v->cam64, sizeof cam));
     TRY_OR_BAIL(hipMemcpy(v->cam64, cam, sizeof cam, hipMemcpyHostToDevice));
   }
-  TRY_OR_BAIL(hipMalloc(&v->counter, 1024 * sizeof(unsigned long long)));
-  TRY_OR_BAIL(hipMemset(v->counter, 0, 1024 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMalloc(&v->counter, 2048 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMemset(v->counter, 0, 2048 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL
   rc = tsdf_hip_reset(v);
   if (rc != TSDF_HIP_OK) return bail(rc);

@@ -23,6 +23,7 @@
 
 #include "tsdf_common.h"
 #include "tsdf_div.h"
+#include "tsdf_buffer.h"
 
 struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
@@ -154,30 +155,7 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
   return w_ok && numerator_ok(d * w + dn);
 }
 
-// ---- memory access through buffer descriptors ----------------------------------------------------------
-// Every global access of the kernel goes through a 128-bit buffer resource built from wave-uniform values
-// (blockIdx-derived plane/row-group base, frame base): the per-lane part is a 32-bit byte offset, so the
-// row loop carries no 64-bit address arithmetic in the VALU, the per-row step is the instruction's scalar
-// offset, and out-of-range lanes (pixel -1, rows past the grid) are absorbed by the hardware bounds check
-// (loads return 0, stores are dropped) instead of by exec-mask branches.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-
-static __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
-}
-static __device__ __forceinline__ uint32_t bload32(rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
-}
-static __device__ __forceinline__ u4 bload128(rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-}
-static __device__ __forceinline__ void bstore32(rsrc_t r, unsigned voff, unsigned soff, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
-}
-static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsigned soff, u4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
-}
+// (buffer-descriptor access helpers: tsdf_buffer.h)
 
 // Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
 // blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
@@ -213,7 +191,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   const int xq = (int)blockIdx.x * a.TX + tx;
   const int zl = (int)blockIdx.z;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0;
+  unsigned cnt = 0, chg = 0;
   // wave-uniform bases
   const int row0 = (int)blockIdx.y * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
@@ -397,11 +375,13 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       }
       uint32_t diff_d = 0u, diff_w = 0u, diff_c = 0u, k4n = 0u;
       uint32_t dn_u[4], wn_u[4];
+      const uint32_t c_before[4] = {c0[0], c0[1], c0[2], c0[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (PACKED) {
           // count after this observation: k' = min(k + 1, kmax), done on byte 3 in place
-          const uint32_t k1 = min((kw[j] & 0xff000000u) + 0x01000000u, a.kmax << 24);
+          // (saturate BEFORE adding: with kmax == 255 the in-place add would wrap byte 3 to zero)
+          const uint32_t k1 = (kw[j] >> 24) >= a.kmax ? (a.kmax << 24) : (kw[j] & 0xff000000u) + 0x01000000u;
           if (COLOR)
             cv[j] = (cv[j] & 0xffffffu) | k1;  // both add_observation flavours return a 24-bit colour
           else
@@ -414,22 +394,29 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         diff_w |= wn_u[j] ^ w0u[j];
         diff_c |= cv[j] ^ c0[j];
         cnt += act[j] ? 1u : 0u;
+        if (COUNT)  // bytes of voxel words whose VALUE changed: what any layout-preserving kernel has to write
+          chg += (dn_u[j] != d0u[j] ? 4u : 0u) + (!PACKED && wn_u[j] != w0u[j] ? 4u : 0u) +
+                 (COLOR && cv[j] != c_before[j] ? 4u : 0u);
       }
+      if (COUNT && PACKED && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
+                                                            ((k4n ^ k4) >> 4) | ((k4n ^ k4) >> 5) | ((k4n ^ k4) >> 6) | ((k4n ^ k4) >> 7)) & 0x01010101u);
       if (diff_d) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
       if (!PACKED && diff_w) bstore128(rsW, voff, soff, (u4){wn_u[0], wn_u[1], wn_u[2], wn_u[3]});
       if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
       if (PACKED && !COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
     }
   }
-  if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host)
-    __shared__ unsigned s_cnt;
-    if (tid == 0) s_cnt = 0;
+  if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes
+    __shared__ unsigned s_cnt, s_chg;
+    if (tid == 0) s_cnt = s_chg = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
+    if (chg) atomicAdd(&s_chg, chg);
     __syncthreads();
     if (tid == 0 && s_cnt) {
       const unsigned b = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
       atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
+      if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
     }
   }
 }
@@ -629,6 +616,74 @@ k_integrate_rgbn(const IntegrateArgs a, float *__restrict__ D, float *__restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight_by_depth_ (hpp:200-202): w_new = 1 * (1 - std::min(pt.z / 10., 1.)) -- a float times a double stored back
+// into the float -- then OctreeNode / RGBNode::addObservation with that w_new (octree.cpp:152-163, 328-337).  Only a
+// loaded .vol can carry the flag (tsdf_volume_octree.cpp:265), so this is the plain form: one thread per voxel, exact
+// fp64 projection, the compiler's IEEE divisions, float weight plane.  BY_DEPTH = false is the same kernel with
+// w_new = 1 (used by the tests to pin the plain kernel itself against the fast one).
+template <int ORDER, bool COLOR, bool BY_DEPTH>
+static __global__ void __launch_bounds__(256)
+k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+                  const float *__restrict__ depth, const uint32_t *__restrict__ bgra, const double *__restrict__ cam,
+                  const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
+                  unsigned long long *__restrict__ n_obs) {
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int y = (int)blockIdx.y, zl = (int)blockIdx.z;
+  bool observed = false;
+  if (x < (int)a.pitch) {  // the x centre table is NaN beyond nx: those lanes fail the range test
+    const float cx = ctrx[x], cy = ctry[y], cz = ctrz[a.z_global0 + zl];
+    float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
+      g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
+                                         : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
+    if (pix >= 0) {
+      const float z = depth[pix];
+      float dn = z - g[2];  // hpp:159
+      if (!isnan(z) && !(dn < -a.neg)) {  // hpp:152, :193-196
+        dn = dn > a.pos ? a.pos_over_neg : dn / a.neg;  // hpp:189-198
+        float wn = 1.f;
+        if (BY_DEPTH) {  // hpp:201-202; std::min(a, b) = (b < a) ? b : a
+          const double q = (double)z / 10.;
+          wn = (float)((double)wn * (1. - ((1. < q) ? 1. : q)));
+        }
+        const int64_t vi = ((int64_t)(a.zl0 + zl) * a.plane_rows + y) * a.pitch + x;
+        float w = Wt[vi], d = D[vi];
+        const float wsum = w + wn;
+        if (COLOR) {  // RGBNode::addObservation, octree.cpp:331-335: the OLD w, static_cast<uint8_t> = cvttss2si & 255
+          const uint32_t c = bgra[pix], old = RGB[vi];  // PCL memory order b, g, r, a
+          uint32_t out = 0u;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float c_old = (float)((old >> (8 * ch)) & 255u);
+            const float c_new = (float)((c >> (16 - 8 * ch)) & 255u);
+            const float qv = (w * c_old + wn * c_new) / wsum;
+            // x86: NaN and anything outside int32 give INT_MIN, whose low byte is 0; v_cvt_i32_f32 gives 0 for NaN
+            const bool in_range = qv > -2147483904.f && qv < 2147483648.f;
+            out |= (in_range ? ((uint32_t)(int)qv & 255u) : 0u) << (8 * ch);
+          }
+          RGB[vi] = out;
+        }
+        d = (d * w + dn * wn) / wsum;  // octree.cpp:156
+        w = wsum;                      // :157
+        if (w > a.wmax) w = a.wmax;    // :158-159
+        D[vi] = d;
+        Wt[vi] = w;
+        observed = true;
+      }
+    }
+  }
+  if (n_obs) {
+    const unsigned long long m = __ballot(observed);
+    if ((threadIdx.x & 63u) == 0u && m)
+      atomicAdd(n_obs + ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 1023u),
+                (unsigned long long)__popcll(m));
+  }
+}
+
 static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = false) {
   // The certified fp32 projection needs a sane camera; anything else takes the exact path only.
   const int knob = tsdf_tuning().fast_projection;
@@ -715,6 +770,62 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   if (color && !d_bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
+  }
+  if (h->weight_by_variance) {
+    tsdf_set_error("this volume was saved with weight_by_variance_ (hpp:203-204): integrating it needs the per-voxel "
+                   "M_ / nsample_ state of the octree, which the dense grid does not keep");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  const int plain_mode = h->weight_by_depth ? 2 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  if (plain_mode) {  // weight_by_depth_ (or the test knob "plain_kernel"): the plain per-voxel kernel, float weights
+    if (h->packed || h->cn[0]) {
+      tsdf_set_error("weight_by_depth needs the F32W layout and TSDF_COLOR_RGB");
+      return TSDF_HIP_E_UNSUPPORTED;
+    }
+    const bool count = n_observed != nullptr;
+    if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
+    bool pose_ok = true;
+    for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
+    if (pose_ok) {
+      const dim3 grid((unsigned)((h->pitch + 255) / 256), (unsigned)h->ny, gz), block(256);
+      if (grid.y > 65535u) {
+        tsdf_set_error("grid too large for one launch");
+        return TSDF_HIP_E_UNSUPPORTED;
+      }
+#define LAUNCH_PLAIN(ORDER, COLOR, BYD)                                                                             \
+  hipLaunchKernelGGL((k_integrate_plain<ORDER, COLOR, BYD>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, d_depth, \
+                     d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], count ? h->counter : nullptr)
+#define LP2(ORDER, COLOR)               \
+  do {                                  \
+    if (plain_mode == 2)                \
+      LAUNCH_PLAIN(ORDER, COLOR, true); \
+    else                                \
+      LAUNCH_PLAIN(ORDER, COLOR, false); \
+  } while (0)
+      if (p.xform_order == TSDF_XFORM_PCL_SSE) {
+        if (color)
+          LP2(TSDF_XFORM_PCL_SSE, true);
+        else
+          LP2(TSDF_XFORM_PCL_SSE, false);
+      } else {
+        if (color)
+          LP2(TSDF_XFORM_LEFT_TO_RIGHT, true);
+        else
+          LP2(TSDF_XFORM_LEFT_TO_RIGHT, false);
+      }
+#undef LP2
+#undef LAUNCH_PLAIN
+      TSDF_HIP_TRY(hipGetLastError());
+    }
+    if (n_observed) {
+      unsigned long long c[1024];
+      TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
+      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      unsigned long long sum = 0;
+      for (int i = 0; i < 1024; ++i) sum += c[i];
+      *n_observed = pose_ok ? sum : 0;
+    }
+    return TSDF_HIP_OK;
   }
   if (h->cn[0]) {  // TSDF_COLOR_RGB_NORMALIZED: its own plain kernel
     const bool count = n_observed != nullptr;
@@ -847,7 +958,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     }
   }
   const bool count = n_observed != nullptr;
-  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
   // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
   // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
@@ -898,13 +1009,37 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     TSDF_HIP_TRY(hipGetLastError());
   }
   if (n_observed) {
-    unsigned long long c[1024];
+    unsigned long long c[2048];
     TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
     TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-    unsigned long long sum = 0;
-    for (int i = 0; i < 1024; ++i) sum += c[i];
-    *n_observed = pose_ok ? sum : 0;
+    unsigned long long sum = 0, changed = 0;
+    for (int i = 0; i < 1024; ++i) sum += c[i], changed += c[1024 + i];
+    const bool ran = pose_ok && !nothing_observable;
+    *n_observed = ran ? sum : 0;
+    h->last_observed = ran ? sum : 0;
+    h->last_changed_bytes = ran ? changed : 0;
   }
+  return TSDF_HIP_OK;
+}
+
+// The measured side of the roofline's algorithmic bytes (bench.py): of the last integrate call that asked for
+// n_observed (fast kernel only), out[0] = voxels that reached addObservation, out[1] = bytes of voxel words whose
+// value changed (4 per d / w / colour word, 1 per count byte).
+extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  out[0] = h->last_observed;
+  out[1] = h->last_changed_bytes;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  if (weight_by_depth && (h->packed || h->cn[0])) {
+    tsdf_set_error("weight_by_depth makes weights non-integer: it needs the F32W layout (and TSDF_COLOR_RGB)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  h->weight_by_depth = weight_by_depth != 0;
+  h->weight_by_variance = weight_by_variance != 0;
   return TSDF_HIP_OK;
 }
 

@@ -2,15 +2,16 @@
 //
 // Replaces MarchingCubesTSDFOctree::reconstruct (src/lib/marching_cubes_tsdf_octree.cpp:108-236) and the
 // PCL pieces it calls (pcl::MarchingCubes::createSurface / interpolateEdge, Bourke's tables).
-//   k_mc_classify  streaming pass, one thread per quad of 4 x-consecutive cells: candidate test (:192-202),
-//                  8 corner values (getValidNeighborList1D :145-177 / getGridValue :91-106), case index,
-//                  triangle count; active cells are compacted through wave-private LDS lists into
+//   k_mc_classify  ONE streaming pass over the distance plane, marching along z: candidate test (:192-202), the
+//                  signs and |d| < 1 of the 8 corner values (getValidNeighborList1D :145-177 / getGridValue
+//                  :91-106) as bit masks, case index, triangle count; candidate cells collect in wave-private LDS
+//                  lists, their corner weights are tested when a list is flushed (all lanes busy), survivors become
 //                  (Morton key, packed cell) pairs
 //   rocprim sort   by key: the reference emits triangles in octree pre-order with child index
 //                  4*(x>cx) + 2*(y>cy) + (z>cz) (octree.cpp:119,257-264) = Morton order, x the high bit
 //   rocprim scan   triangle offsets
 //   k_mc_emit      one thread per active cell: edge interpolation + triangle/colour output
-// Case tables live in LDS.  Streaming stencil read of d and w: HBM-bound, no MFMA.
+// Case tables live in LDS.  Streaming stencil read of d (w only at the surface): HBM-bound, no MFMA.
 #include <string.h>
 
 #include <cstring>
@@ -21,6 +22,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "tsdf_common.h"
+#include "tsdf_buffer.h"
 #define TSDF_MC_TABLE_QUALIFIER __device__
 #include "mc_tables.h"
 
@@ -35,7 +37,9 @@ struct McArgs {
   int color_mode;
   float lower[3], size_voxel[3];
   int flush_at;                  // flush a wave's LDS list once it holds more than this many cells
-  int qpr, log2TX, TX, TY, rpb;  // classify launch shape: TX quads along x, TY rows, rpb row groups per block
+  int qpr;                       // quads per row = ceil(nx / 4)
+  int check_w;                   // the weight test can fail (0: PACKED layout and w_min <= 0, every count passes)
+  int zb;                        // cell planes a classify block marches (<= MC_ZB; zb + 1 planes must span < 4 GB)
 };
 
 // getGridValue (:91-106): NaN if w < w_min or |d| >= 1, else d * max_dist_neg.
@@ -77,175 +81,196 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
   return c;
 }
 
-// Weights of the quad starting at element o (16-byte aligned), per layout:
-// WL 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3 of the colour word), 2 = PACKED
-// without colour (uint8 count plane).
-template <int WL>
-static __device__ __forceinline__ void load_w4(const PlaneView &pv, int64_t o, float w[4]) {
-  if (WL == 0) {
-    const float4 w4 = *reinterpret_cast<const float4 *>(pv.w + o);
-    w[0] = w4.x, w[1] = w4.y, w[2] = w4.z, w[3] = w4.w;
-  } else if (WL == 1) {
-    const uint4 c4 = *reinterpret_cast<const uint4 *>(pv.rgb + o);
-    w[0] = tsdf_decode_w(c4.x >> 24, pv.wmax), w[1] = tsdf_decode_w(c4.y >> 24, pv.wmax);
-    w[2] = tsdf_decode_w(c4.z >> 24, pv.wmax), w[3] = tsdf_decode_w(c4.w >> 24, pv.wmax);
-  } else {
-    const uint32_t k4 = *reinterpret_cast<const uint32_t *>(pv.k8 + o);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = tsdf_decode_w((k4 >> (8 * j)) & 255u, pv.wmax);
-  }
+// Classify: ONE streaming pass over the distance plane d, nothing else.
+//
+// A cell's case index depends only on the SIGNS of its eight corner values d * max_dist_neg (:91-106 for valid
+// corners; createSurface compares them with iso level 0), and seven of the eight validity tests are |d| < 1.  So a
+// thread reduces every quad of 4 x-consecutive distances it loads to two 4-bit masks (negative / inside the
+// truncation band) and the whole cell logic runs on bits.  A wave owns a tile of 64 quads (1 KiB of a row) by
+// MC_R rows and MARCHES along z: the masks of plane z stay in registers while plane z + 1 streams in, so every
+// distance is loaded once (plus one halo row per MC_R rows -- the next wave of the same block loads it anyway, an
+// L1/L2 hit -- and one plane per MC_ZB).  Neighbours along x come from the next lane (one shuffle of the packed
+// bit-0 column; lane 63 loads its five halo words itself), neighbours along y and z are the thread's own registers.
+// No barrier, no dependent global load: the only thing a cell that might emit triangles (mixed signs, all eight
+// corners inside the band, base voxel strictly inside the grid :199-202) costs is an append to the wave-private
+// LDS list.
+//
+// The eighth test, w >= w_min at the eight corners (:91-106,145-177, which includes the base voxel's :192), is
+// deferred to the flush of that list, where every lane holds one listed cell: the weight gathers run with all 64
+// lanes busy instead of stalling a whole wave for the one lane whose quad touches a surface (a box face
+// perpendicular to x puts exactly one such lane into every wave of its x-chunk; that was what bound the previous
+// version: 11.8 ms at 2048^3).  Cells that pass go to the global (Morton key, packed cell) arrays, one atomic per
+// 64 cells.  counters[0] = active cells, counters[1] = triangles.
+#define MC_WAVE_BUF 1024  // 32-bit entries per wave; one plane step of a wave adds at most 64 * 4 * MC_R = 1024
+#define MC_R 4            // cell rows per wave
+#define MC_ZB 32          // cell planes per block
+#define MC_COL0 0x0108421u  // bit 0 of each of the five 5-bit row groups
+
+template <int WL>  // 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3), 2 = PACKED count plane
+static __device__ __forceinline__ float mc_load_w(const PlaneView &pv, int64_t i) {
+  if (WL == 0) return pv.w[i];
+  return tsdf_decode_w(WL == 1 ? (pv.rgb[i] >> 24) : (unsigned)pv.k8[i], pv.wmax);
 }
 
-// Classify: a streaming pass over d and w.  A thread owns a quad of 4 x-consecutive base voxels (one
-// 16-byte load per plane) and walks `rpb` rows; a wave touches 1 KiB contiguous per plane, like
-// k_integrate.  Quads with no candidate voxel (:192: w >= w_min && |d| < 1) -- almost all of the grid --
-// cost one load of d.  A quad with a candidate fetches the distances of the other three rows of its 2x2 row
-// bundle (L1/L2 hits: the neighbouring thread / the block one plane up streams them anyway), and its weights
-// only if one of its up to 4 cells has corners of both signs; active cells go to a wave-private LDS list, flushed to the
-// global (Morton key, packed cell) arrays with ONE atomic per flush and coalesced stores.
-// counters[0] = active cells, counters[1] = triangles.
-#define MC_WAVE_BUF 512  // entries per wave; one append adds at most 256
 template <int WL>
-static __global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, uint64_t capacity,
               unsigned long long *__restrict__ counters) {
   __shared__ unsigned char s_ntri[256];
-  __shared__ uint64_t s_buf[4][MC_WAVE_BUF];
+  __shared__ uint32_t s_buf[4][MC_WAVE_BUF];
   s_ntri[threadIdx.x] = mc_ntri_table[threadIdx.x];
   __syncthreads();
   const unsigned tid = threadIdx.x, lane = tid & 63u;
-  volatile uint64_t *buf = s_buf[tid >> 6];
-  const int tx = (int)(tid & (unsigned)(a.TX - 1));
-  const int ty = (int)(tid >> a.log2TX);
-  const int xq = (int)blockIdx.x * a.TX + tx;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // in an SGPR: row bases stay scalar
+  volatile uint32_t *buf = s_buf[wave];
+  const int xq = (int)blockIdx.x * 64 + (int)lane;
   const int x4 = xq * 4;
-  const int z = a.z_lo + (int)blockIdx.z;
+  const int yw = 1 + ((int)blockIdx.y * 4 + (int)wave) * MC_R;  // first cell row of this wave
+  const int zs = a.z_lo + (int)blockIdx.z * a.zb;
+  const int ze = min(zs + a.zb, a.z_hi);                       // cell planes [zs, ze); plane ze is read
   const int64_t sz = (int64_t)a.ny * a.pitch;
-  const int64_t zbase = (int64_t)(z - a.z_first) * sz;
-  const bool tail = x4 + 4 < (int)a.pitch;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   unsigned n_buf = 0;    // wave-uniform: entries waiting in buf
   unsigned tri_sum = 0;  // per lane
+  if (yw >= a.ny - 1) return;  // the whole wave lies past the last cell row (wave-uniform; no barrier follows)
+  // Cells this thread may emit, as a mask over the packed layout below (row r of the wave at bits 5r .. 5r+3):
+  // base voxel strictly inside the grid along x and y (:199-202)
+  unsigned cell_mask = 0u;
+#pragma unroll
+  for (int r = 0; r < MC_R; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      cell_mask |= (x4 + j >= 1 && x4 + j < a.nx - 1 && yw + r < a.ny - 1 ? 1u : 0u) << (5 * r + j);
+  const bool edge_lane = lane == 63u && x4 + 4 < (int)a.pitch;  // the only lane whose x + 1 neighbour is not in the wave
 
+  const unsigned wbytes = WL == 2 ? 1u : 4u;
+  const void *wbase = WL == 0 ? (const void *)(a.pv.w + (int64_t)(zs - a.z_first) * sz)
+                    : WL == 1 ? (const void *)(a.pv.rgb + (int64_t)(zs - a.z_first) * sz)
+                              : (const void *)(a.pv.k8 + (int64_t)(zs - a.z_first) * sz);
+  const rsrc_t rsW = make_rsrc(wbase, (unsigned)(ze + 1 - zs) * (unsigned)sz * wbytes);
+  const unsigned rows_here = (unsigned)min(MC_R + 1, a.ny - yw);  // rows of this wave's tile that exist (incl. the halo row)
+  const unsigned voff = (unsigned)x4 * 4u;
+  const unsigned row_bytes = (unsigned)a.pitch * 4u;
+
+  // The deferred weight test + the copy-out.  Every lane takes one listed cell:
+  // entry = x - 256 blockIdx.x | row << 8 | (z - zs) << 10 | triangles << 15.
   auto flush = [&]() {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)n_buf);
-    base = __shfl(base, 0);
-    for (unsigned i = lane; i < n_buf; i += 64u) {
-      const uint64_t v = buf[i];
-      const unsigned long long slot = base + i;
-      if (slot < capacity) {
-        const uint64_t x = v & 0xfffffull, y = (v >> 20) & 0xfffffull, zz = (v >> 40) & 0xfffffull;
-        keys[slot] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(zz);
-        vals[slot] = v;
+    for (unsigned i0 = 0; i0 < n_buf; i0 += 64u) {
+      const unsigned i = i0 + lane;
+      bool ok = i < n_buf;
+      const uint32_t e = ok ? buf[i] : 0u;
+      const uint64_t x = (uint64_t)(blockIdx.x * 256u + (e & 255u)), y = (uint64_t)(yw + (int)((e >> 8) & 3u)),
+                     zz = (uint64_t)(zs + (int)((e >> 10) & 31u));
+      if (a.check_w && ok) {
+        // 32-bit offsets into the block's planes [zs, ze] of the weight plane (the host keeps that span < 4 GB)
+        const unsigned o = (((e >> 10) & 31u) * (unsigned)a.ny + (unsigned)y) * (unsigned)a.pitch + (unsigned)x;
+        const unsigned p1 = (unsigned)a.pitch, s1 = (unsigned)sz;
+        const unsigned off[8] = {0u, 1u, 1u + s1, s1, p1, 1u + p1, 1u + p1 + s1, p1 + s1};
+        float w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (WL == 0)
+            w[k] = __uint_as_float(bload32(rsW, (o + off[k]) * 4u, 0u));
+          else if (WL == 1)
+            w[k] = tsdf_decode_w(bload32(rsW, (o + off[k]) * 4u, 0u) >> 24, a.pv.wmax);
+          else
+            w[k] = tsdf_decode_w(bload8(rsW, o + off[k], 0u), a.pv.wmax);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ok = ok && !(w[k] < a.w_min);  // getGridValue :98: NaN iff w < w_min (or |d| >= 1)
+      }
+      const unsigned long long m = __ballot(ok);
+      if (!m) continue;
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(m));
+      base = __shfl(base, 0);
+      const unsigned long long slot = base + (unsigned long long)__popcll(m & lanes_below);
+      if (ok) {
+        tri_sum += e >> 15;
+        if (slot < capacity) {
+          keys[slot] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(zz);
+          vals[slot] = x | (y << 20) | (zz << 40) | ((uint64_t)(e >> 15) << 60);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads done before the next append overwrites
     n_buf = 0;
   };
 
-  const int y0 = 1 + (int)blockIdx.y * a.rpb * a.TY + ty;
-  // One row of this thread's quad column; d4 was loaded by the caller (4 rows are in flight at a time: a
-  // quad that fails the distance test costs nothing but that load, so the loop is pure memory latency
-  // unless several loads overlap).
-  auto row = [&](int r, const float4 d4) {
-    const int y = y0 + r * a.TY;
-    unsigned nt[4] = {0u, 0u, 0u, 0u};
-    if (xq < a.qpr && y < a.ny - 1) {
-      const int64_t o = zbase + (int64_t)y * a.pitch + x4;
-      const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
-      // :192 and :199-202 (base voxel strictly inside the grid).  Three filters, cheapest first:
-      //  1. |d| < 1 at the base voxel: free space (d at the hinge) and unobserved voxels (d = -1) fail, so most of
-      //     the grid costs one load of d;
-      //  2. the SIGNS of the eight corner values d * max_dist_neg (:91-106 for valid corners): a cell whose
-      //     corners agree in sign has case 0 or 255 and emits nothing whatever its weights -- that is the whole
-      //     truncation band except the one or two cells the surface actually crosses -- so the band needs the
-      //     distances of its 2x2 row bundle but not the weights;
-      //  3. only cells with a mixed case load the bundle's weights: every corner must be valid
-      //     (w >= w_min && |d| < 1, :91-106,145-177), which includes the base voxel's own test (:192).
-      bool cand[4], any = false;
+  // Masks of one plane's MC_R + 1 rows, packed: row r occupies bits 5r .. 5r+4; bit 5r + j (j = 0..3) = voxel
+  // x4 + j, bit 5r + 4 = voxel x4 + 4 (the next quad's first).  ng: d * max_dist_neg < 0; bd: |d| < 1.
+  auto load_plane = [&](int z, unsigned &ng, unsigned &bd) {
+    // one descriptor per plane over exactly the rows of the tile that exist: a row past the grid reads 0, which
+    // only ever feeds cells that cell_mask excludes (so do lanes past the row's last quad, which read on into
+    // the next row)
+    const rsrc_t rsD = make_rsrc(a.d + ((int64_t)(z - a.z_first) * a.ny + yw) * a.pitch, rows_here * row_bytes);
+    u4 q[MC_R + 1];
+    float e[MC_R + 1];
+#pragma unroll
+    for (int r = 0; r <= MC_R; ++r) q[r] = bload128(rsD, voff, (unsigned)r * row_bytes);
+#pragma unroll
+    for (int r = 0; r <= MC_R; ++r) e[r] = 1.f;
+    if (edge_lane) {
+#pragma unroll
+      for (int r = 0; r <= MC_R; ++r) e[r] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)r * row_bytes));
+    }
+    ng = bd = 0u;
+#pragma unroll
+    for (int r = 0; r <= MC_R; ++r) {
+      const float dq[4] = {__uint_as_float(q[r].x), __uint_as_float(q[r].y), __uint_as_float(q[r].z), __uint_as_float(q[r].w)};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        cand[j] = fabsf(dq[j]) < 1.f && x4 + j >= 1 && x4 + j < a.nx - 1;
-        any |= cand[j];
-      }
-      if (any) {
-        const int64_t ro[4] = {o, o + a.pitch, o + sz, o + sz + a.pitch};  // rows (y,z) (y+1,z) (y,z+1) (y+1,z+1)
-        float dr[4][5];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float4 q = rr == 0 ? d4 : *reinterpret_cast<const float4 *>(a.d + ro[rr]);
-          dr[rr][0] = q.x, dr[rr][1] = q.y, dr[rr][2] = q.z, dr[rr][3] = q.w;
-          dr[rr][4] = tail ? a.d[ro[rr] + 4] : 1.f;
-        }
-        unsigned sg[4];  // bit x: value of voxel x4 + x in this row is negative
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          sg[rr] = 0u;
-#pragma unroll
-          for (int x = 0; x < 5; ++x) sg[rr] |= (dr[rr][x] * a.neg < 0.f ? 1u : 0u) << x;
-        }
-        // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1) as (dx,dy,dz)
-        auto corners = [](const unsigned m[4], int j) -> unsigned {
-          return ((m[0] >> j) & 1u) | (((m[0] >> (j + 1)) & 1u) << 1) | (((m[2] >> (j + 1)) & 1u) << 2) |
-                 (((m[2] >> j) & 1u) << 3) | (((m[1] >> j) & 1u) << 4) | (((m[1] >> (j + 1)) & 1u) << 5) |
-                 (((m[3] >> (j + 1)) & 1u) << 6) | (((m[3] >> j) & 1u) << 7);
-        };
-        unsigned ci[4];
-        any = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ci[j] = corners(sg, j);
-          cand[j] = cand[j] && ci[j] != 0u && ci[j] != 255u;
-          any |= cand[j];
-        }
-        if (any) {
-          unsigned vm[4];  // bit x: voxel x4 + x of this row is a valid grid value
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            float w[5];
-            load_w4<WL>(a.pv, ro[rr], w);
-            w[4] = tail ? tsdf_load_w(a.pv, ro[rr] + 4) : 0.f;
-            vm[rr] = 0u;
-#pragma unroll
-            for (int x = 0; x < 5; ++x) vm[rr] |= (w[x] >= a.w_min && fabsf(dr[rr][x]) < 1.f ? 1u : 0u) << x;
-            if (!tail) vm[rr] &= 15u;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cand[j] && corners(vm, j) == 255u) nt[j] = s_ntri[ci[j]];
-        }
+        ng |= dq[j] * a.neg < 0.f ? 1u << (5 * r + j) : 0u;  // createSurface: leaf < iso (0), leaf = d * max_dist_neg
+        bd |= fabsf(dq[j]) < 1.f ? 1u << (5 * r + j) : 0u;   // :98
       }
     }
-    const unsigned cnt = (nt[0] > 0) + (nt[1] > 0) + (nt[2] > 0) + (nt[3] > 0);
-    const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
-    if ((b0 | b1 | b2) == 0) return;
-    unsigned pos = n_buf + (unsigned)__popcll(b0 & lanes_below) + 2u * (unsigned)__popcll(b1 & lanes_below) +
-                   4u * (unsigned)__popcll(b2 & lanes_below);
-    n_buf += (unsigned)__popcll(b0) + 2u * (unsigned)__popcll(b1) + 4u * (unsigned)__popcll(b2);
+    // the next lane's first column (both masks in one shuffle)
+    unsigned nb = (unsigned)__shfl_down((int)((ng & MC_COL0) | ((bd & MC_COL0) << 1)), 1);
+    if (lane == 63u) {
+      nb = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (nt[j]) {
-        buf[pos++] = (uint64_t)(x4 + j) | ((uint64_t)y << 20) | ((uint64_t)z << 40) | ((uint64_t)nt[j] << 60);
-        tri_sum += nt[j];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if ((int)n_buf > a.flush_at) flush();
+      for (int r = 0; r <= MC_R; ++r)
+        nb |= (e[r] * a.neg < 0.f ? 1u << (5 * r) : 0u) | (fabsf(e[r]) < 1.f ? 2u << (5 * r) : 0u);
+    }
+    ng |= (nb & MC_COL0) << 4;
+    bd |= ((nb >> 1) & MC_COL0) << 4;
   };
-  const bool col_ok = xq < a.qpr;
-  for (int rg = 0; rg < a.rpb; rg += 4) {
-    if (y0 - ty + rg * a.TY >= a.ny - 1) break;  // whole block past the last cell row (uniform)
-    float4 d4[4];
+
+  unsigned n0, b0, n1, b1;
+  load_plane(zs, n0, b0);
+  for (int z = zs; z < ze; ++z) {
+    load_plane(z + 1, n1, b1);
+    // all 4 * MC_R cells of the thread at once: rows r and r + 1 are 5 bits apart, columns j and j + 1 one bit
+    const unsigned A = n0 & (n0 >> 5) & n1 & (n1 >> 5), O = n0 | (n0 >> 5) | n1 | (n1 >> 5);
+    const unsigned V = b0 & (b0 >> 5) & b1 & (b1 >> 5);
+    // mixed signs (neither all eight negative nor none) and all eight inside the band
+    unsigned cand = ~(A & (A >> 1)) & (O | (O >> 1)) & (V & (V >> 1)) & cell_mask;
+    if (__ballot(cand != 0u)) {
+      const unsigned cnt = (unsigned)__popc(cand);  // 0 .. 16
+      unsigned pos = 0u, add = 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int y = y0 + (rg + u) * a.TY;
-      d4[u] = make_float4(1.f, 1.f, 1.f, 1.f);  // |d| >= 1: no candidate
-      if (col_ok && rg + u < a.rpb && y < a.ny - 1)
-        d4[u] = *reinterpret_cast<const float4 *>(a.d + zbase + (int64_t)y * a.pitch + x4);
+      for (int k = 0; k < 5; ++k) {
+        const unsigned long long bk = __ballot((cnt >> k) & 1u);
+        pos += (unsigned)__popcll(bk & lanes_below) << k;
+        add += (unsigned)__popcll(bk) << k;
+      }
+      if (n_buf && ((int)n_buf > a.flush_at || n_buf + add > MC_WAVE_BUF)) flush();
+      pos += n_buf;
+      n_buf += add;
+      while (cand) {
+        const unsigned bit = (unsigned)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        const unsigned r = (bit * 13u) >> 6, j = bit - 5u * r;  // bit / 5 for bit < 25
+        const unsigned p = n0 >> bit, q = n1 >> bit;
+        // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1) as (dx,dy,dz)
+        const unsigned ci = (p & 3u) | ((q & 2u) << 1) | ((q & 1u) << 3) | (((p >> 5) & 1u) << 4) | (((p >> 6) & 1u) << 5) |
+                            (((q >> 6) & 1u) << 6) | (((q >> 5) & 1u) << 7);
+        buf[pos++] = (lane * 4u + j) | (r << 8) | ((unsigned)(z - zs) << 10) | ((unsigned)s_ntri[ci] << 15);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (rg + u < a.rpb) row(rg + u, d4[u]);
+    n0 = n1;
+    b0 = b1;
   }
   if (n_buf) flush();
   if (__ballot(tri_sum > 0)) {
@@ -399,21 +424,30 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   if (a.z_hi <= a.z_lo || a.nx < 3 || a.ny < 3) return TSDF_HIP_OK;
 
   a.qpr = (a.nx + 3) / 4;
-  a.log2TX = 0;
-  while ((1 << a.log2TX) < a.qpr && a.log2TX < 8) ++a.log2TX;
-  a.TX = 1 << a.log2TX;
-  a.TY = 256 / a.TX;
-  a.rpb = std::max(1, tsdf_tuning().rows_per_block / a.TY);
-  a.flush_at = std::min(MC_WAVE_BUF - 256, std::max(0, tsdf_tuning().mc_flush_at));
+  a.check_w = !(h->packed && !(w_min > 0.f));  // a PACKED weight is min(k, max_weight) >= 0: never below w_min <= 0
+  a.flush_at = std::min(MC_WAVE_BUF, std::max(0, tsdf_tuning().mc_flush_at));
   const int cell_rows = a.ny - 2;
-  const dim3 block(256), grid((unsigned)((a.qpr + a.TX - 1) / a.TX),
-                              (unsigned)((cell_rows + a.rpb * a.TY - 1) / (a.rpb * a.TY)), (unsigned)(a.z_hi - a.z_lo));
+  // a block = 4 waves = 4 * MC_R consecutive cell rows of one 256-voxel x-chunk, marching zb planes; the weight test
+  // addresses the block's zb + 1 planes with 32-bit byte offsets
+  {
+    const uint64_t plane_bytes = (uint64_t)a.ny * (uint64_t)a.pitch * 4u;
+    const int64_t fit = (int64_t)(0xffffffffull / plane_bytes) - 1;
+    if (fit < 1) return TSDF_HIP_E_UNSUPPORTED;
+    a.zb = (int)std::min<int64_t>(MC_ZB, fit);
+  }
+  const dim3 block(256), grid((unsigned)((a.qpr + 63) / 64), (unsigned)((cell_rows + 4 * MC_R - 1) / (4 * MC_R)),
+                              (unsigned)((a.z_hi - a.z_lo + a.zb - 1) / a.zb));
   if (grid.y > 65535u || grid.z > 65535u) return TSDF_HIP_E_UNSUPPORTED;
   unsigned long long counts[2] = {0, 0};
+  for (int i = 0; i < 4; ++i)
+    if (!h->mc_ev[i]) TSDF_HIP_TRY(hipEventCreate(&h->mc_ev[i]));
+  h->mc_ms[0] = h->mc_ms[1] = h->mc_ms[2] = 0.f;
+  h->mc_ncells = 0;
   // pass 1 with the capacity we already have; if the surface turned out larger, grow and repeat
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t cap = h->mc_cells_cap;
     TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2 * sizeof(unsigned long long), h->stream));
+    TSDF_HIP_TRY(hipEventRecord(h->mc_ev[0], h->stream));
     if (!h->packed)
       hipLaunchKernelGGL(k_mc_classify<0>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
     else if (h->rgb)
@@ -421,6 +455,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     else
       hipLaunchKernelGGL(k_mc_classify<2>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
     TSDF_HIP_TRY(hipGetLastError());
+    TSDF_HIP_TRY(hipEventRecord(h->mc_ev[1], h->stream));
     TSDF_HIP_TRY(hipMemcpyAsync(counts, h->counter, sizeof counts, hipMemcpyDeviceToHost, h->stream));
     TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
     if (counts[0] <= cap) break;
@@ -433,6 +468,8 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     h->mc_cells_cap = need;
   }
   const uint64_t n_cells = counts[0], ntri = counts[1];
+  (void)hipEventElapsedTime(&h->mc_ms[0], h->mc_ev[0], h->mc_ev[1]);  // the last (successful) classify pass
+  h->mc_ncells = n_cells;
   if (n_cells == 0) return TSDF_HIP_OK;
   if (n_cells > 0xffffffffull || ntri > 0xffffffffull) {
     tsdf_set_error("mesh too large (more than 2^32 cells or triangles)");
@@ -486,13 +523,25 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     TSDF_HIP_TRY(hipMalloc(&h->mc_cell, cap * sizeof(uint64_t)));
     h->mc_cap = cap;
   }
+  TSDF_HIP_TRY(hipEventRecord(h->mc_ev[2], h->stream));
   hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts,
                      color_mode ? h->mc_rgb : nullptr, h->mc_cell);
   TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipEventRecord(h->mc_ev[3], h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  (void)hipEventElapsedTime(&h->mc_ms[1], h->mc_ev[1], h->mc_ev[2]);  // count read-back, sort, scan (+ buffer growth)
+  (void)hipEventElapsedTime(&h->mc_ms[2], h->mc_ev[2], h->mc_ev[3]);
   h->mc_ntri = ntri;
   h->mc_has_rgb = color_mode != 0;
   if (n_tri) *n_tri = ntri;
+  return TSDF_HIP_OK;
+}
+
+// Report-only: device time of the last tsdf_hip_march by phase (HIP events on the handle's stream).
+extern "C" int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells) {
+  if (!h || !ms) return TSDF_HIP_E_INVALID;
+  for (int i = 0; i < 3; ++i) ms[i] = h->mc_ms[i];
+  if (n_cells) *n_cells = h->mc_ncells;
   return TSDF_HIP_OK;
 }
 

@@ -646,8 +646,8 @@ extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, siz
 static __device__ __forceinline__ int sgn(float x) { return x > 0 ? 1 : -1; }  // :674-678
 
 static __global__ void __launch_bounds__(256)
-k_sample(const GridView g, const float *__restrict__ xyz, size_t n, float *__restrict__ val,
-         float *__restrict__ grad, float *__restrict__ hess, unsigned char *__restrict__ ok) {
+k_sample(const GridView g, const int own_lo, const int own_hi, const float *__restrict__ xyz, size_t n,
+         float *__restrict__ val, float *__restrict__ grad, float *__restrict__ hess, unsigned char *__restrict__ ok) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const float px = xyz[3 * idx], py = xyz[3 * idx + 1], pz = xyz[3 * idx + 2];
@@ -661,7 +661,10 @@ k_sample(const GridView g, const float *__restrict__ xyz, size_t n, float *__res
     if (xi < 0 || xi >= g.nx - 1 || yi < 0 || yi >= g.ny - 1 || zi < 0 || zi >= g.nz - 1) good = false;
   }
   const int kl = zi - g.z_first;
-  if (good && (kl < 0 || kl + 1 >= g.nz_alloc)) good = false;  // not held by this handle
+  // A Z-slab handle answers only for points whose lower-corner plane it OWNS: halo planes are allocated but only
+  // as fresh as the caller's last exchange, and exactly one handle of a partition owns any plane (plane zi + 1
+  // may be the first halo plane: the one-plane exchange marching cubes needs as well).
+  if (good && (zi < own_lo || zi >= own_hi || kl < 0 || kl + 1 >= g.nz_alloc)) good = false;
   float v = NAN, gr[3] = {NAN, NAN, NAN}, h01 = NAN, h02 = NAN, h12 = NAN;
   if (good) {
     const float c = g.size[0] / g.nx;
@@ -722,8 +725,8 @@ extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float 
   unsigned char *d_ok = (unsigned char *)(d_hess + 9 * n);
   if ((rc = tsdf_to_device(h, d_xyz, xyz, 3 * n * sizeof(float)))) return rc;
   const GridView g = make_view(h);
-  hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, d_xyz, n, d_val,
-                     d_grad, d_hess, d_ok);
+  hipLaunchKernelGGL(k_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, g, h->z_begin, h->z_end, d_xyz,
+                     n, d_val, d_grad, d_hess, d_ok);
   TSDF_HIP_TRY(hipGetLastError());
   if (val && (rc = tsdf_to_host(h, val, d_val, n * sizeof(float)))) return rc;
   if (grad && (rc = tsdf_to_host(h, grad, d_grad, 3 * n * sizeof(float)))) return rc;

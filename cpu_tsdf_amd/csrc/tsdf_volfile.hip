@@ -155,7 +155,11 @@ int load_header(void *user, const tsdf_params *p, const tsdf_vol_meta *m) {
   s->p = *p;
   s->m = *m;
   if (s->force_f32w) s->p.layout = TSDF_LAYOUT_F32W;
-  return tsdf_hip_create(&s->p, &s->h);
+  // a depth-weighted volume (hpp:201-202) holds weights that are not counts, and keeps integrating that way
+  if (m->weight_by_depth && s->p.layout == TSDF_LAYOUT_AUTO) s->p.layout = TSDF_LAYOUT_F32W;
+  const int rc = tsdf_hip_create(&s->p, &s->h);
+  if (rc) return rc;
+  return tsdf_hip_set_weighting(s->h, m->weight_by_depth, m->weight_by_variance);
 }
 int load_store(void *user, int x0, int y0, int z0, int c, float *d, float *w, uint8_t *rgb) {
   return tsdf_hip_upload(((LoadState *)user)->h, x0, y0, z0, c, c, c, d, w, rgb);

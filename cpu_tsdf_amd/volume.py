@@ -370,6 +370,7 @@ class TSDFVolumeOctree:
         cell = getattr(self, "_max_cell", None) or tuple(self._p.size[k] / self._p.res[k] for k in range(3))
         m.max_cell_size[:] = cell
         m.is_empty = int(self._is_empty)
+        m.weight_by_depth, m.weight_by_variance = (int(v) for v in getattr(self, "_weighting", (0, 0)))
         m.global_transform[:] = [float(v) for v in self._global_transform.reshape(16)]
         capi.check(capi.load().tsdf_hip_save(self._need(), str(filename).encode(), C.byref(m)), "save")
 
@@ -390,6 +391,8 @@ class TSDFVolumeOctree:
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
         self._max_cell = tuple(m.max_cell_size)
         self._is_empty = bool(m.is_empty)
+        # hpp:200-204: the handle integrates depth-weighted / refuses to integrate variance-weighted from here on
+        self._weighting = (bool(m.weight_by_depth), bool(m.weight_by_variance))
         self._global_transform = np.array(list(m.global_transform), dtype=np.float64).reshape(4, 4)
 
     def centers(self, axis):

@@ -145,6 +145,25 @@ int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, const 
                       const double world_to_cam[12], float *depth_out, uint8_t *bgra_out, uint64_t *n_valid);
 int tsdf_hip_integrate_staged(tsdf_handle h, const float cam_from_vol[12], uint64_t *n_observed);
 
+/* Of the last tsdf_hip_integrate* call on this handle that asked for n_observed: out[0] = that count, out[1] = bytes
+ * of voxel words whose VALUE changed (4 per distance / weight / colour word, 1 per count byte) -- with the bytes read
+ * per observed voxel this is the algorithmic traffic of the chosen HBM layout (bench.py's roofline). */
+int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]);
+
+/* The two observation weightings of updateVoxel -- include/cpu_tsdf/impl/tsdf_volume_octree.hpp:200-204.  The
+ * reference has no setter for them: weight_by_depth_ / weight_by_variance_ only become true through load()
+ * (src/lib/tsdf_volume_octree.cpp:265-266); tsdf_hip_load applies what the file says.
+ *   weight_by_depth     w_new *= (1 - std::min(pt.z / 10., 1.)) (:201-202).  Weights are then no longer counts:
+ *                       needs the F32W layout (E_UNSUPPORTED on a PACKED handle; tsdf_hip_load with layout AUTO
+ *                       picks F32W by itself) and TSDF_COLOR_RGB.  Integrated by a plain per-voxel kernel (exact
+ *                       fp64 projection, IEEE divisions), every operation in the reference's order.
+ *   weight_by_variance  w_new *= exp(logNormal(d_new, d, variance)) once a voxel has more than 5 samples (:203-204),
+ *                       from OctreeNode::M_ / nsample_ (src/lib/octree.cpp:160-161,281-287), which the dense grid
+ *                       does not keep: the flag is remembered (save writes it back, queries and marching cubes
+ *                       work), and every integrate entry point then FAILS with TSDF_HIP_E_UNSUPPORTED rather than
+ *                       integrating unweighted. */
+int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance);
+
 /* renderView -- tsdf_volume_octree.cpp:278-421 (everything except the last line).
  *   rot        3x3 row-major float:  trans.rotation().cast<float>()      (:303)
  *   origin     3 floats:             trans.translation().cast<float>()   (:304)
@@ -196,7 +215,8 @@ int tsdf_hip_render_halo(const tsdf_params *p);
 
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
  *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
- *   ok n bytes: 1 where the reference returns true. */
+ *   ok n bytes: 1 where the reference returns true.  A Z-slab handle answers only for points whose lower-corner
+ *   plane it owns (exactly one handle of a partition does; it needs plane z_end fresh in its halo). */
 int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad,
                     float *hess, uint8_t *ok);
 
@@ -213,6 +233,9 @@ int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb,
  * out in the reference's order (octree pre-order = Morton order with x as the high bit). */
 int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri);
 int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell);
+/* Report-only: device milliseconds of the last tsdf_hip_march by phase -- ms[0] classify (k_mc_classify), ms[1] count
+ * read-back + sort + scan, ms[2] emit (k_mc_emit) -- and the number of active cells. */
+int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
 /* The same copies into DEVICE buffers of the caller, asynchronous on the handle's stream (multi-GPU mesh merge:
  * the buffers go straight to RCCL). */
 int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell);
@@ -314,7 +337,7 @@ int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
 
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
- * "mc_flush_at", "cull", "vol_chunk" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
+ * "mc_flush_at", "cull", "vol_chunk", "plain_kernel" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 
 const char *tsdf_hip_error_string(int code);
@@ -322,7 +345,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 3
+#define TSDF_HIP_ABI_VERSION 4
 
 #ifdef __cplusplus
 }

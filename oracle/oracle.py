@@ -46,6 +46,8 @@ def lib():
         L.oracle_centers.argtypes = [C.c_int, C.c_float, _f]
         L.oracle_integrate.restype = C.c_uint64
         L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
+        L.oracle_integrate_weighted.restype = C.c_uint64
+        L.oracle_integrate_weighted.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, C.c_int]
         L.oracle_integrate_rgbn.restype = C.c_uint64
         L.oracle_integrate_rgbn.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
         L.oracle_raycast.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, _f]
@@ -95,9 +97,16 @@ def params_from(p):
 class OracleVolume:
     """Dense CPU volume driven by the C restatement; arrays are [z][y][x]."""
 
-    def __init__(self, params):
+    def __init__(self, params, adopt=None):
+        """adopt = (d, w, rgb or None): wrap existing whole-grid arrays instead of allocating a reset volume
+        (used to run the oracle's raycast / sampling / meshing on grids too large to fuse on the CPU)."""
         self.p = params_from(params)
         nx, ny, nz = self.p.res
+        if adopt is not None:
+            self.d, self.w, self.rgb = adopt
+            assert self.d.shape == (nz, ny, nx) and self.d.dtype == np.float32 and self.d.flags.c_contiguous
+            assert self.w.shape == (nz, ny, nx) and self.w.dtype == np.float32 and self.w.flags.c_contiguous
+            return
         self.d = np.full((nz, ny, nx), -1.0, dtype=np.float32)  # tsdf_volume_octree.cpp:217
         self.w = np.zeros((nz, ny, nx), dtype=np.float32)
         self.rgb = np.zeros((nz, ny, nx, 3), dtype=np.uint8) if self.p.integrate_color else None
@@ -107,12 +116,13 @@ class OracleVolume:
         lib().oracle_centers(self.p.res[axis], self.p.size[axis], _fp(out))
         return out
 
-    def integrate(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
+    def integrate(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0, weight_by_depth=False):
+        """weight_by_depth: hpp:200-202 (a flag only a loaded .vol can carry)."""
         depth = np.ascontiguousarray(depth, dtype=np.float32)
         T = np.ascontiguousarray(cam_from_vol, dtype=np.float32).reshape(12)
         col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
-        return int(lib().oracle_integrate(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), _fp(depth),
-                                          _bp(col), _fp(T), z_begin, z_end))
+        return int(lib().oracle_integrate_weighted(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), _fp(depth),
+                                                   _bp(col), _fp(T), z_begin, z_end, int(bool(weight_by_depth))))
 
     def integrate_rgbn(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
         """integrate with RGBNormalized voxels (setColorMode("RGBNormalized")); self.cn holds r_n, g_n, b_n, i and

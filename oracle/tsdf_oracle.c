@@ -8,7 +8,7 @@
  * Each function follows the reference (sdmiller/cpu_tsdf) line by line; citations are relative to
  * the reference tree.  The restatement is validated against the reference's own, unmodified
  * sources compiled with the in-repo PCL/Eigen stand-ins (oracle/_ref, see oracle/Makefile and
- * tests/test_oracle_vs_reference.py).  The reference ships no tests or golden vectors of its own
+ * tests/test_oracle_golden.py).  The reference ships no tests or golden vectors of its own
  * (SURVEY.md section 4), and the PCL/Eigen arithmetic it calls is not vendored: the pieces marked
  * [PCL-recall]/[Eigen-recall] restate upstream behaviour from memory and are "parity unpinned"
  * (see DESIGN.md).
@@ -164,8 +164,10 @@ static int observe(const oracle_params *p, const float T[12], float x, float y, 
   return 1;
 }
 
-uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
-                          const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
+/* weight_by_depth: hpp:200-202, `w_new *= (1 - std::min(pt.z / 10., 1.))` -- a float times a double, stored
+ * back into the float; the flag has no setter and only arrives through load() (tsdf_volume_octree.cpp:265). */
+static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
+                               const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth) {
   const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
   float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
         *cz = (float *)malloc(sizeof(float) * nz);
@@ -181,14 +183,19 @@ uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *r
         float dn;
         size_t pixel;
         if (!observe(p, T, cx[i], cy[j], cz[k], depth, &dn, &pixel)) continue;
-        const float wn = 1;     /* hpp:200-204: both weightings unreachable */
+        float wn = 1;           /* hpp:200 (the variance weighting of :203-204 needs M_ / nsample_: not restated) */
+        if (weight_by_depth) {  /* hpp:201-202; std::min(a, b) = (b < a) ? b : a */
+          const double a = depth[pixel] / 10.;
+          wn = (float)((double)wn * (1 - ((1. < a) ? 1. : a)));
+        }
         const size_t vi = ((size_t)k * ny + j) * nx + i;
         if (p->integrate_color && rgb) { /* octree.cpp:331-335 (old w, truncation) */
           const uint8_t *px = bgra + 4 * pixel;
           const float wsum = w[vi] + wn;
-          rgb[3 * vi + 0] = (uint8_t)((w[vi] * rgb[3 * vi + 0] + wn * px[2]) / wsum);
-          rgb[3 * vi + 1] = (uint8_t)((w[vi] * rgb[3 * vi + 1] + wn * px[1]) / wsum);
-          rgb[3 * vi + 2] = (uint8_t)((w[vi] * rgb[3 * vi + 2] + wn * px[0]) / wsum);
+          /* static_cast<uint8_t>(float): cvttss2si, then the low byte (NaN -> 0) */
+          rgb[3 * vi + 0] = (uint8_t)(cvtt((double)((w[vi] * rgb[3 * vi + 0] + wn * px[2]) / wsum)) & 255);
+          rgb[3 * vi + 1] = (uint8_t)(cvtt((double)((w[vi] * rgb[3 * vi + 1] + wn * px[1]) / wsum)) & 255);
+          rgb[3 * vi + 2] = (uint8_t)(cvtt((double)((w[vi] * rgb[3 * vi + 2] + wn * px[0]) / wsum)) & 255);
         }
         d[vi] = (d[vi] * w[vi] + dn * wn) / (w[vi] + wn); /* octree.cpp:156 */
         w[vi] += wn;                                       /* octree.cpp:157 */
@@ -199,6 +206,16 @@ uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *r
   free(cy);
   free(cz);
   return n_obs;
+}
+
+uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
+                          const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0);
+}
+
+uint64_t oracle_integrate_weighted(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
+                                   const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth) {
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth);
 }
 
 /* The same with RGBNormalized voxels (setColorMode("RGBNormalized")): RGBNormalized::addObservation,

@@ -1,0 +1,129 @@
+"""GPU tier: BASELINE.json's configs[0..2] at their stated sizes, run by the driver ("Next round" #2).
+
+configs[0]  256^3, ONE 640x480 frame: the HIP path against the REFERENCE's own code (oracle/_ref, dense mode)
+            directly -- every voxel, renderView, the mesh.  No C oracle in between.
+configs[1]  512^3, 105 distinct noisy 640x480 frames (the weight saturates at max_weight = 100 on the way):
+            sampled plane groups against the C oracle at frames 50 / 100 / 101 / 105.
+configs[2]  1024^3, 300 frames with a renderView every 25: sampled plane groups against the C oracle, and the
+            renderView of frames 150 and 300 against the oracle's raycast run on the SAME (downloaded) grid.
+Reference lines: include/cpu_tsdf/impl/tsdf_volume_octree.hpp:113-218, src/lib/octree.cpp:152-163 (saturation),
+src/lib/tsdf_volume_octree.cpp:278-424 (renderView)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle oracle threads must not spin against the HIP runtime
+from cpu_tsdf_amd import capi, synth  # noqa: E402
+from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree, transform_cloud_with_normals  # noqa: E402
+from oracle import refbind  # noqa: E402
+from oracle.oracle import OracleVolume, SlabOracle  # noqa: E402
+from tests.common import assert_same_f32  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+W, H = 640, 480
+
+
+def product(res, color):
+    sc = synth.scene_a(res, W, H)
+    v = TSDFVolumeOctree()
+    v.setResolution(res, res, res)
+    v.setGridSize(sc.size, sc.size, sc.size)
+    v.setImageSize(W, H)
+    v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    v.setSensorDistanceBounds(0.0, 3 * sc.size)
+    v.setIntegrateColor(color)
+    v.reset()
+    return v, sc
+
+
+def test_config0_256_cubed_one_frame_equals_the_reference_itself(gpu):
+    if not refbind.available():
+        pytest.fail("oracle/_ref/libcpu_tsdf_ref.so is missing: build() makes it where /root/reference exists and it "
+                    "travels with the snapshot; configs[0] is defined as a comparison with the reference's own code")
+    res = 256
+    v, sc = product(res, True)
+    rv = refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True, dense=True)
+    tr = synth.turntable_pose(0, 8, sc.size)
+    dep, col = sc.depth(tr), sc.bgra(0)
+    n = v.integrateCloud(dep, col, tr, count=True)
+    rv.integrate(dep, col, tr)
+    d2, w2, rgb2, leaf, _ = rv.dump_dense()
+    assert (leaf == np.float32(sc.size / res)).all()  # the reference really ran on finest leaves everywhere
+    d, w, rgb = v.download()
+    assert n == int((w2 > 0).sum()) > 0.7 * res ** 3
+    assert_same_f32(d, d2, "d")
+    assert_same_f32(w, w2, "w")
+    assert np.array_equal(rgb, rgb2)
+    for pose, ds in [(tr, 1), (synth.turntable_pose(1, 8, sc.size, tilt=0.3), 2)]:
+        got = v.renderView(pose, ds)
+        want, _ = rv.render_view(pose, ds)
+        assert np.isfinite(want[..., 0]).sum() > 10000 // (ds * ds)
+        assert_same_f32(got[..., :6], want[..., :6], f"renderView ds={ds}")
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(v)
+    for wmin, mode in [(0.0, 1), (1.0, 0)]:
+        mc.setMinWeight(wmin)
+        mc.setColorByRGB(mode == 1)
+        mesh = mc.reconstruct()
+        verts, c, polys, _ = rv.march(wmin, mode)
+        assert len(verts) > 10 ** 6
+        assert_same_f32(mesh["vertices"], verts, "mesh vertices (count and order included)")
+        assert np.array_equal(polys.ravel(), np.arange(len(verts), dtype=np.uint32))
+        if mode:
+            assert np.array_equal(mesh["rgb"], c)
+    rv.close()
+    v.close()
+
+
+def run_sequence(res, n_frames, color, groups, check_at, render_every=0, render_check_at=()):
+    v, sc = product(res, color)
+    assert v.getLayout() == capi.LAYOUT_PACKED
+    oracles = [SlabOracle(v._p, a, b) for a, b in groups]
+    views = 0
+    for i in range(n_frames):
+        tr = synth.turntable_pose(i, n_frames, sc.size)
+        dep = sc.depth(tr, noise_seed=12345 + i)
+        col = sc.bgra(i) if color else None
+        v.integrateCloud(dep, col, tr)
+        T = synth.cam_from_vol_f32(tr)
+        for o in oracles:
+            o.integrate(dep, col, T)
+        frame = i + 1
+        if render_every and frame % render_every == 0:
+            img = v.renderView(tr, 1, camera_frame=False)
+            hits = int(np.isfinite(img[..., 0]).sum())
+            assert hits > 0.1 * W * H, f"frame {frame}: only {hits} rays hit"
+            views += 1
+            if frame in render_check_at:  # the oracle's renderView on the very grid the GPU holds
+                d, w, _ = v.download(want_rgb=False)
+                ov = OracleVolume(v._p, adopt=(d, w, None))
+                assert_same_f32(img[..., :6], ov.raycast(tr, 1)[..., :6], f"renderView after frame {frame}")
+                del ov, d, w
+        if frame in check_at:
+            for (a, b), o in zip(groups, oracles):
+                d, w, rgb = v.download(z0=a, nz=b - a)
+                assert_same_f32(d, o.d, f"d planes {a}:{b} after frame {frame}")
+                assert np.array_equal(w, o.w), f"w planes {a}:{b} after frame {frame}"
+                if color:
+                    assert np.array_equal(rgb, o.rgb), f"rgb planes {a}:{b} after frame {frame}"
+    wmax = max(float(o.w.max()) for o in oracles)
+    v.close()
+    return wmax, views
+
+
+def test_config1_512_cubed_105_frames_through_weight_saturation(gpu):
+    res = 512
+    groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 80, res - 78)]
+    wmax, _ = run_sequence(res, 105, True, groups, check_at={50, 100, 101, 105})
+    assert wmax == 100.0  # octree.cpp:157-159: the running mean has turned into an EMA
+
+
+def test_config2_1024_cubed_300_frames_with_renderview(gpu):
+    if torch.cuda.mem_get_info()[0] / 2 ** 30 < 16:
+        pytest.skip("needs ~10 GB of free HBM")
+    res = 1024
+    groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 150, res - 148)]
+    wmax, views = run_sequence(res, 300, False, groups, check_at={150, 300}, render_every=25, render_check_at={150, 300})
+    assert wmax == 100.0 and views == 12

@@ -219,6 +219,25 @@ def test_parity_both_layouts_through_weight_saturation(gpu, layout, color, wmax)
     compare(vol, ov)
 
 
+@pytest.mark.parametrize("wmax", [255.0, 254.5])
+def test_packed_count_saturates_at_one_byte(gpu, wmax):
+    """max_weight in (254, 255] makes kmax == 255, the largest count byte: the 256th and later observations must
+    leave the count (and so the weight) saturated instead of wrapping it to zero.  270 frames on a
+    small grid, the same 8 noisy turntable frames cycled; every plane vs the oracle at the end and at frame 257."""
+    vol, sc = make_volume(32, color=True, max_weight=wmax)
+    vol.setLayout(capi.LAYOUT_PACKED)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    fr = [(tr, dep, col) for _, tr, dep, col in frames(sc, 8, 8, noise=True)]
+    for i in range(270):
+        tr, dep, col = fr[i % 8]
+        vol.integrateCloud(dep, col, tr)
+        ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+        if i in (255, 256, 269):
+            _, w = compare(vol, ov)
+    assert w.max() == wmax
+
+
 def test_brick_cull_is_conservative_camera_inside_volume(gpu):
     """The brick-level frustum cull (dense counterpart of getFrustumCulledVoxels) may only drop blocks no voxel
     of which can be observed.  Camera INSIDE the volume with a short sensor range, as in the reference's README

@@ -227,6 +227,53 @@ def test_ray_handoff_refuses_a_halo_that_is_too_small(gpu):
         s.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sample_across_slab_handles_with_stale_wide_halo(gpu, world):
+    """getFxn / gradient / Hessian over Z-slab handles that keep a WIDE halo (the renderView one) of which only the
+    first plane is fresh: exactly ZSlabVolume.sample's state after integrating since the last render (ADVICE r01:
+    a handle used to answer from any allocated plane pair, and the stale answer won the merge).  A handle must answer
+    only for points whose lower-corner plane it owns; merged exactly as ZSlabVolume.sample merges, the union must
+    equal the single volume."""
+    ov, sc = truth()
+    halo = render_halo(configure)
+    cuts = [slab_range(RES, world, r) for r in range(world)]
+    slabs = [HipSlab(configure, zb, ze, RES, 0, halo=halo) for zb, ze in cuts]
+    fd, fc = slabs[0].frame_buffers()
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        fd.copy_(torch.from_numpy(sc.depth(tr)))
+        fc.copy_(torch.from_numpy(sc.bgra(i)))
+        for s in slabs:
+            s.integrate_tensor(fd, fc, tr)
+    for r in range(world - 1):  # exchange_halo(planes=1, both=False): plane z_end from its owner, nothing else
+        planes = slabs[r + 1].get_planes(cuts[r][1], 1)
+        slabs[r + 1].synchronize()
+        slabs[r].set_planes(cuts[r][1], *planes)
+    rng = np.random.RandomState(7)
+    pts = rng.uniform(-0.5 * sc.size, 0.5 * sc.size, (4000, 3)).astype(np.float32)
+    vs = sc.size / RES
+    for zb, ze in cuts[:-1]:  # crowd the slab seams, where the stale halo planes sit
+        seam = rng.uniform(-0.45 * sc.size, 0.45 * sc.size, (1500, 3)).astype(np.float32)
+        seam[:, 2] = (-0.5 * sc.size + ze * vs + rng.uniform(-halo * vs, halo * vs, 1500)).astype(np.float32)
+        pts = np.concatenate([pts, seam])
+    parts = [s.sample(pts) for s in slabs]
+    ok, val, grad, hess = [np.array(a) for a in parts[0]]
+    owners = ok.astype(np.int32)
+    for o, v, g, h in parts[1:]:
+        take = o & ~ok
+        val[take], grad[take], hess[take] = v[take], g[take], h[take]
+        ok |= o
+        owners += o
+    ok2, val2, grad2, hess2 = ov.sample(pts)
+    assert owners.max() == 1, "a point was answered by two handles"
+    assert np.array_equal(ok, ok2) and ok.sum() > 3000
+    assert_same_f32(val[ok], val2[ok], "getFxn")
+    assert_same_f32(grad[ok], grad2[ok], "gradient")
+    assert_same_f32(hess[ok], hess2[ok], "Hessian")
+    for s in slabs:
+        s.close()
+
+
 def test_zslab_volume_world1_end_to_end(gpu, tmp_path):
     ov, sc = truth()
     vol = ZSlabVolume(configure, RES)

@@ -1,49 +1,87 @@
 #!/usr/bin/env python3
 """Copy the judged parts of a tools/run_rocprof.sh run (gpurun_out/prof_<tag>/) into profiles/ and derive
-profiles/pmc_traffic.json (HBM bytes per k_integrate launch) the way MI355X_MICROARCH.md prescribes:
-FETCH_SIZE and WRITE_SIZE from separate --pmc passes, in KiB; FETCH_SIZE doubled on gfx950 for wide
-coalesced reads, the factor being CHECKED here against k_calib_rmw's exactly known byte count."""
+profiles/pmc_traffic.json: HBM bytes per TIMED k_integrate launch of bench.py, the way MI355X_MICROARCH.md prescribes
+-- FETCH_SIZE and WRITE_SIZE from separate --pmc passes, in KiB; FETCH_SIZE doubled on gfx950 for wide coalesced
+reads, the factor being CHECKED here against k_calib_rmw's exactly known byte count in the same process.  The entry
+is stamped with the hash of the kernel sources (bench.kernel_sha16) and the commit: bench.py only quotes it while
+that hash matches the tree it runs from."""
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def last_json_line(path):
+    for line in reversed(open(path).read().strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            return json.loads(line)
+    raise RuntimeError(f"no JSON line in {path}")
+
+
+def timed_instance(summary):
+    """The non-counting template instance of k_integrate (4th template argument false) = bench.py's timed launches."""
+    for k in summary:
+        if k.startswith("k_integrate<") and k.rstrip(">").split("<")[1].split(",")[3] == "false":
+            return k
+    raise RuntimeError("no non-counting k_integrate instance in " + ", ".join(summary))
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for name in ("kernel_stats.csv", "summary_trace.json", "summary_pmc_FETCH_SIZE.json", "summary_pmc_WRITE_SIZE.json",
-                 "summary_pmc_SQ.json", "summary_pmc_SQ2.json", "bench_under_rocprof.json", "prof_FETCH_SIZE.json"):
+                 "summary_pmc_SQ.json", "summary_pmc_SQ2.json", "bench_under_rocprof.json", "bench_pmc_FETCH_SIZE.json",
+                 "bench_pmc_WRITE_SIZE.json"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
     fetch = json.load(open(os.path.join(src, "summary_pmc_FETCH_SIZE.json")))
     write = json.load(open(os.path.join(src, "summary_pmc_WRITE_SIZE.json")))
-    prof = json.loads(open(os.path.join(src, "prof_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     trace = json.load(open(os.path.join(src, "summary_trace.json")))
-    cal_r = prof["sweep_bytes_read"] / (fetch["k_calib_rmw"]["FETCH_SIZE"] * 1024)
-    cal_w = prof["sweep_bytes_written"] / (write["k_calib_rmw"]["WRITE_SIZE"] * 1024)
-    rd = fetch["k_integrate"]["FETCH_SIZE"] * 1024 * round(cal_r)
-    wr = write["k_integrate"]["WRITE_SIZE"] * 1024 * round(cal_w)
-    key = f"{prof['res']}x{prof['res']}x{prof['planes']}_c{prof['color']}_{prof.get('layout', 'f32w')}"
+    bf = last_json_line(os.path.join(src, "bench_pmc_FETCH_SIZE.json"))
+    bw = last_json_line(os.path.join(src, "bench_pmc_WRITE_SIZE.json"))
+    bt = last_json_line(os.path.join(src, "bench_under_rocprof.json"))
+    assert bf["roofline"]["kernel_sha16"] == bw["roofline"]["kernel_sha16"] == bt["roofline"]["kernel_sha16"]
+    cal = bf["calibration"]
+    cal_r = cal["known_read_bytes"] / (fetch["k_calib_rmw"]["FETCH_SIZE"] * 1024)
+    cal_w = bw["calibration"]["known_written_bytes"] / (write["k_calib_rmw"]["WRITE_SIZE"] * 1024)
+    inst = timed_instance(fetch)
+    assert fetch[inst]["dispatches"] == bf["steps"] and write[inst]["dispatches"] == bw["steps"], "timed instance != timed launches"
+    rd = fetch[inst]["FETCH_SIZE"] * 1024 * round(cal_r)
+    wr = write[inst]["WRITE_SIZE"] * 1024 * round(cal_w)
+    cfg = bf["config"]
+    planes = bf.get("multi_gpu", {}).get("planes_per_gpu", cfg["grid"][2])
+    key = f"{cfg['grid'][0]}x{cfg['grid'][1]}x{planes}_c{int(cfg['color'])}_{cfg['layout']}"
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        head = None
     out_path = os.path.join(dst, "pmc_traffic.json")
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     out[key] = {
-        "tag": tag,
+        "tag": tag, "kernel_sha16": bf["roofline"]["kernel_sha16"], "git_head_when_summarised": head,
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 "
+                   f"--steps {bf['steps']} --calib 2",
+        "kernel_instance": inst, "timed_launches_averaged": fetch[inst]["dispatches"],
         "hbm_bytes_per_launch": rd + wr,
         "read_bytes": rd, "written_bytes": wr,
         "fetch_size_correction": round(cal_r), "write_size_correction": round(cal_w),
-        "calibration": {"kernel": "k_calib_rmw", "known_read_bytes": prof["sweep_bytes_read"],
+        "calibration": {"kernel": "k_calib_rmw", "known_read_bytes": cal["known_read_bytes"],
                         "FETCH_SIZE_KiB": fetch["k_calib_rmw"]["FETCH_SIZE"], "ratio_read": cal_r,
-                        "known_written_bytes": prof["sweep_bytes_written"],
+                        "known_written_bytes": bw["calibration"]["known_written_bytes"],
                         "WRITE_SIZE_KiB": write["k_calib_rmw"]["WRITE_SIZE"], "ratio_write": cal_w},
-        "algorithmic_bytes_per_launch": prof["alg_bytes_per_launch"],
-        "layout_bytes_per_launch": prof.get("layout_bytes_per_launch"),
-        "k_integrate_avg_ns_kernel_trace": trace["k_integrate"]["duration_ns"],
+        "algorithmic_bytes_per_launch": bf["roofline"]["algorithmic_bytes_per_launch"],
+        "kernel_ms_in_profile": {"kernel_trace_avg_timed_instance": trace[timed_instance(trace)]["duration_ns"] / 1e6,
+                                 "bench_line_same_run": bt["roofline"]["kernel_ms"],
+                                 "bench_line_fetch_pass": bf["roofline"]["kernel_ms"]},
+        "frac_of_8TBps_by_traffic": (rd + wr) / (trace[timed_instance(trace)]["duration_ns"] * 1e-9) / 8e12,
     }
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out[key], indent=1))

@@ -2,22 +2,32 @@
 """Reduce rocprofv3 CSV output (kernel trace / counter collection) to per-kernel averages.
 
 usage: pmc_reduce.py <dir-or-csv> [<dir-or-csv> ...]
-Prints JSON: {kernel: {counter: mean-per-dispatch, "dispatches": n, "avg_ns": mean duration}}.
+Prints JSON: {kernel: {counter: mean-per-dispatch, "dispatches": n, "duration_ns": mean duration}}.
+Template instances of k_integrate and k_mc_classify are kept apart ("k_integrate<0,true,true,false,true>"): bench.py
+warms up through the COUNTING instance (<..., true, ...> in the fourth place), so the non-counting instance holds
+exactly the timed launches; "k_integrate" (no arguments) is the mean over all instances.
 """
 import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
+KEYS = ("k_integrate_rgbn", "k_integrate_plain", "k_integrate", "k_calib_rmw", "k_fill_u32", "k_raycast", "k_ray_begin",
+        "k_mc_classify", "k_mc_emit", "k_mc_counts", "k_sample", "k_block", "k_planes", "k_cull", "k_ingest")
 
-def short(name):
-    for key in ("k_integrate", "k_calib_rmw", "k_fill_u32", "k_raycast", "k_ray_begin", "k_mc_classify", "k_mc_emit",
-                "k_mc_counts", "k_sample", "k_block", "k_planes"):
+
+def names(name):
+    """Short names a dispatch is accounted under: the kernel, and (templates) the instance."""
+    for key in KEYS:
         if key in name:
-            return key
-    return name[:48]
+            m = re.search(re.escape(key) + r"<([^>]*)>", name)
+            if m and key in ("k_integrate", "k_mc_classify", "k_raycast"):
+                return [key, key + "<" + m.group(1).replace(" ", "") + ">"]
+            return [key]
+    return [name[:48]]
 
 
 def main():
@@ -38,13 +48,14 @@ def main():
                 for r in rd:
                     key = (r.get("Dispatch_Id"), r["Counter_Name"])
                     per_dispatch[key] += float(r["Counter_Value"])
-                    kname[r.get("Dispatch_Id")] = short(r["Kernel_Name"])
+                    kname[r.get("Dispatch_Id")] = names(r["Kernel_Name"])
                 for (disp, cname), val in per_dispatch.items():
-                    acc[kname[disp]][cname].append(val)
+                    for k in kname[disp]:
+                        acc[k][cname].append(val)
             elif "Start_Timestamp" in cols and "Kernel_Name" in cols:  # kernel trace
                 for r in rd:
-                    acc[short(r["Kernel_Name"])]["duration_ns"].append(
-                        float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                    for k in names(r["Kernel_Name"]):
+                        acc[k]["duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     out = {}
     for k, d in acc.items():
         out[k] = {c: sum(v) / len(v) for c, v in d.items()}

@@ -1,29 +1,35 @@
 #!/bin/bash
-# Profile the integrate kernel on the GPU box (run via gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats over the SAME command the bench line comes from (bench.py)
-#   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy/wait) over tools/prof_integrate.py,
-#      which also launches k_calib_rmw sweeps of exactly known bytes for calibration.
-# Outputs land in gpurun_out/prof_<tag>/ ; tools/pmc_reduce.py turns them into JSON summaries.
+# Profile the path on the GPU box (run via gpurun from the repo root).  EVERY pass runs bench.py itself -- the
+# command the bench line comes from -- so trace durations and counters belong to the very launches bench.py times:
+#   1. rocprofv3 --kernel-trace --stats                      (durations; extras on: k_mc_*, k_raycast appear too)
+#   2. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)  HBM bytes; bench.py --calib 2 adds k_calib_rmw sweeps of
+#                                                            exactly known bytes to the same process for calibration
+#   3. --pmc SQ_* (two passes)                               VALU / wait / instruction mix
+# bench.py warms up through the COUNTING instance of k_integrate, so the non-counting instance in every table is
+# exactly the timed launches (first-after-reset launch excluded).  Outputs: gpurun_out/prof_<tag>/;
+# tools/pmc_reduce.py -> summary_*.json; tools/make_profile_summary.py <tag> copies the judged parts to profiles/.
 set -u
-TAG=${1:-r01c}
+TAG=${1:-r02}
 STEPS=${2:-20}
+PMC_STEPS=${3:-6}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 cd /tmp
+BENCH="python $ROOT/bench.py --warmup 2 --cpu-baseline 0 --scene-b 0"
 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
-  python $ROOT/bench.py --steps $STEPS --warmup 2 --cpu-baseline 0 --scene-b 0 > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
+  $BENCH --steps $STEPS > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$C -o pmc --output-format csv -- \
-    python $ROOT/tools/prof_integrate.py --steps 4 --warmup 1 --calib 2 > $ROOT/$OUT/prof_$C.json 2> $ROOT/$OUT/prof_$C.err
+    $BENCH --steps $PMC_STEPS --calib 2 > $ROOT/$OUT/bench_pmc_$C.json 2> $ROOT/$OUT/bench_pmc_$C.err
 done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
   -d $ROOT/$OUT/pmc_SQ -o pmc --output-format csv -- \
-  python $ROOT/tools/prof_integrate.py --steps 4 --warmup 1 --calib 1 > $ROOT/$OUT/prof_SQ.json 2> $ROOT/$OUT/prof_SQ.err
+  $BENCH --steps $PMC_STEPS > $ROOT/$OUT/bench_pmc_SQ.json 2> $ROOT/$OUT/bench_pmc_SQ.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD TCC_HIT_sum TCC_MISS_sum \
   -d $ROOT/$OUT/pmc_SQ2 -o pmc --output-format csv -- \
-  python $ROOT/tools/prof_integrate.py --steps 4 --warmup 1 --calib 1 > $ROOT/$OUT/prof_SQ2.json 2> $ROOT/$OUT/prof_SQ2.err
+  $BENCH --steps $PMC_STEPS > $ROOT/$OUT/bench_pmc_SQ2.json 2> $ROOT/$OUT/bench_pmc_SQ2.err
 cd $ROOT
 for d in trace pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ pmc_SQ2; do
   python tools/pmc_reduce.py $OUT/$d > $OUT/summary_$d.json 2>> $OUT/reduce.err
