@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "reference_wdepth_32.npz")
 
 
-def weighted_product(sc, tmp_path, color=True, by_depth=1, by_variance=0, layout=capi.LAYOUT_AUTO):
+def weighted_product(sc, tmp_path, color=True, by_depth=1, by_variance=0, layout=capi.LAYOUT_AUTO, order=0):
     v = TSDFVolumeOctree()
     v.setResolution(RES, RES, RES)
     v.setGridSize(sc.size, sc.size, sc.size)
@@ -34,6 +34,7 @@ def weighted_product(sc, tmp_path, color=True, by_depth=1, by_variance=0, layout
     v.save(path)
     patch_weighting(path, by_depth, by_variance)
     v.setLayout(layout)
+    v.setTransformOrder(order)  # load() builds the new handle with this object's device / layout / transform order
     v.load(path)
     return v
 
@@ -42,9 +43,8 @@ def weighted_product(sc, tmp_path, color=True, by_depth=1, by_variance=0, layout
 def test_weight_by_depth_matches_reference_golden_and_oracle(gpu, tmp_path, order):
     gold = np.load(GOLD)
     sc = synth.scene_a(RES, W, H)
-    v = weighted_product(sc, tmp_path)
+    v = weighted_product(sc, tmp_path, order=order)
     assert v.getLayout() == capi.LAYOUT_F32W  # AUTO: weights stop being counts
-    v.setTransformOrder(order)
     pp = params(RES, W, H, sc.size)
     pp.xform_order = order
     ov = OracleVolume(pp)
