@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+# TSDF_HIP_LIB_PATH: an A/B build of the same library (tools/build_variant.py); still no fallback if it is missing
+LIB_PATH = os.environ.get("TSDF_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "libtsdf_hip.so")
 
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_IO = range(7)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
@@ -93,6 +94,7 @@ SIGNATURES = {
     "tsdf_hip_set_weighting": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
+    "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
     "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),
     "tsdf_hip_raycast_begin": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_void_p]),

@@ -48,7 +48,7 @@ static int env_int(const char *name, int dflt) {
 static TsdfTuning &tuning_storage() {
   static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
-                         env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 256),
+                         env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0)};
   return t;

@@ -88,12 +88,13 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
 // thread reduces every quad of 4 x-consecutive distances it loads to two 4-bit masks (negative / inside the
 // truncation band) and the whole cell logic runs on bits.  A wave owns a tile of 64 quads (1 KiB of a row) by
 // MC_R rows and MARCHES along z: the masks of plane z stay in registers while plane z + 1 streams in, so every
-// distance is loaded once (plus one halo row per MC_R rows -- the next wave of the same block loads it anyway, an
-// L1/L2 hit -- and one plane per MC_ZB).  Neighbours along x come from the next lane (one shuffle of the packed
-// bit-0 column; lane 63 loads its five halo words itself), neighbours along y and z are the thread's own registers.
-// No barrier, no dependent global load: the only thing a cell that might emit triangles (mixed signs, all eight
-// corners inside the band, base voxel strictly inside the grid :199-202) costs is an append to the wave-private
-// LDS list.
+// distance is loaded once (plus one halo row per block of 4 * MC_R rows and one plane per MC_ZB).  Neighbours along x
+// come from the next lane (one shuffle of the packed bit-0 column; lane 63 loads its five halo words itself),
+// neighbours along z are the thread's own registers, and the row below a wave's last cells is the next wave's first
+// row: its 10 mask bits per lane cross through LDS, one barrier per plane.  (A first version had every wave load
+// that row itself and rely on the cache: PMC showed 44 GB fetched for a 34 GB plane, waves of a block drift apart.)
+// No dependent global load: the only thing a cell that might emit triangles (mixed signs, all eight corners inside
+// the band, base voxel strictly inside the grid :199-202) costs is an append to the wave-private LDS list.
 //
 // The eighth test, w >= w_min at the eight corners (:91-106,145-177, which includes the base voxel's :192), is
 // deferred to the flush of that list, where every lane holds one listed cell: the weight gathers run with all 64
@@ -101,9 +102,13 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
 // perpendicular to x puts exactly one such lane into every wave of its x-chunk; that was what bound the previous
 // version: 11.8 ms at 2048^3).  Cells that pass go to the global (Morton key, packed cell) arrays, one atomic per
 // 64 cells.  counters[0] = active cells, counters[1] = triangles.
-#define MC_WAVE_BUF 1024  // 32-bit entries per wave; one plane step of a wave adds at most 64 * 4 * MC_R = 1024
+#ifndef MC_WAVE_BUF
+#define MC_WAVE_BUF 1024  // 32-bit entries per wave; HALF a plane step of a wave (two cell rows) adds at most 512
+#endif
 #define MC_R 4            // cell rows per wave
+#ifndef MC_ZB
 #define MC_ZB 32          // cell planes per block
+#endif
 #define MC_COL0 0x0108421u  // bit 0 of each of the five 5-bit row groups
 
 template <int WL>  // 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3), 2 = PACKED count plane
@@ -118,21 +123,35 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
               unsigned long long *__restrict__ counters) {
   __shared__ unsigned char s_ntri[256];
   __shared__ uint32_t s_buf[4][MC_WAVE_BUF];
+  __shared__ uint32_t s_halo[2][256];
+  // Morton-key parts of this block's x (low 8 bits; the rest is block-uniform) / y / z values
+  __shared__ uint32_t s_xkey[256];
+  __shared__ uint64_t s_ykey[4 * MC_R], s_zkey[MC_ZB];
   s_ntri[threadIdx.x] = mc_ntri_table[threadIdx.x];
-  __syncthreads();
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // in an SGPR: row bases stay scalar
   volatile uint32_t *buf = s_buf[wave];
-  const int xq = (int)blockIdx.x * 64 + (int)lane;
+  // Blocks go to the 8 XCDs round-robin by linear id.  With x fastest and 8 x-chunks per row (2048 voxels) every XCD
+  // would own ONE x-chunk, and the two chunks that hold the scene's x-facing walls would keep their XCDs busy long
+  // after the others finished (measured: half the chip idle on average).  So the linear id is re-read as
+  // (row-group low 3 bits, x-chunk, row-group high bits): an XCD sees every x-chunk and every eighth row group.
+  const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned bx = (lin >> 3) % gridDim.x, by = ((lin >> 3) / gridDim.x) * 8u + (lin & 7u);
+  const int xq = (int)bx * 64 + (int)lane;
   const int x4 = xq * 4;
-  const int yw = 1 + ((int)blockIdx.y * 4 + (int)wave) * MC_R;  // first cell row of this wave
+  const int yw = 1 + ((int)by * 4 + (int)wave) * MC_R;  // first cell row of this wave
+  if (1 + (int)by * 4 * MC_R >= a.ny - 1) return;  // the whole BLOCK lies past the last cell row (block-uniform)
   const int zs = a.z_lo + (int)blockIdx.z * a.zb;
   const int ze = min(zs + a.zb, a.z_hi);                       // cell planes [zs, ze); plane ze is read
+  s_xkey[tid] = (uint32_t)(spread3((uint64_t)tid) << 2);
+  const uint64_t xkey_hi = spread3((uint64_t)bx * 256u) << 2;
+  if (tid < 4u * MC_R) s_ykey[tid] = spread3((uint64_t)(1u + by * 4u * MC_R + tid)) << 1;
+  if (tid < (unsigned)MC_ZB) s_zkey[tid] = spread3((uint64_t)(zs + (int)tid));
+  __syncthreads();
   const int64_t sz = (int64_t)a.ny * a.pitch;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   unsigned n_buf = 0;    // wave-uniform: entries waiting in buf
   unsigned tri_sum = 0;  // per lane
-  if (yw >= a.ny - 1) return;  // the whole wave lies past the last cell row (wave-uniform; no barrier follows)
   // Cells this thread may emit, as a mask over the packed layout below (row r of the wave at bits 5r .. 5r+3):
   // base voxel strictly inside the grid along x and y (:199-202)
   unsigned cell_mask = 0u;
@@ -148,27 +167,35 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
                     : WL == 1 ? (const void *)(a.pv.rgb + (int64_t)(zs - a.z_first) * sz)
                               : (const void *)(a.pv.k8 + (int64_t)(zs - a.z_first) * sz);
   const rsrc_t rsW = make_rsrc(wbase, (unsigned)(ze + 1 - zs) * (unsigned)sz * wbytes);
-  const unsigned rows_here = (unsigned)min(MC_R + 1, a.ny - yw);  // rows of this wave's tile that exist (incl. the halo row)
+  // Rows this wave LOADS: its own MC_R; the row below them (y + 1 of its last cells) is the next wave's first row and
+  // arrives through LDS (s_halo) -- only the block's last wave has no such neighbour and loads it itself.  Rows past
+  // the grid read 0 through the descriptor's bounds check (a wave wholly past the grid still takes part in the
+  // barriers; cell_mask keeps it from emitting anything).
+  const int n_load = wave == 3u ? MC_R + 1 : MC_R;
+  const unsigned rows_here = (unsigned)max(0, min(n_load, a.ny - yw));
   const unsigned voff = (unsigned)x4 * 4u;
   const unsigned row_bytes = (unsigned)a.pitch * 4u;
 
   // The deferred weight test + the copy-out.  Every lane takes one listed cell:
   // entry = x - 256 blockIdx.x | row << 8 | (z - zs) << 10 | triangles << 15.
   auto flush = [&]() {
-    for (unsigned i0 = 0; i0 < n_buf; i0 += 64u) {
-      const unsigned i = i0 + lane;
-      bool ok = i < n_buf;
-      const uint32_t e = ok ? buf[i] : 0u;
-      const uint64_t x = (uint64_t)(blockIdx.x * 256u + (e & 255u)), y = (uint64_t)(yw + (int)((e >> 8) & 3u)),
-                     zz = (uint64_t)(zs + (int)((e >> 10) & 31u));
-      if (a.check_w && ok) {
+    // pass 1 (only if a weight can fail): test the 8 corner weights of every listed cell, 64 cells at a time with every
+    // lane busy; a cell that fails loses its triangle count (a listed cell always has one), which marks it dropped
+    unsigned total = n_buf;
+    if (a.check_w) {
+      total = 0u;
+      for (unsigned i0 = 0; i0 < n_buf; i0 += 64u) {
+        const unsigned i = i0 + lane;
+        const bool have = i < n_buf;
+        const uint32_t e = have ? buf[i] : 0u;
         // 32-bit offsets into the block's planes [zs, ze] of the weight plane (the host keeps that span < 4 GB)
-        const unsigned o = (((e >> 10) & 31u) * (unsigned)a.ny + (unsigned)y) * (unsigned)a.pitch + (unsigned)x;
+        const unsigned o = (((e >> 10) & 31u) * (unsigned)a.ny + (unsigned)(yw + (int)((e >> 8) & 3u))) * (unsigned)a.pitch +
+                           bx * 256u + (e & 255u);
         const unsigned p1 = (unsigned)a.pitch, s1 = (unsigned)sz;
         const unsigned off[8] = {0u, 1u, 1u + s1, s1, p1, 1u + p1, 1u + p1 + s1, p1 + s1};
         float w[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) {  // (a lane without a cell reads cell 0 of the block: in range, ignored)
           if (WL == 0)
             w[k] = __uint_as_float(bload32(rsW, (o + off[k]) * 4u, 0u));
           else if (WL == 1)
@@ -176,20 +203,35 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
           else
             w[k] = tsdf_decode_w(bload8(rsW, o + off[k], 0u), a.pv.wmax);
         }
+        bool ok = have;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ok = ok && !(w[k] < a.w_min);  // getGridValue :98: NaN iff w < w_min (or |d| >= 1)
+        if (have && !ok) buf[i] = e & 0x7fffu;
+        total += (unsigned)__popcll(__ballot(ok));
       }
-      const unsigned long long m = __ballot(ok);
-      if (!m) continue;
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__popcll(m));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ONE atomic per flush reserves the output range (all flushes of the launch queue on this one address: it
+    // was the kernel's bottleneck when every 64 cells paid for one)
+    unsigned long long base = 0;
+    if (total) {
+      if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)total);
       base = __shfl(base, 0);
-      const unsigned long long slot = base + (unsigned long long)__popcll(m & lanes_below);
-      if (ok) {
-        tri_sum += e >> 15;
-        if (slot < capacity) {
-          keys[slot] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(zz);
-          vals[slot] = x | (y << 20) | (zz << 40) | ((uint64_t)(e >> 15) << 60);
+      for (unsigned i0 = 0; i0 < n_buf; i0 += 64u) {
+        const unsigned i = i0 + lane;
+        const uint32_t e = i < n_buf ? buf[i] : 0u;
+        const bool ok = (e >> 15) != 0u;
+        const unsigned long long m = __ballot(ok);
+        const unsigned long long slot = base + (unsigned long long)__popcll(m & lanes_below);
+        base += (unsigned long long)__popcll(m);
+        if (ok) {
+          tri_sum += e >> 15;
+          if (slot < capacity) {
+            const unsigned xr = e & 255u, row = wave * MC_R + ((e >> 8) & 3u), zr = (e >> 10) & 31u;
+            keys[slot] = xkey_hi | (uint64_t)s_xkey[xr] | s_ykey[row] | s_zkey[zr];
+            vals[slot] = (uint64_t)(bx * 256u + xr) | ((uint64_t)(yw + (int)((e >> 8) & 3u)) << 20) |
+                         ((uint64_t)(zs + (int)zr) << 40) | ((uint64_t)(e >> 15) << 60);
+          }
         }
       }
     }
@@ -207,14 +249,43 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     u4 q[MC_R + 1];
     float e[MC_R + 1];
 #pragma unroll
-    for (int r = 0; r <= MC_R; ++r) q[r] = bload128(rsD, voff, (unsigned)r * row_bytes);
+    for (int r = 0; r < MC_R; ++r) q[r] = bload128(rsD, voff, (unsigned)r * row_bytes);
+    q[MC_R] = (u4){0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};  // 1.f: outside the band, not negative
+    if (n_load > MC_R) q[MC_R] = bload128(rsD, voff, (unsigned)MC_R * row_bytes);
 #pragma unroll
     for (int r = 0; r <= MC_R; ++r) e[r] = 1.f;
     if (edge_lane) {
 #pragma unroll
-      for (int r = 0; r <= MC_R; ++r) e[r] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)r * row_bytes));
+      for (int r = 0; r < MC_R; ++r) e[r] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)r * row_bytes));
+      if (n_load > MC_R) e[MC_R] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)MC_R * row_bytes));
+    }
+    // Most of the grid is free space or unobserved: d sits exactly at +-1 there and no cell that touches such a voxel
+    // can emit.  One min over |d| per lane and one ballot decide whether this wave's part of the plane holds ANY
+    // voxel inside the band; if not, both masks are zero (a cell needs all eight corners inside the band) and the
+    // bit assembly below -- the bulk of this kernel's instructions -- is skipped.
+    // (on the bit patterns: |d| < 1 <=> (bits & 0x7fffffff) < bits(1.f); a NaN compares as large, as it must)
+    unsigned mn = 0x7f800000u;
+#pragma unroll
+    for (int r = 0; r <= MC_R; ++r) {
+      const unsigned m = 0x7fffffffu;
+      mn = min(min(mn, min(q[r].x & m, q[r].y & m)), min(min(q[r].z & m, q[r].w & m), __float_as_uint(e[r]) & m));
     }
     ng = bd = 0u;
+    volatile uint32_t *hb = s_halo[z & 1];
+#ifndef MC_PROBE
+    const bool quiet = __ballot(mn < 0x3f800000u) == 0ull;
+#elif MC_PROBE < 3  // bandwidth probes (tools/build_variant.py): 1 = every wave takes the quiet path, 2 = and no barrier
+    const bool quiet = __ballot(mn < 0x00000001u) == 0ull;
+#else
+    const bool quiet = __ballot(mn < 0x3f800000u) == 0ull;
+#endif
+    if (quiet) {
+#if !defined(MC_PROBE) || MC_PROBE < 2
+      hb[wave * 64u + lane] = 0u;
+      __syncthreads();
+#endif
+      return;
+    }
 #pragma unroll
     for (int r = 0; r <= MC_R; ++r) {
       const float dq[4] = {__uint_as_float(q[r].x), __uint_as_float(q[r].y), __uint_as_float(q[r].z), __uint_as_float(q[r].w)};
@@ -234,6 +305,15 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     }
     ng |= (nb & MC_COL0) << 4;
     bd |= ((nb >> 1) & MC_COL0) << 4;
+    // row MC_R of waves 0..2 = row 0 of the next wave, through LDS: one barrier per plane (two buffers, so a wave
+    // that is already writing the next plane's row cannot overwrite what a slower wave still has to read)
+    hb[wave * 64u + lane] = (ng & 31u) | ((bd & 31u) << 5);
+    __syncthreads();
+    if (wave < 3u) {
+      const uint32_t h = hb[(wave + 1u) * 64u + lane];
+      ng = (ng & ~(31u << (5 * MC_R))) | ((h & 31u) << (5 * MC_R));
+      bd = (bd & ~(31u << (5 * MC_R))) | (((h >> 5) & 31u) << (5 * MC_R));
+    }
   };
 
   unsigned n0, b0, n1, b1;
@@ -245,29 +325,38 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     const unsigned V = b0 & (b0 >> 5) & b1 & (b1 >> 5);
     // mixed signs (neither all eight negative nor none) and all eight inside the band
     unsigned cand = ~(A & (A >> 1)) & (O | (O >> 1)) & (V & (V >> 1)) & cell_mask;
+#if defined(MC_PROBE) && MC_PROBE == 3  // probe: mask assembly as usual, but nothing is ever listed
+    cand &= (unsigned)(z < 0);
+#endif
     if (__ballot(cand != 0u)) {
-      const unsigned cnt = (unsigned)__popc(cand);  // 0 .. 16
-      unsigned pos = 0u, add = 0u;
+      // appended in two halves (cell rows 0-1, then 2-3): a half adds at most 512 entries, which is the list's size
+      for (int half = 0; half < 2; ++half) {
+        unsigned c2 = half ? cand >> (5 * (MC_R / 2)) : cand & ((1u << (5 * (MC_R / 2))) - 1u);
+        if (!__ballot(c2 != 0u)) continue;
+        const unsigned cnt = (unsigned)__popc(c2);  // 0 .. 8
+        unsigned pos = 0u, add = 0u;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const unsigned long long bk = __ballot((cnt >> k) & 1u);
-        pos += (unsigned)__popcll(bk & lanes_below) << k;
-        add += (unsigned)__popcll(bk) << k;
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long bk = __ballot((cnt >> k) & 1u);
+          pos += (unsigned)__popcll(bk & lanes_below) << k;
+          add += (unsigned)__popcll(bk) << k;
+        }
+        if (n_buf && ((int)n_buf > a.flush_at || n_buf + add > MC_WAVE_BUF)) flush();
+        pos += n_buf;
+        n_buf += add;
+        const unsigned shift = half ? 5u * (MC_R / 2) : 0u;
+        while (c2) {
+          const unsigned bit = (unsigned)__builtin_ctz(c2) + shift;
+          c2 &= c2 - 1u;
+          const unsigned r = (bit * 13u) >> 6, j = bit - 5u * r;  // bit / 5 for bit < 25
+          const unsigned p = n0 >> bit, q = n1 >> bit;
+          // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1) as (dx,dy,dz)
+          const unsigned ci = (p & 3u) | ((q & 2u) << 1) | ((q & 1u) << 3) | (((p >> 5) & 1u) << 4) | (((p >> 6) & 1u) << 5) |
+                              (((q >> 6) & 1u) << 6) | (((q >> 5) & 1u) << 7);
+          buf[pos++] = (lane * 4u + j) | (r << 8) | ((unsigned)(z - zs) << 10) | ((unsigned)s_ntri[ci] << 15);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      if (n_buf && ((int)n_buf > a.flush_at || n_buf + add > MC_WAVE_BUF)) flush();
-      pos += n_buf;
-      n_buf += add;
-      while (cand) {
-        const unsigned bit = (unsigned)__builtin_ctz(cand);
-        cand &= cand - 1u;
-        const unsigned r = (bit * 13u) >> 6, j = bit - 5u * r;  // bit / 5 for bit < 25
-        const unsigned p = n0 >> bit, q = n1 >> bit;
-        // pcl::MarchingCubes corner order (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1) as (dx,dy,dz)
-        const unsigned ci = (p & 3u) | ((q & 2u) << 1) | ((q & 1u) << 3) | (((p >> 5) & 1u) << 4) | (((p >> 6) & 1u) << 5) |
-                            (((q >> 6) & 1u) << 6) | (((q >> 5) & 1u) << 7);
-        buf[pos++] = (lane * 4u + j) | (r << 8) | ((unsigned)(z - zs) << 10) | ((unsigned)s_ntri[ci] << 15);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     n0 = n1;
     b0 = b1;
@@ -435,7 +524,9 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     if (fit < 1) return TSDF_HIP_E_UNSUPPORTED;
     a.zb = (int)std::min<int64_t>(MC_ZB, fit);
   }
-  const dim3 block(256), grid((unsigned)((a.qpr + 63) / 64), (unsigned)((cell_rows + 4 * MC_R - 1) / (4 * MC_R)),
+  // (row groups rounded up to a multiple of 8 for the kernel's XCD-aware re-reading of the block id; the padding
+  // blocks lie past the grid and leave at once)
+  const dim3 block(256), grid((unsigned)((a.qpr + 63) / 64), (unsigned)(((cell_rows + 4 * MC_R - 1) / (4 * MC_R) + 7) / 8 * 8),
                               (unsigned)((a.z_hi - a.z_lo + a.zb - 1) / a.zb));
   if (grid.y > 65535u || grid.z > 65535u) return TSDF_HIP_E_UNSUPPORTED;
   unsigned long long counts[2] = {0, 0};
@@ -534,6 +625,15 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   h->mc_ntri = ntri;
   h->mc_has_rgb = color_mode != 0;
   if (n_tri) *n_tri = ntri;
+  return TSDF_HIP_OK;
+}
+
+// Test / tuning hook: blocks of 256 threads the runtime admits per CU for the marching-cubes kernels
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0] k_mc_classify<1>, out[1] k_mc_emit.
+extern "C" int tsdf_hip_selftest_occupancy_mc(int out[2]) {
+  if (!out) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], k_mc_classify<1>, 256, 0));
+  TSDF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], k_mc_emit, 256, 0));
   return TSDF_HIP_OK;
 }
 

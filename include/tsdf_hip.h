@@ -336,6 +336,9 @@ int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
 
+/* Test / tuning hook: 256-thread blocks per CU the runtime admits for k_mc_classify (out[0]) and k_mc_emit (out[1]). */
+int tsdf_hip_selftest_occupancy_mc(int out[2]);
+
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
  * "mc_flush_at", "cull", "vol_chunk", "plain_kernel" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);

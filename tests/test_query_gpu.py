@@ -226,7 +226,7 @@ def test_marching_cubes_wave_list_flush_paths(gpu):
         assert _mesh_vs_oracle(vol, ov, 0.0, 1) > 30000
         _mesh_vs_oracle(vol, ov, 2.0, 0)
     finally:
-        capi.set_tuning("mc_flush_at", 256)
+        capi.set_tuning("mc_flush_at", 512)
         capi.set_tuning("rows_per_block", 32)
 
 
