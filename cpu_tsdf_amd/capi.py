@@ -81,6 +81,12 @@ _f64p = C.POINTER(C.c_double)
 SIGNATURES = {
     "tsdf_hip_default_params": (None, [C.POINTER(TsdfParams)]),
     "tsdf_hip_create": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(C.c_void_p)]),
+    "tsdf_hip_create_multi": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]),
+    "tsdf_hip_slab_count": (C.c_int, [C.c_void_p]),
+    "tsdf_hip_slab_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32)]),
+    "tsdf_hip_load_multi": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_reset": (C.c_int, [C.c_void_p]),
     "tsdf_hip_destroy": (C.c_int, [C.c_void_p]),
     "tsdf_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

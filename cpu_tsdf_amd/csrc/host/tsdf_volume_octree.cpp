@@ -131,7 +131,13 @@ void TSDFVolumeOctree::reset() {
   }
   // weight_by_depth_ / weight_by_variance_ (set only by load(), as in the reference) survive a reset there too
   if (weight_by_depth_ && p_.layout == TSDF_LAYOUT_AUTO) p_.layout = TSDF_LAYOUT_F32W;
-  int rc = tsdf_hip_create(&p_, &h_);
+  int rc;
+  if (devices_.empty()) {
+    rc = tsdf_hip_create(&p_, &h_);
+  } else {
+    std::vector<int32_t> dev(devices_.begin(), devices_.end());
+    rc = tsdf_hip_create_multi(&p_, dev.data(), (int)dev.size(), &h_);
+  }
   if (!rc && (weight_by_depth_ || weight_by_variance_)) {
     rc = tsdf_hip_set_weighting(h_, weight_by_depth_, weight_by_variance_);
     if (rc) tsdf_hip_destroy(h_);
@@ -415,7 +421,9 @@ void TSDFVolumeOctree::load(const std::string &filename) {
   tsdf_vol_meta m;
   tsdf_params defaults = p_;  // device, layout, transform order
   defaults.z_begin = defaults.z_end = defaults.halo = 0;
-  const int rc = tsdf_hip_load(filename.c_str(), &defaults, &h, &p, &m);
+  std::vector<int32_t> dev(devices_.begin(), devices_.end());
+  const int rc = dev.empty() ? tsdf_hip_load(filename.c_str(), &defaults, &h, &p, &m)
+                             : tsdf_hip_load_multi(filename.c_str(), &defaults, dev.data(), (int)dev.size(), &h, &p, &m);
   if (rc) {
     report("load", rc);
     return;

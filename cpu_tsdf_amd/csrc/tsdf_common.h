@@ -10,8 +10,12 @@
 #include "tsdf_hip.h"
 
 struct tsdf_hip_pipeline;  // tsdf_integrate.hip: pinned staging ring of tsdf_hip_integrate_async
+struct tsdf_hip_multi;     // tsdf_multi.hip: the Z-slab handles of a multi-GPU volume
 
 struct tsdf_hip_volume {
+  // non-null: this handle is a SET of Z-slab handles on several GPUs (tsdf_hip_create_multi) and owns no voxel plane
+  // itself; every entry point forwards to tsdf_multi_* (tsdf_multi.hip)
+  tsdf_hip_multi *multi = nullptr;
   tsdf_params p;
   int device = 0;
   int nx = 0, ny = 0, nz = 0;  // full grid resolution
@@ -67,6 +71,36 @@ struct tsdf_hip_volume {
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
 };
+
+// Multi-GPU forwarding targets (tsdf_multi.hip); `h` is a handle with h->multi != nullptr.
+void tsdf_multi_free(tsdf_hip_volume *v);
+int tsdf_multi_reset(tsdf_handle h);
+int tsdf_multi_synchronize(tsdf_handle h);
+int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance);
+int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
+                         bool asynchronous);
+int tsdf_multi_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
+                                uint64_t *n_observed);
+int tsdf_multi_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, const uint8_t *bgra, size_t bgra_stride, size_t n,
+                        float cloud_units, int zero_nans, const double world_to_cam[12], float *depth_out, uint8_t *bgra_out,
+                        uint64_t *n_valid);
+int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_observed);
+int tsdf_multi_last_count_detail(tsdf_handle h, uint64_t out[2]);
+int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, uint8_t *rgb);
+int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok);
+int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found);
+int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv, float *out);
+int tsdf_multi_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri);
+int tsdf_multi_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell);
+int tsdf_multi_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
+tsdf_handle tsdf_multi_first(tsdf_handle h);
+#define TSDF_NOT_ON_MULTI(h, what)                                                                          \
+  do {                                                                                                      \
+    if ((h) && (h)->multi) {                                                                                \
+      tsdf_set_error(what " works on ONE slab handle; this handle is a multi-GPU set (tsdf_hip_create_multi)"); \
+      return TSDF_HIP_E_UNSUPPORTED;                                                                        \
+    }                                                                                                       \
+  } while (0)
 
 // Error plumbing -------------------------------------------------------------------------------
 void tsdf_set_error(const std::string &msg);

@@ -262,6 +262,7 @@ int tsdf_to_device(tsdf_hip_volume *v, void *dev_dst, const void *src, size_t by
 
 static void free_volume(tsdf_hip_volume *v) {
   if (!v) return;
+  if (v->multi) tsdf_multi_free(v);
   TsdfDeviceScope scope(v->device);
   tsdf_pipeline_destroy(v);
   if (v->d) (void)hipFree(v->d);
@@ -395,6 +396,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
 // (octree.h:177-180).
 extern "C" int tsdf_hip_reset(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_reset(h);
   TSDF_ON_DEVICE(h->device);
   const int64_t n = h->pitch * h->ny * h->nz_alloc;
   const float minus_one = -1.f;
@@ -424,12 +426,14 @@ extern "C" int tsdf_hip_destroy(tsdf_handle h) {
 
 extern "C" int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream) {
   if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_set_stream (a stream belongs to one device)");
   h->stream = (hipStream_t)hip_stream;
   return TSDF_HIP_OK;
 }
 
 extern "C" int tsdf_hip_synchronize(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_synchronize(h);
   TSDF_ON_DEVICE(h->device);
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
@@ -448,6 +452,7 @@ extern "C" int tsdf_hip_layout(tsdf_handle h) {
 extern "C" int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint32_t **rgb, int64_t *pitch,
                                       int32_t *z_first, int32_t *nz_alloc) {
   if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_device_planes");
   if (d) *d = h->d;
   if (w) *w = h->w;
   if (rgb) *rgb = h->rgb;
@@ -624,11 +629,15 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
 
 extern "C" int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *d,
                                  float *w, uint8_t *rgb) {
+  if (h && h->multi) return tsdf_multi_block(h, true, x0, y0, z0, nx, ny, nz, d, w, rgb);
   return block_transfer<true>(h, x0, y0, z0, nx, ny, nz, d, w, rgb);
 }
 
 extern "C" int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
                                const float *w, const uint8_t *rgb) {
+  if (h && h->multi)
+    return tsdf_multi_block(h, false, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
+                            const_cast<uint8_t *>(rgb));
   return block_transfer<false>(h, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
                                const_cast<uint8_t *>(rgb));
 }
@@ -734,10 +743,12 @@ static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *
 }
 
 extern "C" int tsdf_hip_get_planes_device(tsdf_handle h, int z0, int nz, float *d, float *w, uint32_t *rgb) {
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_get_planes_device");
   return planes_device<true>(h, z0, nz, d, w, rgb);
 }
 
 extern "C" int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const float *d, const float *w,
                                           const uint32_t *rgb) {
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_set_planes_device");
   return planes_device<false>(h, z0, nz, const_cast<float *>(d), const_cast<float *>(w), const_cast<uint32_t *>(rgb));
 }

@@ -95,6 +95,9 @@ extern "C" int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_str
                                  const double world_to_cam[12], float *depth_out, uint8_t *bgra_out,
                                  uint64_t *n_valid) {
   if (!h || (n && !xyz) || xyz_stride < 3 || (bgra && bgra_stride < 4) || n >= (1ull << 32)) return TSDF_HIP_E_INVALID;
+  if (h->multi)
+    return tsdf_multi_organize(h, xyz, xyz_stride, bgra, bgra_stride, n, cloud_units, zero_nans, world_to_cam, depth_out, bgra_out,
+                               n_valid);
   TSDF_ON_DEVICE(h->device);
   const tsdf_params &p = h->p;
   const size_t npx = (size_t)p.image_width * p.image_height;
@@ -139,6 +142,7 @@ extern "C" int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_str
 
 extern "C" int tsdf_hip_integrate_staged(tsdf_handle h, const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_integrate_staged(h, cam_from_vol, n_observed);
   if (!h->frame_staged) {
     tsdf_set_error("no organised frame is staged: call tsdf_hip_organize first");
     return TSDF_HIP_E_INVALID;

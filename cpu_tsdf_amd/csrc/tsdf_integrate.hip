@@ -1027,6 +1027,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
 // value changed (4 per d / w / colour word, 1 per count byte).
 extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
   if (!h || !out) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_last_count_detail(h, out);
   out[0] = h->last_observed;
   out[1] = h->last_changed_bytes;
   return TSDF_HIP_OK;
@@ -1034,6 +1035,7 @@ extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
 
 extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance) {
   if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_set_weighting(h, weight_by_depth, weight_by_variance);
   if (weight_by_depth && (h->packed || h->cn[0])) {
     tsdf_set_error("weight_by_depth makes weights non-integer: it needs the F32W layout (and TSDF_COLOR_RGB)");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -1046,6 +1048,7 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
 extern "C" int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
                                          const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !d_depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_integrate_device(h, d_depth, d_bgra, cam_from_vol, n_observed);
   TSDF_ON_DEVICE(h->device);
   return launch_integrate(h, d_depth, d_bgra, cam_from_vol, n_observed);
 }
@@ -1053,6 +1056,7 @@ extern "C" int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, co
 extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
                                   const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_integrate(h, depth, bgra, cam_from_vol, n_observed, false);
   TSDF_ON_DEVICE(h->device);
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   const bool color = h->p.integrate_color != 0;
@@ -1102,6 +1106,7 @@ void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
 extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
                                         const float cam_from_vol[12]) {
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_integrate(h, depth, bgra, cam_from_vol, nullptr, true);
   TSDF_ON_DEVICE(h->device);
   const bool color = h->p.integrate_color != 0;
   if (color && !bgra) {

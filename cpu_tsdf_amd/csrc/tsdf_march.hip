@@ -479,6 +479,7 @@ static int ensure_buf(T **buf, size_t *cap_elems, size_t need, hipStream_t s) {
 
 extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
   if (!h || color_mode < 0 || color_mode > 2) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_march(h, w_min, color_mode, n_tri);
   TSDF_ON_DEVICE(h->device);
   const tsdf_params &p = h->p;
   if (p.res[0] >= (1 << 20) || p.res[1] >= (1 << 20) || p.res[2] >= (1 << 20)) return TSDF_HIP_E_UNSUPPORTED;
@@ -640,6 +641,7 @@ extern "C" int tsdf_hip_selftest_occupancy_mc(int out[2]) {
 // Report-only: device time of the last tsdf_hip_march by phase (HIP events on the handle's stream).
 extern "C" int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells) {
   if (!h || !ms) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_march_timing(h, ms, n_cells);
   for (int i = 0; i < 3; ++i) ms[i] = h->mc_ms[i];
   if (n_cells) *n_cells = h->mc_ncells;
   return TSDF_HIP_OK;
@@ -647,6 +649,7 @@ extern "C" int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cel
 
 extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell) {
   if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_march_fetch(h, verts, rgb, cell);
   TSDF_ON_DEVICE(h->device);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
@@ -666,6 +669,7 @@ extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, u
 // a Z-slab job hands to RCCL when the per-slab meshes are merged on the GPU.
 extern "C" int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell) {
   if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_march_fetch_device (the merged mesh of a multi-GPU set lives on the host)");
   TSDF_ON_DEVICE(h->device);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;

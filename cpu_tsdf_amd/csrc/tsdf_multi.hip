@@ -1,0 +1,693 @@
+// libtsdf_hip.so -- one volume over several GPUs of one node, behind the SAME handle type.
+//
+// tsdf_hip_create_multi makes a tsdf_handle that owns no voxels itself but N Z-slab handles ("slabs"), one per entry
+// of the device list, each an ordinary handle with `halo` extra planes on both sides.  Every C-ABI entry point that
+// takes a handle forwards to the functions below when the handle is such a set, so cpu_tsdf::TSDFVolumeOctree (and
+// anything else written against include/tsdf_hip.h) drives all GPUs of the node from ONE process without knowing it:
+//
+//   integrateCloud  the frame fans out to every slab's [depth | bgra] staging buffer -- from pinned host memory over
+//                   each GPU's own PCIe link (host entry points), or from the GPU that holds it by
+//                   hipMemcpyPeerAsync over xGMI (device / staged entry points) -- and every slab runs k_integrate
+//                   on its own planes on its own stream.  No voxel ever crosses a link.
+//   reconstruct     plane z_end of each slab comes from its upper neighbour (one raw plane per array, peer copy), the
+//                   slabs mesh concurrently (one host thread each), the per-slab triangle lists -- each already in
+//                   the reference's order -- are merged by Morton key on the host.
+//   renderView      ray hand-off (tsdf_query.hip): halos refreshed on both sides, then rounds of
+//                   tsdf_hip_raycast_advance per slab with the ray records merged on the first slab's GPU.
+//   getFxn etc.     the slab that owns a point's lower-corner plane answers.
+//   save / load     through the block callbacks; a block is split at slab boundaries.
+//
+// The multi-PROCESS form of the same partition (one rank per GPU, RCCL) is cpu_tsdf_amd/zslab.py.
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "tsdf_common.h"
+
+struct tsdf_hip_multi {
+  std::vector<tsdf_handle> slab;
+  int halo = 0;
+  // pinned frame staging for the host entry points: two slots so that tsdf_hip_integrate_async can return while the
+  // uploads of the previous frame are still in flight
+  float *pinned[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> uploaded[2];  // per slot, per slab: the slab's H2D copy out of the slot has finished
+  unsigned long long frames = 0;
+  std::vector<hipEvent_t> ev;           // per slab: general cross-device ordering
+  bool halo1_fresh = false, halo_all_fresh = false;  // plane z_end of every slab / the whole halo is current
+  int frame_staged = 0;
+  // renderView: ray records
+  std::vector<int *> ray_state, ray_delta;  // per slab, on its device
+  int *ray_tmp = nullptr;                   // on slab 0's device: a delta in transit
+  unsigned *ray_count = nullptr;            // on slab 0's device: suspended rays after a merge
+  size_t ray_cap = 0;
+  // merged mesh of the last tsdf_hip_march (host)
+  std::vector<float> verts;
+  std::vector<uint8_t> rgb;
+  std::vector<uint64_t> cell;
+  bool mesh_has_rgb = false;
+  float mc_ms[3] = {0.f, 0.f, 0.f};
+  uint64_t mc_ncells = 0;
+};
+
+static void slab_range(int nz, int n, int k, int *zb, int *ze) {  // contiguous, balanced (zslab.py slab_range)
+  const int base = nz / n, extra = nz % n;
+  *zb = k * base + std::min(k, extra);
+  *ze = *zb + base + (k < extra ? 1 : 0);
+}
+
+static int owner_of(const tsdf_hip_multi *m, int z) {
+  for (size_t k = 0; k < m->slab.size(); ++k)
+    if (z >= m->slab[k]->z_begin && z < m->slab[k]->z_end) return (int)k;
+  return -1;
+}
+
+void tsdf_multi_free(tsdf_hip_volume *v) {
+  tsdf_hip_multi *m = v->multi;
+  if (!m) return;
+  for (tsdf_handle s : m->slab) (void)tsdf_hip_synchronize(s);
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    TsdfDeviceScope scope(m->slab[k]->device);
+    if (k < m->ray_state.size() && m->ray_state[k]) (void)hipFree(m->ray_state[k]);
+    if (k < m->ray_delta.size() && m->ray_delta[k]) (void)hipFree(m->ray_delta[k]);
+    if (k < m->ev.size() && m->ev[k]) (void)hipEventDestroy(m->ev[k]);
+    for (int s = 0; s < 2; ++s)
+      if (k < m->uploaded[s].size() && m->uploaded[s][k]) (void)hipEventDestroy(m->uploaded[s][k]);
+  }
+  if (!m->slab.empty()) {
+    TsdfDeviceScope scope(m->slab[0]->device);
+    if (m->ray_tmp) (void)hipFree(m->ray_tmp);
+    if (m->ray_count) (void)hipFree(m->ray_count);
+  }
+  for (int s = 0; s < 2; ++s)
+    if (m->pinned[s]) (void)hipHostFree(m->pinned[s]);
+  for (tsdf_handle s : m->slab) (void)tsdf_hip_destroy(s);
+  delete m;
+  v->multi = nullptr;
+}
+
+extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *devices, int n_devices, tsdf_handle *out) {
+  if (!p || !devices || n_devices < 1 || !out) return TSDF_HIP_E_INVALID;
+  *out = nullptr;
+  if (p->z_begin != 0 || (p->z_end != 0 && p->z_end != p->res[2])) {
+    tsdf_set_error("tsdf_hip_create_multi partitions the WHOLE grid: leave z_begin / z_end at 0");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (p->res[2] < n_devices) {
+    tsdf_set_error("fewer z planes than devices");
+    return TSDF_HIP_E_INVALID;
+  }
+  const int ndev = tsdf_hip_device_count();
+  if (ndev <= 0) {
+    tsdf_set_error("no HIP device visible");
+    return TSDF_HIP_E_NODEVICE;
+  }
+  for (int k = 0; k < n_devices; ++k)
+    if (devices[k] < 0 || devices[k] >= ndev) {
+      tsdf_set_error("device ordinal out of range");
+      return TSDF_HIP_E_INVALID;
+    }
+  tsdf_hip_volume *v = new tsdf_hip_volume;
+  tsdf_hip_multi *m = new tsdf_hip_multi;
+  v->multi = m;
+  v->p = *p;
+  v->p.z_begin = 0;
+  v->p.z_end = p->res[2];
+  v->p.device = devices[0];
+  v->device = devices[0];
+  v->nx = p->res[0], v->ny = p->res[1], v->nz = p->res[2];
+  v->z_begin = 0, v->z_end = v->nz, v->z_first = 0, v->nz_alloc = 0;
+  v->pitch = ((int64_t)v->nx + 3) / 4 * 4;
+  for (int a = 0; a < 3; ++a) {
+    if (p->res[a] <= 0 || !(p->size[a] > 0.f)) {
+      tsdf_multi_free(v);
+      delete v;
+      tsdf_set_error("resolution and grid size must be positive");
+      return TSDF_HIP_E_INVALID;
+    }
+    tsdf_build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
+  }
+  // halo: what renderView's ray hand-off needs (the refinement walk and the normal's samples look back / ahead);
+  // marching cubes and sampling use the first plane of it
+  m->halo = n_devices > 1 ? std::max(1, tsdf_hip_render_halo(p)) : 0;
+  auto fail = [&](int rc) {
+    tsdf_multi_free(v);
+    delete v;
+    return rc;
+  };
+  for (int k = 0; k < n_devices; ++k) {
+    tsdf_params q = *p;
+    slab_range(p->res[2], n_devices, k, &q.z_begin, &q.z_end);
+    q.halo = m->halo;
+    q.device = devices[k];
+    tsdf_handle s = nullptr;
+    const int rc = tsdf_hip_create(&q, &s);
+    if (rc) return fail(rc);
+    m->slab.push_back(s);
+  }
+  v->packed = m->slab[0]->packed;
+  v->kmax = m->slab[0]->kmax;
+  v->p.layout = m->slab[0]->p.layout;
+  // peer access between every pair of distinct devices (xGMI); a failure only means copies get staged by the runtime
+  for (int a = 0; a < n_devices; ++a)
+    for (int b = 0; b < n_devices; ++b)
+      if (devices[a] != devices[b]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+          TsdfDeviceScope scope(devices[a]);
+          const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+          if (e != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled included
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+  m->ev.resize(n_devices, nullptr);
+  m->uploaded[0].resize(n_devices, nullptr);
+  m->uploaded[1].resize(n_devices, nullptr);
+  m->ray_state.resize(n_devices, nullptr);
+  m->ray_delta.resize(n_devices, nullptr);
+  for (int k = 0; k < n_devices; ++k) {
+    TsdfDeviceScope scope(devices[k]);
+    if (hipEventCreateWithFlags(&m->ev[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->uploaded[0][k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->uploaded[1][k], hipEventDisableTiming) != hipSuccess) {
+      tsdf_set_error("hipEventCreate failed");
+      return fail(TSDF_HIP_E_HIP);
+    }
+  }
+  *out = v;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_slab_count(tsdf_handle h) { return !h ? 0 : (h->multi ? (int)h->multi->slab.size() : 1); }
+
+extern "C" int tsdf_hip_slab_info(tsdf_handle h, int k, int32_t *device, int32_t *z_begin, int32_t *z_end, int32_t *halo) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  const tsdf_hip_volume *s = h;
+  if (h->multi) {
+    if (k < 0 || k >= (int)h->multi->slab.size()) return TSDF_HIP_E_INVALID;
+    s = h->multi->slab[k];
+  } else if (k != 0) {
+    return TSDF_HIP_E_INVALID;
+  }
+  if (device) *device = s->device;
+  if (z_begin) *z_begin = s->z_begin;
+  if (z_end) *z_end = s->z_end;
+  if (halo) *halo = s->p.halo;
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_reset(tsdf_handle h) {
+  tsdf_hip_multi *m = h->multi;
+  for (tsdf_handle s : m->slab) {
+    const int rc = tsdf_hip_reset(s);
+    if (rc) return rc;
+  }
+  m->halo1_fresh = m->halo_all_fresh = true;  // every plane, halo included, is (d = -1, w = 0)
+  m->frame_staged = 0;
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_synchronize(tsdf_handle h) {
+  for (tsdf_handle s : h->multi->slab) {
+    const int rc = tsdf_hip_synchronize(s);
+    if (rc) return rc;
+  }
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance) {
+  for (tsdf_handle s : h->multi->slab) {
+    const int rc = tsdf_hip_set_weighting(s, by_depth, by_variance);
+    if (rc) return rc;
+  }
+  h->weight_by_depth = by_depth != 0;
+  h->weight_by_variance = by_variance != 0;
+  return TSDF_HIP_OK;
+}
+
+// ---- integrateCloud ------------------------------------------------------------------------------------------------
+static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed) {
+  tsdf_hip_multi *m = h->multi;
+  m->halo1_fresh = m->halo_all_fresh = false;
+  unsigned long long total = 0, changed = 0;
+  for (tsdf_handle s : m->slab) {
+    uint64_t n = 0;
+    const int rc = tsdf_hip_integrate_device(s, s->frame_depth, s->p.integrate_color ? s->frame_bgra : nullptr, T,
+                                             n_observed ? &n : nullptr);
+    if (rc) return rc;
+    total += n;
+    changed += s->last_changed_bytes;
+  }
+  if (n_observed) {
+    *n_observed = total;
+    h->last_observed = total;
+    h->last_changed_bytes = changed;
+  }
+  return TSDF_HIP_OK;
+}
+
+// Host frame -> pinned slot -> every slab's staging buffer, each over its own GPU's PCIe link and on its own stream.
+static int upload_frame(tsdf_handle h, const float *depth, const uint8_t *bgra) {
+  tsdf_hip_multi *m = h->multi;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  const bool color = h->p.integrate_color != 0;
+  if (color && !bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  const int slot = (int)(m->frames & 1ull);
+  if (!m->pinned[slot]) TSDF_HIP_TRY(hipHostMalloc((void **)&m->pinned[slot], npx * 8, hipHostMallocPortable));
+  if (m->frames >= 2)  // the slot's previous uploads (two frames ago) must have left it
+    for (size_t k = 0; k < m->slab.size(); ++k) TSDF_HIP_TRY(hipEventSynchronize(m->uploaded[slot][k]));
+  memcpy(m->pinned[slot], depth, npx * 4);
+  if (color) memcpy(m->pinned[slot] + npx, bgra, npx * 4);
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    tsdf_handle s = m->slab[k];
+    TSDF_ON_DEVICE(s->device);
+    TSDF_HIP_TRY(hipMemcpyAsync(s->frame_depth, m->pinned[slot], npx * 4 * (color ? 2 : 1), hipMemcpyHostToDevice, s->stream));
+    TSDF_HIP_TRY(hipEventRecord(m->uploaded[slot][k], s->stream));
+  }
+  m->frames++;
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
+                         bool asynchronous) {
+  int rc = upload_frame(h, depth, bgra);
+  if (rc) return rc;
+  if ((rc = integrate_all(h, T, n_observed))) return rc;
+  return asynchronous ? TSDF_HIP_OK : tsdf_multi_synchronize(h);
+}
+
+// Device frame (anywhere on the node) -> every slab's staging buffer by peer copy, ordered on the receiving slab's
+// stream.  The frame must be complete when the call is made unless it lives in slab `src`'s own staging buffer
+// (tsdf_hip_organize), in which case the copies wait for that slab's stream.
+static int fan_out_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, int src_slab) {
+  tsdf_hip_multi *m = h->multi;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  const bool color = h->p.integrate_color != 0;
+  if (color && !d_bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  int src_dev = -1;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_depth) == hipSuccess)
+      src_dev = attr.device;
+    else
+      (void)hipGetLastError();
+  }
+  if (src_dev < 0) {
+    tsdf_set_error("d_depth is not a device pointer");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (src_slab >= 0) {
+    TSDF_ON_DEVICE(m->slab[src_slab]->device);
+    TSDF_HIP_TRY(hipEventRecord(m->ev[src_slab], m->slab[src_slab]->stream));
+  }
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    tsdf_handle s = m->slab[k];
+    if ((int)k == src_slab) continue;
+    TSDF_ON_DEVICE(s->device);
+    if (src_slab >= 0) TSDF_HIP_TRY(hipStreamWaitEvent(s->stream, m->ev[src_slab], 0));
+    if (s->device == src_dev) {
+      if (d_depth != s->frame_depth)
+        TSDF_HIP_TRY(hipMemcpyAsync(s->frame_depth, d_depth, npx * 4, hipMemcpyDeviceToDevice, s->stream));
+      if (color && d_bgra != s->frame_bgra)
+        TSDF_HIP_TRY(hipMemcpyAsync(s->frame_bgra, d_bgra, npx * 4, hipMemcpyDeviceToDevice, s->stream));
+    } else {
+      TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_depth, s->device, d_depth, src_dev, npx * 4, s->stream));
+      if (color) TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_bgra, s->device, d_bgra, src_dev, npx * 4, s->stream));
+    }
+  }
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
+                                uint64_t *n_observed) {
+  int rc = fan_out_device(h, d_depth, d_bgra, -1);
+  if (rc) return rc;
+  return integrate_all(h, T, n_observed);
+}
+
+int tsdf_multi_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, const uint8_t *bgra, size_t bgra_stride, size_t n,
+                        float cloud_units, int zero_nans, const double world_to_cam[12], float *depth_out, uint8_t *bgra_out,
+                        uint64_t *n_valid) {
+  // the z-buffer runs on the first slab's GPU (the "ingest GPU"); integrate_staged fans its result out over xGMI
+  const int rc = tsdf_hip_organize(h->multi->slab[0], xyz, xyz_stride, bgra, bgra_stride, n, cloud_units, zero_nans, world_to_cam,
+                                   depth_out, bgra_out, n_valid);
+  if (!rc) h->multi->frame_staged = 1;
+  return rc;
+}
+
+int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_observed) {
+  tsdf_hip_multi *m = h->multi;
+  if (!m->frame_staged) {
+    tsdf_set_error("no staged frame: call tsdf_hip_organize first");
+    return TSDF_HIP_E_INVALID;
+  }
+  tsdf_handle s0 = m->slab[0];
+  int rc = fan_out_device(h, s0->frame_depth, s0->p.integrate_color ? s0->frame_bgra : nullptr, 0);
+  if (rc) return rc;
+  return integrate_all(h, T, n_observed);
+}
+
+int tsdf_multi_last_count_detail(tsdf_handle h, uint64_t out[2]) {
+  out[0] = h->last_observed;
+  out[1] = h->last_changed_bytes;
+  return TSDF_HIP_OK;
+}
+
+// ---- halo exchange ---------------------------------------------------------------------------------------------------
+// Copy global planes [z0, z0 + nz) from the slab that owns them into `dst`'s halo: the slabs share pitch and layout,
+// so a plane is one contiguous run per array.  Ordered after the owner's stream, queued on the receiver's.
+static int copy_planes(tsdf_hip_multi *m, int src, int dst, int z0, int nz) {
+  tsdf_handle a = m->slab[src], b = m->slab[dst];
+  const int64_t plane = a->pitch * a->ny;
+  const int64_t oa = (int64_t)(z0 - a->z_first) * plane, ob = (int64_t)(z0 - b->z_first) * plane;
+  {
+    TSDF_ON_DEVICE(a->device);
+    TSDF_HIP_TRY(hipEventRecord(m->ev[src], a->stream));
+  }
+  TSDF_ON_DEVICE(b->device);
+  TSDF_HIP_TRY(hipStreamWaitEvent(b->stream, m->ev[src], 0));
+  auto cp = [&](void *dst_p, const void *src_p, size_t bytes) -> hipError_t {
+    if (a->device == b->device) return hipMemcpyAsync(dst_p, src_p, bytes, hipMemcpyDeviceToDevice, b->stream);
+    return hipMemcpyPeerAsync(dst_p, b->device, src_p, a->device, bytes, b->stream);
+  };
+  const size_t n = (size_t)(plane * nz);
+  TSDF_HIP_TRY(cp(b->d + ob, a->d + oa, n * 4));
+  if (a->w) TSDF_HIP_TRY(cp(b->w + ob, a->w + oa, n * 4));
+  if (a->rgb) TSDF_HIP_TRY(cp(b->rgb + ob, a->rgb + oa, n * 4));
+  if (a->k8) TSDF_HIP_TRY(cp(b->k8 + ob, a->k8 + oa, n));
+  for (int c = 0; c < 4; ++c)
+    if (a->cn[c]) TSDF_HIP_TRY(cp(b->cn[c] + ob, a->cn[c] + oa, n * 4));
+  return TSDF_HIP_OK;
+}
+
+// Refresh `planes` halo planes above every slab (and below, with `both`) from their owners.
+static int exchange_halo(tsdf_handle h, int planes, bool both) {
+  tsdf_hip_multi *m = h->multi;
+  const int n = (int)m->slab.size();
+  if (n == 1) return TSDF_HIP_OK;
+  planes = std::min(planes, m->halo);
+  if (both ? m->halo_all_fresh : (m->halo1_fresh && planes <= 1)) return TSDF_HIP_OK;
+  for (int k = 0; k < n; ++k) {
+    tsdf_handle s = m->slab[k];
+    const int ranges[2][2] = {{s->z_end, std::min(h->nz, s->z_end + planes)},
+                              {both ? std::max(0, s->z_begin - planes) : s->z_begin, s->z_begin}};
+    for (int r = 0; r < 2; ++r)
+      for (int z = ranges[r][0]; z < ranges[r][1];) {
+        const int o = owner_of(m, z);
+        if (o < 0) return TSDF_HIP_E_INVALID;
+        const int run = std::min(ranges[r][1], m->slab[o]->z_end) - z;
+        const int rc = copy_planes(m, o, k, z, run);
+        if (rc) return rc;
+        z += run;
+      }
+  }
+  // the owners must not run ahead and change planes that are still being read: receivers' copies are ordered after
+  // the owners' streams above; order the owners' NEXT work after the copies
+  for (int k = 0; k < n; ++k) {
+    TSDF_ON_DEVICE(m->slab[k]->device);
+    TSDF_HIP_TRY(hipEventRecord(m->ev[k], m->slab[k]->stream));
+  }
+  for (int k = 0; k < n; ++k) {
+    TSDF_ON_DEVICE(m->slab[k]->device);
+    for (int j = 0; j < n; ++j)
+      if (j != k) TSDF_HIP_TRY(hipStreamWaitEvent(m->slab[k]->stream, m->ev[j], 0));
+  }
+  m->halo1_fresh = true;
+  if (both && planes >= m->halo) m->halo_all_fresh = true;
+  return TSDF_HIP_OK;
+}
+
+// ---- raw voxel blocks --------------------------------------------------------------------------------------------------
+int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, uint8_t *rgb) {
+  tsdf_hip_multi *m = h->multi;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || z0 < 0 || z0 + nz > h->nz) {
+    tsdf_set_error("block outside the grid");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (!down) m->halo1_fresh = m->halo_all_fresh = false;
+  const size_t per_plane = (size_t)nx * ny;
+  for (int z = z0; z < z0 + nz;) {
+    const int o = owner_of(m, z);
+    const int run = std::min(z0 + nz, m->slab[o]->z_end) - z;
+    const size_t off = (size_t)(z - z0) * per_plane;
+    const int rc = down ? tsdf_hip_download(m->slab[o], x0, y0, z, nx, ny, run, d ? d + off : nullptr, w ? w + off : nullptr,
+                                            rgb ? rgb + 3 * off : nullptr)
+                        : tsdf_hip_upload(m->slab[o], x0, y0, z, nx, ny, run, d ? d + off : nullptr, w ? w + off : nullptr,
+                                          rgb ? rgb + 3 * off : nullptr);
+    if (rc) return rc;
+    z += run;
+  }
+  return TSDF_HIP_OK;
+}
+
+// ---- getFxn / getGradient / getHessian, renderColoredView's lookup -------------------------------------------------------
+int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok) {
+  tsdf_hip_multi *m = h->multi;
+  int rc = exchange_halo(h, 1, false);
+  if (rc) return rc;
+  std::vector<float> v(n), g(grad ? 3 * n : 0), hs(hess ? 9 * n : 0);
+  std::vector<uint8_t> o(n);
+  std::vector<uint8_t> done(n, 0);
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    rc = tsdf_hip_sample(m->slab[k], xyz, n, v.data(), grad ? g.data() : nullptr, hess ? hs.data() : nullptr, o.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+      // exactly one slab owns a point's lower-corner plane; a point no slab answers keeps the first slab's NaNs
+      if (!(o[i] || (k == 0))) continue;
+      if (done[i]) continue;
+      if (val) val[i] = v[i];
+      if (grad) memcpy(grad + 3 * i, g.data() + 3 * i, 12);
+      if (hess) memcpy(hess + 9 * i, hs.data() + 9 * i, 36);
+      if (ok) ok[i] = o[i];
+      if (o[i]) done[i] = 1;
+    }
+  }
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
+  tsdf_hip_multi *m = h->multi;
+  std::vector<uint8_t> c(3 * n), f(n);
+  memset(rgb, 0, 3 * n);
+  memset(found, 0, n);
+  for (tsdf_handle s : m->slab) {
+    const int rc = tsdf_hip_lookup_rgb(s, xyz, n, c.data(), f.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i)
+      if (f[i] && !found[i]) {
+        found[i] = 1;
+        memcpy(rgb + 3 * i, c.data() + 3 * i, 3);
+      }
+  }
+  return TSDF_HIP_OK;
+}
+
+// ---- renderView: ray hand-off between the slabs ------------------------------------------------------------------------
+int tsdf_ray_merge(hipStream_t stream, int *state, const int *delta, int64_t n, unsigned *suspended);  // tsdf_query.hip
+
+int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv, float *out) {
+  tsdf_hip_multi *m = h->multi;
+  const int n_slab = (int)m->slab.size();
+  if (downsample < 1) return TSDF_HIP_E_INVALID;
+  const int nw = h->p.image_width / downsample, nh = h->p.image_height / downsample;
+  const int64_t n = (int64_t)nw * nh;
+  if (n <= 0) return TSDF_HIP_E_INVALID;
+  int rc = exchange_halo(h, m->halo, true);
+  if (rc) return rc;
+  const size_t words = (size_t)n * TSDF_HIP_RAY_RECORD_INTS, bytes = words * sizeof(int);
+  if (words > m->ray_cap) {
+    for (int k = 0; k < n_slab; ++k) {
+      TSDF_ON_DEVICE(m->slab[k]->device);
+      if (m->ray_state[k]) (void)hipFree(m->ray_state[k]);
+      if (m->ray_delta[k]) (void)hipFree(m->ray_delta[k]);
+      m->ray_state[k] = m->ray_delta[k] = nullptr;
+      TSDF_HIP_TRY(hipMalloc(&m->ray_state[k], bytes));
+      TSDF_HIP_TRY(hipMalloc(&m->ray_delta[k], bytes));
+    }
+    TSDF_ON_DEVICE(m->slab[0]->device);
+    if (m->ray_tmp) (void)hipFree(m->ray_tmp);
+    m->ray_tmp = nullptr;
+    TSDF_HIP_TRY(hipMalloc(&m->ray_tmp, bytes));
+    if (!m->ray_count) TSDF_HIP_TRY(hipMalloc(&m->ray_count, sizeof(unsigned)));
+    m->ray_cap = words;
+  }
+  tsdf_handle s0 = m->slab[0];
+  int *master = m->ray_state[0];
+  if ((rc = tsdf_hip_raycast_begin(s0, rot, origin, downsample, master))) return rc;
+  TSDF_ON_DEVICE(s0->device);
+  unsigned suspended = 1;
+  for (int round = 0; suspended && round < n_slab + 4; ++round) {
+    for (int k = 0; k < n_slab; ++k) {  // every slab advances its rays from the same snapshot of the records
+      tsdf_handle s = m->slab[k];
+      if (k > 0) {
+        TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
+        if (s->device == s0->device)
+          TSDF_HIP_TRY(hipMemcpy(m->ray_state[k], master, bytes, hipMemcpyDeviceToDevice));
+        else
+          TSDF_HIP_TRY(hipMemcpyPeer(m->ray_state[k], s->device, master, s0->device, bytes));
+      }
+      if ((rc = tsdf_hip_raycast_advance(s, rot, origin, downsample, k, n_slab, m->ray_state[k], m->ray_delta[k]))) return rc;
+    }
+    TSDF_HIP_TRY(hipMemsetAsync(m->ray_count, 0, sizeof(unsigned), s0->stream));
+    for (int k = 0; k < n_slab; ++k) {  // exactly one slab touched a ray: overwrite the touched records
+      const int *delta = m->ray_delta[k];
+      if (k > 0) {
+        tsdf_handle s = m->slab[k];
+        TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
+        if (s->device == s0->device)
+          TSDF_HIP_TRY(hipMemcpy(m->ray_tmp, m->ray_delta[k], bytes, hipMemcpyDeviceToDevice));
+        else
+          TSDF_HIP_TRY(hipMemcpyPeer(m->ray_tmp, s0->device, m->ray_delta[k], s->device, bytes));
+        delta = m->ray_tmp;
+      }
+      if ((rc = tsdf_ray_merge(s0->stream, master, delta, n, k == n_slab - 1 ? m->ray_count : nullptr))) return rc;
+    }
+    TSDF_HIP_TRY(hipMemcpyAsync(&suspended, m->ray_count, sizeof suspended, hipMemcpyDeviceToHost, s0->stream));
+    TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
+  }
+  if (suspended) {
+    tsdf_set_error("ray hand-off did not converge (rays still suspended after slabs + 4 rounds)");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  std::vector<int> host(words);
+  if ((rc = tsdf_to_host(s0, host.data(), master, bytes))) return rc;
+  for (int64_t i = 0; i < n; ++i) {
+    float o[8];
+    memcpy(o, &host[(size_t)i * TSDF_HIP_RAY_RECORD_INTS + 16], sizeof o);
+    // :422 transformPointCloudWithNormals(trans^-1), the arithmetic of k_raycast's to_camera branch
+    if (inv && std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2])) {
+      const double px = o[0], py = o[1], pz = o[2], nx = o[3], ny = o[4], nz = o[5];
+      for (int r = 0; r < 3; ++r) {
+        o[r] = (float)(px * inv[4 * r] + (py * inv[4 * r + 1] + (pz * inv[4 * r + 2] + inv[4 * r + 3])));
+        o[3 + r] = (float)(nx * inv[4 * r] + (ny * inv[4 * r + 1] + nz * inv[4 * r + 2]));
+      }
+    }
+    memcpy(out + 8 * i, o, sizeof o);
+  }
+  return TSDF_HIP_OK;
+}
+
+// ---- marching cubes ------------------------------------------------------------------------------------------------------
+static inline uint64_t spread3_host(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+static inline uint64_t morton_of_cell(uint64_t c) {  // cell = x<<42 | y<<21 | z; the reference's order: x is the high bit
+  return (spread3_host(c >> 42) << 2) | (spread3_host((c >> 21) & 0x1fffff) << 1) | spread3_host(c & 0x1fffff);
+}
+
+int tsdf_multi_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
+  tsdf_hip_multi *m = h->multi;
+  const int n = (int)m->slab.size();
+  if (n_tri) *n_tri = 0;
+  int rc = exchange_halo(h, 1, false);
+  if (rc) return rc;
+  if ((rc = tsdf_multi_synchronize(h))) return rc;
+  struct Part {
+    std::vector<float> verts;
+    std::vector<uint8_t> rgb;
+    std::vector<uint64_t> cell;
+    uint64_t ntri = 0;
+    int rc = 0;
+    std::string err;
+    float ms[3] = {0, 0, 0};
+    uint64_t cells = 0;
+  };
+  std::vector<Part> part(n);
+  std::vector<std::thread> th;
+  for (int k = 0; k < n; ++k)
+    th.emplace_back([&, k]() {  // one host thread per slab: the slabs' kernels and downloads overlap
+      Part &p = part[k];
+      tsdf_handle s = m->slab[k];
+      p.rc = tsdf_hip_march(s, w_min, color_mode, &p.ntri);
+      if (!p.rc && p.ntri) {
+        p.verts.resize(p.ntri * 9);
+        if (color_mode) p.rgb.resize(p.ntri * 9);
+        p.cell.resize(p.ntri);
+        p.rc = tsdf_hip_march_fetch(s, p.verts.data(), color_mode ? p.rgb.data() : nullptr, p.cell.data());
+      }
+      if (p.rc) p.err = tsdf_hip_last_error();
+      (void)tsdf_hip_march_timing(s, p.ms, &p.cells);
+    });
+  for (auto &t : th) t.join();
+  uint64_t total = 0;
+  m->mc_ms[0] = m->mc_ms[1] = m->mc_ms[2] = 0.f;
+  m->mc_ncells = 0;
+  for (int k = 0; k < n; ++k) {
+    if (part[k].rc) {
+      tsdf_set_error(part[k].err);
+      return part[k].rc;
+    }
+    total += part[k].ntri;
+    m->mc_ncells += part[k].cells;
+    for (int i = 0; i < 3; ++i) m->mc_ms[i] = std::max(m->mc_ms[i], part[k].ms[i]);
+  }
+  // k-way merge by Morton key: every part is sorted, the triangles of one cell are adjacent and stay in order, and no
+  // key occurs in two parts (a cell belongs to the slab of its base voxel)
+  m->verts.resize(total * 9);
+  m->rgb.resize(color_mode ? total * 9 : 0);
+  m->cell.resize(total);
+  m->mesh_has_rgb = color_mode != 0;
+  std::vector<uint64_t> pos(n, 0), key(n, ~0ull);
+  for (int k = 0; k < n; ++k)
+    if (part[k].ntri) key[k] = morton_of_cell(part[k].cell[0]);
+  for (uint64_t t = 0; t < total;) {
+    int best = 0;
+    for (int k = 1; k < n; ++k)
+      if (key[k] < key[best]) best = k;
+    Part &p = part[best];
+    uint64_t i = pos[best], j = i;
+    // take the run of this part up to the smallest key of the other parts
+    uint64_t limit = ~0ull;
+    for (int k = 0; k < n; ++k)
+      if (k != best) limit = std::min(limit, key[k]);
+    while (j < p.ntri && morton_of_cell(p.cell[j]) < limit) ++j;
+    if (j == i) j = i + 1;  // (cannot happen: keys are unique across parts)
+    const uint64_t cnt = j - i;
+    memcpy(&m->verts[t * 9], &p.verts[i * 9], cnt * 9 * sizeof(float));
+    if (color_mode) memcpy(&m->rgb[t * 9], &p.rgb[i * 9], cnt * 9);
+    memcpy(&m->cell[t], &p.cell[i], cnt * sizeof(uint64_t));
+    t += cnt;
+    pos[best] = j;
+    key[best] = j < p.ntri ? morton_of_cell(p.cell[j]) : ~0ull;
+  }
+  h->mc_ntri = total;
+  h->mc_has_rgb = color_mode != 0;
+  if (n_tri) *n_tri = total;
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell) {
+  tsdf_hip_multi *m = h->multi;
+  const size_t n = (size_t)h->mc_ntri;
+  if (!n) return TSDF_HIP_OK;
+  if (rgb && !m->mesh_has_rgb) {
+    tsdf_set_error("the last tsdf_hip_march ran without a colour mode");
+    return TSDF_HIP_E_INVALID;
+  }
+  if (verts) memcpy(verts, m->verts.data(), n * 9 * sizeof(float));
+  if (rgb) memcpy(rgb, m->rgb.data(), n * 9);
+  if (cell) memcpy(cell, m->cell.data(), n * sizeof(uint64_t));
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells) {
+  for (int i = 0; i < 3; ++i) ms[i] = h->multi->mc_ms[i];
+  if (n_cells) *n_cells = h->multi->mc_ncells;
+  return TSDF_HIP_OK;
+}
+
+tsdf_handle tsdf_multi_first(tsdf_handle h) { return h->multi->slab[0]; }

@@ -444,6 +444,7 @@ static int make_ray_args(tsdf_handle h, const float rot[9], const float origin[3
 static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv,
                         float *out) {
   if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_raycast(h, rot, origin, downsample, inv, out);
   TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
@@ -489,6 +490,7 @@ extern "C" int tsdf_hip_raycast_camera(tsdf_handle h, const float rot[9], const 
 extern "C" int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const float origin[3], int downsample,
                                       int32_t *d_state) {
   if (!h || !rot || !origin || !d_state || downsample < 1) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_begin");
   TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
@@ -502,6 +504,7 @@ extern "C" int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const
                                         int rank, int world, const int32_t *d_state, int32_t *d_delta) {
   if (!h || !rot || !origin || !d_state || !d_delta || downsample < 1 || world < 1 || rank < 0 || rank >= world)
     return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_advance");
   TSDF_ON_DEVICE(h->device);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
@@ -535,6 +538,7 @@ extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], 
   if (!h || !rot || !origin || downsample < 1 || world < 1 || rank < 0 || rank >= world || count >= (1ull << 31) ||
       (count && !d_records))
     return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_advance_list");
   if (!count) return TSDF_HIP_OK;
   TSDF_ON_DEVICE(h->device);
   RayArgs a;
@@ -558,6 +562,28 @@ extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], 
   return TSDF_HIP_OK;
 }
 
+// Merge of one slab's delta into the record array (multi-GPU renderView in one process, tsdf_multi.hip): a record the
+// slab touched (status word non-zero) replaces the old one; `suspended` (optional) counts the rays still waiting
+// for another slab afterwards.
+static __global__ void __launch_bounds__(256)
+k_ray_merge(int *__restrict__ state, const int *__restrict__ delta, int64_t n, unsigned *__restrict__ suspended) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int *s = state + RAY_REC * i;
+  const int *d = delta + RAY_REC * i;
+  if (d[0] != 0) {
+#pragma unroll
+    for (int k = 0; k < RAY_REC; ++k) s[k] = d[k];
+  }
+  if (suspended && s[0] == 1) atomicAdd(suspended, 1u);
+}
+
+int tsdf_ray_merge(hipStream_t stream, int *state, const int *delta, int64_t n, unsigned *suspended) {
+  hipLaunchKernelGGL(k_ray_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, delta, n, suspended);
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
 // Planes of halo a Z-slab handle needs on each side for tsdf_hip_raycast_advance: the refinement walk goes
 // back at most one main-loop step (<= max(leaf/4, max_dist_neg) for |d| <= 1) plus one refinement step,
 // and the trilinear / central-difference samples reach two more voxels.
@@ -572,14 +598,16 @@ extern "C" int tsdf_hip_render_halo(const tsdf_params *p) {
 // renderColoredView's per-hit lookup (tsdf_volume_octree.cpp:443-448): octree_->getContainingVoxel(v) then
 // voxel->getRGB, batched.  found[i] = 0 where the reference gets NULL (or the plane is not held by this handle).
 static __global__ void __launch_bounds__(256)
-k_lookup_rgb(const GridView g, const float *__restrict__ xyz, size_t n, unsigned char *__restrict__ rgb,
-             unsigned char *__restrict__ found) {
+k_lookup_rgb(const GridView g, const int own_lo, const int own_hi, const float *__restrict__ xyz, size_t n,
+             unsigned char *__restrict__ rgb, unsigned char *__restrict__ found) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   int64_t vi;
   bool local;
   int k;
-  const bool hit = containing(g, xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], vi, local, k) && local;
+  // (a Z-slab handle answers only for voxels in planes it OWNS: halo planes may be stale, and exactly one handle of a
+  // partition owns any plane)
+  const bool hit = containing(g, xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], vi, local, k) && local && k >= own_lo && k < own_hi;
   uint32_t c = 0u;
   if (hit && g.pv.rgb) c = tsdf_load_rgb(g.pv, vi);
   rgb[3 * t] = (unsigned char)(c & 255u);
@@ -590,14 +618,15 @@ k_lookup_rgb(const GridView g, const float *__restrict__ xyz, size_t n, unsigned
 
 extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
   if (!h || !xyz || !n || !rgb || !found) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_lookup_rgb(h, xyz, n, rgb, found);
   TSDF_ON_DEVICE(h->device);
   int rc = tsdf_ensure_scratch(h, n * 16);
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
   unsigned char *d_rgb = (unsigned char *)(d_xyz + 3 * n), *d_found = d_rgb + 3 * n;
   if ((rc = tsdf_to_device(h, d_xyz, xyz, n * 12))) return rc;
-  hipLaunchKernelGGL(k_lookup_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), d_xyz, n, d_rgb,
-                     d_found);
+  hipLaunchKernelGGL(k_lookup_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), h->z_begin, h->z_end,
+                     d_xyz, n, d_rgb, d_found);
   TSDF_HIP_TRY(hipGetLastError());
   if ((rc = tsdf_to_host(h, rgb, d_rgb, n * 3))) return rc;
   return tsdf_to_host(h, found, d_found, n);
@@ -626,6 +655,7 @@ k_selftest_containing(const GridView g, const float *__restrict__ xyz, size_t n,
 
 extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx) {
   if (!h || !xyz || !n || !idx) return TSDF_HIP_E_INVALID;
+  if (h->multi) h = tsdf_multi_first(h);  // the descent only reads the centre tables, which every slab holds
   TSDF_ON_DEVICE(h->device);
   int rc = tsdf_ensure_scratch(h, n * 24);
   if (rc) return rc;
@@ -716,6 +746,7 @@ k_sample(const GridView g, const int own_lo, const int own_hi, const float *__re
 extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess,
                                uint8_t *ok) {
   if (!h || !xyz || !n) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_sample(h, xyz, n, val, grad, hess, ok);
   TSDF_ON_DEVICE(h->device);
   // scratch layout: xyz[3n] val[n] grad[3n] hess[9n] floats, ok[n] bytes
   const size_t fl = 16 * n;

@@ -135,7 +135,7 @@ extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol
     tsdf_set_error("save needs a handle that owns the whole grid (Z-slabs: tsdf_hip_save_blocks)");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  if (h->cn[0]) {
+  if ((h->multi ? tsdf_multi_first(h) : h)->cn[0]) {
     tsdf_set_error("RGB_NORMALIZED volumes have no usable .vol form (the reference writes one byte of each float, "
                    "octree.cpp:417-433)");
     return TSDF_HIP_E_UNSUPPORTED;
@@ -149,6 +149,8 @@ struct LoadState {
   tsdf_params p;
   tsdf_vol_meta m;
   bool force_f32w = false;
+  const int32_t *devices = nullptr;  // non-null: build a multi-GPU set (tsdf_hip_create_multi)
+  int n_devices = 0;
 };
 int load_header(void *user, const tsdf_params *p, const tsdf_vol_meta *m) {
   LoadState *s = (LoadState *)user;
@@ -157,7 +159,7 @@ int load_header(void *user, const tsdf_params *p, const tsdf_vol_meta *m) {
   if (s->force_f32w) s->p.layout = TSDF_LAYOUT_F32W;
   // a depth-weighted volume (hpp:201-202) holds weights that are not counts, and keeps integrating that way
   if (m->weight_by_depth && s->p.layout == TSDF_LAYOUT_AUTO) s->p.layout = TSDF_LAYOUT_F32W;
-  const int rc = tsdf_hip_create(&s->p, &s->h);
+  const int rc = s->devices ? tsdf_hip_create_multi(&s->p, s->devices, s->n_devices, &s->h) : tsdf_hip_create(&s->p, &s->h);
   if (rc) return rc;
   return tsdf_hip_set_weighting(s->h, m->weight_by_depth, m->weight_by_variance);
 }
@@ -166,14 +168,16 @@ int load_store(void *user, int x0, int y0, int z0, int c, float *d, float *w, ui
 }
 }  // namespace
 
-extern "C" int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out,
-                             tsdf_params *params_out, tsdf_vol_meta *meta_out) {
+static int load_impl(const char *filename, const tsdf_params *defaults, const int32_t *devices, int n_devices, tsdf_handle *out,
+                     tsdf_params *params_out, tsdf_vol_meta *meta_out) {
   if (!filename || !out) return TSDF_HIP_E_INVALID;
   *out = nullptr;
   const int asked = defaults ? defaults->layout : TSDF_LAYOUT_AUTO;
   for (int attempt = 0; attempt < 2; ++attempt) {
     LoadState s;
     s.force_f32w = attempt == 1;
+    s.devices = devices;
+    s.n_devices = n_devices;
     const int rc = tsdf_hip_load_blocks(filename, defaults, load_header, load_store, &s);
     if (rc == TSDF_HIP_OK) {
       *out = s.h;
@@ -191,4 +195,15 @@ extern "C" int tsdf_hip_load(const char *filename, const tsdf_params *defaults, 
     if (!(packed_misfit && attempt == 0 && asked == TSDF_LAYOUT_AUTO)) return rc;
   }
   return TSDF_HIP_E_UNSUPPORTED;
+}
+
+extern "C" int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out,
+                             tsdf_params *params_out, tsdf_vol_meta *meta_out) {
+  return load_impl(filename, defaults, nullptr, 0, out, params_out, meta_out);
+}
+
+extern "C" int tsdf_hip_load_multi(const char *filename, const tsdf_params *defaults, const int32_t *devices, int n_devices,
+                                   tsdf_handle *out, tsdf_params *params_out, tsdf_vol_meta *meta_out) {
+  if (!devices || n_devices < 1) return TSDF_HIP_E_INVALID;
+  return load_impl(filename, defaults, devices, n_devices, out, params_out, meta_out);
 }

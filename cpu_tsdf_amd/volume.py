@@ -109,6 +109,22 @@ class TSDFVolumeOctree:
         """Not in the reference: own only planes [z_begin, z_end) (multi-GPU Z-slab partition)."""
         self._p.z_begin, self._p.z_end, self._p.halo, self._p.device = int(z_begin), int(z_end), int(halo), int(device)
 
+    def setDevices(self, devices):
+        """Not in the reference: spread the volume over several GPUs of this node (tsdf_hip_create_multi): Z-slabs, one
+        per entry of `devices` (ordinals may repeat); every method then drives all of them from this one process.
+        None / [] = one handle on setZSlab's device."""
+        self._devices = [int(d) for d in devices] if devices else None
+
+    def slabs(self):
+        """[(device, z_begin, z_end, halo)] of the handle(s) behind this volume."""
+        lib, h = capi.load(), self._need()
+        out = []
+        for k in range(lib.tsdf_hip_slab_count(h)):
+            v = [C.c_int32() for _ in range(4)]
+            capi.check(lib.tsdf_hip_slab_info(h, k, *[C.byref(x) for x in v]), "slab_info")
+            out.append(tuple(x.value for x in v))
+        return out
+
     def setStream(self, stream_ptr):
         self._stream = stream_ptr
         if self._h:
@@ -125,9 +141,14 @@ class TSDFVolumeOctree:
             capi.check(lib.tsdf_hip_destroy(self._h), "destroy")
             self._h = None
         h = C.c_void_p()
-        capi.check(lib.tsdf_hip_create(C.byref(self._p), C.byref(h)), "create")
+        devs = getattr(self, "_devices", None)
+        if devs:
+            arr = (C.c_int32 * len(devs))(*devs)
+            capi.check(lib.tsdf_hip_create_multi(C.byref(self._p), arr, len(devs), C.byref(h)), "create_multi")
+        else:
+            capi.check(lib.tsdf_hip_create(C.byref(self._p), C.byref(h)), "create")
         self._h = h
-        if self._stream is not None:
+        if self._stream is not None and not getattr(self, "_devices", None):  # (a stream belongs to one device)
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
         self._is_empty = True
 
@@ -381,13 +402,19 @@ class TSDFVolumeOctree:
         h, p, m = C.c_void_p(), capi.TsdfParams(), capi.TsdfVolMeta()
         defaults = capi.TsdfParams.from_buffer_copy(self._p)
         defaults.z_begin = defaults.z_end = defaults.halo = 0
-        capi.check(lib.tsdf_hip_load(str(filename).encode(), C.byref(defaults), C.byref(h), C.byref(p), C.byref(m)), "load")
+        devs = getattr(self, "_devices", None)
+        if devs:
+            arr = (C.c_int32 * len(devs))(*devs)
+            capi.check(lib.tsdf_hip_load_multi(str(filename).encode(), C.byref(defaults), arr, len(devs), C.byref(h), C.byref(p),
+                                               C.byref(m)), "load_multi")
+        else:
+            capi.check(lib.tsdf_hip_load(str(filename).encode(), C.byref(defaults), C.byref(h), C.byref(p), C.byref(m)), "load")
         self.close()
         asked = self._p.layout
         self._h, self._p = h, p
         if not (asked == capi.LAYOUT_AUTO and p.layout == capi.LAYOUT_F32W and 0 <= p.max_weight <= 255):
             self._p.layout = asked
-        if self._stream is not None:
+        if self._stream is not None and not getattr(self, "_devices", None):  # (a stream belongs to one device)
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
         self._max_cell = tuple(m.max_cell_size)
         self._is_empty = bool(m.is_empty)

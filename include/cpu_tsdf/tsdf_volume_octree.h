@@ -104,6 +104,13 @@ class TSDFVolumeOctree : public TSDFInterface {
   tsdf_handle handle() const { return h_; }
   void setTransformOrder(int order) { p_.xform_order = order; }
   void setDevice(int device) { p_.device = device; }
+  // Spread the volume over several GPUs of this node: contiguous Z-slabs, one per entry (tsdf_hip_create_multi);
+  // takes effect at the next reset() / load().  Every method of this class and MarchingCubesTSDFOctree then drives
+  // all of them from this one process: the frame of integrateCloud fans out to every GPU, each integrates its own
+  // planes, reconstruct / renderView / getFxn exchange halo planes and ray records between them.  Results do not
+  // depend on the partition.  An empty list = one GPU (setDevice).
+  void setDevices(const std::vector<int> &devices) { devices_ = devices; }
+  const std::vector<int> &getDevices() const { return devices_; }
   // TSDF_LAYOUT_* (include/tsdf_hip.h): how the weight is stored in HBM; default AUTO
   void setLayout(int layout) { p_.layout = layout; }
 
@@ -117,6 +124,7 @@ class TSDFVolumeOctree : public TSDFInterface {
   int num_random_splits_;
   bool is_empty_, weight_by_depth_, weight_by_variance_;
   std::string color_mode_;
+  std::vector<int> devices_;
   Eigen::Affine3d global_transform_;
 
  public:

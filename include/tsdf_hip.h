@@ -104,6 +104,27 @@ int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out);
 int tsdf_hip_reset(tsdf_handle h);
 int tsdf_hip_destroy(tsdf_handle h);
 
+/* One volume over several GPUs of ONE node, in one process, behind the same handle type -- the drop-in form of the
+ * Z-slab partition: the handle owns n_devices Z-slab handles (contiguous, balanced ranges of z planes, one per entry
+ * of `devices`, which may repeat an ordinal), each with tsdf_hip_render_halo(p) halo planes, and EVERY entry point
+ * below that takes a handle works on it:
+ *   integrate*      the frame fans out to every slab (from pinned host memory over each GPU's own PCIe link, or from
+ *                   the GPU that holds it by peer copy over xGMI) and every slab integrates its own planes; no voxel
+ *                   crosses a link.  n_observed is the sum over the slabs.
+ *   march / fetch   one plane of halo per slab from its upper neighbour (peer copy), the slabs mesh concurrently, the
+ *                   triangle lists are merged by the reference's order; the merged mesh lives on the host.
+ *   raycast*        ray hand-off between the slabs (tsdf_hip_raycast_begin / _advance underneath).
+ *   sample, lookup_rgb, download, upload, save, reset, synchronize, set_weighting, centers, layout: as for one handle.
+ * Not available on such a handle (TSDF_HIP_E_UNSUPPORTED): set_stream, device_planes, get/set_planes_device,
+ * raycast_begin/advance*, march_fetch_device -- they expose ONE device's memory.
+ * p->z_begin / z_end must be 0 (the whole grid); p->device is ignored.  Results are bit-identical to one handle
+ * holding the whole grid (tests/test_multi_gpu.py).  cpu_tsdf::TSDFVolumeOctree::setDevices() is the C++ face of it;
+ * cpu_tsdf_amd/zslab.py is the multi-PROCESS form of the same partition (one rank per GPU, RCCL). */
+int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *devices, int n_devices, tsdf_handle *out);
+/* Number of Z-slab handles behind h (1 for an ordinary handle) and the device / owned planes / halo of slab k. */
+int tsdf_hip_slab_count(tsdf_handle h);
+int tsdf_hip_slab_info(tsdf_handle h, int k, int32_t *device, int32_t *z_begin, int32_t *z_end, int32_t *halo);
+
 /* Work is queued on this hipStream_t (default: the null stream). */
 int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream);
 int tsdf_hip_synchronize(tsdf_handle h);
@@ -269,6 +290,9 @@ typedef struct tsdf_vol_meta {
 int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta);
 int tsdf_hip_load(const char *filename, const tsdf_params *defaults, tsdf_handle *out, tsdf_params *params_out,
                   tsdf_vol_meta *meta_out);
+/* The same into a multi-GPU set (tsdf_hip_create_multi). */
+int tsdf_hip_load_multi(const char *filename, const tsdf_params *defaults, const int32_t *devices, int n_devices,
+                        tsdf_handle *out, tsdf_params *params_out, tsdf_vol_meta *meta_out);
 
 /* The same writer and reader for a volume that is not one handle (Z-slabs on several GPUs): the voxels
  * move through callbacks, one cubic block of `edge`^3 voxels at a time (d, w: edge^3 floats; rgb: 3 edge^3
@@ -348,7 +372,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 4
+#define TSDF_HIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 }

@@ -249,6 +249,8 @@ int ct_download(void *h, float *d, float *w, uint8_t *rgb) {
   V(h)->getResolution(rx, ry, rz);
   return V(h)->downloadBlock(0, 0, 0, rx, ry, rz, d, w, rgb) ? 1 : 0;
 }
+// Drop-in build only: the multi-GPU extension (takes effect at the next reset / load).
+void ct_set_devices(void *h, const int *devices, int n) { V(h)->setDevices(std::vector<int>(devices, devices + n)); }
 #endif
 
 }  // extern "C"

@@ -25,10 +25,10 @@ def dropin(gpu):
     return lib
 
 
-def make_pair(dropin, res=64, W=160, H=120, color=True, n_frames=5):
+def make_pair(dropin, res=64, W=160, H=120, color=True, n_frames=5, devices=None):
     sc = synth.scene_a(res, W, H)
     dv = refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=color,
-                           lib_path=dropin)
+                           lib_path=dropin, devices=devices)
     ov = OracleVolume(params(res, W, H, sc.size, color))
     for i in range(n_frames):
         tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
@@ -38,9 +38,12 @@ def make_pair(dropin, res=64, W=160, H=120, color=True, n_frames=5):
     return dv, ov, sc
 
 
-def test_dropin_integrate_render_sample_mesh(dropin):
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_dropin_integrate_render_sample_mesh(dropin, devices):
+    """devices = [0, 0, 0]: the same through TSDFVolumeOctree::setDevices -- three Z-slab handles behind the C++ class
+    (on the one GPU gpurun has), i.e. the multi-GPU path as a user of the reference API reaches it."""
     from cpu_tsdf_amd.volume import transform_cloud_with_normals
-    dv, ov, sc = make_pair(dropin)
+    dv, ov, sc = make_pair(dropin, devices=devices)
     d, w, rgb = dv.download()
     assert_same_f32(d, ov.d, "d")
     assert_same_f32(w, ov.w, "w")

@@ -1,0 +1,204 @@
+"""GPU tier: one volume over several "GPUs" behind ONE handle (tsdf_hip_create_multi / TSDFVolumeOctree.setDevices).
+
+gpurun exposes one GPU, so the device list repeats ordinal 0: the Z-slab handles then live on the same device, but
+every code path is the multi-GPU one -- frame fan-out into each slab's staging buffer, one integrate launch per slab,
+halo planes by (peer) copy, concurrent per-slab meshing + Morton merge, ray hand-off with the records merged on the
+first slab's device, ownership-routed sampling / block transfer / save / load.  Everything must equal a single handle
+holding the whole grid, bit for bit (VERDICT r01 "Next round" #4)."""
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import capi, synth
+from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32
+
+pytestmark = pytest.mark.gpu
+RES, W, H, NF = 48, 160, 120, 5
+
+
+def make(devices, color=True, layout=capi.LAYOUT_AUTO, max_weight=100.0):
+    sc = synth.scene_a(64, W, H)  # the 64-voxel scene on a 48^3 grid of a different voxel size: slabs of 16 / 9.6 planes
+    v = TSDFVolumeOctree()
+    v.setResolution(RES, RES, RES)
+    v.setGridSize(sc.size, sc.size, sc.size)
+    v.setImageSize(W, H)
+    v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    v.setSensorDistanceBounds(0.0, 3 * sc.size)
+    v.setIntegrateColor(color)
+    v.setWeightTruncationLimit(max_weight)
+    v.setLayout(layout)
+    v.setDevices(devices)
+    v.reset()
+    return v, sc
+
+
+def fuse(vols, sc, n=NF, counts=True, pipelined=False):
+    ov = OracleVolume(vols[0]._p)
+    for i in range(n):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        dep, col = sc.depth(tr, noise_seed=7 + i), sc.bgra(i)
+        c = col if vols[0]._p.integrate_color else None
+        want = ov.integrate(dep, c, synth.cam_from_vol_f32(tr))
+        for v in vols:
+            got = v.integrateCloud(dep, c, tr, count=counts, pipelined=pipelined)
+            if counts:
+                assert got == want
+    return ov
+
+
+@pytest.mark.parametrize("n_slabs", [2, 3, 5])
+@pytest.mark.parametrize("layout", [capi.LAYOUT_AUTO, capi.LAYOUT_F32W])
+def test_multi_handle_equals_one_handle(gpu, n_slabs, layout):
+    multi, sc = make([0] * n_slabs, layout=layout)
+    slabs = multi.slabs()
+    assert len(slabs) == n_slabs and slabs[0][1] == 0 and slabs[-1][2] == RES and all(s[3] >= 1 for s in slabs)
+    assert all(a[2] == b[1] for a, b in zip(slabs, slabs[1:]))
+    ov = fuse([multi], sc)
+    d, w, rgb = multi.download()
+    assert_same_f32(d, ov.d, "d")
+    assert_same_f32(w, ov.w, "w")
+    assert np.array_equal(rgb, ov.rgb)
+    # a block that straddles two slab boundaries
+    z0, z1 = slabs[0][2] - 2, min(RES, slabs[1][2] + 3)
+    bd, bw, brgb = multi.download(3, 5, z0, 20, 17, z1 - z0)
+    assert np.array_equal(bd, ov.d[z0:z1, 5:22, 3:23]) and np.array_equal(bw, ov.w[z0:z1, 5:22, 3:23])
+    # marching cubes: count, order, vertex bits, colours
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(multi)
+    for wmin, by_rgb, by_conf, mode in [(2.0, True, False, 1), (0.0, False, True, 2), (2.5, False, False, 0)]:
+        mc.setMinWeight(wmin)
+        mc.setColorByRGB(by_rgb)
+        mc.setColorByConfidence(by_conf)
+        mesh = mc.reconstruct(want_cells=True)
+        v2, c2, cells2 = ov.march(wmin, mode)
+        assert len(cells2) > 500
+        assert np.array_equal(mesh["cells"], cells2)
+        assert_same_f32(mesh["vertices"], v2, "mesh vertices")
+        if mode:
+            assert np.array_equal(mesh["rgb"], c2)
+    # renderView (ray hand-off between the slabs), both frames, with and without downsampling
+    for tr, ds in [(synth.turntable_pose(1, 8, sc.size), 1), (synth.look_at_pose((0.05, -0.3, -0.2)), 2),
+                   (synth.look_at_pose((0.0, 0.02, -0.6 * sc.size), target=(0.0, 0.0, 1.0)), 1)]:
+        got = multi.renderView(tr, ds, camera_frame=False)
+        want = ov.raycast(tr, ds)
+        assert np.isfinite(want[..., 0]).sum() > 50
+        assert_same_f32(got, want, f"renderView ds={ds}")
+    # getFxn / gradient / Hessian, crowded around the slab seams
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(-0.5 * sc.size, 0.5 * sc.size, (3000, 3)).astype(np.float32)
+    ok, val, grad, hess = multi.sample(pts)
+    ok2, val2, grad2, hess2 = ov.sample(pts)
+    assert np.array_equal(ok, ok2) and ok.sum() > 2000
+    assert_same_f32(val[ok], val2[ok], "getFxn")
+    assert_same_f32(grad[ok], grad2[ok], "gradient")
+    assert_same_f32(hess[ok], hess2[ok], "Hessian")
+    multi.close()
+
+
+def test_multi_handle_more_frames_after_queries_and_upload(gpu):
+    """Halo freshness: integrate -> mesh -> integrate -> render -> upload -> sample must each see current planes."""
+    multi, sc = make([0, 0, 0], color=False)
+    one, _ = make(None, color=False)
+    mc = MarchingCubesTSDFOctree()
+    for rnd in range(3):
+        for i in range(2):
+            tr = synth.turntable_pose(2 * rnd + i, 8, sc.size)
+            dep = sc.depth(tr)
+            multi.integrateCloud(dep, None, tr)
+            one.integrateCloud(dep, None, tr)
+        meshes = []
+        for v in (multi, one):
+            mc.setInputTSDF(v)
+            mc.setMinWeight(1.0)
+            meshes.append(mc.reconstruct())
+        assert_same_f32(meshes[0]["vertices"], meshes[1]["vertices"], f"mesh after round {rnd}")
+        tr = synth.turntable_pose(rnd, 8, sc.size, tilt=0.2)
+        assert_same_f32(multi.renderView(tr), one.renderView(tr), f"renderView after round {rnd}")
+    d, w, _ = one.download()
+    d2 = d.copy()
+    d2[20:30] = np.float32(0.25)
+    multi.upload(d2, w, None)
+    one.upload(d2, w, None)
+    pts = np.random.RandomState(9).uniform(-0.4 * sc.size, 0.4 * sc.size, (2000, 3)).astype(np.float32)
+    a, b = multi.sample(pts), one.sample(pts)
+    assert np.array_equal(a[0], b[0])
+    assert_same_f32(a[1][a[0]], b[1][b[0]], "getFxn after upload")
+    multi.close()
+    one.close()
+
+
+def test_multi_handle_pipelined_host_frames_and_unorganized_ingest(gpu):
+    multi, sc = make([0, 0])
+    ov = fuse([multi], sc, counts=False, pipelined=True)
+    multi.synchronize()
+    d, w, rgb = multi.download()
+    assert_same_f32(d, ov.d, "d (pipelined)")
+    assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+    # the ingest path: the z-buffer runs on the first slab's GPU, its frame fans out to the others
+    one, _ = make(None)
+    tr = synth.turntable_pose(0, 8, sc.size)
+    dep = sc.depth(tr)
+    u, vv = np.meshgrid(np.arange(W), np.arange(H))
+    z = np.where(np.isfinite(dep), dep, 0).astype(np.float32)
+    xyz = np.stack([(u - sc.cx) / sc.fx * z, (vv - sc.cy) / sc.fy * z, z], -1).reshape(-1, 3).astype(np.float32)
+    col = sc.bgra(0).reshape(-1, 4)
+    for v in (multi, one):
+        v.organize(xyz, col, zero_nans=True, fetch=False)
+        v.integrateStaged(tr)
+        v.organize(xyz[::3], col[::3], zero_nans=True)  # (with the host copies: synchronous form)
+        assert v.integrateStaged(synth.turntable_pose(1, 8, sc.size), count=True) > 0
+    a, b = multi.download(), one.download()
+    assert_same_f32(a[0], b[0], "d after integrateUnorganized")
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    multi.close()
+    one.close()
+
+
+def test_multi_handle_save_load_roundtrip(gpu, tmp_path):
+    multi, sc = make([0, 0, 0], max_weight=3.0)
+    v = TSDFVolumeOctree()  # the .vol format needs a cubic power-of-two grid: 32^3 here
+    s = synth.scene_a(32, W, H)
+    for vol in (v,):
+        vol.setResolution(32, 32, 32)
+        vol.setGridSize(s.size, s.size, s.size)
+        vol.setImageSize(W, H)
+        vol.setCameraIntrinsics(s.fx, s.fy, s.cx, s.cy)
+        vol.setSensorDistanceBounds(0.0, 3 * s.size)
+        vol.setIntegrateColor(True)
+        vol.setDevices([0, 0, 0])
+        vol.reset()
+    one = TSDFVolumeOctree()
+    one.setResolution(32, 32, 32)
+    one.setGridSize(s.size, s.size, s.size)
+    one.setImageSize(W, H)
+    one.setCameraIntrinsics(s.fx, s.fy, s.cx, s.cy)
+    one.setSensorDistanceBounds(0.0, 3 * s.size)
+    one.setIntegrateColor(True)
+    one.reset()
+    for i in range(4):
+        tr = synth.turntable_pose(i, 8, s.size)
+        for vol in (v, one):
+            vol.integrateCloud(s.depth(tr), s.bgra(i), tr)
+    pa, pb = str(tmp_path / "multi.vol"), str(tmp_path / "one.vol")
+    v.save(pa)
+    one.save(pb)
+    assert open(pa, "rb").read() == open(pb, "rb").read()
+    back = TSDFVolumeOctree()
+    back.setDevices([0, 0])
+    back.load(pb)
+    assert len(back.slabs()) == 2
+    a, b = back.download(), one.download()
+    assert_same_f32(a[0], b[0], "d after load into two slabs")
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for vol in (multi, v, one, back):
+        vol.close()
+
+
+def test_single_device_entry_points_refuse_a_multi_handle(gpu):
+    multi, _ = make([0, 0])
+    lib, h = capi.load(), multi._need()
+    assert lib.tsdf_hip_set_stream(h, None) == capi.E_UNSUPPORTED
+    assert lib.tsdf_hip_get_planes_device(h, 0, 1, None, None, None) == capi.E_UNSUPPORTED
+    assert b"multi-GPU set" in lib.tsdf_hip_last_error()
+    multi.close()
