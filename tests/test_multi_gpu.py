@@ -136,6 +136,7 @@ def test_multi_handle_pipelined_host_frames_and_unorganized_ingest(gpu):
     assert_same_f32(d, ov.d, "d (pipelined)")
     assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
     # the ingest path: the z-buffer runs on the first slab's GPU, its frame fans out to the others
+    multi.reset()
     one, _ = make(None)
     tr = synth.turntable_pose(0, 8, sc.size)
     dep = sc.depth(tr)
