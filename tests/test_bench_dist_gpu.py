@@ -1,0 +1,58 @@
+"""GPU tier: bench.py's N>1 code path, as far as one GPU allows (VERDICT r01 "Next round" #5).
+
+(1) world size 1 on the `nccl` backend (= RCCL): communicator init, device-tensor broadcast (overlapped, two-slot
+    receive buffer), all-reduce and all-gather really execute on RCCL, through the same step function the driver's
+    `--gpus 8` run uses.
+(2) two ranks on the one GPU over `gloo` (RCCL refuses two ranks per device): strong scaling of one grid over two
+    Z-slabs, rank 1 receiving every frame by broadcast; its observed-voxel total must equal the one-rank run's.
+Numbers from these runs mean nothing; the JSON contract and the counts do."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--res", "256", "--steps", "4", "--warmup", "2", "--extras", "0", "--cpu-baseline", "0"]
+
+
+def run(cmd, env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_contract(j, n_gpus):
+    assert j["n_gpus"] == n_gpus and j["steps"] == 4 and j["warmup"] == 2 and j["unit"] == "Mvoxels/s"
+    assert j["scaling"] == "strong" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["config"]["grid"] == [256, 256, 256] and j["value"] > 0
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1 and r["achieved"] == pytest.approx(r["frac"] * r["peak"])
+
+
+def test_bench_world1_on_rccl(gpu):
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    check_contract(single, 1)
+    assert "multi_gpu" not in single
+    j = run([sys.executable, "bench.py"] + COMMON, {"TSDF_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29531"})
+    check_contract(j, 1)
+    assert j["multi_gpu"]["backend"] == "nccl" and j["multi_gpu"]["overlap"] is True
+    assert len(j["multi_gpu"]["per_rank_kernel_ms"]) == 1 and j["multi_gpu"]["frame_broadcast_ms_isolated"] > 0
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+
+
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_bench_two_ranks_one_gpu_over_gloo(gpu, overlap):
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    j = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(29541 + overlap), "bench.py", "--gpus", "2", "--overlap", str(overlap)] + COMMON,
+            {"TSDF_BENCH_ONE_DEVICE": "1", "TSDF_BENCH_BACKEND": "gloo"})
+    check_contract(j, 2)
+    assert j["multi_gpu"]["planes_per_gpu"] == 128 and len(j["multi_gpu"]["per_rank_kernel_ms"]) == 2
+    # every voxel is observed by exactly one slab: the two ranks' counts add up to the single-handle count
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
