@@ -388,7 +388,8 @@ class TSDFVolumeOctree:
     def save(self, filename):
         """The reference's .vol checkpoint (tsdf_hip_save); streamed, host memory stays at one 256^3 block."""
         m = capi.TsdfVolMeta()
-        cell = getattr(self, "_max_cell", None) or tuple(self._p.size[k] / self._p.res[k] for k in range(3))
+        # setMaxVoxelSize, else the reference's default 0.5 m (tsdf_volume_octree.cpp:72-74) -- what the C++ class writes
+        cell = getattr(self, "_max_cell", None) or (0.5, 0.5, 0.5)
         m.max_cell_size[:] = cell
         m.is_empty = int(self._is_empty)
         m.weight_by_depth, m.weight_by_variance = (int(v) for v in getattr(self, "_weighting", (0, 0)))

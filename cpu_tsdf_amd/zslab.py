@@ -263,6 +263,8 @@ class ZSlabVolume:
         self._frame = self.slab.frame_buffers()
         self.global_transform = np.eye(4)
         self._is_empty = True
+        self.max_cell_size = (0.5, 0.5, 0.5)  # the reference's default (tsdf_volume_octree.cpp:72-74); only save() uses it
+        self._store_failed, self._store_error = 0, ""
 
     # -- integrateCloud -------------------------------------------------------------------------------
     def integrateCloud(self, depth, bgra, trans, src=0):
@@ -683,13 +685,29 @@ class ZSlabVolume:
                 part = (blk[0][lo - z0:lo - z0 + n], blk[1][lo - z0:lo - z0 + n],
                         blk[2][lo - z0:lo - z0 + n] if self.slab.color else None)
                 if r == root:
-                    self.slab.set_block(x0, y0, lo, *part)
+                    self._store(x0, y0, lo, *part)
                 else:
                     dist.send(torch.from_numpy(self._pack_block(*part)).to(dev), r, group=self.group)
             elif self.rank == r:
                 buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device=dev)
                 dist.recv(buf, root, group=self.group)
-                self.slab.set_block(x0, y0, lo, *self._unpack_block(buf.cpu().numpy(), c, n))
+                self._store(x0, y0, lo, *self._unpack_block(buf.cpu().numpy(), c, n))
+
+    def _store(self, x0, y0, z0, d, w, rgb):
+        """set_block that never raises in the middle of the collective block protocol (a rank that left the loop would
+        leave the root blocked in its next send): the first failure is remembered -- 2 = weights a PACKED slab cannot
+        hold (the load is then repeated with float weights), 1 = anything else -- and later blocks are still received
+        and dropped; load() agrees on the outcome with one all-reduce at the end."""
+        if self._store_failed:
+            return
+        try:
+            self.slab.set_block(x0, y0, z0, d, w, rgb)
+        except capi.TsdfHipError as e:
+            self._store_failed = 2 if e.code == capi.E_UNSUPPORTED else 1
+            self._store_error = str(e)
+        except Exception as e:
+            self._store_failed = 1
+            self._store_error = repr(e)
 
     def _request(self, root, req=None):
         """The root announces the next block (x0, y0, z0, edge), or edge <= 0 = done / failed; everyone gets it."""
@@ -736,7 +754,7 @@ class ZSlabVolume:
         lib = capi.load()
         p = self.slab.params()
         m = capi.TsdfVolMeta()
-        m.max_cell_size[:] = [p.size[k] / p.res[k] for k in range(3)]
+        m.max_cell_size[:] = list(self.max_cell_size)  # what TSDFVolumeOctree::save writes (max_cell_size_x_ ...)
         m.is_empty = int(self._is_empty)
         m.global_transform[:] = [float(v) for v in np.asarray(self.global_transform, np.float64).reshape(16)]
         self.slab.synchronize()
@@ -744,7 +762,7 @@ class ZSlabVolume:
                            self._serve_fetch)
 
     @classmethod
-    def load(cls, filename, group=None, slab_factory=None, halo=None, src=0, configure_more=None):
+    def load(cls, filename, group=None, slab_factory=None, halo=None, src=0, configure_more=None, _retry_f32w=False):
         """Collective: rank `src` reads `filename` (written by either side); the volume is built from its header and
         every block goes to the ranks that own its planes.  `configure_more(vol)` is applied after the file's
         settings (device-side choices the file does not carry: setTransformOrder, setLayout)."""
@@ -782,6 +800,7 @@ class ZSlabVolume:
         self = cls(configure, p.res[2], group=group, slab_factory=slab_factory, halo=halo)
         self.global_transform = np.array(list(m.global_transform), dtype=np.float64).reshape(4, 4)
         self._is_empty = bool(m.is_empty)
+        self.max_cell_size = tuple(m.max_cell_size)
         keep = []  # (the header callback object must outlive the call)
 
         def run(cb):
@@ -789,6 +808,25 @@ class ZSlabVolume:
             return lib.tsdf_hip_load_blocks(str(filename).encode(), None, keep[0], cb, None)
         self._drive_blocks(src, run, self._serve_store)
         self.slab.synchronize()
+        # every rank learns whether any rank failed to store a block (no rank raised inside the protocol)
+        status = torch.tensor([self._store_failed], dtype=torch.int32, device=self._frame[0].device)
+        if world > 1:
+            dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+        status = int(status.item())
+        if status:
+            err = self._store_error
+            self.close()
+            if status == 2 and not _retry_f32w:
+                # weights that are not min(k, max_weight) (a file written with another weighting) do not fit the PACKED
+                # layout AUTO picked: read the file again into float weight planes, as tsdf_hip_load does
+                def more(v):
+                    if configure_more is not None:
+                        configure_more(v)
+                    v.setLayout(capi.LAYOUT_F32W)
+                return cls.load(filename, group=group, slab_factory=slab_factory, halo=halo, src=src, configure_more=more,
+                                _retry_f32w=True)
+            raise capi.TsdfHipError(capi.E_UNSUPPORTED if status == 2 else capi.E_INVALID, "ZSlabVolume.load",
+                                    err or "a block could not be stored on another rank")
         return self
 
     def slab_image_size(self):

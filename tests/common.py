@@ -47,7 +47,7 @@ def assert_same_f32(a, b, what):
                              f"got {a[ne][:5]} want {b[ne][:5]}; max abs diff {np.nanmax(np.abs(a - b))}")
 
 
-def write_vol_from_arrays(path, params, d, w, rgb, global_transform=None, chunk=None):
+def write_vol_from_arrays(path, params, d, w, rgb, global_transform=None, chunk=None, max_cell=(0.5, 0.5, 0.5)):
     """A .vol written by the product's streaming writer (tsdf_hip_save_blocks) from whole-grid host arrays."""
     import ctypes as C
 
@@ -55,7 +55,7 @@ def write_vol_from_arrays(path, params, d, w, rgb, global_transform=None, chunk=
     lib = capi.load()
     color = bool(params.integrate_color)
     m = capi.TsdfVolMeta()
-    m.max_cell_size[:] = [params.size[k] / params.res[k] for k in range(3)]
+    m.max_cell_size[:] = list(max_cell)  # the reference's default, which the product classes write too
     m.global_transform[:] = [float(v) for v in (np.eye(4) if global_transform is None else np.asarray(global_transform)).reshape(16)]
 
     def fetch(_user, x0, y0, z0, c, pd, pw, prgb):

@@ -43,6 +43,9 @@ class _Cfg:
     def setTransformOrder(self, o):
         self._p.xform_order = o
 
+    def setLayout(self, layout):
+        self._p.layout = layout
+
 
 class OracleSlab:
     def __init__(self, configure, z_begin, z_end, nz, rank, halo=1):
@@ -67,6 +70,13 @@ class OracleSlab:
     def set_block(self, x0, y0, z0, d, w, rgb):
         nz, ny, nx = d.shape
         assert self.z_begin <= z0 and z0 + nz <= self.z_end
+        from cpu_tsdf_amd import capi
+        if self.p.layout != capi.LAYOUT_F32W and 0 <= self.p.max_weight <= 255:
+            # what the HIP slab does in the PACKED layout AUTO resolves to: a weight no observation count represents
+            # is refused (tsdf_hip_upload -> TSDF_HIP_E_UNSUPPORTED)
+            wmax = np.float32(self.p.max_weight)
+            if not (((w == np.floor(w)) & (w >= 0) & (w < np.ceil(wmax))) | (w == wmax)).all():
+                raise capi.TsdfHipError(capi.E_UNSUPPORTED, "upload", "weight is not min(k, max_weight)")
         sl = (slice(z0, z0 + nz), slice(y0, y0 + ny), slice(x0, x0 + nx))
         self.ov.d[sl], self.ov.w[sl] = d, w
         if self.color:

@@ -270,3 +270,50 @@ def test_slabs_thinner_than_the_render_halo(tmp_path):
     assert len(cells) > 300 and np.array_equal(got["cells"], cells) and np.array_equal(got["verts"], verts)
     ok, val, _, _ = ov.sample(np.random.RandomState(3).uniform(-0.05, 0.05, (200, 3)).astype(np.float32))
     assert np.array_equal(got["ok"], ok) and ok.sum() > 20 and np.array_equal(got["val"][ok], val[ok])
+
+
+def _load_worker(rank, world, port, vol_path, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_tsdf_amd import capi
+    from tests.fake_slab import OracleSlab
+    capi.set_tuning("vol_chunk", 16)
+    back = ZSlabVolume.load(vol_path, slab_factory=OracleSlab, src=0)
+    zb, ze = back.z_begin, back.z_end
+    got = [None] * world if rank == 0 else None
+    dist.gather_object((zb, ze, back.slab.p.layout, back.slab.ov.d[zb:ze].copy(), back.slab.ov.w[zb:ze].copy()), got, dst=0)
+    if rank == 0:
+        np.savez(out_path, d=np.concatenate([g[3] for g in got]), w=np.concatenate([g[4] for g in got]),
+                 layouts=np.array([g[2] for g in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_load_of_fractional_weights_falls_back_to_float_weights_on_every_rank(tmp_path):
+    """a .vol whose weights are not observation counts (another weighting wrote it) makes a PACKED slab
+    refuse the upload -- on a NON-root rank here (only the upper half of the grid holds such weights).  That rank
+    used to raise inside the block protocol and leave the root blocked in its next send; now every rank finishes
+    the protocol, the outcome is agreed by an all-reduce, and the whole load is repeated with float weights."""
+    from cpu_tsdf_amd import capi
+    from tests.common import write_vol_from_arrays
+    from tests.fake_slab import _Cfg
+    res = 32
+    cfg = _Cfg()
+    sc = synth.scene_a(res, W, H)
+    cfg.setResolution(res, res, res)
+    cfg.setGridSize(sc.size, sc.size, sc.size)
+    cfg.setImageSize(W, H)
+    cfg.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    cfg.setIntegrateColor(False)
+    rng = np.random.RandomState(4)
+    d = rng.uniform(-1, 1, (res, res, res)).astype(np.float32)
+    w = rng.randint(0, 5, (res, res, res)).astype(np.float32)
+    w[res // 2 + 3:] += np.float32(0.25)  # only rank 1's planes
+    path = str(tmp_path / "frac.vol")
+    write_vol_from_arrays(path, cfg._p, d, w, None, chunk=16)
+    out = str(tmp_path / "out.npz")
+    port = _free_port()
+    mp.spawn(_load_worker, args=(2, port, path, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert (got["layouts"] == capi.LAYOUT_F32W).all()
+    assert np.array_equal(got["d"], d) and np.array_equal(got["w"], w)
