@@ -136,6 +136,17 @@ struct TsdfDeviceScope {
 
 // Per-axis voxel-centre table (tsdf_core.hip): the octree's node-centre recurrence, or the closed form.
 void tsdf_build_centers(int res, float size, std::vector<float> &out, int *levels);
+// The size an axis' octree node centres are built from: OctreeNode keeps ONE size_, initialised from size_x
+// (include/cpu_tsdf/octree.h:63-66), and split() offsets all three centre coordinates by size_ / 4
+// (src/lib/octree.cpp:244-266) -- under a non-cubic setGridSize the reference's octree is still a cube of edge size_x,
+// and integrateCloud updates THOSE leaves (pinned against the compiled reference, tests/test_oracle_golden.py).
+// Grids without an octree equivalent (not a power of two on every axis, or not cubic in resolution) use the axis' own
+// size with the closed-form centres.
+static inline float tsdf_node_size(const tsdf_params &p, int axis) {
+  const int r = p.res[0];
+  const bool cubic_pow2 = r > 0 && (r & (r - 1)) == 0 && p.res[1] == r && p.res[2] == r;
+  return cubic_pow2 ? p.size[0] : p.size[axis];
+}
 int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes);
 // Copies between DEVICE memory and the CALLER's host memory, through the handle's pinned bounce buffer in chunks
 // (two slots, the host memcpy of one chunk overlapping the DMA of the next).  tsdf_to_host returns with the

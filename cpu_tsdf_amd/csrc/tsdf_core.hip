@@ -366,7 +366,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (rgbn)
     for (int c = 0; c < 4; ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
   for (int a = 0; a < 3; ++a) {
-    tsdf_build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
+    tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v->h_ctr[a], &v->levels[a]);
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
     // fails k_integrate's sensor-range test, so voxels of the pitch padding are never observed
     std::vector<float> padded(v->h_ctr[a]);

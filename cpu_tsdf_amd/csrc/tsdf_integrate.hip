@@ -1229,7 +1229,7 @@ extern "C" int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam
   v.p = *p;
   for (int a = 0; a < 3; ++a) {
     if (p->res[a] <= 0 || !(p->size[a] > 0.f)) return TSDF_HIP_E_INVALID;
-    tsdf_build_centers(p->res[a], p->size[a], v.h_ctr[a], &v.levels[a]);
+    tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v.h_ctr[a], &v.levels[a]);
   }
   int lo[3], hi[3];
   bool empty = false;
@@ -1255,7 +1255,7 @@ extern "C" int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float c
   for (int a = 0; a < 3; ++a) {
     int levels;
     if (p->res[a] <= 0 || !(p->size[a] > 0.f)) return TSDF_HIP_E_INVALID;
-    tsdf_build_centers(p->res[a], p->size[a], ctr[a], &levels);
+    tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), ctr[a], &levels);
   }
   CullArgs c;
   for (int i = 0; i < 12; ++i) c.m[i] = cam_from_vol[i];

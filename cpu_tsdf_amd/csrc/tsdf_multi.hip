@@ -126,7 +126,7 @@ extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *device
       tsdf_set_error("resolution and grid size must be positive");
       return TSDF_HIP_E_INVALID;
     }
-    tsdf_build_centers(p->res[a], p->size[a], v->h_ctr[a], &v->levels[a]);
+    tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v->h_ctr[a], &v->levels[a]);
   }
   // halo: what renderView's ray hand-off needs (the refinement walk and the normal's samples look back / ahead);
   // marching cubes and sampling use the first plane of it

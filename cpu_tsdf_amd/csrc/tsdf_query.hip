@@ -22,6 +22,7 @@ struct GridView {
   int z_first, nz_alloc; // allocated plane range
   int lv[3];             // octree levels per axis (log2 res) or -1
   float size[3];
+  float nsize[3];        // size the axis' node centres descend from (tsdf_node_size: size_x on an octree grid)
   float half[3];         // size/2 in float (root bounds test, octree.cpp:630)
   int64_t pitch;
   const float *d;
@@ -39,6 +40,7 @@ static GridView make_view(const tsdf_hip_volume *v) {
   for (int a = 0; a < 3; ++a) {
     g.lv[a] = v->levels[a];
     g.size[a] = v->p.size[a];
+    g.nsize[a] = tsdf_node_size(v->p, a);
     g.half[a] = v->p.size[a] / 2;
     g.ctr[a] = v->ctr[a];
   }
@@ -68,7 +70,7 @@ static __device__ __forceinline__ int descend_axis(float x, float size, int L) {
 }
 
 static __device__ __forceinline__ int axis_index(const GridView &g, int a, float x) {
-  if (g.lv[a] >= 0) return descend_axis(x, g.size[a], g.lv[a]);
+  if (g.lv[a] >= 0) return descend_axis(x, g.nsize[a], g.lv[a]);
   const int res = a == 0 ? g.nx : a == 1 ? g.ny : g.nz;
   int i = cvtt(floor(((double)x + (double)g.size[a] / 2.0) / (double)g.size[a] * (double)res));
   return i < 0 ? 0 : (i >= res ? res - 1 : i);

@@ -111,9 +111,15 @@ class OracleVolume:
         self.w = np.zeros((nz, ny, nx), dtype=np.float32)
         self.rgb = np.zeros((nz, ny, nx, 3), dtype=np.uint8) if self.p.integrate_color else None
 
+    def node_size(self, axis):
+        """tsdf_oracle.c node_size(): the reference's octree is a cube of edge size_x (octree.h:63-66)."""
+        r = self.p.res[0]
+        cubic_pow2 = r > 0 and (r & (r - 1)) == 0 and self.p.res[1] == r and self.p.res[2] == r
+        return self.p.size[0] if cubic_pow2 else self.p.size[axis]
+
     def centers(self, axis):
         out = np.empty(self.p.res[axis], dtype=np.float32)
-        lib().oracle_centers(self.p.res[axis], self.p.size[axis], _fp(out))
+        lib().oracle_centers(self.p.res[axis], self.node_size(axis), _fp(out))
         return out
 
     def integrate(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0, weight_by_depth=False):

@@ -108,6 +108,16 @@ static int descend_axis(float x, float size, int L) {
   return i;
 }
 
+/* The size an axis' node centres are built from.  OctreeNode keeps ONE size_, initialised from size_x
+ * (octree.h:63-66), and split() offsets all three centre coordinates by size_/4 (octree.cpp:244-266): on a grid whose
+ * setGridSize is not cubic the octree is still a cube of edge size_x.  (The bounds tests and the closed-form
+ * getVoxelCenter / getVoxelIndex keep using the per-axis sizes, as in the reference.)  Without an octree equivalent
+ * (a resolution that is not a power of two on every axis, or not cubic) the axis' own size is used. */
+static float node_size(const oracle_params *p, int axis) {
+  const int cubic = p->res[0] == p->res[1] && p->res[1] == p->res[2] && ilog2_exact(p->res[0]) >= 0;
+  return cubic ? p->size[0] : p->size[axis];
+}
+
 /* Octree::getContainingVoxel, octree.cpp:628-643, on a fully split tree.  Returns 0 for NULL. */
 int oracle_containing(const oracle_params *p, float x, float y, float z, int idx[3]) {
   if (isnan(z) || fabsf(x) > p->size[0] / 2 || fabsf(y) > p->size[1] / 2 || fabsf(z) > p->size[2] / 2)
@@ -116,7 +126,7 @@ int oracle_containing(const oracle_params *p, float x, float y, float z, int idx
   for (int a = 0; a < 3; ++a) {
     const int L = ilog2_exact(p->res[a]);
     if (L >= 0) {
-      idx[a] = descend_axis(v[a], p->size[a], L);
+      idx[a] = descend_axis(v[a], node_size(p, a), L);
     } else { /* no octree for this resolution: nearest cell by the closed form */
       int i = cvtt(floor(((double)v[a] + (double)p->size[a] / 2.0) / (double)p->size[a] * (double)p->res[a]));
       if (i < 0) i = 0;
@@ -171,9 +181,9 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
   const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
   float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
         *cz = (float *)malloc(sizeof(float) * nz);
-  oracle_centers(nx, p->size[0], cx);
-  oracle_centers(ny, p->size[1], cy);
-  oracle_centers(nz, p->size[2], cz);
+  oracle_centers(nx, node_size(p, 0), cx);
+  oracle_centers(ny, node_size(p, 1), cy);
+  oracle_centers(nz, node_size(p, 2), cz);
   if (z_begin == 0 && z_end == 0) z_end = nz;
   uint64_t n_obs = 0;
 #pragma omp parallel for schedule(static) reduction(+ : n_obs)
@@ -228,9 +238,9 @@ uint64_t oracle_integrate_rgbn(const oracle_params *p, float *d, float *w, float
   float *r_n = cn, *g_n = cn + n, *b_n = cn + 2 * n, *i_m = cn + 3 * n;
   float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
         *cz = (float *)malloc(sizeof(float) * nz);
-  oracle_centers(nx, p->size[0], cx);
-  oracle_centers(ny, p->size[1], cy);
-  oracle_centers(nz, p->size[2], cz);
+  oracle_centers(nx, node_size(p, 0), cx);
+  oracle_centers(ny, node_size(p, 1), cy);
+  oracle_centers(nz, node_size(p, 2), cz);
   if (z_begin == 0 && z_end == 0) z_end = nz;
   uint64_t n_obs = 0;
 #pragma omp parallel for schedule(static) reduction(+ : n_obs)
@@ -671,9 +681,9 @@ int oracle_sample(const oracle_params *p, const float *d, const float pt[3], flo
   if (pt[2] < voxel_center(p, 2, zi)) zi -= 1;
   if (xi < 0 || xi >= nx - 1 || yi < 0 || yi >= ny - 1 || zi < 0 || zi >= nz - 1) return 0;
   float *tx = (float *)malloc(sizeof(float) * (nx + ny + nz)), *ty = tx + nx, *tz = ty + ny;
-  oracle_centers(nx, p->size[0], tx);
-  oracle_centers(ny, p->size[1], ty);
-  oracle_centers(nz, p->size[2], tz);
+  oracle_centers(nx, node_size(p, 0), tx);
+  oracle_centers(ny, node_size(p, 1), ty);
+  oracle_centers(nz, node_size(p, 2), tz);
   const float c = p->size[0] / p->res[0];
   float v = 0, g[3] = {0, 0, 0}, h01 = 0, h02 = 0, h12 = 0;
   for (int dx = 0; dx <= 1; dx++)

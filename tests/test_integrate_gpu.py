@@ -91,6 +91,16 @@ def test_parity_odd_resolutions(gpu):
     compare(vol, ov)
 
 
+def test_parity_non_cubic_grid_size(gpu):
+    """setGridSize with three different extents on a power-of-two grid: node centres descend from size_x on every
+    axis, as in the reference's octree (tests/test_oracle_golden.py pins the oracle on this against oracle/_ref)."""
+    vol, sc = make_volume(64, size3=(0.25, 0.2, 0.3), color=True)
+    ov = run_pair(vol, sc, 3, total=8)
+    compare(vol, ov)
+    for a in range(3):
+        assert np.array_equal(vol.centers(a), ov.centers(a)) and np.array_equal(vol.centers(a), vol.centers(0))
+
+
 def test_depth_edge_cases_nan_inf_zero(gpu):
     # only NaN is "no return" (hpp:152); +Inf clamps to max_dist_pos, 0 is far behind every voxel
     vol, sc = make_volume(64)
