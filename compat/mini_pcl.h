@@ -613,10 +613,23 @@ class MarchingCubes {
     output.polygons.clear();
     performReconstruction(output);
   }
+  // pcl::SurfaceReconstruction::reconstruct(PointCloud&, std::vector<Vertices>&) [PCL-recall]: the same with
+  // the second performReconstruction overload
+  void reconstruct(PointCloud<PointNT> &points, std::vector<Vertices> &polygons) {
+    points.header = input_ ? input_->header : PCLHeader();
+    polygons.clear();
+    performReconstruction(points, polygons);
+  }
 
  protected:
   virtual void voxelizeData() = 0;
   virtual void performReconstruction(PolygonMesh &output) = 0;
+  // upstream pcl::MarchingCubes implements this one itself (voxelizeData + createSurface over grid_); the stand-in
+  // has no grid, and nothing in the reference calls it
+  virtual void performReconstruction(PointCloud<PointNT> &points, std::vector<Vertices> &polygons) {
+    points.clear();
+    polygons.clear();
+  }
 
   void getBoundingBox() {
     PointNT max_pt, min_pt;

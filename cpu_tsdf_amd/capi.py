@@ -98,6 +98,8 @@ SIGNATURES = {
                                     _f64p, _f32p, _u8p, _u64p]),
     "tsdf_hip_integrate_staged": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_set_weighting": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "tsdf_hip_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(_f32p), C.POINTER(_u8p)]),
+    "tsdf_hip_frame_commit": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),

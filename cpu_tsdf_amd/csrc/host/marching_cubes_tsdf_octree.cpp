@@ -11,6 +11,36 @@
 
 namespace cpu_tsdf {
 
+// reference: src/lib/marching_cubes_tsdf_octree.cpp:44-83.  The base class is set up exactly as there so that code
+// reading it back (getGridResolution, getIsoLevel, ...) sees the reference's values; the kernels take the same
+// lower_boundary_ / size_voxel_ from the volume's parameters (tsdf_march.hip), where the two +- terms of :64-66 cancel.
+void MarchingCubesTSDFOctree::setInputTSDF(TSDFVolumeOctree::ConstPtr tsdf_volume) {
+  tsdf_volume_ = tsdf_volume;
+  if (!tsdf_volume_) return;
+  int res_x, res_y, res_z;
+  tsdf_volume_->getResolution(res_x, res_y, res_z);
+  setGridResolution(res_x, res_y, res_z);
+  float size_x, size_y, size_z;
+  tsdf_volume_->getGridSize(size_x, size_y, size_z);
+  pcl::PointCloud<pcl::PointXYZ>::Ptr corner_cloud(new pcl::PointCloud<pcl::PointXYZ>);
+  for (int x_i = 0; x_i <= res_x; x_i += res_x)
+    for (int y_i = 0; y_i <= res_y; y_i += res_y)
+      for (int z_i = 0; z_i <= res_z; z_i += res_z) {
+        pcl::PointXYZ center = tsdf_volume_->getVoxelCenter(x_i, y_i, z_i);
+        center.x += (x_i == 0 ? -1 : 1) * 0.5 * size_x / res_x + (x_i == 0 ? 1 : -1) * (0.5 * size_x / (double)res_x);
+        center.y += (y_i == 0 ? -1 : 1) * 0.5 * size_y / res_y + (y_i == 0 ? 1 : -1) * (0.5 * size_y / (double)res_y);
+        center.z += (z_i == 0 ? -1 : 1) * 0.5 * size_z / res_z + (z_i == 0 ? 1 : -1) * (0.5 * size_z / (double)res_z);
+        corner_cloud->points.push_back(center);
+      }
+  corner_cloud->width = (uint32_t)corner_cloud->points.size();
+  corner_cloud->height = 1;
+  setInputCloud(corner_cloud);
+  setPercentageExtendGrid(0);
+  setIsoLevel(0.f);
+  getBoundingBox();
+  size_voxel_ = (upper_boundary_ - lower_boundary_) * Eigen::Array3f(res_x_, res_y_, res_z_).inverse();
+}
+
 static bool run_march(const TSDFVolumeOctree::ConstPtr &vol, float w_min, int mode, std::vector<float> &verts,
                       std::vector<unsigned char> &rgb) {
   verts.clear();
@@ -46,7 +76,7 @@ static void fill_polygons(size_t n_vertices, std::vector<pcl::Vertices> &polygon
   }
 }
 
-void MarchingCubesTSDFOctree::reconstruct(pcl::PolygonMesh &output) {
+void MarchingCubesTSDFOctree::performReconstruction(pcl::PolygonMesh &output) {
   output.polygons.clear();
   // color_by_confidence_ wins over color_by_rgb_ (marching_cubes_tsdf_octree.cpp:215-231)
   const int mode = color_by_confidence_ ? 2 : (color_by_rgb_ ? 1 : 0);
@@ -88,8 +118,8 @@ void MarchingCubesTSDFOctree::reconstruct(pcl::PolygonMesh &output) {
   fill_polygons(n, output.polygons);
 }
 
-void MarchingCubesTSDFOctree::reconstruct(pcl::PointCloud<pcl::PointXYZ> &points,
-                                          std::vector<pcl::Vertices> &polygons) {
+void MarchingCubesTSDFOctree::performReconstruction(pcl::PointCloud<pcl::PointXYZ> &points,
+                                                    std::vector<pcl::Vertices> &polygons) {
   std::vector<float> verts;
   std::vector<unsigned char> rgb;
   run_march(tsdf_volume_, w_min_, 0, verts, rgb);

@@ -170,6 +170,32 @@ bool TSDFVolumeOctree::integratePlanar(const float *depth, const unsigned char *
   return true;
 }
 
+bool TSDFVolumeOctree::beginFrame(int width, int height, float **depth, unsigned char **bgra) {
+  if (!ready("integrateCloud")) return false;
+  if (width != p_.image_width || height != p_.image_height) {
+    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::integrateCloud] cloud is %dx%d but setImageSize said %dx%d\n", width,
+              height, p_.image_width, p_.image_height);
+    return false;
+  }
+  const int rc = tsdf_hip_frame_begin(h_, depth, bgra);
+  if (rc) report("integrateCloud", rc);
+  return rc == 0;
+}
+
+bool TSDFVolumeOctree::commitFrame(const Eigen::Affine3d &trans) {
+  const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
+  float T[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) T[4 * r + c] = trans_inv.matrix()(r, c);
+  const int rc = tsdf_hip_frame_commit(h_, T);
+  if (rc) {
+    report("integrateCloud", rc);
+    return false;
+  }
+  is_empty_ = false;
+  return true;
+}
+
 // reference: src/prog/integrate.cpp:559-618 (prepare) + :650,673 (integrate)
 bool TSDFVolumeOctree::integrateUnorganized(const pcl::PointCloud<pcl::PointXYZRGBA> &cloud, const Eigen::Affine3d &trans,
                                             float cloud_units, bool zero_nans, const Eigen::Affine3d *world_to_cam,

@@ -1103,34 +1103,56 @@ void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
   v->pipe = nullptr;
 }
 
-extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
-                                        const float cam_from_vol[12]) {
-  if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
-  if (h->multi) return tsdf_multi_integrate(h, depth, bgra, cam_from_vol, nullptr, true);
+// The ring itself: tsdf_hip_frame_begin hands out the next pinned slot (waiting until the kernel that last read it
+// has finished), tsdf_hip_frame_commit uploads it on the private copy stream and queues the integrate launch behind
+// the upload.  A caller that can write its frame straight into the slot (the C++ integrateCloud template stripping a
+// PCL cloud) saves the intermediate copy; tsdf_hip_integrate_async is begin + memcpy + commit.
+static int pipeline_ready(tsdf_handle h) {
+  if (h->pipe) return TSDF_HIP_OK;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  tsdf_hip_pipeline *p = new tsdf_hip_pipeline;
+  h->pipe = p;
+  TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
+    TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
+    TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
+    TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
+  }
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra);
+int tsdf_multi_frame_commit(tsdf_handle h, const float T[12]);
+
+extern "C" int tsdf_hip_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra) {
+  if (!h || !depth) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_frame_begin(h, depth, bgra);
   TSDF_ON_DEVICE(h->device);
-  const bool color = h->p.integrate_color != 0;
-  if (color && !bgra) {
-    tsdf_set_error("integrate_color is set but no colour image was given");
-    return TSDF_HIP_E_INVALID;
-  }
-  const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
-  if (!h->pipe) {
-    tsdf_hip_pipeline *p = new tsdf_hip_pipeline;
-    h->pipe = p;
-    TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
-      TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
-      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
-      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
-    }
-  }
+  const int rc = pipeline_ready(h);
+  if (rc) return rc;
   tsdf_hip_pipeline *p = h->pipe;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   const int slot = (int)(p->frames & 1ull);
   // the slot was last used two frames ago: its kernel must be done before the staging buffers are reused
   if (p->frames >= 2) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot]));
-  memcpy(p->pinned[slot], depth, npx * 4);
-  if (color) memcpy(p->pinned[slot] + npx, bgra, npx * 4);
+  *depth = p->pinned[slot];
+  if (bgra) *bgra = h->p.integrate_color ? reinterpret_cast<uint8_t *>(p->pinned[slot] + npx) : nullptr;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]) {
+  if (!h || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_frame_commit(h, cam_from_vol);
+  if (!h->pipe) {
+    tsdf_set_error("tsdf_hip_frame_commit without tsdf_hip_frame_begin");
+    return TSDF_HIP_E_INVALID;
+  }
+  TSDF_ON_DEVICE(h->device);
+  tsdf_hip_pipeline *p = h->pipe;
+  const bool color = h->p.integrate_color != 0;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
+  const int slot = (int)(p->frames & 1ull);
   TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], p->pinned[slot], bytes, hipMemcpyHostToDevice, p->copy_stream));
   TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
   TSDF_HIP_TRY(hipStreamWaitEvent(h->stream, p->copied[slot], 0));
@@ -1140,6 +1162,23 @@ extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const
   TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
   p->frames++;
   return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
+                                        const float cam_from_vol[12]) {
+  if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->p.integrate_color && !bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  float *sd = nullptr;
+  uint8_t *sc = nullptr;
+  const int rc = tsdf_hip_frame_begin(h, &sd, &sc);
+  if (rc) return rc;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  memcpy(sd, depth, npx * 4);
+  if (sc) memcpy(sc, bgra, npx * 4);
+  return tsdf_hip_frame_commit(h, cam_from_vol);
 }
 
 // ---------------------------------------------------------------------------------------------

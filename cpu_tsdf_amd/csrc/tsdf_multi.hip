@@ -249,20 +249,27 @@ static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed)
 }
 
 // Host frame -> pinned slot -> every slab's staging buffer, each over its own GPU's PCIe link and on its own stream.
-static int upload_frame(tsdf_handle h, const float *depth, const uint8_t *bgra) {
+int tsdf_multi_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra) {
   tsdf_hip_multi *m = h->multi;
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
-  const bool color = h->p.integrate_color != 0;
-  if (color && !bgra) {
-    tsdf_set_error("integrate_color is set but no colour image was given");
-    return TSDF_HIP_E_INVALID;
-  }
   const int slot = (int)(m->frames & 1ull);
   if (!m->pinned[slot]) TSDF_HIP_TRY(hipHostMalloc((void **)&m->pinned[slot], npx * 8, hipHostMallocPortable));
   if (m->frames >= 2)  // the slot's previous uploads (two frames ago) must have left it
     for (size_t k = 0; k < m->slab.size(); ++k) TSDF_HIP_TRY(hipEventSynchronize(m->uploaded[slot][k]));
-  memcpy(m->pinned[slot], depth, npx * 4);
-  if (color) memcpy(m->pinned[slot] + npx, bgra, npx * 4);
+  *depth = m->pinned[slot];
+  if (bgra) *bgra = h->p.integrate_color ? reinterpret_cast<uint8_t *>(m->pinned[slot] + npx) : nullptr;
+  return TSDF_HIP_OK;
+}
+
+static int upload_slot(tsdf_handle h) {
+  tsdf_hip_multi *m = h->multi;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  const bool color = h->p.integrate_color != 0;
+  const int slot = (int)(m->frames & 1ull);
+  if (!m->pinned[slot]) {
+    tsdf_set_error("tsdf_hip_frame_commit without tsdf_hip_frame_begin");
+    return TSDF_HIP_E_INVALID;
+  }
   for (size_t k = 0; k < m->slab.size(); ++k) {
     tsdf_handle s = m->slab[k];
     TSDF_ON_DEVICE(s->device);
@@ -273,10 +280,25 @@ static int upload_frame(tsdf_handle h, const float *depth, const uint8_t *bgra) 
   return TSDF_HIP_OK;
 }
 
+int tsdf_multi_frame_commit(tsdf_handle h, const float T[12]) {
+  const int rc = upload_slot(h);
+  return rc ? rc : integrate_all(h, T, nullptr);
+}
+
 int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
                          bool asynchronous) {
-  int rc = upload_frame(h, depth, bgra);
+  if (h->p.integrate_color && !bgra) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  float *sd = nullptr;
+  uint8_t *sc = nullptr;
+  int rc = tsdf_multi_frame_begin(h, &sd, &sc);
   if (rc) return rc;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  memcpy(sd, depth, npx * 4);
+  if (sc) memcpy(sc, bgra, npx * 4);
+  if ((rc = upload_slot(h))) return rc;
   if ((rc = integrate_all(h, T, n_observed))) return rc;
   return asynchronous ? TSDF_HIP_OK : tsdf_multi_synchronize(h);
 }

@@ -1,32 +1,33 @@
-// integrateCloud template of the MI355X drop-in: strips the organised PCL cloud down to the two planar
-// images the kernel reads (pt.z, and b,g,r,a when colour is on) and forwards to integratePlanar.
-// The reference reads exactly these fields (include/cpu_tsdf/impl/tsdf_volume_octree.hpp:150-159,206);
-// like there, PointT needs r,g,b members.
+// integrateCloud template of the MI355X drop-in: strips the organised PCL cloud down to the two planar images the
+// kernel reads (pt.z, and b,g,r,a when colour is on) -- straight into the volume's pinned staging slot
+// (tsdf_hip_frame_begin), in parallel when the caller compiles with OpenMP -- and queues upload + integrate
+// (tsdf_hip_frame_commit).  The call returns once the frame is staged: the upload overlaps the previous frame's kernel
+// and every later call on the volume is ordered after it, so a stream of clouds runs at the kernel's rate.
+// The reference reads exactly these fields (include/cpu_tsdf/impl/tsdf_volume_octree.hpp:150-159,206); like there,
+// PointT needs r,g,b members.
 #pragma once
-
-#include <vector>
 
 namespace cpu_tsdf {
 
 template <typename PointT, typename NormalT>
 bool TSDFVolumeOctree::integrateCloud(const pcl::PointCloud<PointT> &cloud, const pcl::PointCloud<NormalT> &,
                                       const Eigen::Affine3d &trans) {
-  const size_t n = cloud.points.size();
-  std::vector<float> depth(n);
-  for (size_t i = 0; i < n; ++i) depth[i] = cloud.points[i].z;
-  std::vector<unsigned char> bgra;
-  if (p_.integrate_color) {
-    bgra.resize(4 * n);
-    for (size_t i = 0; i < n; ++i) {
-      const PointT &pt = cloud.points[i];
-      bgra[4 * i + 0] = pt.b;
-      bgra[4 * i + 1] = pt.g;
-      bgra[4 * i + 2] = pt.r;
+  float *depth = nullptr;
+  unsigned char *bgra = nullptr;
+  if (!beginFrame((int)cloud.width, (int)cloud.height, &depth, &bgra)) return false;
+  const long n = (long)cloud.points.size();
+  const PointT *pts = n ? &cloud.points[0] : nullptr;
+#pragma omp parallel for schedule(static) num_threads(8)
+  for (long i = 0; i < n; ++i) {
+    depth[i] = pts[i].z;
+    if (bgra) {
+      bgra[4 * i + 0] = pts[i].b;
+      bgra[4 * i + 1] = pts[i].g;
+      bgra[4 * i + 2] = pts[i].r;
       bgra[4 * i + 3] = 255;
     }
   }
-  return integratePlanar(depth.data(), bgra.empty() ? nullptr : bgra.data(), (int)cloud.width, (int)cloud.height,
-                         trans);
+  return commitFrame(trans);
 }
 
 }  // namespace cpu_tsdf

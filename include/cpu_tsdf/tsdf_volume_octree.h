@@ -91,6 +91,11 @@ class TSDFVolumeOctree : public TSDFInterface {
   // 4 bytes per pixel in PointXYZRGBA byte order or NULL.
   bool integratePlanar(const float *depth, const unsigned char *bgra, int width, int height,
                        const Eigen::Affine3d &trans);
+  // The two halves the integrateCloud template is made of: beginFrame hands out the pinned staging slot of the next
+  // frame (*depth: height x width floats; *bgra: 4 bytes per pixel, or NULL when colour is off), commitFrame queues its
+  // upload and the integrate launch and returns (pipelined: see impl/tsdf_volume_octree.hpp).
+  bool beginFrame(int width, int height, float **depth, unsigned char **bgra);
+  bool commitFrame(const Eigen::Affine3d &trans);
   // The `integrate` program's per-cloud preparation + integrateCloud in one call (src/prog/integrate.cpp:
   // 559-618, 650, 673): an UNORGANISED cloud in sensor units is scaled by cloud_units, (0,0,0) becomes NaN if
   // zero_nans, it is moved by *world_to_cam (= poses[i].inverse()) when given, z-buffered into the configured

@@ -148,6 +148,13 @@ int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_
  * before every later call on this handle; asynchronous errors surface at the next synchronising call. */
 int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,
                              const float cam_from_vol[12]);
+/* The two halves of tsdf_hip_integrate_async, for a caller that can WRITE its frame straight into the pinned slot
+ * (the C++ integrateCloud template strips the z / b,g,r fields of a pcl::PointCloud into it, in parallel) instead of
+ * building planar images first: _begin returns the slot's host pointers (*depth: image_height x image_width floats,
+ * *bgra: as many 4-byte pixels, NULL without integrate_color), waiting only for the kernel that read the slot two frames
+ * ago; _commit uploads and queues the integrate launch, as tsdf_hip_integrate_async does.  One begin per commit. */
+int tsdf_hip_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra);
+int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]);
 
 /* The `integrate` program's per-cloud preparation -- src/prog/integrate.cpp:559-618 and reprojectPoint
  * :201-207: scale by cloud_units, optionally turn (0,0,0) into NaN, optionally move the cloud by
@@ -372,7 +379,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 5
+#define TSDF_HIP_ABI_VERSION 6
 
 #ifdef __cplusplus
 }

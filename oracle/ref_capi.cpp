@@ -166,8 +166,15 @@ uint64_t ct_march(void *h, float w_min, int color_mode, double *seconds) {
   mc.setInputTSDF(c->vol);
   if (color_mode == 1) mc.setColorByRGB(true);
   if (color_mode == 2) mc.setColorByConfidence(true);
+  // used the way PCL code uses any surface reconstruction: through the base class (the reference's mesher IS a
+  // pcl::MarchingCubes<pcl::PointXYZ>, marching_cubes_tsdf_octree.h:50; the drop-in must be one too)
+  pcl::MarchingCubes<pcl::PointXYZ> &base = mc;
+  int rx = 0, ry = 0, rz = 0, vx = 0, vy = 0, vz = 0;
+  base.getGridResolution(rx, ry, rz);
+  c->vol->getResolution(vx, vy, vz);
+  if (rx != vx || ry != vy || rz != vz || base.getIsoLevel() != 0.f || base.getPercentageExtendGrid() != 0.f) return ~0ull;
   const auto t0 = std::chrono::steady_clock::now();
-  mc.reconstruct(c->mesh);
+  base.reconstruct(c->mesh);
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return (uint64_t)c->mesh.cloud.width * c->mesh.cloud.height;
 }
