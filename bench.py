@@ -134,8 +134,14 @@ def extras(vol, pose, W, H):
         vol.renderView(pose, 1, camera_frame=False)  # warm-up (scratch allocation)
         t0 = time.perf_counter()
         img = vol.renderView(pose, 1, camera_frame=False)
+        dt_pageable = time.perf_counter() - t0
+        # the same into pinned caller memory (tsdf_hip_host_alloc): detected, DMA straight into it, no bounce copy
+        vol.renderView(pose, 1, camera_frame=False, pinned=True)
+        t0 = time.perf_counter()
+        img = vol.renderView(pose, 1, camera_frame=False, pinned=True)
         dt = time.perf_counter() - t0
         out["renderView_ms"] = dt * 1e3
+        out["renderView_ms_pageable_destination"] = dt_pageable * 1e3
         out["renderView_rays_per_s"] = W * H / dt
         out["renderView_hits"] = int(np.isfinite(img[..., 0]).sum())
         out["renderView_mean_steps"] = float(img[..., 7].mean())

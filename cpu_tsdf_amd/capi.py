@@ -87,6 +87,8 @@ SIGNATURES = {
                                     C.POINTER(C.c_int32)]),
     "tsdf_hip_load_multi": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p),
                                      C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta)]),
+    "tsdf_hip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tsdf_hip_host_free": (C.c_int, [C.c_void_p]),
     "tsdf_hip_reset": (C.c_int, [C.c_void_p]),
     "tsdf_hip_destroy": (C.c_int, [C.c_void_p]),
     "tsdf_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -191,3 +193,27 @@ def as_u8p(a):
 
 def f32c(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class PinnedArray:
+    """A numpy array over pinned host memory (tsdf_hip_host_alloc): transfers into / out of it skip the library's
+    bounce buffer.  Keep the object alive as long as `.array` (or views of it) are in use."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(load().tsdf_hip_host_alloc(self.nbytes, C.byref(p)), "host_alloc")
+        self._p = p
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(p.value), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            load().tsdf_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -27,7 +27,9 @@ TSDFVolumeOctree::TSDFVolumeOctree()
       is_empty_(true),
       weight_by_depth_(false),
       weight_by_variance_(false),
-      color_mode_("RGB") {
+      color_mode_("RGB"),
+      view_buf_(nullptr),
+      view_cap_(0) {
   tsdf_hip_default_params(&p_);
   max_cell_size_[0] = max_cell_size_[1] = max_cell_size_[2] = 0.5f;
   global_transform_ = Eigen::Affine3d::Identity();
@@ -35,6 +37,7 @@ TSDFVolumeOctree::TSDFVolumeOctree()
 
 TSDFVolumeOctree::~TSDFVolumeOctree() {
   if (h_) tsdf_hip_destroy(h_);
+  if (view_buf_) tsdf_hip_host_free(view_buf_);
 }
 
 void TSDFVolumeOctree::setResolution(int xres, int yres, int zres) {
@@ -245,8 +248,22 @@ pcl::PointCloud<pcl::PointNormal>::Ptr TSDFVolumeOctree::renderView(const Eigen:
     o3[r] = org(r);
     for (int c = 0; c < 3; ++c) r9[3 * r + c] = rot(r, c);
   }
-  std::vector<float> buf((size_t)new_width * new_height * 8);
-  const int rc = tsdf_hip_raycast(h_, r9, o3, downsampleBy, buf.data());
+  // pinned staging (kept between calls): the library detects it and lets the DMA engine write it directly
+  const size_t need = (size_t)new_width * new_height * 8;
+  if (need > view_cap_) {
+    if (view_buf_) tsdf_hip_host_free(view_buf_);
+    view_buf_ = nullptr;
+    view_cap_ = 0;
+    void *p = nullptr;
+    if (tsdf_hip_host_alloc(need * sizeof(float), &p) == 0) {
+      view_buf_ = static_cast<float *>(p);
+      view_cap_ = need;
+    }
+  }
+  std::vector<float> pageable;  // (only if pinned memory could not be had)
+  if (!view_buf_) pageable.resize(need);
+  const float *buf = view_buf_ ? view_buf_ : pageable.data();
+  const int rc = tsdf_hip_raycast(h_, r9, o3, downsampleBy, const_cast<float *>(buf));
   if (rc) {
     report("renderView", rc);
     const float nan = std::numeric_limits<float>::quiet_NaN();

@@ -83,6 +83,22 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
 
 extern "C" int tsdf_hip_abi_version(void) { return TSDF_HIP_ABI_VERSION; }
 
+// Pinned host memory for callers that have no HIP of their own (the C++ shell, ctypes): buffers handed to the
+// transfer entry points (raycast, sample, march_fetch, download, integrate, ...) from such memory are DMA targets /
+// sources directly.
+extern "C" int tsdf_hip_host_alloc(size_t bytes, void **out) {
+  if (!out || !bytes) return TSDF_HIP_E_INVALID;
+  *out = nullptr;
+  TSDF_HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_host_free(void *p) {
+  if (!p) return TSDF_HIP_OK;
+  TSDF_HIP_TRY(hipHostFree(p));
+  return TSDF_HIP_OK;
+}
+
 extern "C" int tsdf_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -214,8 +230,24 @@ static int bounce_wait(tsdf_hip_volume *v, int slot) {
   return TSDF_HIP_OK;
 }
 
+// Is `p` host memory the runtime already knows as pinned (hipHostMalloc / hipHostRegister / tsdf_hip_host_alloc)?
+// Then the DMA engine can write it directly and the bounce buffer -- one host memcpy per transfer -- is skipped.
+static bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary pageable pointer: not an error
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 int tsdf_to_host(tsdf_hip_volume *v, void *dst, const void *dev_src, size_t bytes) {
   if (!bytes) return TSDF_HIP_OK;
+  if (bytes >= (64u << 10) && is_pinned_host(dst)) {
+    TSDF_HIP_TRY(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, v->stream));
+    TSDF_HIP_TRY(hipStreamSynchronize(v->stream));
+    return TSDF_HIP_OK;
+  }
   int rc = bounce_ready(v);
   if (rc) return rc;
   const size_t chunks = (bytes + kBounceChunk - 1) / kBounceChunk;
@@ -243,6 +275,12 @@ int tsdf_to_host(tsdf_hip_volume *v, void *dst, const void *dev_src, size_t byte
 
 int tsdf_to_device(tsdf_hip_volume *v, void *dev_dst, const void *src, size_t bytes) {
   if (!bytes) return TSDF_HIP_OK;
+  if (bytes >= (64u << 10) && is_pinned_host(src)) {
+    // (the caller may reuse `src` when the call returns, as with the bounce path: wait for the copy)
+    TSDF_HIP_TRY(hipMemcpyAsync(dev_dst, src, bytes, hipMemcpyHostToDevice, v->stream));
+    TSDF_HIP_TRY(hipStreamSynchronize(v->stream));
+    return TSDF_HIP_OK;
+  }
   int rc = bounce_ready(v);
   if (rc) return rc;
   const size_t chunks = (bytes + kBounceChunk - 1) / kBounceChunk;

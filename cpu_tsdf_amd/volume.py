@@ -247,14 +247,22 @@ class TSDFVolumeOctree:
         self._is_empty = False
         return int(c.value) if count else True
 
-    def renderView(self, trans=None, downsampleBy=1, camera_frame=True):
+    def renderView(self, trans=None, downsampleBy=1, camera_frame=True, pinned=False):
         """tsdf_volume_octree.cpp:278-424.  Returns (H/ds, W/ds, 8) float32: xyz, normal, t*, iterations.
-        With camera_frame (the reference's behaviour) xyz/normal are moved back by trans^-1 (:422)."""
+        With camera_frame (the reference's behaviour) xyz/normal are moved back by trans^-1 (:422).
+        pinned: the result is a view of a pinned buffer owned by this volume, which the GPU writes by DMA (no host
+        copy); it is overwritten by the next pinned renderView of the same size."""
         h = self._need()
         trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
         ds = int(downsampleBy)
         nh, nw = self._p.image_height // ds, self._p.image_width // ds
-        out = np.empty((nh, nw, 8), dtype=np.float32)
+        if pinned:
+            cache = self.__dict__.setdefault("_pinned_views", {})
+            if (nh, nw) not in cache:
+                cache[(nh, nw)] = capi.PinnedArray((nh, nw, 8), np.float32)
+            out = cache[(nh, nw)].array
+        else:
+            out = np.empty((nh, nw, 8), dtype=np.float32)
         rot = np.ascontiguousarray(trans[:3, :3].astype(np.float32).reshape(9))
         org = np.ascontiguousarray(trans[:3, 3].astype(np.float32))
         if camera_frame:  # the final transformPointCloudWithNormals(trans^-1) (:422) runs in the kernel

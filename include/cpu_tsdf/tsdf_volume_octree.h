@@ -130,6 +130,10 @@ class TSDFVolumeOctree : public TSDFInterface {
   bool is_empty_, weight_by_depth_, weight_by_variance_;
   std::string color_mode_;
   std::vector<int> devices_;
+  // pinned staging for renderView's readback (tsdf_hip_host_alloc): the GPU writes it by DMA, the conversion into the
+  // returned PointCloud reads it -- no intermediate copy
+  mutable float *view_buf_;
+  mutable size_t view_cap_;
   Eigen::Affine3d global_transform_;
 
  public:

@@ -125,6 +125,14 @@ int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *devices, int n_de
 int tsdf_hip_slab_count(tsdf_handle h);
 int tsdf_hip_slab_info(tsdf_handle h, int k, int32_t *device, int32_t *z_begin, int32_t *z_end, int32_t *halo);
 
+/* Host memory and the boundary.  Every entry point that takes or returns HOST arrays moves them through a pinned
+ * two-slot bounce buffer owned by the handle (one extra host memcpy, the same cost whatever memory the caller hands
+ * over) -- unless the caller's buffer is itself pinned or registered (hipHostMalloc, hipHostRegister, or
+ * tsdf_hip_host_alloc below): that is detected (hipPointerGetAttributes) and the DMA engine reads / writes it
+ * directly.  tsdf_hip_host_alloc gives callers without HIP of their own (the C++ shell, ctypes) such memory. */
+int tsdf_hip_host_alloc(size_t bytes, void **out);
+int tsdf_hip_host_free(void *p);
+
 /* Work is queued on this hipStream_t (default: the null stream). */
 int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream);
 int tsdf_hip_synchronize(tsdf_handle h);
@@ -379,7 +387,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 6
+#define TSDF_HIP_ABI_VERSION 7
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from cpu_tsdf_amd import synth
+from cpu_tsdf_amd import capi, synth
 from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree
 from oracle.oracle import OracleVolume
 from tests.common import assert_same_f32, frames, make_volume
@@ -381,4 +381,31 @@ def test_raycast_and_sampling_on_a_random_volume(gpu):
     assert_same_f32(val[ok], val2[ok], "getFxn")
     assert_same_f32(grad[ok], grad2[ok], "getGradient")
     assert_same_f32(hess[ok], hess2[ok], "getHessian")
+    vol.close()
+
+
+def test_pinned_caller_memory_takes_the_direct_dma_path(gpu):
+    """Host buffers from tsdf_hip_host_alloc are detected (hipPointerGetAttributes) and written by DMA without the
+    bounce buffer: same bytes as the pageable path, for renderView, block download and the mesh."""
+    vol, sc = make_volume(64, color=True)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i, tr, dep, col in frames(sc, 4, 8):
+        vol.integrateCloud(dep, col, tr)
+        ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+    tr = synth.turntable_pose(1, 8, sc.size)
+    a = vol.renderView(tr, 1)
+    b = vol.renderView(tr, 1, pinned=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.isfinite(a[..., 0]).sum() > 100
+    pd = capi.PinnedArray((64, 64, 64), np.float32)
+    pw = capi.PinnedArray((64, 64, 64), np.float32)
+    capi.check(capi.load().tsdf_hip_download(vol._need(), 0, 0, 0, 64, 64, 64, capi.as_f32p(pd.array), capi.as_f32p(pw.array), None),
+               "download into pinned memory")
+    assert np.array_equal(pd.array.view(np.uint32), ov.d.view(np.uint32)) and np.array_equal(pw.array, ov.w)
+    up = capi.PinnedArray((64, 64, 64), np.float32)  # and the other direction: upload FROM pinned memory
+    up.array[:] = ov.d[::-1]
+    capi.check(capi.load().tsdf_hip_upload(vol._need(), 0, 0, 0, 64, 64, 64, capi.as_f32p(up.array), None, None), "upload")
+    assert np.array_equal(vol.download()[0], ov.d[::-1])
+    for x in (pd, pw, up):
+        x.free()
     vol.close()
