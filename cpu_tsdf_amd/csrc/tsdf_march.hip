@@ -42,13 +42,6 @@ struct McArgs {
   int zb;                        // cell planes a classify block marches (<= MC_ZB; zb + 1 planes must span < 4 GB)
 };
 
-// getGridValue (:91-106): NaN if w < w_min or |d| >= 1, else d * max_dist_neg.
-static __device__ __forceinline__ float grid_value(const McArgs &a, int64_t vi) {
-  const float d = a.d[vi], w = tsdf_load_w(a.pv, vi);
-  if (w < a.w_min || fabsf(d) >= 1.f) return NAN;
-  return d * a.neg;
-}
-
 static __device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> every third bit
   v &= 0x1fffffull;
   v = (v | v << 32) & 0x1f00000000ffffull;
@@ -57,20 +50,6 @@ static __device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> 
   v = (v | v << 4) & 0x10c30c30c30c30c3ull;
   v = (v | v << 2) & 0x1249249249249249ull;
   return v;
-}
-
-// Corner order of pcl::MarchingCubes: (0,0,0)(1,0,0)(1,0,1)(0,0,1)(0,1,0)(1,1,0)(1,1,1)(0,1,1)
-static __device__ __forceinline__ bool corner_values(const McArgs &a, int x, int y, int z, float leaf[8]) {
-  const int64_t sy = a.pitch, sz = (int64_t)a.ny * a.pitch;
-  const int64_t o = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
-  const int64_t off[8] = {0, 1, 1 + sz, sz, sy, 1 + sy, 1 + sy + sz, sy + sz};
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    leaf[k] = grid_value(a, o + off[k]);
-    ok = ok && !isnan(leaf[k]);
-  }
-  return ok;
 }
 
 static __device__ __forceinline__ int cube_index(const float leaf[8]) {
@@ -375,87 +354,106 @@ k_mc_counts(const uint64_t *__restrict__ vals, uint32_t *__restrict__ counts, ui
   if (i < n) counts[i] = (uint32_t)(vals[i] >> 60);
 }
 
+// Emit: one thread per active cell (they are all valid: classify tested the eight corner weights).  The eight corner
+// values sit in LDS so that the triangle table can index them dynamically (in registers that costs a select chain per
+// access); every triangle vertex is interpolated on its own edge when it is needed -- a cell uses 3 to 15 of them, the
+// old version computed all twelve edges with twelve IEEE divisions and staged 144 B per thread -- and a triangle
+// leaves as three 12-byte stores + its packed colour + its cell key.  k_mc_expand_rgb turns the per-triangle colours
+// into the r,g,b-per-vertex bytes of the output with coalesced dword stores.
 static __global__ void __launch_bounds__(256)
 k_mc_emit(const McArgs a, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ offsets, uint64_t n_cells,
-          float *__restrict__ verts, unsigned char *__restrict__ rgb_out, uint64_t *__restrict__ cell_out) {
+          float *__restrict__ verts, uint32_t *__restrict__ tri_rgb, uint64_t *__restrict__ cell_out) {
   __shared__ signed char s_tri[256 * 16];
-  __shared__ unsigned short s_edge[256];
+  __shared__ float s_leaf[256 * 9];  // 8 corner values per thread, stride 9: lanes fall on different banks
   for (int i = threadIdx.x; i < 256 * 16; i += blockDim.x) s_tri[i] = mc_tri_table[i >> 4][i & 15];
-  s_edge[threadIdx.x] = mc_edge_table[threadIdx.x];
   __syncthreads();
   const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= n_cells) return;
   const uint64_t v = vals[ci];
   const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
+  // getGridValue (:91-106) of a valid corner: d * max_dist_neg, corners in pcl::MarchingCubes order
+  const int64_t sy = a.pitch, sz = (int64_t)a.ny * a.pitch;
+  const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+  const int64_t off[8] = {0, 1, 1 + sz, sz, sy, 1 + sy, 1 + sy + sz, sy + sz};
   float leaf[8];
-  corner_values(a, x, y, z, leaf);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) leaf[k] = a.d[vi + off[k]] * a.neg;
   const int cubeindex = cube_index(leaf);
+  float *mine = s_leaf + threadIdx.x * 9;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mine[k] = leaf[k];
   // createSurface [PCL-recall]: centre = lower_boundary_ + size_voxel_ * index; corner k adds size_voxel_
   // in y if k&4, in z if k&2, in x if (k&1)^((k>>1)&1)
   const int idx[3] = {x, y, z};
-  float center[3];
+  float center[3], far_[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) center[k] = a.lower[k] + a.size_voxel[k] * (float)idx[k];
-  float pc[8][3];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    pc[k][0] = ((k & 1) ^ ((k >> 1) & 1)) ? center[0] + a.size_voxel[0] : center[0];
-    pc[k][1] = (k & 4) ? center[1] + a.size_voxel[1] : center[1];
-    pc[k][2] = (k & 2) ? center[2] + a.size_voxel[2] : center[2];
+  for (int k = 0; k < 3; ++k) {
+    center[k] = a.lower[k] + a.size_voxel[k] * (float)idx[k];
+    far_[k] = center[k] + a.size_voxel[k];
   }
-  const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
-  float vl[12][3];
-  const unsigned edges = s_edge[cubeindex];
-#pragma unroll
-  for (int e = 0; e < 12; ++e) {
-    // interpolateEdge: mu = (iso - v1) / (v2 - v1); out = p1 + mu * (p2 - p1)
-    const float mu = (0.f - leaf[ea[e]]) / (leaf[eb[e]] - leaf[ea[e]]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vl[e][k] = pc[ea[e]][k] + mu * (pc[eb[e]][k] - pc[ea[e]][k]);
-  }
-  (void)edges;  // unused edges produce garbage that no triangle references
-  unsigned char col[3] = {0, 0, 0};
-  const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+  uint32_t col = 0u;  // r | g << 8 | b << 16
   if (a.color_mode == 2) {  // :217-224 colour by confidence, evaluated in double like the reference
     const float std_dev = (float)((100. - (double)tsdf_load_w(a.pv, vi)) / 100.);
     const double r = (double)(1 - std_dev) * 255., b = (double)std_dev * 255.;
     const double rmin = (255. < r) ? 255. : r, bmin = (255. < b) ? 255. : b;  // std::min(x, 255.)
-    col[0] = (unsigned char)((0. < rmin) ? rmin : 0.);                        // std::max(0., x)
-    col[2] = (unsigned char)((0. < bmin) ? bmin : 0.);
+    col = (uint32_t)(unsigned char)((0. < rmin) ? rmin : 0.) |                 // std::max(0., x)
+          ((uint32_t)(unsigned char)((0. < bmin) ? bmin : 0.) << 16);
   } else if (a.color_mode == 1 && a.pv.rgb) {  // :226-231
-    const uint32_t c = tsdf_load_rgb(a.pv, vi);
-    col[0] = (unsigned char)(c & 255u);
-    col[1] = (unsigned char)((c >> 8) & 255u);
-    col[2] = (unsigned char)((c >> 16) & 255u);
+    col = tsdf_load_rgb(a.pv, vi);
   }
   uint64_t t = offsets[ci];
   const signed char *tri = s_tri + cubeindex * 16;
+  const uint64_t key = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+  struct __attribute__((packed, aligned(4))) F3 {
+    float x, y, z;
+  };
+  // edge e joins corners ea[e], eb[e]: {0,1,2,3,4,5,6,7,0,1,2,3} / {1,2,3,0,5,6,7,4,4,5,6,7}, packed 4 bits each
+  const uint64_t EA = 0x321076543210ull, EB = 0x765447650321ull;
   for (int i = 0; tri[i] != -1; i += 3, ++t) {
 #pragma unroll
     for (int vtx = 0; vtx < 3; ++vtx) {
-      const int e = tri[i + vtx];
-      float *o = verts + 9 * t + 3 * vtx;
-      // select the edge vertex without dynamic register indexing
-      float vx = 0, vy = 0, vz = 0;
-#pragma unroll
-      for (int q = 0; q < 12; ++q)
-        if (q == e) {
-          vx = vl[q][0];
-          vy = vl[q][1];
-          vz = vl[q][2];
-        }
-      o[0] = vx;
-      o[1] = vy;
-      o[2] = vz;
-      if (rgb_out) {
-        unsigned char *c = rgb_out + 9 * t + 3 * vtx;
-        c[0] = col[0];
-        c[1] = col[1];
-        c[2] = col[2];
+      const int e = (int)tri[i + vtx];
+      const int ka = (int)((EA >> (4 * e)) & 15u), kb = (int)((EB >> (4 * e)) & 15u);
+      const float va = mine[ka], vb = mine[kb];
+      // interpolateEdge: mu = (iso - v1) / (v2 - v1); out = p1 + mu * (p2 - p1)
+      const float mu = (0.f - va) / (vb - va);
+      F3 p;
+      {
+        const float pa = ((ka & 1) ^ ((ka >> 1) & 1)) ? far_[0] : center[0], pb = ((kb & 1) ^ ((kb >> 1) & 1)) ? far_[0] : center[0];
+        p.x = pa + mu * (pb - pa);
       }
+      {
+        const float pa = (ka & 4) ? far_[1] : center[1], pb = (kb & 4) ? far_[1] : center[1];
+        p.y = pa + mu * (pb - pa);
+      }
+      {
+        const float pa = (ka & 2) ? far_[2] : center[2], pb = (kb & 2) ? far_[2] : center[2];
+        p.z = pa + mu * (pb - pa);
+      }
+      *reinterpret_cast<F3 *>(verts + 9 * t + 3 * vtx) = p;
     }
-    if (cell_out) cell_out[t] = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+    if (tri_rgb) tri_rgb[t] = col;
+    if (cell_out) cell_out[t] = key;
   }
+}
+
+// rgb_out[9 t + 3 v + c] = channel c of triangle t's colour (all three vertices of a triangle take the base voxel's
+// colour, :208-233): one thread per output dword.
+static __global__ void __launch_bounds__(256)
+k_mc_expand_rgb(const uint32_t *__restrict__ tri_rgb, uint32_t *__restrict__ rgb_out, uint64_t n_bytes) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * w >= n_bytes) return;
+  uint32_t out = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t b = 4 * w + k;
+    if (b < n_bytes) {
+      const uint64_t t = b / 9u;
+      const unsigned c = (unsigned)(b - 9u * t) % 3u;
+      out |= ((tri_rgb[t] >> (8u * c)) & 255u) << (8 * k);
+    }
+  }
+  rgb_out[w] = out;
 }
 
 static float host_voxel_center(const tsdf_params &p, int a, int i) {  // tsdf_volume_octree.cpp:553-560
@@ -581,8 +579,8 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
                                        rocprim::plus<uint32_t>(), h->stream));
   const size_t al = 256;
   auto up = [&](size_t v) { return (v + al - 1) / al * al; };
-  const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4);
-  const size_t total = 2 * b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan));
+  const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4), b_trgb = color_mode ? up(ntri * 4) : 0;
+  const size_t total = 2 * b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan)) + b_trgb;
   int rc = tsdf_ensure_scratch(h, total);
   if (rc) return rc;
   char *sp = (char *)h->scratch;
@@ -591,6 +589,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   cnt = (uint32_t *)(sp + 2 * b_keys);
   off = (uint32_t *)(sp + 2 * b_keys + b_cnt);
   void *tmp = sp + 2 * b_keys + 2 * b_cnt;
+  uint32_t *tri_rgb = color_mode ? (uint32_t *)(sp + total - b_trgb) : nullptr;
   TSDF_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
                                          (size_t)n_cells, 0, key_bits, h->stream));
   const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
@@ -616,9 +615,15 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     h->mc_cap = cap;
   }
   TSDF_HIP_TRY(hipEventRecord(h->mc_ev[2], h->stream));
-  hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts,
-                     color_mode ? h->mc_rgb : nullptr, h->mc_cell);
+  hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts, tri_rgb,
+                     h->mc_cell);
   TSDF_HIP_TRY(hipGetLastError());
+  if (color_mode) {
+    const uint64_t n_bytes = 9ull * ntri;  // (the buffer holds mc_cap * 9 >= n_bytes + 3 bytes: whole dwords fit)
+    hipLaunchKernelGGL(k_mc_expand_rgb, dim3((unsigned)((n_bytes / 4 + 256) / 256)), dim3(256), 0, h->stream, tri_rgb,
+                       (uint32_t *)h->mc_rgb, n_bytes);
+    TSDF_HIP_TRY(hipGetLastError());
+  }
   TSDF_HIP_TRY(hipEventRecord(h->mc_ev[3], h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   (void)hipEventElapsedTime(&h->mc_ms[1], h->mc_ev[1], h->mc_ev[2]);  // count read-back, sort, scan (+ buffer growth)
