@@ -32,3 +32,20 @@ static __device__ __forceinline__ uint32_t bload8(rsrc_t r, unsigned voff, unsig
 static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsigned soff, u4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
+
+// Structured (2-D) buffer access: the descriptor carries a row stride and a row count, the instruction a row index
+// and a byte offset inside the row (`buffer_load_dword ... idxen offen`).  Clang has no builtin for the struct form;
+// the LLVM intrinsic is reached through its name (the <4 x i32> descriptor flavour).
+typedef int i4_rsrc __attribute__((ext_vector_type(4)));
+__device__ unsigned tsdf_struct_buffer_load_u32(i4_rsrc rsrc, int vindex, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.struct.buffer.load.i32");
+
+static __device__ __forceinline__ i4_rsrc make_rsrc_2d(const void *p, unsigned row_bytes, unsigned rows) {
+  const unsigned long long a = (unsigned long long)p;
+  i4_rsrc r;
+  r.x = (int)(a & 0xffffffffull);
+  r.y = (int)(((a >> 32) & 0xffffull) | ((unsigned long long)(row_bytes & 0x3fffu) << 16));  // STRIDE: 14 bits
+  r.z = (int)rows;        // NUM_RECORDS counts rows when STRIDE != 0
+  r.w = 0x00020000;       // DATA_FORMAT = 32, everything else off (no swizzle, no add-tid)
+  return r;
+}

@@ -1331,6 +1331,37 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
   return TSDF_HIP_OK;
 }
 
+// Test hook: what the hardware returns for structured buffer loads at (u, v) inside and outside a W x H float image
+// (row index v, byte offset 4 u): the frame gather relies on out-of-range rows AND columns reading 0.
+static __global__ void k_selftest_struct_oob(const float *img, int W, int H, unsigned soff, const int *uv, unsigned *out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const i4_rsrc r = make_rsrc_2d(img, (unsigned)W * 4u, (unsigned)H);
+  out[i] = tsdf_struct_buffer_load_u32(r, uv[2 * i + 1], uv[2 * i] * 4, (int)soff, 0);
+}
+
+extern "C" int tsdf_hip_selftest_struct_oob(const float *img, int W, int H, int planes, int plane, const int32_t *uv, uint32_t *out,
+                                            int n) {
+  if (!img || !uv || !out || n <= 0 || W <= 0 || H <= 0 || planes < 1 || plane < 0 || plane >= planes) return TSDF_HIP_E_INVALID;
+  float *d_img = nullptr;
+  int *d_uv = nullptr;
+  unsigned *d_out = nullptr;
+  const size_t npx = (size_t)W * H;
+  TSDF_HIP_TRY(hipMalloc(&d_img, npx * 4 * planes));
+  TSDF_HIP_TRY(hipMalloc(&d_uv, (size_t)n * 8));
+  TSDF_HIP_TRY(hipMalloc(&d_out, (size_t)n * 4));
+  TSDF_HIP_TRY(hipMemcpy(d_img, img, npx * 4 * planes, hipMemcpyHostToDevice));
+  TSDF_HIP_TRY(hipMemcpy(d_uv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_struct_oob, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_img, W, H,
+                     (unsigned)(npx * 4 * plane), d_uv, d_out, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_img);
+  (void)hipFree(d_uv);
+  (void)hipFree(d_out);
+  return TSDF_HIP_OK;
+}
+
 // Test hook: the kernel's pixel projection (certified fp32 path and exact fp64 path) on arbitrary
 // camera-frame points g (n x 3), with this volume's intrinsics and image size.
 static __global__ void k_selftest_project(const IntegrateArgs a, const double *cam, const float *g, size_t n, int *pix_fast,

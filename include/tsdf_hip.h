@@ -359,6 +359,11 @@ int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, siz
 int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
                               int32_t *pix_exact, uint8_t *ambiguous);
 
+/* Test hook: structured buffer loads (row index v, byte offset 4 u, descriptor of H rows of W floats, image `plane` of
+ * `planes` back-to-back images selected by the scalar offset) at n (u, v) pairs, inside and outside the image: the
+ * integrate kernel's frame gather relies on what the hardware returns out of range. */
+int tsdf_hip_selftest_struct_oob(const float *img, int W, int H, int planes, int plane, const int32_t *uv, uint32_t *out, int n);
+
 /* Test hook: the voxel Octree::getContainingVoxel (src/lib/octree.cpp:112-133,628-643) returns for n points,
  * as the raycast kernel computes it: idx = i, j, k per point, or -1, -1, -1 where the reference returns NULL. */
 int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx);
