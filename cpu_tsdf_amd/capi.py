@@ -105,6 +105,7 @@ SIGNATURES = {
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
+    "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
     "tsdf_hip_selftest_struct_oob": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
     "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),

@@ -33,6 +33,7 @@ struct IntegrateArgs {
   unsigned kmax;             // PACKED layout: saturation count ceil(max_weight)
   int wmax_is_int;           // PACKED layout: max_weight is an integer (then every stored weight is)
   float zmin, zmax;   // min/max_sensor_dist_
+  float zlo;          // gz > zlo  <=>  !(gz < zmin) && gz > 0  (see make_args)
   float pos, neg;     // max_dist_pos_/neg_
   float wmax;         // max_weight_
   float pos_over_neg; // max_dist_pos_ / max_dist_neg_ (IEEE fp32, host)
@@ -169,8 +170,14 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 // K8 (no colour); w = min(k, max_weight), k' = min(k + 1, kmax); a thread then moves 8 (5) bytes per voxel
 // each way instead of 12 (8), and 1/(k+1) comes from a 256-entry LDS table of refined reciprocals.
 // COUNT = accumulate the observed-voxel counter.
+#ifndef TSDF_GUARD_ON_RESULT
+#define TSDF_GUARD_ON_RESULT 1  // PACKED update: guard the divider on its result (v_cmp_class) instead of on its numerator
+#endif
+#ifndef TSDF_WPE_PACKED
+#define TSDF_WPE_PACKED 6  // waves per SIMD the PACKED / colourless instances ask for (80 VGPRs: 7 waves = 72 VGPRs spills since the result-side guard)
+#endif
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED || !COLOR) ? 7 : 6, 8)))
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6, 8)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
@@ -239,7 +246,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
-        const bool in = !(gz < a.zmin || gz > a.zmax) && gz > 0.f;
+        // hpp:146 + .cpp:616: !(gz < zmin || gz > zmax) && gz > 0, as two compares: zlo is the largest float every
+        // accepted gz exceeds (the float below zmin when zmin > 0, else 0; a NaN gz fails, as there)
+        const bool in = gz > a.zlo && !(gz > a.zmax);
         gzs[j] = gz;
         lowz |= in && gz < 0x1p-14f;
         int p;
@@ -342,11 +351,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       if (!PACKED) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) safe &= !act[j] || update_is_safe(d0[j], w0[j], dn[j]);
-      } else {
+      }
+#if !TSDF_GUARD_ON_RESULT
+      else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && numerator_ok(d0[j] * w0[j] + dn[j]));
       }
+#endif
       if (safe) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -362,8 +374,18 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rcp32_prepare(w0[j] + 1.f));
           }
         }
+#if TSDF_GUARD_ON_RESULT
+        if (PACKED) {
+          // the guard, on the RESULT (one v_cmp_class per voxel): a normal quotient is the correctly rounded one
+          // (tests/test_div_gpu.py::test_count_divider_*); zero, subnormal, infinite or NaN -- or a weight sitting
+          // at a non-integer max_weight, whose divisor is no count -- sends the quad through the IEEE path below
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && __builtin_amdgcn_classf(dv[j], 0x108));
+        }
+#endif
       }
-      else {
+      if (!safe) {
         asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -525,6 +547,9 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
     a.hb_v = nextafterf(0.5f - hh.band_v, 0.f);
   }
   a.zmin = p.min_sensor_dist;
+  // !(gz < zmin) && gz > 0 for a non-NaN gz: gz >= zmin when zmin > 0 (<=> gz > the float just below zmin), else gz > 0
+  // (zmin <= 0, or NaN: `gz < NaN` never rejects)
+  a.zlo = p.min_sensor_dist > 0.f ? nextafterf(p.min_sensor_dist, -INFINITY) : 0.f;
   a.zmax = p.max_sensor_dist;
   a.pos = p.max_dist_pos;
   a.neg = p.max_dist_neg;
@@ -1328,6 +1353,43 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
   const uint64_t bytes_per_quad = 16u + (h->w ? 16u : 0u) + (h->rgb ? 16u : 0u) + (h->k8 ? 4u : 0u);
   if (bytes_read) *bytes_read = bytes_per_quad * (uint64_t)n4;
   if (bytes_written) *bytes_written = bytes_per_quad * (uint64_t)n4;
+  return TSDF_HIP_OK;
+}
+
+// Test hook: the PACKED update's divider -- numerator a over an integer count k in [1, 256] through the refined
+// table reciprocal and the scale-free ladder, accepted when the RESULT is a normal number, else IEEE division.
+static __global__ void k_selftest_div_count(const float *a, const uint32_t *k, float *out, unsigned char *fast, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float b = (float)k[i];
+  Rcp32 rs;
+  rs.nb = -b;
+  rs.y = rcp32_prepare(b).y;  // what s_rcp[k - 1] holds
+  const float q = div32_fast(a[i], rs);
+  const bool ok = __builtin_amdgcn_classf(q, 0x108);
+  fast[i] = ok ? 1 : 0;
+  out[i] = ok ? q : a[i] / b;
+}
+
+extern "C" int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, uint8_t *fast, size_t n) {
+  if (!a || !k || !out || !fast || !n) return TSDF_HIP_E_INVALID;
+  float *da = nullptr, *dout = nullptr;
+  uint32_t *dk = nullptr;
+  unsigned char *df = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&da, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&dk, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&dout, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&df, n));
+  TSDF_HIP_TRY(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+  TSDF_HIP_TRY(hipMemcpy(dk, k, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_div_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, dk, dout, df, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  TSDF_HIP_TRY(hipMemcpy(fast, df, n, hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(dk);
+  (void)hipFree(dout);
+  (void)hipFree(df);
   return TSDF_HIP_OK;
 }
 

@@ -352,6 +352,10 @@ int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
 int tsdf_hip_selftest_div_f32(const float *a, const float *b, float *out, size_t n);
 int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, size_t n);
 
+/* Test hook: the PACKED layout's weighted-mean divider, out[i] = a[i] / k[i] for integer counts k in [1, 256]: the table
+ * reciprocal + scale-free ladder where its result is a normal number (fast[i] = 1), IEEE division elsewhere. */
+int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, uint8_t *fast, size_t n);
+
 /* Test hook: the integrate kernel's pixel projection (reprojectPoint, tsdf_volume_octree.cpp:611-617) on
  * n arbitrary camera-frame points g (x,y,z triples, z > 0) with this volume's intrinsics: pix_fast =
  * certified-fp32 path with exact fallback (what the kernel uses), pix_exact = fp64 path, both v*W+u or

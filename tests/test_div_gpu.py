@@ -137,3 +137,36 @@ def test_certified_fp32_projection_matches_double(gpu, W, H):
     assert 0.0 < frac < 0.55  # boundary-engineered points (half of them) are flagged, random ones almost never
     rnd = amb[2 * k + 8:]
     assert rnd.mean() < 0.01
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_count_divider_equals_ieee_division(gpu, seed):
+    """The PACKED layout's weighted-mean divider: numerator / integer count k in [1, 256] through the table
+    reciprocal and the scale-free ladder, guarded on the RESULT -- a normal quotient stands, anything else (zero,
+    subnormal, overflow, NaN) is redone with IEEE division.  Numerators from every binade, every k, plus the corners
+    where the ladder could go wrong if the claim were false (quotients around the smallest normal, the largest finite
+    numerator, exact multiples and their neighbours)."""
+    rng = np.random.RandomState(seed)
+    n = 1 << 22
+    k = rng.randint(1, 257, n).astype(np.uint32)
+    a = (rng.uniform(1.0, 2.0, n) * np.exp2(rng.randint(-149, 128, n).astype(np.float64)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    m = n // 8
+    a[:m] = rng.randint(0, 1 << 20, m).astype(np.float32) * k[:m]                          # exact quotients
+    a[m:2 * m] = np.nextafter((rng.randint(1, 1 << 20, m).astype(np.float32) * k[m:2 * m]).astype(np.float32),
+                              np.float32(np.inf) * rng.choice([-1.0, 1.0], m).astype(np.float32))  # their neighbours
+    tiny = np.float32(2.0 ** -126)
+    a[2 * m:3 * m] = (tiny * k[2 * m:3 * m] * rng.uniform(0.5, 2.0, m)).astype(np.float32)  # quotients around the smallest normal
+    a[3 * m:3 * m + 6] = [0.0, -0.0, np.inf, -np.inf, np.nan, np.finfo(np.float32).max]
+    # the typical case: d * w + dn with d in [-1, 1], w = k - 1, dn in [-1, 1]
+    a[4 * m:5 * m] = (rng.uniform(-1, 1, m).astype(np.float32) * (k[4 * m:5 * m] - 1).astype(np.float32) +
+                      rng.uniform(-1, 1, m).astype(np.float32)).astype(np.float32)
+    out = np.empty(n, np.float32)
+    fast = np.empty(n, np.uint8)
+    capi.check(capi.load().tsdf_hip_selftest_div_count(capi.as_f32p(a), k.ctypes.data_as(C.POINTER(C.c_uint32)), capi.as_f32p(out),
+                                                       capi.as_u8p(fast), n), "selftest_div_count")
+    with np.errstate(all="ignore"):
+        want = a / k.astype(np.float32)
+    same = (out.view(np.uint32) == want.view(np.uint32)) | (np.isnan(out) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), a[~same][:5], k[~same][:5], out[~same][:5], want[~same][:5])
+    assert fast[4 * m:5 * m].mean() > 0.999          # the kernel's own numerators take the ladder
+    assert fast[np.abs(want) < tiny].sum() == 0       # subnormal and zero quotients never do

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+for round in 1 2 3; do
+for v in g0w7 g1w6 g1w5; do
+export TSDF_HIP_LIB_PATH=$PWD/cpu_tsdf_amd/lib/variants/$v/libtsdf_hip.so
+timeout 300 python bench.py --steps 20 --warmup 3 --cpu-baseline 0 --extras 0 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v kernel_ms', round(j['roofline']['kernel_ms'],3))"
+done; done
