@@ -173,6 +173,9 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #ifndef TSDF_GUARD_ON_RESULT
 #define TSDF_GUARD_ON_RESULT 1  // PACKED update: guard the divider on its result (v_cmp_class) instead of on its numerator
 #endif
+#ifndef TSDF_EARLY_VOXEL_LOADS
+#define TSDF_EARLY_VOXEL_LOADS 0
+#endif
 #ifndef TSDF_WPE_PACKED
 #define TSDF_WPE_PACKED 6  // waves per SIMD the PACKED / colourless instances ask for (80 VGPRs: 7 waves = 72 VGPRs spills since the result-side guard)
 #endif
@@ -278,6 +281,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (j == 2) pix[2] = p;
         if (j == 3) pix[3] = p;
       }
+#if TSDF_EARLY_VOXEL_LOADS
+      // the voxel words of the quad are requested TOGETHER with the frame gather instead of after its result: one
+      // memory latency per row instead of two in a row, at the price of reading the planes for quads none of whose
+      // voxels turns out to be observed (behind the surface, no return)
+      const u4 d4 = bload128(rsD, voff, soff);
+      u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
+      uint32_t k4 = 0u;
+      if (!PACKED) w4 = bload128(rsW, voff, soff);
+      if (COLOR) c4 = bload128(rsC, voff, soff);
+      if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+#endif
       // ---- gather the frame (L2-resident); pixel -1 is out of the descriptor's range and reads 0 ----------
       float zs[4];
       uint32_t cs[4] = {0u, 0u, 0u, 0u};
@@ -319,12 +333,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (act[j] && !(raw[j] > a.pos)) dn[j] = raw[j] / a.neg;
       }
       // ---- read-modify-write -----------------------------------------------------------------------------
+#if !TSDF_EARLY_VOXEL_LOADS
       const u4 d4 = bload128(rsD, voff, soff);
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
       if (!PACKED) w4 = bload128(rsW, voff, soff);
       if (COLOR) c4 = bload128(rsC, voff, soff);
       if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+#endif
       const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       const uint32_t w0u[4] = {w4.x, w4.y, w4.z, w4.w};
