@@ -1,4 +1,4 @@
-"""GPU tier: BASELINE.json's configs[0..2] at their stated sizes, run by the driver ("Next round" #2).
+"""GPU tier: BASELINE.json's configs[0..3] at their stated sizes, run by the driver ("Next round" #2).
 
 configs[0]  256^3, ONE 640x480 frame: the HIP path against the REFERENCE's own code (oracle/_ref, dense mode)
             directly -- every voxel, renderView, the mesh.  No C oracle in between.
@@ -6,6 +6,7 @@ configs[1]  512^3, 105 distinct noisy 640x480 frames (the weight saturates at ma
             sampled plane groups against the C oracle at frames 50 / 100 / 101 / 105.
 configs[2]  1024^3, 300 frames with a renderView every 25: sampled plane groups against the C oracle, and the
             renderView of frames 150 and 300 against the oracle's raycast run on the SAME (downloaded) grid.
+configs[3]  2048^3 with colour, 104 frames through saturation, sampled planes against the C oracle, then the mesh.
 Reference lines: include/cpu_tsdf/impl/tsdf_volume_octree.hpp:113-218, src/lib/octree.cpp:152-163 (saturation),
 src/lib/tsdf_volume_octree.cpp:278-424 (renderView)."""
 import os
@@ -127,3 +128,44 @@ def test_config2_1024_cubed_300_frames_with_renderview(gpu):
     groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 150, res - 148)]
     wmax, views = run_sequence(res, 300, False, groups, check_at={150, 300}, render_every=25, render_check_at={150, 300})
     assert wmax == 100.0 and views == 12
+
+
+def test_config3_2048_cubed_colour_through_weight_saturation_then_mesh(gpu):
+    """configs[3] at its stated size, shortened to the part that matters for parity: 2048^3 with colour, 104 distinct
+    noisy frames -- past max_weight = 100, so the last frames run in the saturated regime the 1000-frame job spends
+    90 % of its time in -- sampled plane groups against the C oracle at frames 50 / 100 / 104, then
+    MarchingCubesTSDFOctree::reconstruct of the whole grid (tens of millions of triangles on the analytic surfaces).
+    The full 1000-frame run is profiles/r02_long_run_2048_1000frames_pipelined.json (same checks at 250/500/750/1000)."""
+    if torch.cuda.mem_get_info()[0] / 2 ** 30 < 80:
+        pytest.skip("needs ~70 GB of free HBM")
+    res = 2048
+    groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 300, res - 298)]
+    v, sc = product(res, True)
+    oracles = [SlabOracle(v._p, a, b) for a, b in groups]
+    n_frames = 104
+    for i in range(n_frames):
+        tr = synth.turntable_pose(i, n_frames, sc.size, tilt=0.15 * np.sin(i * 0.05))
+        dep, col = sc.depth(tr, noise_seed=12345 + i), sc.bgra(i)
+        v.integrateCloud(dep, col, tr, pipelined=True)  # the host entry point a sequence would use
+        T = synth.cam_from_vol_f32(tr)
+        for o in oracles:
+            o.integrate(dep, col, T)
+        if i + 1 in (50, 100, 104):
+            for (a, b), o in zip(groups, oracles):
+                d, w, rgb = v.download(z0=a, nz=b - a)
+                assert_same_f32(d, o.d, f"d planes {a}:{b} after frame {i + 1}")
+                assert np.array_equal(w, o.w) and np.array_equal(rgb, o.rgb), f"w / rgb planes {a}:{b} after frame {i + 1}"
+    assert max(float(o.w.max()) for o in oracles) == 100.0
+    assert np.mean([float((o.w == 100.0).mean()) for o in oracles[:2]]) > 0.3
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(v)
+    mc.setMinWeight(2.0)
+    mc.setColorByRGB(True)
+    mesh = mc.reconstruct()
+    vert = mesh["vertices"]
+    assert len(vert) > 3 * 10 ** 7 and mesh["rgb"].shape == vert.shape
+    r = np.linalg.norm(vert[::97].astype(np.float64), axis=1)
+    box = np.abs(np.abs(vert[::97]).max(1) - sc.h)
+    resid = np.minimum(np.abs(r - sc.r), box)
+    assert np.median(resid) < 0.03 and np.quantile(resid, 0.99) < 0.25, (np.median(resid), np.quantile(resid, 0.99))
+    v.close()
