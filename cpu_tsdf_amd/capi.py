@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("TSDF_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "li
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_IO = range(7)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
 LAYOUT_AUTO, LAYOUT_F32W, LAYOUT_PACKED = 0, 1, 2
-COLOR_RGB, COLOR_RGB_NORMALIZED = 0, 1
+COLOR_RGB, COLOR_RGB_NORMALIZED, COLOR_LAB = 0, 1, 2
 
 
 class TsdfParams(C.Structure):
@@ -106,6 +106,8 @@ SIGNATURES = {
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
     "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
+    "tsdf_hip_selftest_rgb2lab": (C.c_int, [_u8p, C.c_size_t, _f32p]),
+    "tsdf_hip_selftest_lab2rgb": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "tsdf_hip_selftest_struct_oob": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
     "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),
@@ -120,6 +122,7 @@ SIGNATURES = {
     "tsdf_hip_march_fetch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsdf_hip_download": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
     "tsdf_hip_upload": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, _f32p, _u8p]),
+    "tsdf_hip_download_color_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]),
     "tsdf_hip_get_planes_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsdf_hip_set_planes_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsdf_hip_device_planes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -102,8 +102,9 @@ void TSDFVolumeOctree::setColorMode(const std::string &color_mode) {
     p_.color_mode = TSDF_COLOR_RGB;
   } else if (color_mode == "RGBNormalized") {
     p_.color_mode = TSDF_COLOR_RGB_NORMALIZED;
-  } else {
-    // "LAB" goes through std::pow (octree.cpp:437-560), whose last bit belongs to the host's libm
+  } else if (color_mode == "LAB") {
+    p_.color_mode = TSDF_COLOR_LAB;
+  } else {  // octree.cpp:203-205 prints and returns NULL, which reset() would then dereference
     PCL_WARN("[cpu_tsdf::TSDFVolumeOctree::setColorMode] \"%s\" voxels do not exist in the HIP volume; keeping %s\n",
              color_mode.c_str(), color_mode_.c_str());
     return;

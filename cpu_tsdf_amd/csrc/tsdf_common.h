@@ -32,7 +32,11 @@ struct tsdf_hip_volume {
   uint8_t *k8 = nullptr;
   // TSDF_COLOR_RGB_NORMALIZED: running means r/i, g/i, b/i, i (RGBNormalized, octree.cpp:380-402); the rgb
   // plane then caches getRGB() of that state for every reader (queries, marching cubes, downloads)
+  // TSDF_COLOR_LAB: cn[0..2] are the L, A, B means (LABNode, octree.cpp:531-551); lab_lut is the sRGB curve of
+  // RGB2LAB tabulated by the host's libm, lab_img the frame's pixels converted once per frame (k_lab_image)
   float *cn[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *lab_lut = nullptr;
+  float4 *lab_img = nullptr;
   int packed = 0;
   unsigned kmax = 0;
   // hpp:200-204: weightings only a loaded .vol can switch on (tsdf_hip_set_weighting).  weight_by_depth integrates
@@ -142,6 +146,20 @@ void tsdf_build_centers(int res, float size, std::vector<float> &out, int *level
 // and integrateCloud updates THOSE leaves (pinned against the compiled reference, tests/test_oracle_golden.py).
 // Grids without an octree equivalent (not a power of two on every axis, or not cubic in resolution) use the axis' own
 // size with the closed-form centres.
+// RGB2LAB's per-channel prefix (octree.cpp:441-458): float(v)/255., the sRGB curve through std::pow, times 100.
+// A function of one byte, so the host's own libm tabulates it -- the same libm the reference would call here.
+static inline void tsdf_lab_curve(float lut[256]) {
+  for (int v = 0; v < 256; ++v) {
+    float f = ((float)v / 255.);
+    if (f > 0.0405)
+      f = std::pow(((f + 0.055) / 1.055), 2.4);
+    else
+      f /= 12.92;
+    f *= 100;
+    lut[v] = f;
+  }
+}
+
 static inline float tsdf_node_size(const tsdf_params &p, int axis) {
   const int r = p.res[0];
   const bool cubic_pow2 = r > 0 && (r & (r - 1)) == 0 && p.res[1] == r && p.res[2] == r;

@@ -309,6 +309,8 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->k8) (void)hipFree(v->k8);
   for (int c = 0; c < 4; ++c)
     if (v->cn[c]) (void)hipFree(v->cn[c]);
+  if (v->lab_lut) (void)hipFree(v->lab_lut);
+  if (v->lab_img) (void)hipFree(v->lab_img);
   for (int a = 0; a < 3; ++a)
     if (v->ctr[a]) (void)hipFree(v->ctr[a]);
   if (v->frame_depth) (void)hipFree(v->frame_depth);
@@ -340,13 +342,14 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (p->image_width <= 0 || p->image_height <= 0 || !(p->max_dist_neg > 0.f) || p->halo < 0 ||
       (p->xform_order != TSDF_XFORM_PCL_SSE && p->xform_order != TSDF_XFORM_LEFT_TO_RIGHT) ||
       p->layout < TSDF_LAYOUT_AUTO || p->layout > TSDF_LAYOUT_PACKED ||
-      (p->color_mode != TSDF_COLOR_RGB && p->color_mode != TSDF_COLOR_RGB_NORMALIZED)) {
+      p->color_mode < TSDF_COLOR_RGB || p->color_mode > TSDF_COLOR_LAB) {
     tsdf_set_error("bad image size / truncation / halo / xform_order / layout / color_mode");
     return TSDF_HIP_E_INVALID;
   }
-  const bool rgbn = p->integrate_color && p->color_mode == TSDF_COLOR_RGB_NORMALIZED;
+  const bool lab = p->integrate_color && p->color_mode == TSDF_COLOR_LAB;
+  const bool rgbn = (p->integrate_color && p->color_mode == TSDF_COLOR_RGB_NORMALIZED) || lab;  // float colour state
   if (rgbn && p->layout == TSDF_LAYOUT_PACKED) {
-    tsdf_set_error("RGB_NORMALIZED colour keeps float weights: no PACKED layout");
+    tsdf_set_error("RGB_NORMALIZED / LAB colour keeps float weights: no PACKED layout");
     return TSDF_HIP_E_UNSUPPORTED;
   }
   const bool packable = !rgbn && p->max_weight >= 0.f && p->max_weight <= 255.f;  // false for NaN
@@ -402,7 +405,14 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
   if (v->packed && !p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->k8, n));
   if (rgbn)
-    for (int c = 0; c < 4; ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
+    for (int c = 0; c < (lab ? 3 : 4); ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
+  if (lab) {
+    float lut[256];
+    tsdf_lab_curve(lut);
+    TRY_OR_BAIL(hipMalloc(&v->lab_lut, sizeof lut));
+    TRY_OR_BAIL(hipMemcpy(v->lab_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMalloc(&v->lab_img, (size_t)p->image_width * p->image_height * sizeof(float4)));
+  }
   for (int a = 0; a < 3; ++a) {
     tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v->h_ctr[a], &v->levels[a]);
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
@@ -598,7 +608,7 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
     return TSDF_HIP_E_INVALID;
   }
   if (!DOWN && rgb && h->cn[0]) {
-    tsdf_set_error("RGB_NORMALIZED colour state cannot be set from r,g,b bytes");
+    tsdf_set_error("RGB_NORMALIZED / LAB colour state cannot be set from r,g,b bytes");
     return TSDF_HIP_E_UNSUPPORTED;
   }
   TSDF_ON_DEVICE(h->device);
@@ -669,6 +679,34 @@ extern "C" int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, 
                                  float *w, uint8_t *rgb) {
   if (h && h->multi) return tsdf_multi_block(h, true, x0, y0, z0, nx, ny, nz, d, w, rgb);
   return block_transfer<true>(h, x0, y0, z0, nx, ny, nz, d, w, rgb);
+}
+
+// The float colour state of RGB_NORMALIZED (planes r_n, g_n, b_n, i) and LAB (planes L, A, B) voxels, which no
+// reference accessor exposes (the members are public: octree.h:217-222, :296-298); the parity tests read it here.
+extern "C" int tsdf_hip_download_color_state(tsdf_handle h, int plane_index, int z0, int nz, float *out) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_download_color_state");
+  if (plane_index < 0 || plane_index > 3 || !h->cn[plane_index]) {
+    tsdf_set_error("this volume has no such colour-state plane");
+    return TSDF_HIP_E_INVALID;
+  }
+  int rc = check_block(h, 0, 0, z0, h->nx, h->ny, nz);
+  if (rc) return rc;
+  TSDF_ON_DEVICE(h->device);
+  const int64_t plane = (int64_t)h->nx * h->ny;
+  const int64_t max_planes = std::max<int64_t>(1, (int64_t)(64 << 20) / plane);
+  rc = tsdf_ensure_scratch(h, (size_t)std::min<int64_t>(max_planes, nz) * plane * sizeof(float));
+  if (rc) return rc;
+  for (int zc = 0; zc < nz; zc += (int)max_planes) {
+    const int bz = (int)std::min<int64_t>(max_planes, nz - zc);
+    const int64_t n = plane * bz;
+    BlockArgs a{0, 0, z0 + zc - h->z_first, h->nx, h->ny, bz, h->ny, h->pitch};
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, h->cn[plane_index], (float *)h->scratch);
+    TSDF_HIP_TRY(hipGetLastError());
+    if ((rc = tsdf_to_host(h, out + (int64_t)zc * plane, h->scratch, n * sizeof(float)))) return rc;
+  }
+  return TSDF_HIP_OK;
 }
 
 extern "C" int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,

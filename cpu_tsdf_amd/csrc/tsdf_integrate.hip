@@ -658,6 +658,116 @@ k_integrate_rgbn(const IntegrateArgs a, float *__restrict__ D, float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// TSDF_COLOR_LAB: updateVoxel with LABNode::addObservation (src/lib/octree.cpp:531-545).  RGB2LAB depends on the
+// pixel alone, so it runs once per PIXEL of the frame (k_lab_image, 0.3 M conversions) instead of once per voxel
+// observation (~100 M at 512^3): the sRGB curve comes from the host-built table (tsdf_lab_curve), the XYZ sums are
+// the reference's double expressions rounded to float where it stores them, and the three cube roots are fp64 pow
+// on the device rounded to float like `X = std::pow(double, 1/3.)`.  k_integrate_lab then is the RGB_NORMALIZED
+// kernel with three float means and LAB2RGB (octree.cpp:483-527) for the cached getRGB() bytes.
+static __device__ __forceinline__ float lab_f(float t) {  // octree.cpp:466-477
+  return (double)t > 0.008856 ? (float)pow((double)t, 1 / 3.) : (float)(7.787 * (double)t + (16 / 116.));
+}
+
+static __global__ void __launch_bounds__(256)
+k_lab_image(const uint32_t *__restrict__ bgra, const float *__restrict__ lut, float4 *__restrict__ lab, int n) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= n) return;
+  const uint32_t c = bgra[i];  // PCL memory order b, g, r, a
+  const double rf = (double)lut[(c >> 16) & 255u], gf = (double)lut[(c >> 8) & 255u], bf = (double)lut[c & 255u];
+  float X = (float)(rf * 0.4124 + gf * 0.3576 + bf * 0.1805);  // :459-461
+  float Y = (float)(rf * 0.2126 + gf * 0.7152 + bf * 0.0722);
+  float Z = (float)(rf * 0.0193 + gf * 0.1192 + bf * 0.9505);
+  X = (float)((double)X / 95.047);  // :463-465
+  Y = (float)((double)Y / 100.);
+  Z = (float)((double)Z / 108.883);
+  X = lab_f(X);
+  Y = lab_f(Y);
+  Z = lab_f(Z);
+  lab[i] = make_float4((116.f * Y) - 16.f, 500.f * (X - Y), 200.f * (Y - Z), 0.f);  // :478-480, float arithmetic
+}
+
+static __device__ __forceinline__ float lab_cube(float t) {  // octree.cpp:491-502; t * t is exact in fp64
+  const double c = ((double)t * (double)t) * (double)t;
+  return c > 0.008856 ? (float)c : (float)(((double)t - 16 / 116.) / 7.787);
+}
+static __device__ __forceinline__ float lab_gamma(float t) {  // octree.cpp:514-525
+  return (double)t > 0.0031308 ? (float)(1.055 * pow((double)t, 1. / 2.4) - 0.055) : (float)((double)t * 12.92);
+}
+// LAB2RGB (octree.cpp:483-527) -> r | g<<8 | b<<16; uint8_t = float is cvttss2si and the low byte, as in getRGB above
+static __device__ __forceinline__ uint32_t lab_to_rgb(float L, float A, float B) {
+  float Y = (float)((double)(L + 16.f) / 116.);  // :488-490
+  float X = (float)((double)A / 500. + (double)Y);
+  float Z = (float)((double)Y - ((double)B / 200.));
+  X = lab_cube(X);
+  Y = lab_cube(Y);
+  Z = lab_cube(Z);
+  X = (float)((double)X * 95.047);  // :503-505
+  Y = (float)((double)Y * 100.);
+  Z = (float)((double)Z * 108.883);
+  X /= 100.f;  // :507-509: float / int
+  Y /= 100.f;
+  Z /= 100.f;
+  const double x = X, y = Y, z = Z;
+  const float rf = lab_gamma((float)(x * +3.2406 + y * -1.5372 + z * -0.4986));  // :511-513
+  const float gf = lab_gamma((float)(x * -0.9689 + y * +1.8758 + z * +0.0415));
+  const float bf = lab_gamma((float)(x * +0.0557 + y * -0.2040 + z * +1.0570));
+  return ((uint32_t)(int)(rf * 255.f) & 255u) | (((uint32_t)(int)(gf * 255.f) & 255u) << 8) |
+         (((uint32_t)(int)(bf * 255.f) & 255u) << 16);
+}
+
+template <int ORDER>
+static __global__ void __launch_bounds__(256)
+k_integrate_lab(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+                float *__restrict__ LM, float *__restrict__ AM, float *__restrict__ BM,
+                const float *__restrict__ depth, const float4 *__restrict__ lab, const double *__restrict__ cam,
+                const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
+                unsigned long long *__restrict__ n_obs) {
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int y = (int)blockIdx.y, zl = (int)blockIdx.z;
+  bool observed = false;
+  if (x < (int)a.pitch) {  // the x centre table is NaN beyond nx: those lanes fail the range test
+    const float cx = ctrx[x], cy = ctry[y], cz = ctrz[a.z_global0 + zl];
+    float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
+      g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
+                                         : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
+    if (pix >= 0) {
+      const float z = depth[pix];
+      float dn = z - g[2];  // hpp:159
+      if (!isnan(z) && !(dn < -a.neg)) {  // hpp:152, :193-196
+        dn = dn > a.pos ? a.pos_over_neg : dn / a.neg;  // hpp:189-198
+        const int64_t vi = ((int64_t)(a.zl0 + zl) * a.plane_rows + y) * a.pitch + x;
+        const float4 n = lab[pix];  // RGB2LAB of the pixel (octree.cpp:537)
+        float w = Wt[vi], d = D[vi];
+        const float wn = 1.f;
+        const float wsum = w + wn;  // octree.cpp:535
+        const float lm = (w * LM[vi] + wn * n.x) / wsum;  // :540-542
+        const float am = (w * AM[vi] + wn * n.y) / wsum;
+        const float bm = (w * BM[vi] + wn * n.z) / wsum;
+        LM[vi] = lm;
+        AM[vi] = am;
+        BM[vi] = bm;
+        RGB[vi] = lab_to_rgb(lm, am, bm);  // getRGB (octree.cpp:547-551)
+        uint32_t unused = 0;
+        add_observation_ieee<false>(d, w, unused, dn, 0u, a.wmax);
+        D[vi] = d;
+        Wt[vi] = w;
+        observed = true;
+      }
+    }
+  }
+  if (n_obs) {
+    const unsigned long long m = __ballot(observed);
+    if ((threadIdx.x & 63u) == 0u && m)
+      atomicAdd(n_obs + ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 1023u),
+                (unsigned long long)__popcll(m));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight_by_depth_ (hpp:200-202): w_new = 1 * (1 - std::min(pt.z / 10., 1.)) -- a float times a double stored back
 // into the float -- then OctreeNode / RGBNode::addObservation with that w_new (octree.cpp:152-163, 328-337).  Only a
 // loaded .vol can carry the flag (tsdf_volume_octree.cpp:265), so this is the plain form: one thread per voxel, exact
@@ -868,7 +978,7 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
     }
     return TSDF_HIP_OK;
   }
-  if (h->cn[0]) {  // TSDF_COLOR_RGB_NORMALIZED: its own plain kernel
+  if (h->cn[0]) {  // TSDF_COLOR_RGB_NORMALIZED / TSDF_COLOR_LAB: their own plain kernels
     const bool count = n_observed != nullptr;
     if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
     bool pose_ok = true;
@@ -879,10 +989,22 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
         tsdf_set_error("grid too large for one launch");
         return TSDF_HIP_E_UNSUPPORTED;
       }
-#define LAUNCH_RGBN(ORDER)                                                                                       \
-  hipLaunchKernelGGL((k_integrate_rgbn<ORDER>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->cn[0],      \
-                     h->cn[1], h->cn[2], h->cn[3], d_depth, d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], \
-                     count ? h->counter : nullptr)
+      if (h->lab_img) {  // TSDF_COLOR_LAB: convert the frame's pixels once, then the per-voxel kernel
+        const int npx = p.image_width * p.image_height;
+        hipLaunchKernelGGL(k_lab_image, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, h->stream, d_bgra,
+                           h->lab_lut, h->lab_img, npx);
+      }
+#define LAUNCH_RGBN(ORDER)                                                                                        \
+  do {                                                                                                            \
+    if (h->lab_img)                                                                                               \
+      hipLaunchKernelGGL((k_integrate_lab<ORDER>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->cn[0],    \
+                         h->cn[1], h->cn[2], d_depth, h->lab_img, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2],      \
+                         count ? h->counter : nullptr);                                                           \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_integrate_rgbn<ORDER>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->cn[0],   \
+                         h->cn[1], h->cn[2], h->cn[3], d_depth, d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], \
+                         count ? h->counter : nullptr);                                                           \
+  } while (0)
       if (p.xform_order == TSDF_XFORM_PCL_SSE)
         LAUNCH_RGBN(TSDF_XFORM_PCL_SSE);
       else
@@ -1406,6 +1528,49 @@ extern "C" int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, fl
   (void)hipFree(dk);
   (void)hipFree(dout);
   (void)hipFree(df);
+  return TSDF_HIP_OK;
+}
+
+// Test hooks: the device's RGB2LAB (k_lab_image, with the host-built curve) and LAB2RGB on caller-chosen inputs, so
+// the tests can sweep all 2^24 pixel colours and millions of L, A, B means against the reference's conversions.
+static __global__ void k_selftest_lab2rgb(const float *lab, uint32_t *rgb, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rgb[i] = lab_to_rgb(lab[3 * i], lab[3 * i + 1], lab[3 * i + 2]);
+}
+
+extern "C" int tsdf_hip_selftest_rgb2lab(const uint8_t *bgra, size_t n, float *lab4) {
+  if (!bgra || !lab4 || !n || n > (size_t)1 << 30) return TSDF_HIP_E_INVALID;
+  float lut[256];
+  tsdf_lab_curve(lut);
+  uint32_t *d_px = nullptr;
+  float *d_lut = nullptr;
+  float4 *d_lab = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&d_px, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&d_lut, sizeof lut));
+  TSDF_HIP_TRY(hipMalloc(&d_lab, n * sizeof(float4)));
+  TSDF_HIP_TRY(hipMemcpy(d_px, bgra, n * 4, hipMemcpyHostToDevice));
+  TSDF_HIP_TRY(hipMemcpy(d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_lab_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_px, d_lut, d_lab, (int)n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(lab4, d_lab, n * sizeof(float4), hipMemcpyDeviceToHost));
+  (void)hipFree(d_px);
+  (void)hipFree(d_lut);
+  (void)hipFree(d_lab);
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_selftest_lab2rgb(const float *lab3, size_t n, uint32_t *rgb) {
+  if (!lab3 || !rgb || !n) return TSDF_HIP_E_INVALID;
+  float *d_lab = nullptr;
+  uint32_t *d_rgb = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&d_lab, n * 12));
+  TSDF_HIP_TRY(hipMalloc(&d_rgb, n * 4));
+  TSDF_HIP_TRY(hipMemcpy(d_lab, lab3, n * 12, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_lab2rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_lab, d_rgb, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(rgb, d_rgb, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_lab);
+  (void)hipFree(d_rgb);
   return TSDF_HIP_OK;
 }
 

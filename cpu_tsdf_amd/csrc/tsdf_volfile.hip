@@ -136,7 +136,7 @@ extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol
     return TSDF_HIP_E_UNSUPPORTED;
   }
   if ((h->multi ? tsdf_multi_first(h) : h)->cn[0]) {
-    tsdf_set_error("RGB_NORMALIZED volumes have no usable .vol form (the reference writes one byte of each float, "
+    tsdf_set_error("RGB_NORMALIZED / LAB volumes have no usable .vol form (the reference writes one byte of each float, "
                    "octree.cpp:417-433)");
     return TSDF_HIP_E_UNSUPPORTED;
   }

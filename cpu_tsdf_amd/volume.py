@@ -81,8 +81,9 @@ class TSDFVolumeOctree:
         self._p.integrate_color = 1 if flag else 0
 
     def setColorMode(self, color_mode):
-        """tsdf_volume_octree.h:290: "RGB" (default) or "RGBNormalized"; "LAB" is not offered (std::pow)."""
-        modes = {"RGB": capi.COLOR_RGB, "RGBNormalized": capi.COLOR_RGB_NORMALIZED}
+        """tsdf_volume_octree.h:290: "RGB" (default), "RGBNormalized" or "LAB" (OctreeNode::instantiateByTypeString,
+        octree.cpp:193-206)."""
+        modes = {"RGB": capi.COLOR_RGB, "RGBNormalized": capi.COLOR_RGB_NORMALIZED, "LAB": capi.COLOR_LAB}
         if color_mode not in modes:
             raise ValueError(f"colour mode {color_mode!r} does not exist in the HIP volume (have {sorted(modes)})")
         self._p.color_mode = modes[color_mode]
@@ -378,6 +379,21 @@ class TSDFVolumeOctree:
             capi.load().tsdf_hip_download(h, x0, y0, z0, nx, ny, nz, capi.as_f32p(d), capi.as_f32p(w),
                                           capi.as_u8p(rgb) if rgb is not None else None), "download")
         return d, w, rgb
+
+    def downloadColorState(self, z0=None, nz=None):
+        """Not in the reference (its members are public): the float colour state of "RGBNormalized" (r_n, g_n, b_n, i)
+        or "LAB" (L, A, B) voxels as an array (planes, nz, ny, nx)."""
+        h = self._need()
+        rx, ry, rz = self._p.res
+        zb = self._p.z_begin
+        ze = self._p.z_end if (self._p.z_begin or self._p.z_end) else rz
+        z0 = zb if z0 is None else z0
+        nz = ze - z0 if nz is None else nz
+        planes = {capi.COLOR_RGB_NORMALIZED: 4, capi.COLOR_LAB: 3}.get(self._p.color_mode, 0)
+        out = np.empty((planes, nz, ry, rx), dtype=np.float32)
+        for c in range(planes):
+            capi.check(capi.load().tsdf_hip_download_color_state(h, c, z0, nz, capi.as_f32p(out[c])), "colour state")
+        return out
 
     def upload(self, d=None, w=None, rgb=None, x0=0, y0=0, z0=0):
         h = self._need()

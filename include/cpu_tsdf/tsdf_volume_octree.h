@@ -2,8 +2,8 @@
 // (include/cpu_tsdf/tsdf_volume_octree.h:49-377).  Public signatures are kept; the octree of
 // shared_ptr voxels is gone: voxels live in a flat SoA grid in HBM behind the C ABI of tsdf_hip.h, and
 // every heavy method forwards to a HIP kernel.  What is intentionally absent: the public `octree_`
-// member and getFrustumCulledVoxels (they expose OctreeNode pointers), and setColorMode("LAB") (it goes
-// through std::pow, whose last bit belongs to the host's libm; "RGB" and "RGBNormalized" exist).
+// member and getFrustumCulledVoxels (they expose OctreeNode pointers).  setColorMode takes "RGB", "RGBNormalized"
+// and "LAB" like the reference (LAB: L, A, B state bit-identical, displayed bytes within 1 -- see tsdf_hip.h).
 //
 // Host-side arithmetic that decides results is done here with the caller's own Eigen/PCL, exactly where
 // the reference does it: trans.inverse().cast<float>() (hpp:54), trans.rotation().cast<float>() /

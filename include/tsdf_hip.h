@@ -67,11 +67,20 @@ enum { TSDF_LAYOUT_AUTO = 0, TSDF_LAYOUT_F32W = 1, TSDF_LAYOUT_PACKED = 2 };
  *                   Four more float planes per voxel, float weights (no PACKED layout), a plain per-voxel
  *                   kernel; tsdf_hip_upload of rgb and save/load are refused (the reference's own
  *                   serialisation of this class writes one byte of each float, octree.cpp:417-433).
- * "LAB" (octree.cpp:437-560) is not offered: it goes through std::pow, whose last bit belongs to the host's
- * libm. */
+ *   LAB             LABNode (octree.cpp:531-551): float running means of the CIE L*a*b* image of each pixel
+ *                   (RGB2LAB, octree.cpp:436-481); the colour read back is LAB2RGB of the means
+ *                   (octree.cpp:483-527).  Three more float planes, float weights, a plain kernel, no rgb
+ *                   upload and no save/load, like RGB_NORMALIZED.  Both conversions go through std::pow in
+ *                   the reference.  Here the sRGB curve (a function of one byte) is tabulated by the host's
+ *                   own libm at create, and the cube roots run on the device in fp64 before the same rounding
+ *                   to float: the L, A, B state equals the reference's bit for bit for every one of the 2^24
+ *                   pixel colours (the GPU tests sweep them all); the bytes LAB2RGB returns may differ by 1
+ *                   where (float) * 255 lands within an ulp of an integer (tolerance stated in
+ *                   tests/test_lab_gpu.py: +-1, > 99.9 % identical). */
 enum {
   TSDF_COLOR_RGB = 0,
-  TSDF_COLOR_RGB_NORMALIZED = 1
+  TSDF_COLOR_RGB_NORMALIZED = 1,
+  TSDF_COLOR_LAB = 2
 };
 
 /* Everything TSDFVolumeOctree's setters configure before reset()
@@ -284,6 +293,11 @@ int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int
 int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *d,
                     const float *w, const uint8_t *rgb);
 
+/* The float colour state of the voxels of planes z0 .. z0+nz (nz * ny * nx floats): plane_index 0..3 = r_n_, g_n_,
+ * b_n_, i_ of RGBNormalized (octree.h:217-222) or 0..2 = L_, A_, B_ of LABNode (octree.h:296-298).  The reference has
+ * no accessor for it (the members are public); the parity tests read it.  Single-device handles only. */
+int tsdf_hip_download_color_state(tsdf_handle h, int plane_index, int z0, int nz, float *out);
+
 /* save / load -- src/lib/tsdf_volume_octree.cpp:222-275 (+ Octree::serialize / deserialize,
  * src/lib/octree.cpp:289-304,360-367,645-678): the reference's .vol checkpoint, readable and writable by both
  * sides.  The dense grid becomes an octree whose uniform subtrees are single leaves (lossless for every
@@ -356,6 +370,11 @@ int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, siz
  * reciprocal + scale-free ladder where its result is a normal number (fast[i] = 1), IEEE division elsewhere. */
 int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, uint8_t *fast, size_t n);
 
+/* Test hooks for TSDF_COLOR_LAB: the device's RGB2LAB of n pixels (b,g,r,a bytes each -> L,A,B,0 floats each) and
+ * LAB2RGB of n L,A,B triples (-> r | g<<8 | b<<16 each); references octree.cpp:436-481 and :483-527. */
+int tsdf_hip_selftest_rgb2lab(const uint8_t *bgra, size_t n, float *lab4);
+int tsdf_hip_selftest_lab2rgb(const float *lab3, size_t n, uint32_t *rgb);
+
 /* Test hook: the integrate kernel's pixel projection (reprojectPoint, tsdf_volume_octree.cpp:611-617) on
  * n arbitrary camera-frame points g (x,y,z triples, z > 0) with this volume's intrinsics: pix_fast =
  * certified-fp32 path with exact fallback (what the kernel uses), pix_exact = fp64 path, both v*W+u or
@@ -396,7 +415,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 7
+#define TSDF_HIP_ABI_VERSION 8
 
 #ifdef __cplusplus
 }

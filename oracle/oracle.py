@@ -48,6 +48,12 @@ def lib():
         L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
         L.oracle_integrate_weighted.restype = C.c_uint64
         L.oracle_integrate_weighted.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, C.c_int]
+        L.oracle_integrate_lab.restype = C.c_uint64
+        L.oracle_integrate_lab.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
+        L.oracle_rgb2lab_many.restype = None
+        L.oracle_rgb2lab_many.argtypes = [_u8, C.c_size_t, _f]
+        L.oracle_lab2rgb_many.restype = None
+        L.oracle_lab2rgb_many.argtypes = [_f, C.c_size_t, _u8]
         L.oracle_integrate_rgbn.restype = C.c_uint64
         L.oracle_integrate_rgbn.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
         L.oracle_raycast.argtypes = [C.POINTER(OracleParams), _f, _f, _f, _f, C.c_int, _f]
@@ -140,6 +146,17 @@ class OracleVolume:
         col = np.ascontiguousarray(bgra, dtype=np.uint8)
         return int(lib().oracle_integrate_rgbn(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(self.cn), _bp(self.rgb),
                                                _fp(depth), _bp(col), _fp(T), z_begin, z_end))
+
+    def integrate_lab(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
+        """integrate with LABNode voxels (setColorMode("LAB")); self.cn holds the L, A, B means and self.rgb what
+        getRGB() returns (LAB2RGB of the means)."""
+        if not hasattr(self, "cn"):
+            self.cn = np.zeros((3,) + self.d.shape, dtype=np.float32)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        T = np.ascontiguousarray(cam_from_vol, dtype=np.float32).reshape(12)
+        col = np.ascontiguousarray(bgra, dtype=np.uint8)
+        return int(lib().oracle_integrate_lab(C.byref(self.p), _fp(self.d), _fp(self.w), _fp(self.cn), _bp(self.rgb),
+                                              _fp(depth), _bp(col), _fp(T), z_begin, z_end))
 
     def raycast(self, trans, ds=1):
         trans = np.asarray(trans, dtype=np.float64)
@@ -247,3 +264,19 @@ class SlabOracle:
         return lib().oracle_integrate(C.byref(self.p), d, w, rgb, depth.ctypes.data_as(fp),
                                         col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None,
                                         T.ctypes.data_as(fp), self.zb, self.ze)
+
+
+def rgb2lab(rgb):
+    """RGB2LAB (octree.cpp:436-481) of an (n,3) uint8 array of r,g,b -> (n,3) float32 L,A,B."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    out = np.empty(rgb.shape, dtype=np.float32)
+    lib().oracle_rgb2lab_many(_bp(rgb), rgb.shape[0], _fp(out))
+    return out
+
+
+def lab2rgb(lab):
+    """LAB2RGB (octree.cpp:483-527) of an (n,3) float32 array -> (n,3) uint8."""
+    lab = np.ascontiguousarray(lab, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(lab.shape, dtype=np.uint8)
+    lib().oracle_lab2rgb_many(_fp(lab), lab.shape[0], _bp(out))
+    return out

@@ -59,6 +59,17 @@ void ct_set_max_weight(void *h, float w) { V(h)->setWeightTruncationLimit(w); }
 void ct_set_max_voxel_size(void *h, float x, float y, float z) { V(h)->setMaxVoxelSize(x, y, z); }
 void ct_set_integrate_color(void *h, int f) { V(h)->setIntegrateColor(f != 0); }
 void ct_set_color_mode(void *h, const char *mode) { V(h)->setColorMode(mode); }
+#ifdef CT_REFERENCE
+// the reference's own colour conversions (octree.cpp:436-527), for pinning the oracle's restatement
+void ct_rgb2lab_many(const uint8_t *rgb, size_t n, float *lab) {
+  for (size_t i = 0; i < n; ++i)
+    cpu_tsdf::RGB2LAB(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], lab[3 * i], lab[3 * i + 1], lab[3 * i + 2]);
+}
+void ct_lab2rgb_many(const float *lab, size_t n, uint8_t *rgb) {
+  for (size_t i = 0; i < n; ++i)
+    cpu_tsdf::LAB2RGB(lab[3 * i], lab[3 * i + 1], lab[3 * i + 2], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+#endif
 void ct_set_num_random_splits(void *h, int n) { V(h)->setNumRandomSplts(n); }
 void ct_set_global_transform(void *h, const double *m16) { V(h)->setGlobalTransform(to_affine(m16)); }
 void ct_reset(void *h) { V(h)->reset(); }

@@ -71,6 +71,11 @@ def load(path=LIB):
     }.items():
         getattr(L, name).argtypes = args
         getattr(L, name).restype = None
+    if hasattr(L, "ct_rgb2lab_many"):  # the reference build only
+        L.ct_rgb2lab_many.restype = None
+        L.ct_rgb2lab_many.argtypes = [_u8, C.c_size_t, _f]
+        L.ct_lab2rgb_many.restype = None
+        L.ct_lab2rgb_many.argtypes = [_f, C.c_size_t, _u8]
     L.ct_integrate.restype = C.c_double
     L.ct_integrate.argtypes = [C.c_void_p, _f, _u8, C.c_int, C.c_int, _d]
     L.ct_render_view.restype = C.c_double
@@ -240,3 +245,19 @@ def time_integrate(sc, res3, size3, color, budget_s, cores):
             "sample": f"reference TSDFVolumeOctree (own sources + PCL/Eigen stand-ins, -O3 -fopenmp, {cores} threads), "
                       f"native adaptive octree (max cell 0.5 m), first {n} frames of the same {res}^3 workload, "
                       f"{spent:.1f} s in integrateCloud, {leaves} leaves at the end, peak RSS {rss_gb:.1f} GB; nominal-grid Mvoxels/s"}
+
+
+def ref_rgb2lab(rgb):
+    """The reference's own RGB2LAB (octree.cpp:436-481) on an (n,3) uint8 array."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    out = np.empty(rgb.shape, dtype=np.float32)
+    load().ct_rgb2lab_many(rgb.ctypes.data_as(_u8), rgb.shape[0], _fp(out))
+    return out
+
+
+def ref_lab2rgb(lab):
+    """The reference's own LAB2RGB (octree.cpp:483-527) on an (n,3) float32 array."""
+    lab = np.ascontiguousarray(lab, dtype=np.float32).reshape(-1, 3)
+    out = np.empty(lab.shape, dtype=np.uint8)
+    load().ct_lab2rgb_many(_fp(lab), lab.shape[0], out.ctypes.data_as(_u8))
+    return out

@@ -277,6 +277,108 @@ uint64_t oracle_integrate_rgbn(const oracle_params *p, float *d, float *w, float
 }
 
 /* ------------------------------------------------------------------------------------------
+ * setColorMode("LAB"): RGB2LAB octree.cpp:436-481, LAB2RGB octree.cpp:483-527, LABNode octree.cpp:531-551.
+ * Every literal below is a double in the reference too, so the mixed float/double arithmetic is the same in C;
+ * std::pow(float, int) is the C++11 <cmath> overload that promotes both to double (octree.cpp:491-502). */
+void oracle_rgb2lab(uint8_t r, uint8_t g, uint8_t b, float *L, float *A, float *B) {
+  float rf = ((float)r / 255.), gf = ((float)g / 255.), bf = ((float)b / 255.); /* :441-443 */
+  if (rf > 0.0405) rf = pow(((rf + 0.055) / 1.055), 2.4); else rf /= 12.92;     /* :444-447 */
+  if (gf > 0.0405) gf = pow(((gf + 0.055) / 1.055), 2.4); else gf /= 12.92;
+  if (bf > 0.0405) bf = pow(((bf + 0.055) / 1.055), 2.4); else bf /= 12.92;
+  rf *= 100;
+  gf *= 100;
+  bf *= 100;
+  float X = rf * 0.4124 + gf * 0.3576 + bf * 0.1805; /* :459-461 */
+  float Y = rf * 0.2126 + gf * 0.7152 + bf * 0.0722;
+  float Z = rf * 0.0193 + gf * 0.1192 + bf * 0.9505;
+  X /= 95.047;
+  Y /= 100.;
+  Z /= 108.883;
+  if (X > 0.008856) X = pow((double)X, 1 / 3.); else X = 7.787 * X + (16 / 116.); /* :466-477 */
+  if (Y > 0.008856) Y = pow((double)Y, 1 / 3.); else Y = 7.787 * Y + (16 / 116.);
+  if (Z > 0.008856) Z = pow((double)Z, 1 / 3.); else Z = 7.787 * Z + (16 / 116.);
+  *L = (116 * Y) - 16; /* :478-480: float arithmetic */
+  *A = 500 * (X - Y);
+  *B = 200 * (Y - Z);
+}
+
+void oracle_lab2rgb(float L, float A, float B, uint8_t *r, uint8_t *g, uint8_t *b) {
+  float Y = (L + 16) / 116.; /* :488-490 */
+  float X = A / 500. + Y;
+  float Z = Y - (B / 200.);
+  if (pow((double)X, 3.0) > 0.008856) X = pow((double)X, 3.0); else X = (X - 16 / 116.) / 7.787; /* :491-502 */
+  if (pow((double)Y, 3.0) > 0.008856) Y = pow((double)Y, 3.0); else Y = (Y - 16 / 116.) / 7.787;
+  if (pow((double)Z, 3.0) > 0.008856) Z = pow((double)Z, 3.0); else Z = (Z - 16 / 116.) / 7.787;
+  X *= 95.047;
+  Y *= 100.;
+  Z *= 108.883;
+  X /= 100;
+  Y /= 100;
+  Z /= 100;
+  float rf = X * +3.2406 + Y * -1.5372 + Z * -0.4986; /* :511-513 */
+  float gf = X * -0.9689 + Y * +1.8758 + Z * +0.0415;
+  float bf = X * +0.0557 + Y * -0.2040 + Z * +1.0570;
+  if (rf > 0.0031308) rf = 1.055 * pow((double)rf, 1. / 2.4) - 0.055; else rf *= 12.92; /* :514-525 */
+  if (gf > 0.0031308) gf = 1.055 * pow((double)gf, 1. / 2.4) - 0.055; else gf *= 12.92;
+  if (bf > 0.0031308) bf = 1.055 * pow((double)bf, 1. / 2.4) - 0.055; else bf *= 12.92;
+  /* static_cast<uint8_t>(float) is cvttss2si + low byte on x86-64, as in getRGB above */
+  *r = (uint8_t)cvtt((double)(rf * 255));
+  *g = (uint8_t)cvtt((double)(gf * 255));
+  *b = (uint8_t)cvtt((double)(bf * 255));
+}
+
+void oracle_rgb2lab_many(const uint8_t *rgb, size_t n, float *lab) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) oracle_rgb2lab(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], lab + 3 * i, lab + 3 * i + 1, lab + 3 * i + 2);
+}
+void oracle_lab2rgb_many(const float *lab, size_t n, uint8_t *rgb) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) oracle_lab2rgb(lab[3 * i], lab[3 * i + 1], lab[3 * i + 2], rgb + 3 * i, rgb + 3 * i + 1, rgb + 3 * i + 2);
+}
+
+/* integrate with LABNode voxels.  cn = three planes (L, A, B) starting at 0 (octree.h:267-270); rgb receives what
+ * getRGB() returns (LAB2RGB of the means, octree.cpp:547-551) for every voxel touched. */
+uint64_t oracle_integrate_lab(const oracle_params *p, float *d, float *w, float *cn, uint8_t *rgb,
+                              const float *depth, const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
+  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+  const size_t n = (size_t)nx * ny * nz;
+  float *Lm = cn, *Am = cn + n, *Bm = cn + 2 * n;
+  float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
+        *cz = (float *)malloc(sizeof(float) * nz);
+  oracle_centers(nx, node_size(p, 0), cx);
+  oracle_centers(ny, node_size(p, 1), cy);
+  oracle_centers(nz, node_size(p, 2), cz);
+  if (z_begin == 0 && z_end == 0) z_end = nz;
+  uint64_t n_obs = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_obs)
+  for (int k = z_begin; k < z_end; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        float dn;
+        size_t pixel;
+        if (!observe(p, T, cx[i], cy[j], cz[k], depth, &dn, &pixel)) continue;
+        const float w_new = 1;
+        const size_t vi = ((size_t)k * ny + j) * nx + i;
+        const uint8_t *px = bgra + 4 * pixel;
+        const float wsum = w[vi] + w_new; /* octree.cpp:535 */
+        float Ln, An, Bn;
+        oracle_rgb2lab(px[2], px[1], px[0], &Ln, &An, &Bn);
+        Lm[vi] = (w[vi] * Lm[vi] + w_new * Ln) / wsum; /* :540-542 */
+        Am[vi] = (w[vi] * Am[vi] + w_new * An) / wsum;
+        Bm[vi] = (w[vi] * Bm[vi] + w_new * Bn) / wsum;
+        oracle_lab2rgb(Lm[vi], Am[vi], Bm[vi], rgb + 3 * vi, rgb + 3 * vi + 1, rgb + 3 * vi + 2);
+        d[vi] = (d[vi] * w[vi] + dn * w_new) / (w[vi] + w_new); /* octree.cpp:156 */
+        w[vi] += w_new;
+        if (w[vi] > p->max_weight) w[vi] = p->max_weight;
+        ++n_obs;
+      }
+  free(cx);
+  free(cy);
+  free(cz);
+  return n_obs;
+}
+
+/* ------------------------------------------------------------------------------------------
  * interpolateTrilinearly, tsdf_volume_octree.cpp:486-541.  *valid is AND-ed (never set to 1). */
 /* Slab bookkeeping for the ray hand-off restatement (oracle_raycast_advance): planes a slab may read. */
 static _Thread_local int tl_zlo = INT_MIN, tl_zhi = INT_MAX, tl_bad = 0;

@@ -1,0 +1,208 @@
+"""GPU tier: setColorMode("LAB") -- k_lab_image + k_integrate_lab (RGB2LAB, LAB2RGB, LABNode: src/lib/octree.cpp:436-551)
+vs the reference's own outputs (tests/golden/reference_lab_32.npz) and vs the oracle on seeded inputs.
+
+The reference's conversions go through std::pow.  What is asserted here, and it is the tolerance include/tsdf_hip.h
+states for this mode:
+  * RGB2LAB: bit for bit, for EVERY one of the 2^24 pixel colours (the sRGB curve is the host libm's table, the
+    cube roots are device fp64 pow rounded to float);
+  * hence d, w and the L, A, B state of every voxel: bit for bit;
+  * LAB2RGB (what getRGB / marching cubes / renderColoredView show): each byte within 1 of the reference's and more
+    than 99.9 % of them identical -- (float) * 255 is truncated, so a last-bit difference in a device pow can move a
+    byte that sits on an integer."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import capi, synth
+from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree
+from oracle import oracle, refbind
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32, make_volume
+from tests.golden.make_golden_lab import colour_image
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "reference_lab_32.npz")
+
+
+def assert_bytes_within_one(got, want, what, min_same=0.999):
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1, f"{what}: a byte is off by {diff.max()}"
+    same = (diff == 0).mean()
+    assert same >= min_same, f"{what}: only {same:.5f} of the bytes are identical"
+
+
+def device_rgb2lab(rgb):
+    px = np.zeros((len(rgb), 4), dtype=np.uint8)
+    px[:, 0], px[:, 1], px[:, 2], px[:, 3] = rgb[:, 2], rgb[:, 1], rgb[:, 0], 255
+    out = np.empty((len(rgb), 4), dtype=np.float32)
+    capi.check(capi.load().tsdf_hip_selftest_rgb2lab(capi.as_u8p(px), len(rgb), capi.as_f32p(out)), "rgb2lab")
+    assert (out[:, 3] == 0).all()
+    return np.ascontiguousarray(out[:, :3])
+
+
+def device_lab2rgb(lab):
+    lab = np.ascontiguousarray(lab, dtype=np.float32)
+    out = np.empty(len(lab), dtype=np.uint32)
+    capi.check(capi.load().tsdf_hip_selftest_lab2rgb(capi.as_f32p(lab), len(lab),
+                                                     out.ctypes.data_as(C.POINTER(C.c_uint32))), "lab2rgb")
+    return np.stack([out & 255, (out >> 8) & 255, (out >> 16) & 255], 1).astype(np.uint8)
+
+
+def test_device_rgb2lab_equals_the_reference_for_every_colour(gpu):
+    gold = np.load(GOLD)
+    assert_same_f32(device_rgb2lab(gold["probe_rgb"]), gold["probe_lab"], "RGB2LAB vs the reference's own outputs")
+    i = np.arange(1 << 24, dtype=np.uint32)
+    rgb = np.stack([(i >> 16) & 255, (i >> 8) & 255, i & 255], 1).astype(np.uint8)
+    assert_same_f32(device_rgb2lab(rgb), oracle.rgb2lab(rgb), "RGB2LAB of all 2^24 colours")
+
+
+def test_device_lab2rgb_within_one_byte(gpu):
+    gold = np.load(GOLD)
+    assert_bytes_within_one(device_lab2rgb(gold["probe_mix"]), gold["probe_mix_rgb"], "LAB2RGB vs the reference")
+    rng = np.random.RandomState(3)
+    i = rng.randint(0, 1 << 24, 3_000_000).astype(np.uint32)
+    lab = oracle.rgb2lab(np.stack([(i >> 16) & 255, (i >> 8) & 255, i & 255], 1).astype(np.uint8))
+    assert_bytes_within_one(device_lab2rgb(lab), oracle.lab2rgb(lab), "LAB2RGB of colour images")
+    wild = (rng.rand(2_000_000, 3) * [140, 400, 400] - [20, 200, 200]).astype(np.float32)   # out of gamut, negative
+    got, want = device_lab2rgb(wild), oracle.lab2rgb(wild)
+    d = (got.astype(np.int16) - want.astype(np.int16)) % 256      # the low byte wraps there, as in the reference
+    assert np.isin(d, (0, 1, 255)).all() and (d == 0).mean() > 0.999
+
+
+def test_lab_matches_the_reference_golden(gpu):
+    gold = np.load(GOLD)
+    res, W, H = int(gold["res"]), int(gold["width"]), int(gold["height"])
+    vol, sc = make_volume(res, W, H, color=True)
+    vol.setColorMode("LAB")
+    vol.reset()
+    assert vol.getLayout() == capi.LAYOUT_F32W
+    for i in range(int(gold["n_frames"])):
+        tr = synth.turntable_pose(i, int(gold["total"]), sc.size)
+        vol.integrateCloud(sc.depth(tr), colour_image(sc, i), tr)
+        d, w, rgb = vol.download()
+        assert_same_f32(d, gold[f"d{i}"], f"d after frame {i}")
+        assert np.array_equal(w, gold[f"w{i}"].astype(np.float32))
+        assert_bytes_within_one(rgb, gold[f"rgb{i}"], f"colours after frame {i}")
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(vol)
+    mc.setMinWeight(0.0)
+    mc.setColorByRGB(True)
+    mesh = mc.reconstruct()
+    assert_same_f32(mesh["vertices"], gold["mc_verts"], "mesh")
+    assert_bytes_within_one(mesh["rgb"], gold["mc_rgb"], "mesh colours")
+    cloud, rgb = vol.renderColoredView(gold["view_pose"], 1)
+    assert_same_f32(cloud[..., :6], gold["view"], "renderColoredView cloud")
+    assert_bytes_within_one(rgb, gold["view_rgb"], "renderColoredView colours")
+    assert (gold["view_rgb"] > 0).sum() > 100
+    vol.close()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_lab_matches_the_oracle_on_random_colours(gpu, order):
+    vol, sc = make_volume(64, 96, 72, color=True, order=order, max_weight=3.0)
+    vol.setColorMode("LAB")
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    rng = np.random.RandomState(11 + order)
+    for i in range(6):
+        tr = synth.turntable_pose(i, 6, sc.size, tilt=0.1 * i)
+        col = rng.randint(0, 256, (72, 96, 4)).astype(np.uint8)
+        col[rng.rand(72, 96) < 0.02, :3] = 0
+        dep = sc.depth(tr, noise_seed=50 + i)
+        n_gpu = vol.integrateCloud(dep, col, tr, count=True)
+        n_cpu = ov.integrate_lab(dep, col, synth.cam_from_vol_f32(tr))
+        assert n_gpu == n_cpu
+    d, w, rgb = vol.download()
+    assert_same_f32(d, ov.d, "d")
+    assert np.array_equal(w, ov.w) and w.max() == 3.0
+    state = vol.downloadColorState()
+    for c, name in enumerate("LAB"):
+        assert_same_f32(state[c], ov.cn[c], f"the {name} means")
+    assert (state[0][ov.w > 0] > 1).mean() > 0.9
+    assert_bytes_within_one(rgb, ov.rgb, "getRGB")
+    vol.close()
+
+
+def test_lab_slab_handle_and_pipelined_entry_points(gpu):
+    """A Z-slab handle, the one-process multi-GPU handle and the host entry points reach the same kernels."""
+    full, sc = make_volume(64, 96, 72, color=True)
+    full.setColorMode("LAB")
+    full.reset()
+    slab, _ = make_volume(64, 96, 72, color=True)
+    slab.setColorMode("LAB")
+    slab.setZSlab(20, 41, halo=2)
+    slab.reset()
+    multi, _ = make_volume(64, 96, 72, color=True)
+    multi.setColorMode("LAB")
+    multi.setDevices([0, 0, 0])
+    multi.reset()
+    for i in range(4):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        full.integrateCloud(sc.depth(tr), sc.bgra(i), tr)
+        slab.integrateCloud(sc.depth(tr), sc.bgra(i), tr, pipelined=True)
+        multi.integrateCloud(sc.depth(tr), sc.bgra(i), tr)
+    slab.synchronize()
+    d, w, rgb = full.download()
+    ds, ws, cs = slab.download(z0=20, nz=21)
+    assert_same_f32(ds, d[20:41], "slab d")
+    assert np.array_equal(ws, w[20:41]) and np.array_equal(cs, rgb[20:41]) and cs.max() > 0
+    assert_same_f32(slab.downloadColorState()[1], full.downloadColorState()[1, 20:41], "slab A means")
+    dm, wm, cm = multi.download()
+    assert_same_f32(dm, d, "multi d")
+    assert np.array_equal(wm, w) and np.array_equal(cm, rgb)
+    cloud_f, rgb_f = full.renderColoredView(synth.turntable_pose(2, 8, sc.size), 1)
+    cloud_m, rgb_m = multi.renderColoredView(synth.turntable_pose(2, 8, sc.size), 1)
+    assert_same_f32(cloud_m, cloud_f, "multi renderColoredView")
+    assert np.array_equal(rgb_m, rgb_f)
+    for v in (full, slab, multi):
+        v.close()
+
+
+def test_lab_refusals(gpu, tmp_path):
+    vol, sc = make_volume(32, 80, 60, color=True)
+    vol.setColorMode("LAB")
+    vol.setLayout(capi.LAYOUT_PACKED)
+    with pytest.raises(capi.TsdfHipError) as e:
+        vol.reset()
+    assert e.value.code == capi.E_UNSUPPORTED
+    vol.setLayout(capi.LAYOUT_AUTO)
+    vol.reset()
+    d, w, rgb = vol.download()
+    assert (rgb == 0).all()                         # LAB2RGB(0, 0, 0) of an untouched voxel (octree.h:267-270)
+    with pytest.raises(capi.TsdfHipError) as e:     # the colour STATE is three floats: r,g,b bytes cannot set it
+        vol.upload(d, w, rgb)
+    assert e.value.code == capi.E_UNSUPPORTED
+    vol.upload(d, w)
+    with pytest.raises(capi.TsdfHipError) as e:     # the reference's file form of it is one byte of each float
+        vol.save(str(tmp_path / "x.vol"))
+    assert e.value.code == capi.E_UNSUPPORTED
+    vol.close()
+
+
+def test_dropin_set_color_mode_lab(gpu):
+    """setColorMode("LAB") through the C++ classes: the drop-in against the reference's own library, driven by the same
+    C driver (colours read back through getRGB / marching cubes)."""
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    dropin = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
+    res, W, H = 32, 80, 60
+    sc = synth.scene_a(res, W, H)
+    vols = [refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True,
+                              color_mode="LAB", lib_path=lib) for lib in (dropin, refbind.LIB)]
+    for i in range(4):
+        tr = synth.turntable_pose(i, 8, sc.size, tilt=0.05 * i)
+        for v in vols:
+            v.integrate(sc.depth(tr), colour_image(sc, i), tr)
+    d, w, rgb = vols[0].download()
+    rd, rw, rrgb, _, _ = vols[1].dump_dense()
+    assert_same_f32(d, rd, "d")
+    assert np.array_equal(w, rw) and rgb.max() > 30
+    assert_bytes_within_one(rgb, rrgb, "getRGB")
+    meshes = [v.march(1.0, 1) for v in vols]
+    assert len(meshes[0][0]) > 500
+    assert_same_f32(meshes[0][0], meshes[1][0], "mesh")
+    assert_bytes_within_one(meshes[0][1], meshes[1][1], "mesh colours")
+    for v in vols:
+        v.close()

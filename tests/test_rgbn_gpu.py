@@ -109,5 +109,5 @@ def test_rgbn_refusals(gpu, tmp_path):
         vol.save(str(tmp_path / "x.vol"))
     assert e.value.code == capi.E_UNSUPPORTED
     with pytest.raises(ValueError):
-        vol.setColorMode("LAB")
+        vol.setColorMode("HSV")
     vol.close()
