@@ -106,6 +106,7 @@ SIGNATURES = {
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
     "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
+    "tsdf_hip_selftest_cvt_pk_u8": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "tsdf_hip_selftest_rgb2lab": (C.c_int, [_u8p, C.c_size_t, _f32p]),
     "tsdf_hip_selftest_lab2rgb": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "tsdf_hip_selftest_struct_oob": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]),

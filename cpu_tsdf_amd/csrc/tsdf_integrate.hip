@@ -27,8 +27,9 @@
 
 struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
-  float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path)
-  float hb_u, hb_v;          // 1/2 - band
+  float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path); cxf/cyf carry the +band shift
+  float hb_u, hb_v;          // certificate threshold: fract(R~) > 2 * band
+  int hinge_fixed;           // PACKED: (p*w + p)/(w + 1) == p for every stored weight w, p = pos_over_neg (host-checked)
   int neg_in_window;         // max_dist_pos/neg inside the scale-free divider's window
   unsigned kmax;             // PACKED layout: saturation count ceil(max_weight)
   int wmax_is_int;           // PACKED layout: max_weight is an integer (then every stored weight is)
@@ -63,22 +64,21 @@ static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, cons
   return in ? v * a.W + u : -1;
 }
 
-// The same in fp32, with a certificate.  R~ = (g*f~)*rcp(z) + c~ differs from the reference's double
-// value R by less than `band` whenever R~ lies in [-1-band, W+band] (derivation in DESIGN.md: three
-// roundings of 2^-24, v_rcp_f32's 1 ulp taken as 2^-22, fx/cx conversion, the final add; host computes
-// band with a 1.5x margin).  Therefore:
-//   * R~ outside that interval  =>  R is outside the image too, and so is trunc(R~) (or the point is
-//     flagged below);
-//   * R~ farther than band from every integer (|fract(R~) - 1/2| < 1/2 - band)  =>  trunc(R~) == trunc(R).
-// Anything else (including a non-finite R~, whose fract is 0 or NaN) is flagged ambiguous and recomputed
-// by project_exact.  hb = 1/2 - band.
+// The same in fp32, with a certificate.  R~ = fma(g*f~, rcp(z), c~ + s) is the reference's double value R shifted
+// by s = band, computed with an error below band whenever R~ lies within a pixel of the image (one rounding of g*f~,
+// v_rcp_f32's 1 ulp taken as 2^-22, the conversions of f and of c + s, the single rounding of the fma; the host
+// computes band with a 1.5x margin), so R lies in (R~ - 2 band, R~).  Therefore:
+//   * fract(R~) > 2 band  =>  floor(R~) < R < R~ < floor(R~) + 1: R and R~ share the integer cell, and a cell has one
+//     truncation ((-1, 0) and [0, 1) both give 0, for R and for R~ alike);
+//   * R~ far outside the image  =>  R is outside too, and so is trunc(R~) (or the point is flagged below).
+// Anything else (an R~ sitting on an integer, a non-finite R~ whose fract is 0 or NaN) is flagged ambiguous and
+// recomputed by project_exact.  One multiply, one fma, one fract, one compare and one conversion per coordinate.
 static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float gx, float gy, float gz,
                                                    bool &ambiguous) {
   const float y = __builtin_amdgcn_rcpf(gz);
-  const float ru = (gx * a.fxf) * y + a.cxf;
-  const float rv = (gy * a.fyf) * y + a.cyf;
-  const bool cert = fabsf(__builtin_amdgcn_fractf(ru) - 0.5f) < a.hb_u &&
-                    fabsf(__builtin_amdgcn_fractf(rv) - 0.5f) < a.hb_v;  // false for NaN
+  const float ru = __builtin_fmaf(gx * a.fxf, y, a.cxf);
+  const float rv = __builtin_fmaf(gy * a.fyf, y, a.cyf);
+  const bool cert = __builtin_amdgcn_fractf(ru) > a.hb_u && __builtin_amdgcn_fractf(rv) > a.hb_v;  // false for NaN
   const int u = (int)ru, v = (int)rv;  // v_cvt_i32_f32: truncates, saturates, NaN -> 0
   // an uncertified point far outside the image is recomputed needlessly, never wrongly
   ambiguous = !cert;
@@ -135,18 +135,30 @@ static __device__ __forceinline__ void add_observation_ieee(float &d, float &w, 
 //    the 1/D that separates a non-integer N/D from the next integer.  floor(N/D) is computed as
 //    trunc(fma(N, y, y/2)) = trunc((N + 1/2) * y): the true value lies >= 1/(2D) >= 4.8e-4 from the integers
 //    on either side, the two roundings and y's error move it by < 256 * 2^-23 = 3.1e-5.
-template <bool COLOR>
+//    With TSDF_COLOR_PK the conversion and the packing are one v_cvt_pk_u8_f32 per channel (it writes one byte of a
+//    word and keeps the others: `base` carries byte 3, the PACKED layout's count).  That instruction rounds to nearest
+//    even (tsdf_hip_selftest_cvt_pk_u8 / tests/test_div_gpu.py), so the value converted is (N + 1/2) * y - 1/2, which
+//    lies within 1/2 - 1/(2D) of floor(N/D).
+template <bool COLOR, bool DIST = true>
 static __device__ __forceinline__ void add_observation_fast(float &d, float &w, uint32_t &rgb, float dn,
-                                                            uint32_t bgra, float wmax, const Rcp32 &rs) {
+                                                            uint32_t bgra, float wmax, const Rcp32 &rs, uint32_t base = 0u) {
   const float wsum = w + 1.f;  // rs = rcp32_prepare(wsum) (nb and y are all that is used)
   if (COLOR) {
+#if TSDF_COLOR_PK
+    const float hy = TSDF_COLOR_PK == 2 ? __builtin_fmaf(0.5f, rs.y, -0.5f) : 0.5f * rs.y;
+    const float t0 = __builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
+    const float t1 = __builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 8) & 255u), (float)((bgra >> 8) & 255u)), rs.y, hy);
+    const float t2 = __builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 16) & 255u), (float)(bgra & 255u)), rs.y, hy);
+    rgb = __builtin_amdgcn_cvt_pk_u8_f32(t0, 0u, __builtin_amdgcn_cvt_pk_u8_f32(t1, 1u, __builtin_amdgcn_cvt_pk_u8_f32(t2, 2u, base)));
+#else
     const float hy = 0.5f * rs.y;
     const uint32_t q0 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
     const uint32_t q1 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 8) & 255u), (float)((bgra >> 8) & 255u)), rs.y, hy);
     const uint32_t q2 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 16) & 255u), (float)(bgra & 255u)), rs.y, hy);
-    rgb = q0 | (q1 << 8) | (q2 << 16);
+    rgb = q0 | (q1 << 8) | (q2 << 16) | base;
+#endif
   }
-  d = div32_fast(d * w + dn, rs);
+  if (DIST) d = div32_fast(d * w + dn, rs);
   w = wsum;
   if (w > wmax) w = wmax;
 }
@@ -175,6 +187,12 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #endif
 #ifndef TSDF_EARLY_VOXEL_LOADS
 #define TSDF_EARLY_VOXEL_LOADS 0
+#endif
+#ifndef TSDF_COLOR_PK
+#define TSDF_COLOR_PK 0  // 1 / 2: colour bytes through v_cvt_pk_u8_f32, assuming it truncates / rounds to nearest even
+#endif
+#ifndef TSDF_SKIP_FIXED_HINGE
+#define TSDF_SKIP_FIXED_HINGE 1  // PACKED: waves whose observed voxels all stay at the hinge value skip the d ladder
 #endif
 #ifndef TSDF_WPE_PACKED
 #define TSDF_WPE_PACKED 6  // waves per SIMD the PACKED / colourless instances ask for (80 VGPRs: 7 waves = 72 VGPRs spills since the result-side guard)
@@ -313,7 +331,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         raw[j] = zs[j] - gzs[j];                                        // hpp:159
-        act[j] = pix[j] >= 0 && !isnan(zs[j]) && !(raw[j] < -a.neg);    // hpp:152, :193-196
+        // hpp:152, :193-196: pcl_isnan(pt.z) and raw < -neg both reject; gz is finite here, so a NaN depth is a NaN
+        // raw, and "raw >= -neg" is false for it and for every raw below -neg: one compare for both tests
+        act[j] = pix[j] >= 0 && raw[j] >= -a.neg;
         dn[j] = a.pos_over_neg;                                         // hpp:189-192: raw > pos clamps
         any |= act[j];
         any_div |= act[j] && !(raw[j] > a.pos);
@@ -357,7 +377,11 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         }
       }
       float dv[4], wv[4];
-      uint32_t cv[4];
+      uint32_t cv[4], k1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)  // PACKED: the count after this observation, k' = min(k + 1, kmax), as byte 3 of a word
+        // (saturate BEFORE adding: with kmax == 255 an in-place add would wrap byte 3 to zero)
+        k1[j] = !PACKED ? 0u : (kw[j] >> 24) >= a.kmax ? (a.kmax << 24) : (kw[j] & 0xff000000u) + 0x01000000u;
       // F32W: the fast update is exact if update_is_safe().  PACKED: the divisor k + 1 is an integer in
       // [1, 256] (unless the weight sits at a non-integer max_weight), for which the scale-free ladder is
       // exact whenever its RESULT is a normal number (residuals of a normal numerator against an integer
@@ -375,31 +399,47 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && numerator_ok(d0[j] * w0[j] + dn[j]));
       }
 #endif
-      if (safe) {
+      // PACKED, free space: a wave none of whose observed voxels is inside the truncation band (no `any_div`) and all of
+      // whose observed voxels already sit at the hinge value p sees (p*w + p)/(w + 1), which the host has checked to
+      // be p for every weight (a.hinge_fixed): d keeps its bits and the four ladders and their guards are skipped.
+      bool d_moves = true;
+#if TSDF_SKIP_FIXED_HINGE
+      if (PACKED && a.hinge_fixed) {
+        bool off_hinge = any_div;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) off_hinge |= act[j] && d0u[j] != __float_as_uint(a.pos_over_neg);
+        d_moves = __ballot(off_hinge) != 0ull;  // wave-uniform: one scalar branch
+      }
+#endif
+      if (safe) {
+        Rcp32 rs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // colour and weight: every observed voxel
           dv[j] = d0[j];
           wv[j] = w0[j];
           cv[j] = c0[j];
           if (PACKED) {
-            Rcp32 rs;
-            rs.nb = -(w0[j] + 1.f);
-            rs.y = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
-            add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs);
+            rs[j].nb = -(w0[j] + 1.f);
+            rs[j].y = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
           } else {
-            add_observation_fast<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rcp32_prepare(w0[j] + 1.f));
+            rs[j] = rcp32_prepare(w0[j] + 1.f);
           }
+          add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
         }
-#if TSDF_GUARD_ON_RESULT
-        if (PACKED) {
-          // the guard, on the RESULT (one v_cmp_class per voxel): a normal quotient is the correctly rounded one
-          // (tests/test_div_gpu.py::test_count_divider_*); zero, subnormal, infinite or NaN -- or a weight sitting
-          // at a non-integer max_weight, whose divisor is no count -- sends the quad through the IEEE path below
+        if (d_moves) {  // distance
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && __builtin_amdgcn_classf(dv[j], 0x108));
-        }
+          for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
+#if TSDF_GUARD_ON_RESULT
+          if (PACKED) {
+            // the guard, on the RESULT (one v_cmp_class per voxel): a normal quotient is the correctly rounded one
+            // (tests/test_div_gpu.py::test_count_divider_*); zero, subnormal, infinite or NaN -- or a weight sitting
+            // at a non-integer max_weight, whose divisor is no count -- sends the quad through the IEEE path below
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && __builtin_amdgcn_classf(dv[j], 0x108));
+          }
 #endif
+        }
       }
       if (!safe) {
         asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
@@ -409,6 +449,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           wv[j] = w0[j];
           cv[j] = c0[j] & 0xffffffu;
           add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax);
+          if (COLOR) cv[j] |= k1[j];  // both flavours return the colour with the new count in byte 3
         }
       }
       uint32_t diff_d = 0u, diff_w = 0u, diff_c = 0u, k4n = 0u;
@@ -416,15 +457,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const uint32_t c_before[4] = {c0[0], c0[1], c0[2], c0[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (PACKED) {
-          // count after this observation: k' = min(k + 1, kmax), done on byte 3 in place
-          // (saturate BEFORE adding: with kmax == 255 the in-place add would wrap byte 3 to zero)
-          const uint32_t k1 = (kw[j] >> 24) >= a.kmax ? (a.kmax << 24) : (kw[j] & 0xff000000u) + 0x01000000u;
-          if (COLOR)
-            cv[j] = (cv[j] & 0xffffffu) | k1;  // both add_observation flavours return a 24-bit colour
-          else
-            k4n |= (act[j] ? k1 : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
-        }
+        if (PACKED && !COLOR) k4n |= (act[j] ? k1[j] : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
         dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
         wn_u[j] = act[j] ? __float_as_uint(wv[j]) : w0u[j];
         cv[j] = act[j] ? cv[j] : c0[j];
@@ -546,21 +579,21 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   hh.fy = p.fy;
   a.fxf = (float)p.fx;
   a.fyf = (float)p.fy;
-  a.cxf = (float)p.cx;
-  a.cyf = (float)p.cy;
   {
-    // |R~ - R| <= |q|*(3*2^-24 + 2^-22) + (|c| + |R~|)*2^-24 + conversion of f and c, for R~ within one
-    // pixel of the image; see project_fast.  1.5x margin on top.
+    // |R~ - (R + s)| <= |q|*(2*2^-24 + 2^-22) + (n + 2)*2^-24 + conversion of f and of c + s, for R~ within one
+    // pixel of the image (q = g*f/z, |q| <= max(|c| + 1, n + 1 - c)); see project_fast.  1.5x margin on top; s = band.
     auto band = [](double c, int n) {
       const double q = std::max(fabs(c) + 1.0, fabs((double)n + 1.0 - c));
-      const double e = q * (3.0 / 16777216.0 + 1.0 / 4194304.0) * 1.0000005 + (fabs(c) + n + 1.0) / 16777216.0 +
-                       f32_ulp((float)c) + 1e-9;
-      return (float)(1.5 * e);
+      const double e = q * (2.0 / 16777216.0 + 1.0 / 4194304.0) * 1.0000005 + ((double)n + 2.0) / 16777216.0 +
+                       2.0 * f32_ulp((float)c) + 1e-9;
+      return nextafterf((float)(1.5 * e), INFINITY);
     };
     hh.band_u = band(p.cx, p.image_width);
     hh.band_v = band(p.cy, p.image_height);
-    a.hb_u = nextafterf(0.5f - hh.band_u, 0.f);  // rounded toward the conservative side
-    a.hb_v = nextafterf(0.5f - hh.band_v, 0.f);
+    a.cxf = (float)(p.cx + (double)hh.band_u);
+    a.cyf = (float)(p.cy + (double)hh.band_v);
+    a.hb_u = nextafterf(2.f * hh.band_u, INFINITY);  // rounded toward the conservative side
+    a.hb_v = nextafterf(2.f * hh.band_v, INFINITY);
   }
   a.zmin = p.min_sensor_dist;
   // !(gz < zmin) && gz > 0 for a non-NaN gz: gz >= zmin when zmin > 0 (<=> gz > the float just below zmin), else gz > 0
@@ -573,6 +606,21 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.kmax = h->kmax;
   a.wmax_is_int = p.max_weight == floorf(p.max_weight);
   a.pos_over_neg = p.max_dist_pos / p.max_dist_neg;
+  {
+    // A voxel sitting at the hinge value p that is observed in free space again stays at p if (p*w + p)/(w + 1) == p in
+    // fp32 for every weight the PACKED layout can hold (always so for p == 1): then such a quad skips the d ladder.
+    const volatile float pv = a.pos_over_neg;
+    bool fixed = h->packed && a.wmax_is_int && std::isnormal(a.pos_over_neg);
+    for (unsigned k = 0; fixed && k <= h->kmax; ++k) {
+      const volatile float w = fminf((float)k, p.max_weight);
+      const volatile float num = pv * w;
+      const volatile float sum = num + pv;
+      const volatile float den = w + 1.f;
+      const volatile float q = sum / den;
+      fixed = q == pv;
+    }
+    a.hinge_fixed = fixed ? 1 : 0;
+  }
   a.neg_in_window = p.max_dist_neg >= 0x1p-20f && p.max_dist_neg <= 0x1p20f && p.max_dist_pos <= 0x1p20f;
   a.W = p.image_width;
   a.H = p.image_height;
@@ -1528,6 +1576,28 @@ extern "C" int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, fl
   (void)hipFree(dk);
   (void)hipFree(dout);
   (void)hipFree(df);
+  return TSDF_HIP_OK;
+}
+
+// Test hook: v_cvt_pk_u8_f32 of in[i] into byte 1 of 0xAABBCCDD (how it rounds, that it saturates, that it keeps the
+// other bytes).
+static __global__ void k_selftest_cvt_pk_u8(const float *in, uint32_t *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __builtin_amdgcn_cvt_pk_u8_f32(in[i], 1u, 0xAABBCCDDu);
+}
+
+extern "C" int tsdf_hip_selftest_cvt_pk_u8(const float *in, size_t n, uint32_t *out) {
+  if (!in || !out || !n) return TSDF_HIP_E_INVALID;
+  float *d_in = nullptr;
+  uint32_t *d_out = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&d_in, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&d_out, n * 4));
+  TSDF_HIP_TRY(hipMemcpy(d_in, in, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_cvt_pk_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, d_out, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
   return TSDF_HIP_OK;
 }
 

@@ -370,6 +370,10 @@ int tsdf_hip_selftest_div_f64(const double *a, const double *b, double *out, siz
  * reciprocal + scale-free ladder where its result is a normal number (fast[i] = 1), IEEE division elsewhere. */
 int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, uint8_t *fast, size_t n);
 
+/* Test hook: out[i] = v_cvt_pk_u8_f32(in[i], byte 1, 0xAABBCCDD) -- the instruction the colour update packs its bytes
+ * with; the tests pin its rounding (nearest even), saturation and byte selection. */
+int tsdf_hip_selftest_cvt_pk_u8(const float *in, size_t n, uint32_t *out);
+
 /* Test hooks for TSDF_COLOR_LAB: the device's RGB2LAB of n pixels (b,g,r,a bytes each -> L,A,B,0 floats each) and
  * LAB2RGB of n L,A,B triples (-> r | g<<8 | b<<16 each); references octree.cpp:436-481 and :483-527. */
 int tsdf_hip_selftest_rgb2lab(const uint8_t *bgra, size_t n, float *lab4);

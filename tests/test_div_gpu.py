@@ -170,3 +170,21 @@ def test_count_divider_equals_ieee_division(gpu, seed):
     assert same.all(), (int((~same).sum()), a[~same][:5], k[~same][:5], out[~same][:5], want[~same][:5])
     assert fast[4 * m:5 * m].mean() > 0.999          # the kernel's own numerators take the ladder
     assert fast[np.abs(want) < tiny].sum() == 0       # subnormal and zero quotients never do
+
+
+def test_cvt_pk_u8_rounds_to_nearest_even_and_saturates(gpu):
+    """v_cvt_pk_u8_f32, the one-instruction convert-and-pack the colour update can be built with (TSDF_COLOR_PK, an A/B
+    switch that is off: measured slower than convert + shift-or): it rounds to nearest even, saturates to [0, 255],
+    turns NaN into 0 and leaves the other three bytes alone.  The shipped path truncates with v_cvt_u32_f32."""
+    rng = np.random.RandomState(5)
+    x = np.concatenate([np.float32([0.25, 0.5, 0.75, 1.5, 2.5, 3.5, 254.5, 255.4, 255.5, 256.7, 1e9, -0.25, -0.5, -3.0,
+                                    np.nan, np.inf, -np.inf, 0.49999997, 1.4999999]),
+                        rng.uniform(-2, 258, 1 << 16).astype(np.float32),
+                        (rng.randint(0, 256, 1 << 12) + 0.5).astype(np.float32)])
+    out = np.empty(len(x), dtype=np.uint32)
+    capi.check(capi.load().tsdf_hip_selftest_cvt_pk_u8(capi.as_f32p(x), len(x), out.ctypes.data_as(C.POINTER(C.c_uint32))),
+               "cvt_pk_u8")
+    assert ((out & 0xffff00ff) == 0xAABB00DD).all()
+    want = np.where(np.isnan(x), 0, np.clip(np.rint(np.nan_to_num(x.astype(np.float64), nan=0.0, posinf=1e9, neginf=-1e9)),
+                                            0, 255)).astype(np.uint32)
+    assert np.array_equal((out >> 8) & 255, want)

@@ -65,6 +65,27 @@ def test_parity_sensor_bounds_and_truncation(gpu):
     assert d.max() == pytest.approx(0.02 / 0.05, rel=1e-6)
 
 
+@pytest.mark.parametrize("trunc", [(0.03, 0.03), (0.06, 0.03), (0.1, 0.03), (0.02, 0.05), (0.0301, 0.0299)])
+@pytest.mark.parametrize("color", [False, True])
+def test_free_space_voxels_resting_at_the_hinge(gpu, trunc, color):
+    """Waves whose observed voxels all sit at the hinge value p = pos/neg and see free space again skip the d update
+    when the host has checked (p*w + p)/(w + 1) == p for every weight; hinge values for which that identity holds
+    (1, 2) and for which it may not (3.33.., 0.4, 1.0067) must all equal the oracle, frame after frame from the same
+    pose (every free-space voxel re-observed at the hinge) and through weight saturation."""
+    vol, sc = make_volume(64, color=color, trunc=trunc, max_weight=4.0)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i in range(7):
+        tr = synth.turntable_pose(i // 3, 8, sc.size)      # three frames per pose
+        dep, col = sc.depth(tr, noise_seed=5 + i), sc.bgra(i)
+        n_gpu = vol.integrateCloud(dep, col if color else None, tr, count=True)
+        assert n_gpu == ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+        compare(vol, ov)
+    p = np.float32(trunc[0]) / np.float32(trunc[1])
+    assert (ov.d == p).mean() > 0.2
+    vol.close()
+
+
 def test_parity_default_grid_3m_512_nondyadic(gpu):
     # reference defaults: 3 m / 512 (voxel 3*2^-9), 640x480 f=525, sensor 0.3..3 m; 64-plane slab
     from cpu_tsdf_amd.volume import TSDFVolumeOctree
