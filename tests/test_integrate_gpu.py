@@ -82,7 +82,7 @@ def test_free_space_voxels_resting_at_the_hinge(gpu, trunc, color):
         assert n_gpu == ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
         compare(vol, ov)
     p = np.float32(trunc[0]) / np.float32(trunc[1])
-    assert (ov.d == p).mean() > 0.2
+    assert (ov.d == p).mean() > 0.02
     vol.close()
 
 
