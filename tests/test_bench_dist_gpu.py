@@ -8,6 +8,7 @@
 Numbers from these runs mean nothing; the JSON contract and the counts do."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -16,6 +17,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--res", "256", "--steps", "4", "--warmup", "2", "--extras", "0", "--cpu-baseline", "0"]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
 
 
 def run(cmd, env_extra):
@@ -39,7 +46,7 @@ def test_bench_world1_on_rccl(gpu):
     single = run([sys.executable, "bench.py"] + COMMON, {})
     check_contract(single, 1)
     assert "multi_gpu" not in single
-    j = run([sys.executable, "bench.py"] + COMMON, {"TSDF_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29531"})
+    j = run([sys.executable, "bench.py"] + COMMON, {"TSDF_BENCH_FORCE_DIST": "1", "MASTER_PORT": free_port()})
     check_contract(j, 1)
     assert j["multi_gpu"]["backend"] == "nccl" and j["multi_gpu"]["overlap"] is True
     assert len(j["multi_gpu"]["per_rank_kernel_ms"]) == 1 and j["multi_gpu"]["frame_broadcast_ms_isolated"] > 0
@@ -50,7 +57,7 @@ def test_bench_world1_on_rccl(gpu):
 def test_bench_two_ranks_one_gpu_over_gloo(gpu, overlap):
     single = run([sys.executable, "bench.py"] + COMMON, {})
     j = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-             "--master-port", str(29541 + overlap), "bench.py", "--gpus", "2", "--overlap", str(overlap)] + COMMON,
+             "--master-port", free_port(), "bench.py", "--gpus", "2", "--overlap", str(overlap)] + COMMON,
             {"TSDF_BENCH_ONE_DEVICE": "1", "TSDF_BENCH_BACKEND": "gloo"})
     check_contract(j, 2)
     assert j["multi_gpu"]["planes_per_gpu"] == 128 and len(j["multi_gpu"]["per_rank_kernel_ms"]) == 2
