@@ -4,6 +4,8 @@
 
 #include <string>
 #include <stdlib.h>
+#include <stdio.h>
+
 #include <algorithm>
 #include <string.h>
 
@@ -331,6 +333,25 @@ static void free_volume(tsdf_hip_volume *v) {
   delete v;
 }
 
+// integrateCloud in the reference first drops octree cells with pcl::FrustumCulling (getFrustumCulledVoxels,
+// tsdf_volume_octree.cpp:619-652): a pyramid of 1.1 x the angle 2 atan(W/2 / fx) (and likewise vertically) around the
+// optical AXIS, between min_ and max_sensor_dist_ -- the principal point does not enter.  For an ordinary camera that
+// pyramid contains every ray of the image, the cull removes only voxels updateVoxel would reject anyway, and the dense
+// grid (which has no cull that could change results) agrees with the reference voxel for voxel.  It does NOT contain
+// the image when the principal point sits more than ~10 % of the half-width off centre, or when max_sensor_dist is not
+// a finite, moderate number (the frustum's corners become inf/NaN and the reference integrates nothing): then the
+// reference skips voxels that project into the image and this library integrates them.  This function says which
+// regime a parameter set is in (1 = the reference's cull is a no-op, results are identical).
+extern "C" int tsdf_hip_reference_cull_is_noop(const tsdf_params *p) {
+  if (!p || !(p->fx > 0.0) || !(p->fy > 0.0) || p->image_width <= 0 || p->image_height <= 0) return 0;
+  if (!(p->max_sensor_dist > 0.f) || !(p->max_sensor_dist < 1e15f)) return 0;
+  const double W = p->image_width, H = p->image_height;
+  const double th = tan(1.1 * atan(0.5 * W / p->fx)) * (1.0 - 1e-5), tv = tan(1.1 * atan(0.5 * H / p->fy)) * (1.0 - 1e-5);
+  if (!(th > 0.0) || !(tv > 0.0)) return 0;  // 1.1 x the half angle reaches 90 degrees
+  // (int)(x * fx / z + cx) in [0, W) accepts x * fx / z + cx in (-1, W)
+  return (p->cx + 1.0) / p->fx <= th && (W - p->cx) / p->fx <= th && (p->cy + 1.0) / p->fy <= tv && (H - p->cy) / p->fy <= tv;
+}
+
 extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (!p || !out) return TSDF_HIP_E_INVALID;
   *out = nullptr;
@@ -345,6 +366,15 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
       p->color_mode < TSDF_COLOR_RGB || p->color_mode > TSDF_COLOR_LAB) {
     tsdf_set_error("bad image size / truncation / halo / xform_order / layout / color_mode");
     return TSDF_HIP_E_INVALID;
+  }
+  if (!tsdf_hip_reference_cull_is_noop(p)) {
+    static bool said = false;
+    if (!said) {
+      said = true;
+      fprintf(stderr, "libtsdf_hip: note: with this principal point / sensor range the reference's frustum cull "
+                      "(tsdf_volume_octree.cpp:619-652) drops voxels that project into the image; this library "
+                      "integrates them (tsdf_hip_reference_cull_is_noop, INTEGRATION.md)\n");
+    }
   }
   const bool lab = p->integrate_color && p->color_mode == TSDF_COLOR_LAB;
   const bool rgbn = (p->integrate_color && p->color_mode == TSDF_COLOR_RGB_NORMALIZED) || lab;  // float colour state

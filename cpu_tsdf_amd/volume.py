@@ -380,6 +380,11 @@ class TSDFVolumeOctree:
                                           capi.as_u8p(rgb) if rgb is not None else None), "download")
         return d, w, rgb
 
+    def referenceCullIsNoop(self):
+        """Not in the reference: True if its frustum cull (tsdf_volume_octree.cpp:619-652) cannot change results for the
+        configured camera, i.e. this volume's voxels equal the reference's (tsdf_hip_reference_cull_is_noop)."""
+        return bool(capi.load().tsdf_hip_reference_cull_is_noop(C.byref(self._p)))
+
     def downloadColorState(self, z0=None, nz=None):
         """Not in the reference (its members are public): the float colour state of "RGBNormalized" (r_n, g_n, b_n, i)
         or "LAB" (L, A, B) voxels as an array (planes, nz, ny, nx)."""

@@ -258,6 +258,14 @@ int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], const float
                                   int rank, int world, int32_t *d_records, size_t count);
 int tsdf_hip_render_halo(const tsdf_params *p);
 
+/* 1 if the reference's frustum cull (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652: pcl::FrustumCulling with
+ * 1.1 x the field of view AROUND THE OPTICAL AXIS, near = min_sensor_dist, far = max_sensor_dist) cannot change results
+ * for these parameters, i.e. the culling pyramid contains every ray of the image: then this library's voxels equal the
+ * reference's.  0 if the principal point lies so far off centre (more than ~10 % of the half-width) or max_sensor_dist
+ * is so large (>= 1e15, inf) that the reference drops voxels which project into the image -- this library integrates
+ * them and says so once on stderr.  tests/test_oracle_golden.py shows both regimes against the compiled reference. */
+int tsdf_hip_reference_cull_is_noop(const tsdf_params *p);
+
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
  *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
  *   ok n bytes: 1 where the reference returns true.  A Z-slab handle answers only for points whose lower-corner
@@ -419,7 +427,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 8
+#define TSDF_HIP_ABI_VERSION 9
 
 #ifdef __cplusplus
 }
