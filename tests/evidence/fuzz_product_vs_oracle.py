@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""The GPU twin of fuzz_oracle_vs_reference.py: the PRODUCT (HIP kernels through the C ABI) against the oracle over the
+same random space of volumes, cameras and depth images -- voxels after fusion (both layouts), renderView, marching cubes
+and getFxn / gradient / Hessian.  Needs a GPU.  One line per case, exit code 1 if anything differs.
+usage: python tests/evidence/fuzz_product_vs_oracle.py [--cases 100] [--seed 1]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from cpu_tsdf_amd import capi, synth  # noqa: E402
+from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree  # noqa: E402
+from oracle.oracle import OracleVolume  # noqa: E402
+from tests.evidence.fuzz_oracle_vs_reference import same  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.RandomState(a.seed)
+    bad = []
+    for case in range(a.cases):
+        res = int(rng.choice([16, 32, 64, 64, 128, 136]))   # 136: not a power of two (no octree levels), pitch padding
+        size = float(rng.choice([0.125, 0.3, 1.0, 3.0]))
+        W, H = [(48, 36), (64, 48), (80, 60), (160, 120)][rng.randint(4)]
+        f = float(rng.uniform(0.5, 1.6)) * W
+        fx, fy = f, f * float(rng.uniform(0.9, 1.1))
+        cx, cy = W / 2 - 0.5 + float(rng.uniform(-0.3, 0.3)) * W / 2, H / 2 - 0.5 + float(rng.uniform(-0.3, 0.3)) * H / 2
+        zmin, zmax = float(rng.choice([0.0, 0.05 * size, 0.4 * size])), float(rng.uniform(1.5, 4.0)) * size
+        pos, neg = float(rng.uniform(0.03, 0.25)) * size, float(rng.uniform(0.03, 0.25)) * size
+        wmax = float(rng.choice([100.0, 2.0, 3.5, 1.0, 255.0, 300.0]))
+        color = bool(rng.randint(2))
+        layout = int(rng.choice([capi.LAYOUT_AUTO, capi.LAYOUT_F32W]))
+        order = int(rng.randint(2))
+        v = TSDFVolumeOctree()
+        v.setResolution(res, res, res)
+        v.setGridSize(size, size, size)
+        v.setImageSize(W, H)
+        v.setCameraIntrinsics(fx, fy, cx, cy)
+        v.setSensorDistanceBounds(zmin, zmax)
+        v.setDepthTruncationLimits(pos, neg)
+        v.setWeightTruncationLimit(wmax)
+        v.setIntegrateColor(color)
+        v.setTransformOrder(order)
+        v.setLayout(layout)
+        v.reset()
+        ov = OracleVolume(v._p)
+        sc = synth.Scene(size, W, H, sphere=float(rng.uniform(0.15, 0.35)), box=float(rng.uniform(0.35, 0.49)))
+        sc.fx, sc.fy, sc.cx, sc.cy = fx, fy, cx, cy
+        what = []
+        for i in range(int(rng.randint(2, 6))):
+            r = float(rng.uniform(0.1, 2.4)) * size
+            eye = rng.normal(size=3)
+            eye *= r / np.linalg.norm(eye)
+            tr = synth.look_at_pose(eye, target=rng.uniform(-0.2, 0.2, 3) * size)
+            dep = sc.depth(tr, noise_seed=int(rng.randint(1 << 30)), noise_sigma=0.01 * size)
+            junk = rng.rand(H, W)
+            dep[junk < 0.03] = np.nan
+            dep[(junk >= 0.03) & (junk < 0.04)] = 0.0
+            dep[(junk >= 0.04) & (junk < 0.05)] = np.inf
+            col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
+            n_gpu = v.integrateCloud(dep, col if color else None, tr, count=True)
+            n_cpu = ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+            if n_gpu != n_cpu:
+                what.append(f"count{i}")
+        d, w, rgb = v.download()
+        if not (same(d, ov.d) and same(w, ov.w)):
+            what.append("voxels")
+        if color and not np.array_equal(rgb, ov.rgb):
+            what.append("rgb")
+        for k in range(2):
+            r = float(rng.uniform(0.05, 2.0)) * size
+            eye = rng.normal(size=3)
+            eye *= r / np.linalg.norm(eye)
+            tr = synth.look_at_pose(eye, target=rng.uniform(-0.3, 0.3, 3) * size)
+            if not same(v.renderView(tr, 1 + k, camera_frame=False), ov.raycast(tr, 1 + k)):
+                what.append(f"renderView{k}")
+        for wmin in (0.0, 1.5):
+            mc = MarchingCubesTSDFOctree()
+            mc.setInputTSDF(v)
+            mc.setMinWeight(wmin)
+            mc.setColorByRGB(color)
+            mesh = mc.reconstruct()
+            v_m, c_m, _ = ov.march(wmin, 1 if color else 0)
+            if not same(mesh["vertices"], v_m) or (color and not np.array_equal(mesh["rgb"], c_m)):
+                what.append(f"mesh(w>={wmin})")
+        pts = (rng.uniform(-0.55, 0.55, (400, 3)) * size).astype(np.float32)
+        ok, val, grad, hess = v.sample(pts)
+        ook, oval, ograd, ohess = ov.sample(pts)
+        if not (np.array_equal(ok, ook) and same(val[ok], oval[ok]) and same(grad[ok], ograd[ok]) and same(hess[ok], ohess[ok])):
+            what.append("getFxn")
+        packed = v.getLayout() == capi.LAYOUT_PACKED
+        v.close()
+        print(f"case {case:4d}: res {res:3d} size {size:5.3f} {W}x{H} f {fx:6.1f} c ({cx - (W / 2 - 0.5):+5.1f},{cy - (H / 2 - 0.5):+5.1f}) "
+              f"z [{zmin:.3f},{zmax:.2f}] trunc {pos / size:.2f}/{neg / size:.2f} wmax {wmax} colour {int(color)} "
+              f"{'packed' if packed else 'f32w'} order {order} observed {int((ov.w > 0).sum()):8d}  "
+              f"{'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
+        if what:
+            bad.append((case, what))
+    print(f"{a.cases} cases, seed {a.seed}: {len(bad)} with differences {bad[:20]}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
