@@ -587,13 +587,15 @@ int tsdf_ray_merge(hipStream_t stream, int *state, const int *delta, int64_t n, 
 }
 
 // Planes of halo a Z-slab handle needs on each side for tsdf_hip_raycast_advance: the refinement walk goes
-// back at most one main-loop step (<= max(leaf/4, max_dist_neg) for |d| <= 1) plus one refinement step,
-// and the trilinear / central-difference samples reach two more voxels.
+// back at most one main-loop step plus one refinement step, and the trilinear / central-difference samples reach two
+// more voxels.  A main-loop step is max(leaf/4, |d| * max_dist_neg) (.cpp:360) and d lies in [-1, max_dist_pos /
+// max_dist_neg], so the longest one is max(max_dist_neg, max_dist_pos) -- the hinge value exceeds 1 when the
+// truncation is asymmetric (found by tests/evidence/fuzz_product_vs_oracle.py; before, the halo assumed |d| <= 1).
 extern "C" int tsdf_hip_render_halo(const tsdf_params *p) {
   if (!p || p->res[2] <= 0 || !(p->size[2] > 0)) return -1;
   const double vs = (double)p->size[2] / p->res[2];
   const double leaf = (double)p->size[0] / p->res[0];
-  const double step = std::max(leaf / 4, (double)p->max_dist_neg);
+  const double step = std::max(leaf / 4, (double)std::max(p->max_dist_neg, p->max_dist_pos));
   return (int)ceil(step / vs) + 4;
 }
 

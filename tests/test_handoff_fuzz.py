@@ -21,7 +21,9 @@ def test_random_small_configurations():
         world = int(rng.randint(2, 6))
         W, H = 64, 48
         sc = synth.scene_a(res, W, H)
-        trunc = float(rng.choice([0.03, 0.012]))
+        # asymmetric truncation too: the hinge value max_dist_pos / max_dist_neg then exceeds 1 and free-space steps are
+        # max_dist_pos long, which the halo has to cover (tsdf_hip_render_halo once assumed |d| <= 1)
+        pos, neg = [(0.03, 0.03), (0.012, 0.012), (0.09, 0.02), (0.02, 0.05)][rng.randint(4)]
 
         def configure(v):
             v.setResolution(res, res, res)
@@ -29,7 +31,7 @@ def test_random_small_configurations():
             v.setImageSize(W, H)
             v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
             v.setSensorDistanceBounds(0.0, 3 * sc.size)
-            v.setDepthTruncationLimits(trunc, trunc)
+            v.setDepthTruncationLimits(pos, neg)
             v.setIntegrateColor(False)
         halo = render_halo(configure)
         cuts = [slab_range(res, world, r) for r in range(world)]
