@@ -332,6 +332,10 @@ def main():
     vol.reset()
     lib = capi.load()
     h = vol._need()
+    probe_ms, chosen = (C.c_float * 4)(), C.c_int32(0)
+    n_tried = lib.tsdf_hip_alloc_probe(h, probe_ms, C.byref(chosen))
+    placement = {"candidates_tried": int(n_tried), "probe_sweep_ms": [round(float(x), 3) for x in probe_ms[:max(1, n_tried)]],
+                 "kept": int(chosen.value)}
 
     calibration = None
     if args.calib:
@@ -491,6 +495,7 @@ def main():
                 "grid": list(res3), "image": [W, H], "color": bool(args.color),
                 "layout": "packed" if packed else "f32w",
                 "observed_voxels_per_frame": n_obs_all,
+                "plane_placement": placement,   # tsdf_hip_create keeps the fastest of up to 3 allocations of the planes
                 "parallelism": f"zslab{world}",
             },
             "roofline": {

@@ -117,6 +117,7 @@ SIGNATURES = {
     "tsdf_hip_raycast_advance_list": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "tsdf_hip_render_halo": (C.c_int, [C.POINTER(TsdfParams)]),
     "tsdf_hip_reference_cull_is_noop": (C.c_int, [C.POINTER(TsdfParams)]),
+    "tsdf_hip_alloc_probe": (C.c_int, [C.c_void_p, _f32p, C.POINTER(C.c_int32)]),
     "tsdf_hip_sample": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, _f32p, _f32p, _u8p]),
     "tsdf_hip_lookup_rgb": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _u8p, _u8p]),
     "tsdf_hip_march": (C.c_int, [C.c_void_p, C.c_float, C.c_int, _u64p]),

@@ -37,6 +37,9 @@ struct tsdf_hip_volume {
   float *cn[4] = {nullptr, nullptr, nullptr, nullptr};
   float *lab_lut = nullptr;
   float4 *lab_img = nullptr;
+  // placement selection at create (tsdf_core.hip): probe sweep of each candidate allocation, which one was kept
+  float alloc_probe_ms[4] = {-1.f, -1.f, -1.f, -1.f};
+  int alloc_tried = 0, alloc_chosen = 0;
   int packed = 0;
   unsigned kmax = 0;
   // hpp:200-204: weightings only a loaded .vol can switch on (tsdf_hip_set_weighting).  weight_by_depth integrates
@@ -185,6 +188,7 @@ struct TsdfTuning {
   int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
   int vol_chunk;       // edge of the voxel blocks save / load stream through host memory
   int plain_kernel;    // F32W volumes integrate through the plain per-voxel kernel (the weight_by_depth one, w_new = 1)
+  int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
 };
 const TsdfTuning &tsdf_tuning();
 

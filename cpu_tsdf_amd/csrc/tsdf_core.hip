@@ -52,7 +52,7 @@ static TsdfTuning &tuning_storage() {
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
-                         env_int("TSDF_HIP_PLAIN_KERNEL", 0)};
+                         env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3)};
   return t;
 }
 
@@ -78,6 +78,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.vol_chunk = std::max(1, value);
   else if (n == "plain_kernel")
     t.plain_kernel = value;
+  else if (n == "alloc_tries")
+    t.alloc_tries = std::max(1, value);
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;
@@ -333,6 +335,69 @@ static void free_volume(tsdf_hip_volume *v) {
   delete v;
 }
 
+// ---- placement of the voxel planes -----------------------------------------------------------------------------------
+// On MI355X the physical pages behind an allocation decide how well a streaming read-modify-write of it runs: the same
+// 2048^3 volume integrates in 17.9 ms or in 18.4-19.0 ms depending on the ALLOCATION (not on the process: destroying and
+// re-creating the volume inside one process changes it; tools/bimodal_probe.py), and a plain sweep of the planes shows
+// the same split (26.1-26.5 ms against 27.3-27.7 ms).  So tsdf_hip_create allocates a large volume's planes up to
+// `alloc_tries` times (tuning knob, default 3; two candidates are alive at once, so only while twice the volume fits),
+// sweeps each candidate once with the probe below and keeps the fastest placement.  Costs a few tenths of a second at
+// create; every later integrateCloud runs in the fast mode with probability 1 - 0.4^3 instead of 0.6.
+struct PlaneSet {
+  float *d = nullptr, *w = nullptr;
+  uint32_t *rgb = nullptr;
+  uint8_t *k8 = nullptr;
+};
+
+static __global__ void __launch_bounds__(256)
+k_probe_rmw(uint4 *__restrict__ a, uint4 *__restrict__ b, uint4 *__restrict__ c, int64_t n4, unsigned zero) {
+  // reads every word of the planes and writes it back unchanged (`zero` is 0, but only at run time)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint4 x = a[i];
+    x.x ^= zero;
+    a[i] = x;
+    if (b) {
+      uint4 y = b[i];
+      y.x ^= zero;
+      b[i] = y;
+    }
+    if (c) {
+      uint4 z = c[i];
+      z.x ^= zero;
+      c[i] = z;
+    }
+  }
+}
+
+static void release_planes(PlaneSet &s) {
+  if (s.d) (void)hipFree(s.d);
+  if (s.w) (void)hipFree(s.w);
+  if (s.rgb) (void)hipFree(s.rgb);
+  if (s.k8) (void)hipFree(s.k8);
+  s = PlaneSet();
+}
+
+// milliseconds of one probe sweep over the candidate (second of two sweeps), or a negative number on any error
+static float probe_planes(const PlaneSet &s, int64_t n, hipStream_t stream) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  const int64_t n4 = n / 4;
+  const unsigned grid = 256u * (unsigned)tsdf_tuning().blocks_per_cu;
+  bool ok = true;
+  for (int pass = 0; pass < 2 && ok; ++pass) {
+    ok &= hipEventRecord(e0, stream) == hipSuccess;
+    hipLaunchKernelGGL(k_probe_rmw, dim3(grid), dim3(256), 0, stream, (uint4 *)s.d, (uint4 *)s.w, (uint4 *)s.rgb, n4, 0u);
+    ok &= hipGetLastError() == hipSuccess;
+    ok &= hipEventRecord(e1, stream) == hipSuccess;
+    ok &= hipEventSynchronize(e1) == hipSuccess;
+    if (ok) ok &= hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ok ? ms : -1.f;
+}
+
 // integrateCloud in the reference first drops octree cells with pcl::FrustumCulling (getFrustumCulledVoxels,
 // tsdf_volume_octree.cpp:619-652): a pyramid of 1.1 x the angle 2 atan(W/2 / fx) (and likewise vertically) around the
 // optical AXIS, between min_ and max_sensor_dist_ -- the principal point does not enter.  For an ordinary camera that
@@ -430,10 +495,47 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     hipError_t _e = (expr);                                                \
     if (_e != hipSuccess) return bail(tsdf_hip_fail(_e, #expr, __FILE__, __LINE__)); \
   } while (0)
-  TRY_OR_BAIL(hipMalloc(&v->d, n * sizeof(float)));
-  if (!v->packed) TRY_OR_BAIL(hipMalloc(&v->w, n * sizeof(float)));
-  if (p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->rgb, n * sizeof(uint32_t)));
-  if (v->packed && !p->integrate_color) TRY_OR_BAIL(hipMalloc(&v->k8, n));
+  auto alloc_planes = [&](PlaneSet &s) -> hipError_t {
+    hipError_t e = hipMalloc(&s.d, n * sizeof(float));
+    if (e == hipSuccess && !v->packed) e = hipMalloc(&s.w, n * sizeof(float));
+    if (e == hipSuccess && p->integrate_color) e = hipMalloc(&s.rgb, n * sizeof(uint32_t));
+    if (e == hipSuccess && v->packed && !p->integrate_color) e = hipMalloc(&s.k8, n);
+    if (e != hipSuccess) release_planes(s);
+    return e;
+  };
+  PlaneSet best;
+  TRY_OR_BAIL(alloc_planes(best));
+  {
+    const size_t plane_bytes = (size_t)n * (4 + (v->packed ? 0 : 4) + (p->integrate_color ? 4 : 0) + (v->packed && !p->integrate_color ? 1 : 0));
+    const int tries = plane_bytes >= ((size_t)4 << 30) ? std::max(1, tsdf_tuning().alloc_tries) : 1;  // small volumes: nothing to gain
+    float best_ms = tries > 1 ? probe_planes(best, n, v->stream) : -1.f;
+    v->alloc_probe_ms[0] = best_ms;
+    v->alloc_tried = 1;
+    for (int t = 1; t < tries && best_ms > 0.f; ++t) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < plane_bytes + ((size_t)2 << 30)) break;
+      PlaneSet cand;
+      if (alloc_planes(cand) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      const float ms = probe_planes(cand, n, v->stream);
+      v->alloc_probe_ms[t < 4 ? t : 3] = ms;
+      v->alloc_tried = t + 1;
+      if (ms > 0.f && ms < best_ms) {
+        release_planes(best);
+        best = cand;
+        best_ms = ms;
+        v->alloc_chosen = t;
+      } else {
+        release_planes(cand);
+      }
+    }
+  }
+  v->d = best.d;
+  v->w = best.w;
+  v->rgb = best.rgb;
+  v->k8 = best.k8;
   if (rgbn)
     for (int c = 0; c < (lab ? 3 : 4); ++c) TRY_OR_BAIL(hipMalloc(&v->cn[c], n * sizeof(float)));
   if (lab) {
@@ -521,6 +623,17 @@ extern "C" int tsdf_hip_centers(tsdf_handle h, int axis, float *out) {
   if (!h || axis < 0 || axis > 2 || !out) return TSDF_HIP_E_INVALID;
   memcpy(out, h->h_ctr[axis].data(), h->h_ctr[axis].size() * sizeof(float));
   return TSDF_HIP_OK;
+}
+
+// Which placement tsdf_hip_create kept: ms[i] = probe sweep of candidate i (up to 4; negative = not probed), *chosen = its
+// index, return value = candidates tried (1 for small volumes, for alloc_tries = 1 and for multi handles' slabs in turn).
+extern "C" int tsdf_hip_alloc_probe(tsdf_handle h, float ms[4], int32_t *chosen) {
+  if (!h) return 0;
+  const tsdf_hip_volume *s = h->multi ? tsdf_multi_first(h) : h;
+  if (ms)
+    for (int i = 0; i < 4; ++i) ms[i] = s->alloc_probe_ms[i];
+  if (chosen) *chosen = s->alloc_chosen;
+  return s->alloc_tried;
 }
 
 extern "C" int tsdf_hip_layout(tsdf_handle h) {

@@ -258,6 +258,15 @@ int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], const float
                                   int rank, int world, int32_t *d_records, size_t count);
 int tsdf_hip_render_halo(const tsdf_params *p);
 
+/* Placement of the voxel planes (not in the reference).  On MI355X the physical pages behind an allocation decide how
+ * fast a streaming read-modify-write of it runs (a 2048^3 volume integrates in 17.9 ms or in 18.4-19.0 ms depending on
+ * the allocation), so tsdf_hip_create allocates the planes of a volume of 4 GiB or more up to
+ * `alloc_tries` times (tsdf_hip_set_tuning / TSDF_HIP_ALLOC_TRIES, default 3, 1 = off; a second candidate is only
+ * tried while it fits next to the first), sweeps each candidate once and keeps the fastest.  This reports what
+ * happened: ms[i] = probe sweep of candidate i (negative = not probed), *chosen = the one kept; returns the number of
+ * candidates tried. */
+int tsdf_hip_alloc_probe(tsdf_handle h, float ms[4], int32_t *chosen);
+
 /* 1 if the reference's frustum cull (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652: pcl::FrustumCulling with
  * 1.1 x the field of view AROUND THE OPTICAL AXIS, near = min_sensor_dist, far = max_sensor_dist) cannot change results
  * for these parameters, i.e. the culling pyramid contains every ray of the image: then this library's voxels equal the
@@ -425,7 +434,8 @@ int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes
 int tsdf_hip_selftest_occupancy_mc(int out[2]);
 
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
- * "mc_flush_at", "cull", "vol_chunk", "plain_kernel" -- the TSDF_HIP_* environment variables) at run time.  No knob changes results. */
+ * "mc_flush_at", "cull", "vol_chunk", "plain_kernel", "alloc_tries" -- the TSDF_HIP_* environment variables) at run time.  No knob
+ * changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 
 const char *tsdf_hip_error_string(int code);
@@ -433,7 +443,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 9
+#define TSDF_HIP_ABI_VERSION 10
 
 #ifdef __cplusplus
 }
