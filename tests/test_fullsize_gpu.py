@@ -94,3 +94,34 @@ def test_4096_grid_slab_with_1280x960_frames_matches_oracle(gpu):
     assert np.array_equal(w, o.w) and np.array_equal(rgb, o.rgb)
     assert (w > 0).mean() > 0.3
     vol.close()
+
+
+def test_plane_placement_is_probed_for_large_volumes_only(gpu):
+    """tsdf_hip_create keeps the fastest of up to `alloc_tries` placements of a >= 4 GiB volume's planes and says what it
+    did (tsdf_hip_alloc_probe); small volumes and alloc_tries = 1 allocate once."""
+    import ctypes as C
+
+    from cpu_tsdf_amd import capi
+    from tests.common import make_volume
+
+    def probe(vol):
+        ms, chosen = (C.c_float * 4)(), C.c_int32(-1)
+        n = capi.load().tsdf_hip_alloc_probe(vol._need(), ms, C.byref(chosen))
+        return n, list(ms), chosen.value
+    big, _ = make_volume(1024, color=True)      # 8 GiB of planes
+    big.reset()
+    n, ms, chosen = probe(big)
+    assert n == 3 and 0 <= chosen < 3 and all(m > 0 for m in ms[:3]) and ms[chosen] == min(ms[:3])
+    big.close()
+    capi.check(capi.load().tsdf_hip_set_tuning(b"alloc_tries", 1), "tuning")
+    try:
+        once, _ = make_volume(1024, color=True)
+        once.reset()
+        assert probe(once)[0] == 1
+        once.close()
+    finally:
+        capi.check(capi.load().tsdf_hip_set_tuning(b"alloc_tries", 3), "tuning")
+    small, _ = make_volume(128, color=True)
+    small.reset()
+    assert probe(small)[0] == 1
+    small.close()
