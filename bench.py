@@ -13,6 +13,11 @@ broadcast of frame i+1 is issued before the kernel of frame i is launched and la
 two-slot receive buffer, so it runs on RCCL's stream under that kernel.  `--config 4` is BASELINE configs[4]
 (4096^3, 1280x960 frames, needs >= 4 GPUs); `--scaling weak` keeps --planes planes per GPU instead.
 
+`python bench.py --gpus N` without a launcher re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N` (one rank per GPU), so the plain command line measures the same thing as the launcher form.
+`--host inprocess` times the OTHER host of the same partition instead: one process, one tsdf_hip_create_multi handle
+over N GPUs (what cpu_tsdf::TSDFVolumeOctree::setDevices uses), frame fan-out by peer copies instead of RCCL.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
 (k_integrate, HBM-bound) and `cpu_baseline` (the reference CPU path timed on this host on a bounded sample).
 
@@ -73,6 +78,9 @@ def parse():
     ap.add_argument("--extras", type=int, default=1, help="also time renderView + marching cubes once (N=1, untimed region)")
     ap.add_argument("--scene-b", type=int, default=1, help="with --extras: the Scene-B (camera inside the volume) leg; the "
                     "rocprof run turns it off so that k_integrate's average is the headline workload's alone")
+    ap.add_argument("--host", choices=["process", "inprocess"], default="process",
+                    help="N>1: one process per GPU over RCCL (default) or ONE process driving all GPUs through tsdf_hip_create_multi")
+    ap.add_argument("--host-path", type=int, default=1, help="N=1: also time the host-pointer entry point (report-only side field)")
     ap.add_argument("--calib", type=int, default=0, help="run this many k_calib_rmw sweeps of exactly known bytes first "
                     "(PMC passes: calibrates FETCH_SIZE / WRITE_SIZE in the same process)")
     a = ap.parse_args()
@@ -242,6 +250,31 @@ def scene_b_leg(res, color, cpu_seconds):
     return out
 
 
+def host_path_leg(vol, sc, poses, color, n_host=6, calls=24):
+    """Report-only: the reference's integrateCloud takes a HOST cloud, so this is the PCIe-inclusive rate of the same
+    workload -- `calls` frames handed over as host pointers, back to back, through tsdf_hip_integrate (upload + kernel +
+    synchronise per call) and through tsdf_hip_integrate_async (pinned two-slot ring, upload under the previous kernel).
+    Never `value`: the headline is timed with frames resident in HBM."""
+    out = {}
+    try:
+        frames = [(np.ascontiguousarray(sc.depth(poses[i])), np.ascontiguousarray(sc.bgra(i)) if color else None) for i in range(n_host)]
+        for name, pipelined in (("frames_per_s_sync_calls", False), ("frames_per_s_async_ring", True)):
+            vol.integrateCloud(frames[0][0], frames[0][1], poses[0], pipelined=pipelined)
+            vol.synchronize()
+            t0 = time.perf_counter()
+            for i in range(calls):
+                d, c = frames[i % n_host]
+                vol.integrateCloud(d, c, poses[i % n_host], pipelined=pipelined)
+            vol.synchronize()
+            out[name] = calls / (time.perf_counter() - t0)
+        out["calls"] = calls
+        out["note"] = ("host-pointer entry points, 2.4 MB frame per call over PCIe; report-only, the headline `value` is timed "
+                       "with frames resident in HBM")
+    except Exception as e:  # never let a report-only leg break the bench line
+        out["error"] = repr(e)
+    return out
+
+
 def pmc_traffic(key, sha):
     """HBM bytes per timed k_integrate launch from the committed PMC profile of this very command -- only if the
     profile was taken on the kernel sources that are running now."""
@@ -257,8 +290,28 @@ def pmc_traffic(key, sha):
     return e, None
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` as the driver may call it: become `python -m torch.distributed.run ... bench.py ...`
+    with one rank per GPU (the same command line the driver uses when it launches the ranks itself)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and args.host == "process" and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)  # does not return
+    if args.host == "inprocess":
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--host inprocess is ONE process driving all GPUs: do not launch it under torch.distributed.run")
+        return main_inprocess(args)
     import torch
     import torch.distributed as dist
 
@@ -266,8 +319,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # Test hooks for boxes with ONE GPU (gpurun): TSDF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # TSDF_BENCH_BACKEND=gloo moves the collectives off RCCL (which refuses two ranks per device), so the N>1
@@ -521,7 +572,8 @@ def main():
             },
         }
         if use_dist:
-            out["multi_gpu"] = {"per_rank_kernel_ms": per_rank_kernel_ms, "frame_broadcast_ms_isolated": bcast_ms,
+            out["multi_gpu"] = {"host": "one process per GPU, torch.distributed", "world_size": dist.get_world_size(),
+                                "per_rank_kernel_ms": per_rank_kernel_ms, "frame_broadcast_ms_isolated": bcast_ms,
                                 "overlap": bool(args.overlap), "backend": backend, "planes_per_gpu": z_end - z_begin}
         if calibration:
             out["calibration"] = calibration
@@ -529,6 +581,8 @@ def main():
             out["extras"] = extras(vol, poses[-1], W, H)
             if args.scene_b:
                 out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
+        if world == 1 and not use_dist and args.host_path:
+            out["host_path"] = host_path_leg(vol, sc, poses, bool(args.color))
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -537,6 +591,122 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_inprocess(args):
+    """--host inprocess: ONE process, one tsdf_hip_create_multi handle over N GPUs -- the host the C++ drop-in
+    (TSDFVolumeOctree::setDevices) uses.  Frames are resident on the first GPU; every step fans the frame out to the
+    other slabs by peer copy (xGMI) and launches k_integrate on every slab's own stream.  Strong scaling of the same
+    grid.  TSDF_BENCH_ONE_DEVICE=1 (one-GPU boxes) repeats ordinal 0: the code path, not the numbers."""
+    import torch
+    from cpu_tsdf_amd import capi, synth
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    lib = capi.load()
+    n = args.gpus
+    one_dev = os.environ.get("TSDF_BENCH_ONE_DEVICE") == "1"
+    devices = [0] * n if one_dev else list(range(n))
+    if not one_dev and lib.tsdf_hip_device_count() < n:
+        raise SystemExit(f"--gpus {n} but only {lib.tsdf_hip_device_count()} HIP devices are visible")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    res, voxel = args.res, 2.0 ** -8
+    planes = args.planes or res
+    res3 = (res, res, planes * n) if args.scaling == "weak" else (res, res, planes)
+    size3 = tuple(r * voxel for r in res3)
+    S, W, H = size3[0], args.width, args.height
+    sc = synth.Scene(S, W, H)
+    if res3[2] != res3[0]:
+        sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
+    vol = TSDFVolumeOctree()
+    vol.setResolution(*res3)
+    vol.setGridSize(*size3)
+    vol.setImageSize(W, H)
+    vol.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    vol.setSensorDistanceBounds(0.0, 3.0 * max(size3))
+    vol.setDepthTruncationLimits(0.03, 0.03)
+    vol.setIntegrateColor(bool(args.color))
+    vol.setLayout({"auto": capi.LAYOUT_AUTO, "f32w": capi.LAYOUT_F32W, "packed": capi.LAYOUT_PACKED}[args.layout])
+    vol.setDevices(devices)
+    vol.reset()
+    h = vol._need()
+    slabs = vol.slabs()
+
+    n_total = args.warmup + args.steps
+    n_distinct = args.frames or n_total
+    radius = 2.2 * max(size3) / S
+    poses = [synth.turntable_pose(i, n_distinct, S, radius_factor=radius) for i in range(n_total)]
+    T_all = [synth.cam_from_vol_f32(p) for p in poses]
+    fplanes = 2 if args.color else 1
+    frames_dev = torch.empty((n_total, fplanes, H, W), dtype=torch.float32, device=dev)
+    for i, p in enumerate(poses):
+        frames_dev[i, 0].copy_(torch.from_numpy(sc.depth(p)))
+        if args.color:
+            frames_dev[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
+    torch.cuda.synchronize(dev)  # the frames are complete before the library's own streams read them
+
+    def launch(i, count=None):
+        fr = frames_dev[i]
+        capi.check(lib.tsdf_hip_integrate_device(h, C.c_void_p(fr[0].data_ptr()), C.c_void_p(fr[1].data_ptr()) if args.color else None,
+                                                 capi.as_f32p(T_all[i]), count), "integrate_device")
+
+    detail = (C.c_uint64 * 2)()
+    for i in range(args.warmup):  # warm-up through the counting instance, as in the per-process host
+        launch(i, C.byref(C.c_uint64(0)))
+    vol.synchronize()
+    capi.check(lib.tsdf_hip_multi_timing(h, 1), "multi_timing")
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        launch(i)
+    vol.synchronize()
+    wall = time.perf_counter() - t0
+    per_slab_ms = []
+    for k in range(len(slabs)):
+        ms, cnt = C.c_float(0), C.c_int32(0)
+        capi.check(lib.tsdf_hip_multi_kernel_ms(h, k, C.byref(ms), C.byref(cnt)), "multi_kernel_ms")
+        per_slab_ms.append(ms.value / max(1, cnt.value))
+    capi.check(lib.tsdf_hip_multi_timing(h, 0), "multi_timing")
+    n_obs = chg = 0
+    for i in range(args.warmup, n_total):  # the same frames once more through the counting instance
+        launch(i, C.byref(C.c_uint64(0)))
+        capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+        n_obs += int(detail[0])
+        chg += int(detail[1])
+    n_obs /= args.steps
+    chg /= args.steps
+
+    vox_total = float(res3[0]) * res3[1] * res3[2]
+    fps = args.steps / wall
+    packed = vol.getLayout() == capi.LAYOUT_PACKED
+    bpp = 8 if args.color else 4
+    read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))
+    alg_bytes = read_bpv * n_obs + chg + n * bpp * W * H  # all slabs' launches of one step together
+    kern_ms = max(per_slab_ms)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": f"integrateCloud throughput, Scene A turntable depth frames, {W}x{H} -> voxel grid",
+        "value": vox_total * fps / 1e6, "unit": "Mvoxels/s", "frames_per_s": fps, "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"integrateCloud {res3[0]}x{res3[1]}x{res3[2]} grid (voxel 2^-8 m), integrateColor="
+                        f"{'true' if args.color else 'false'}, {W}x{H} Scene-A turntable frames resident in HBM on GPU 0 "
+                        f"(BASELINE configs[{args.config}] integrate leg), ONE process / one tsdf_hip_create_multi handle over "
+                        f"{n} GPUs, frame fan-out by peer copy",
+            "grid": list(res3), "image": [W, H], "color": bool(args.color), "layout": "packed" if packed else "f32w",
+            "observed_voxels_per_frame": n_obs, "parallelism": f"zslab{n}-inprocess",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * n, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n),
+            "traffic": None, "kernel": "k_integrate", "kernel_ms": kern_ms, "kernel_sha16": kernel_sha16(),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "all slabs of one step together: algorithmic bytes summed over the slabs / the slowest slab's average k_integrate "
+                    "time (HIP events on every slab's own stream, tsdf_hip_multi_kernel_ms), against N x the per-GPU HBM peak",
+        },
+        "multi_gpu": {"host": "one process, tsdf_hip_create_multi", "devices": devices, "per_slab_kernel_ms": per_slab_ms,
+                      "slabs": [{"device": s[0], "z_begin": s[1], "z_end": s[2], "halo": s[3]} for s in slabs]},
+    }
+    print(json.dumps(out), flush=True)
+    vol.close()
 
 
 if __name__ == "__main__":

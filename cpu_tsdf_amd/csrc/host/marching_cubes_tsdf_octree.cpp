@@ -11,30 +11,28 @@
 
 namespace cpu_tsdf {
 
-// reference: src/lib/marching_cubes_tsdf_octree.cpp:44-83.  The base class is set up exactly as there so that code
-// reading it back (getGridResolution, getIsoLevel, ...) sees the reference's values; the kernels take the same
-// lower_boundary_ / size_voxel_ from the volume's parameters (tsdf_march.hip), where the two +- terms of :64-66 cancel.
+// setInputTSDF (reference: src/lib/marching_cubes_tsdf_octree.cpp:44-83) leaves the pcl::MarchingCubes base in the
+// state the reference leaves it in, so that code reading it back (getGridResolution, getIsoLevel, the input cloud's
+// bounding box) sees the same values.  What that state IS: the "input cloud" is the eight corners of the box spanned by
+// the centres of voxel (0, 0, 0) and of voxel (res_x, res_y, res_z) -- the reference adds a half-voxel offset to each
+// centre and subtracts the same number again (:64-66), which leaves the centres themselves; getVoxelCenter is separable
+// per axis, so the eight points are the combinations of those two -- no grid extension, iso level 0, and size_voxel_
+// the box divided by the resolution.  The kernels derive the same lower boundary / voxel size from the volume's
+// parameters (tsdf_march.hip).
 void MarchingCubesTSDFOctree::setInputTSDF(TSDFVolumeOctree::ConstPtr tsdf_volume) {
   tsdf_volume_ = tsdf_volume;
   if (!tsdf_volume_) return;
-  int res_x, res_y, res_z;
-  tsdf_volume_->getResolution(res_x, res_y, res_z);
-  setGridResolution(res_x, res_y, res_z);
-  float size_x, size_y, size_z;
-  tsdf_volume_->getGridSize(size_x, size_y, size_z);
-  pcl::PointCloud<pcl::PointXYZ>::Ptr corner_cloud(new pcl::PointCloud<pcl::PointXYZ>);
-  for (int x_i = 0; x_i <= res_x; x_i += res_x)
-    for (int y_i = 0; y_i <= res_y; y_i += res_y)
-      for (int z_i = 0; z_i <= res_z; z_i += res_z) {
-        pcl::PointXYZ center = tsdf_volume_->getVoxelCenter(x_i, y_i, z_i);
-        center.x += (x_i == 0 ? -1 : 1) * 0.5 * size_x / res_x + (x_i == 0 ? 1 : -1) * (0.5 * size_x / (double)res_x);
-        center.y += (y_i == 0 ? -1 : 1) * 0.5 * size_y / res_y + (y_i == 0 ? 1 : -1) * (0.5 * size_y / (double)res_y);
-        center.z += (z_i == 0 ? -1 : 1) * 0.5 * size_z / res_z + (z_i == 0 ? 1 : -1) * (0.5 * size_z / (double)res_z);
-        corner_cloud->points.push_back(center);
-      }
-  corner_cloud->width = (uint32_t)corner_cloud->points.size();
-  corner_cloud->height = 1;
-  setInputCloud(corner_cloud);
+  int res[3];
+  tsdf_volume_->getResolution(res[0], res[1], res[2]);
+  setGridResolution(res[0], res[1], res[2]);
+  const pcl::PointXYZ first = tsdf_volume_->getVoxelCenter(0, 0, 0);
+  const pcl::PointXYZ beyond = tsdf_volume_->getVoxelCenter(res[0], res[1], res[2]);
+  pcl::PointCloud<pcl::PointXYZ>::Ptr corners(new pcl::PointCloud<pcl::PointXYZ>);
+  for (int c = 0; c < 8; ++c)  // x slowest, z fastest, like the reference's three loops
+    corners->points.push_back(pcl::PointXYZ((c & 4) ? beyond.x : first.x, (c & 2) ? beyond.y : first.y, (c & 1) ? beyond.z : first.z));
+  corners->width = (uint32_t)corners->points.size();
+  corners->height = 1;
+  setInputCloud(corners);
   setPercentageExtendGrid(0);
   setIsoLevel(0.f);
   getBoundingBox();

@@ -62,6 +62,8 @@ struct tsdf_hip_volume {
   size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
   unsigned long long last_observed = 0, last_changed_bytes = 0;  // tsdf_hip_last_count_detail
+  int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
+  bool count_ran = false;  // that launch really ran (finite pose, something observable)
   hipStream_t stream = nullptr;
   // marching-cubes result buffers (owned, reused between calls)
   float *mc_verts = nullptr;
@@ -108,6 +110,22 @@ tsdf_handle tsdf_multi_first(tsdf_handle h);
       return TSDF_HIP_E_UNSUPPORTED;                                                                        \
     }                                                                                                       \
   } while (0)
+
+// integrateCloud in two halves (tsdf_integrate.hip): queue the launch; read the counting instance's counters later.
+int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12], bool count);
+int tsdf_integrate_collect(tsdf_handle h, uint64_t *n_observed);
+
+// Compact ray lists of the one-process multi-GPU renderView (tsdf_query.hip; all asynchronous on the slab's stream).
+#define TSDF_MAX_SLABS 64
+#define TSDF_RAY_FIN_INTS 9  // a finished ray on the wire: pixel index + 8 output floats
+unsigned tsdf_ray_list_share(int64_t n_rays, int rank, int world);
+int tsdf_ray_list_begin(tsdf_handle s, const float rot[9], const float origin[3], int downsample, int rank, int world,
+                        int32_t *d_list, unsigned *count);
+int tsdf_ray_list_advance(tsdf_handle s, const float rot[9], const float origin[3], int downsample, int rank, int world,
+                          int32_t *d_list, unsigned count, unsigned *d_incomplete);
+int tsdf_ray_list_route(tsdf_handle s, const int32_t *d_list, unsigned count, int n_slab, const int *z_end,
+                        unsigned *d_counters, int32_t *d_outbox, int32_t *d_finbox);
+int tsdf_ray_deliver(tsdf_handle s, const int32_t *d_fin, unsigned count, float *d_out, int64_t n_pix, const double *inv);
 
 // Error plumbing -------------------------------------------------------------------------------
 void tsdf_set_error(const std::string &msg);

@@ -953,9 +953,13 @@ static bool observable_index_box(const tsdf_hip_volume *h, const float T[12], in
   return true;
 }
 
-static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
-                            uint64_t *n_observed) {
+// Asynchronous half: queues the launch on the handle's stream.  `count` selects the counting instance, whose striped
+// counters stay in h->counter until tsdf_integrate_collect reads them (a multi-GPU set launches every slab first and
+// collects afterwards, so the slabs count concurrently).
+int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12], bool count) {
   const tsdf_params &p = h->p;
+  h->count_slots = 0;
+  h->count_ran = false;
   const IntegrateHost hh = make_args(h, T);
   IntegrateArgs a = hh.a;
   unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
@@ -981,7 +985,6 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
       tsdf_set_error("weight_by_depth needs the F32W layout and TSDF_COLOR_RGB");
       return TSDF_HIP_E_UNSUPPORTED;
     }
-    const bool count = n_observed != nullptr;
     if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
     bool pose_ok = true;
     for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
@@ -1016,18 +1019,11 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
 #undef LAUNCH_PLAIN
       TSDF_HIP_TRY(hipGetLastError());
     }
-    if (n_observed) {
-      unsigned long long c[1024];
-      TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
-      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-      unsigned long long sum = 0;
-      for (int i = 0; i < 1024; ++i) sum += c[i];
-      *n_observed = pose_ok ? sum : 0;
-    }
+    h->count_slots = count ? 1024 : 0;  // these kernels count observations only (no changed-byte slots)
+    h->count_ran = pose_ok;
     return TSDF_HIP_OK;
   }
   if (h->cn[0]) {  // TSDF_COLOR_RGB_NORMALIZED / TSDF_COLOR_LAB: their own plain kernels
-    const bool count = n_observed != nullptr;
     if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 1024 * sizeof(unsigned long long), h->stream));
     bool pose_ok = true;
     for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
@@ -1060,14 +1056,8 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
 #undef LAUNCH_RGBN
       TSDF_HIP_TRY(hipGetLastError());
     }
-    if (n_observed) {
-      unsigned long long c[1024];
-      TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
-      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-      unsigned long long sum = 0;
-      for (int i = 0; i < 1024; ++i) sum += c[i];
-      *n_observed = pose_ok ? sum : 0;
-    }
+    h->count_slots = count ? 1024 : 0;  // these kernels count observations only (no changed-byte slots)
+    h->count_ran = pose_ok;
     return TSDF_HIP_OK;
   }
   // The kernel reads the frame through ONE buffer descriptor based at the depth image, with the colour
@@ -1168,7 +1158,6 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
       }
     }
   }
-  const bool count = n_observed != nullptr;
   if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
   // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
@@ -1219,18 +1208,38 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
   }
-  if (n_observed) {
-    unsigned long long c[2048];
-    TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
-    TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-    unsigned long long sum = 0, changed = 0;
-    for (int i = 0; i < 1024; ++i) sum += c[i], changed += c[1024 + i];
-    const bool ran = pose_ok && !nothing_observable;
-    *n_observed = ran ? sum : 0;
-    h->last_observed = ran ? sum : 0;
-    h->last_changed_bytes = ran ? changed : 0;
-  }
+  h->count_slots = count ? 2048 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed
+  h->count_ran = pose_ok && !nothing_observable;
   return TSDF_HIP_OK;
+}
+
+// Synchronising half: reads the counters of the last tsdf_integrate_launch(count = true) on this handle.  The plain
+// kernels (weight_by_depth, RGB_NORMALIZED, LAB) do not count changed bytes: last_changed_bytes is then 0, never a
+// stale figure of an earlier fast-kernel call.
+int tsdf_integrate_collect(tsdf_handle h, uint64_t *n_observed) {
+  if (!h->count_slots) {
+    tsdf_set_error("tsdf_integrate_collect without a counting launch");
+    return TSDF_HIP_E_INVALID;
+  }
+  unsigned long long c[2048];
+  const int slots = h->count_slots;
+  TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, (size_t)slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned long long sum = 0, changed = 0;
+  for (int i = 0; i < 1024; ++i) sum += c[i];
+  for (int i = 1024; i < slots; ++i) changed += c[i];
+  h->last_observed = h->count_ran ? sum : 0;
+  h->last_changed_bytes = h->count_ran ? changed : 0;
+  h->count_slots = 0;
+  if (n_observed) *n_observed = h->last_observed;
+  return TSDF_HIP_OK;
+}
+
+static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
+                            uint64_t *n_observed) {
+  const int rc = tsdf_integrate_launch(h, d_depth, d_bgra, T, n_observed != nullptr);
+  if (rc || !n_observed) return rc;
+  return tsdf_integrate_collect(h, n_observed);
 }
 
 // The measured side of the roofline's algorithmic bytes (bench.py): of the last integrate call that asked for
@@ -1322,15 +1331,22 @@ static int pipeline_ready(tsdf_handle h) {
   if (h->pipe) return TSDF_HIP_OK;
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   tsdf_hip_pipeline *p = new tsdf_hip_pipeline;
+  // the ring is attached to the handle only once every allocation has succeeded: a half-built one would hand NULL
+  // slot pointers to the next tsdf_hip_frame_begin
+  auto build = [&]() -> int {
+    TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
+      TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
+      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
+      TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
+    }
+    return TSDF_HIP_OK;
+  };
+  const int rc = build();
   h->pipe = p;
-  TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) {
-    TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
-    TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
-    TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
-    TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
-  }
-  return TSDF_HIP_OK;
+  if (rc) tsdf_pipeline_destroy(h);  // frees what was built and detaches it
+  return rc;
 }
 
 int tsdf_multi_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra);
@@ -1528,6 +1544,7 @@ extern "C" int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float c
 
 extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written) {
   if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_selftest_sweep");
   TSDF_ON_DEVICE(h->device);
   const int64_t plane = h->pitch * h->ny;
   const int64_t first4 = (int64_t)(h->z_begin - h->z_first) * plane / 4;
@@ -1694,6 +1711,7 @@ static __global__ void k_selftest_project(const IntegrateArgs a, const double *c
 extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n, int32_t *pix_fast,
                                          int32_t *pix_exact, uint8_t *ambiguous) {
   if (!h || !g || !n || !pix_fast || !pix_exact || !ambiguous) return TSDF_HIP_E_INVALID;
+  if (h->multi) h = tsdf_multi_first(h);  // the projection only reads the intrinsics, which every slab holds
   TSDF_ON_DEVICE(h->device);
   const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const IntegrateHost a = make_args(h, ident);

@@ -28,20 +28,31 @@
 
 struct tsdf_hip_multi {
   std::vector<tsdf_handle> slab;
+  std::vector<hipStream_t> stream;  // per slab: its own non-blocking stream (slabs overlap; every dependency is an event)
   int halo = 0;
   // pinned frame staging for the host entry points: two slots so that tsdf_hip_integrate_async can return while the
   // uploads of the previous frame are still in flight
   float *pinned[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> uploaded[2];  // per slot, per slab: the slab's H2D copy out of the slot has finished
   unsigned long long frames = 0;
-  std::vector<hipEvent_t> ev;           // per slab: general cross-device ordering
+  std::vector<hipEvent_t> ev, ev2;      // per slab: general cross-device ordering (two, so a wait may follow a wait)
   bool halo1_fresh = false, halo_all_fresh = false;  // plane z_end of every slab / the whole halo is current
   int frame_staged = 0;
-  // renderView: ray records
-  std::vector<int *> ray_state, ray_delta;  // per slab, on its device
-  int *ray_tmp = nullptr;                   // on slab 0's device: a delta in transit
-  unsigned *ray_count = nullptr;            // on slab 0's device: suspended rays after a merge
-  size_t ray_cap = 0;
+  // renderView: compact ray lists (tsdf_query.hip).  Per slab, on its device: the records it is responsible for, the
+  // same sorted by destination after a round, the finished rays of the round, routing counters + one "touched a plane
+  // this slab does not hold" counter; on the first slab: the finished rays in transit and the image.  Pinned: the
+  // count table the host sizes the copies with.
+  std::vector<int *> ray_list, ray_outbox, ray_finbox;
+  std::vector<unsigned *> ray_counters;  // 2 * (n_slab + 1) routing words + 1 incomplete word
+  int *ray_fin_in = nullptr;
+  float *ray_image = nullptr;
+  unsigned *ray_table = nullptr;         // pinned: [n_slab][n_slab + 2] (counts per destination, finished, incomplete)
+  size_t ray_cap = 0;                    // rays the buffers above hold
+  uint64_t rv_stats[4] = {0, 0, 0, 0};   // last renderView: rounds, records handed between slabs, bytes between slabs, host waits
+  // per-slab k_integrate timing (tsdf_hip_multi_timing): event pairs around every slab's launches while enabled
+  bool timing = false;
+  std::vector<std::vector<hipEvent_t>> t_ev;  // per slab: start, stop, start, stop, ...
+  std::vector<size_t> t_used;
   // merged mesh of the last tsdf_hip_march (host)
   std::vector<float> verts;
   std::vector<uint8_t> rgb;
@@ -69,20 +80,33 @@ void tsdf_multi_free(tsdf_hip_volume *v) {
   for (tsdf_handle s : m->slab) (void)tsdf_hip_synchronize(s);
   for (size_t k = 0; k < m->slab.size(); ++k) {
     TsdfDeviceScope scope(m->slab[k]->device);
-    if (k < m->ray_state.size() && m->ray_state[k]) (void)hipFree(m->ray_state[k]);
-    if (k < m->ray_delta.size() && m->ray_delta[k]) (void)hipFree(m->ray_delta[k]);
+    if (k < m->ray_list.size() && m->ray_list[k]) (void)hipFree(m->ray_list[k]);
+    if (k < m->ray_outbox.size() && m->ray_outbox[k]) (void)hipFree(m->ray_outbox[k]);
+    if (k < m->ray_finbox.size() && m->ray_finbox[k]) (void)hipFree(m->ray_finbox[k]);
+    if (k < m->ray_counters.size() && m->ray_counters[k]) (void)hipFree(m->ray_counters[k]);
     if (k < m->ev.size() && m->ev[k]) (void)hipEventDestroy(m->ev[k]);
+    if (k < m->ev2.size() && m->ev2[k]) (void)hipEventDestroy(m->ev2[k]);
     for (int s = 0; s < 2; ++s)
       if (k < m->uploaded[s].size() && m->uploaded[s][k]) (void)hipEventDestroy(m->uploaded[s][k]);
+    if (k < m->t_ev.size())
+      for (hipEvent_t e : m->t_ev[k]) (void)hipEventDestroy(e);
   }
   if (!m->slab.empty()) {
     TsdfDeviceScope scope(m->slab[0]->device);
-    if (m->ray_tmp) (void)hipFree(m->ray_tmp);
-    if (m->ray_count) (void)hipFree(m->ray_count);
+    if (m->ray_fin_in) (void)hipFree(m->ray_fin_in);
+    if (m->ray_image) (void)hipFree(m->ray_image);
   }
+  if (m->ray_table) (void)hipHostFree(m->ray_table);
   for (int s = 0; s < 2; ++s)
     if (m->pinned[s]) (void)hipHostFree(m->pinned[s]);
-  for (tsdf_handle s : m->slab) (void)tsdf_hip_destroy(s);
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    const int dev = m->slab[k]->device;
+    (void)tsdf_hip_destroy(m->slab[k]);
+    if (k < m->stream.size() && m->stream[k]) {
+      TsdfDeviceScope scope(dev);
+      (void)hipStreamDestroy(m->stream[k]);
+    }
+  }
   delete m;
   v->multi = nullptr;
 }
@@ -145,6 +169,20 @@ extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *device
     const int rc = tsdf_hip_create(&q, &s);
     if (rc) return fail(rc);
     m->slab.push_back(s);
+    m->stream.push_back(nullptr);
+    // Every slab works on its OWN non-blocking stream -- also when several slabs share a device -- so the slabs
+    // overlap and every cross-slab dependency has to be an explicit event (on the null stream a missing one would be
+    // hidden by the implicit serialisation).  What tsdf_hip_create queued on the null stream finishes first.
+    TsdfDeviceScope scope(devices[k]);
+    if (hipDeviceSynchronize() != hipSuccess || hipStreamCreateWithFlags(&m->stream[k], hipStreamNonBlocking) != hipSuccess) {
+      tsdf_set_error("hipStreamCreate failed");
+      return fail(TSDF_HIP_E_HIP);
+    }
+    s->stream = m->stream[k];
+  }
+  if (n_devices > TSDF_MAX_SLABS) {
+    tsdf_set_error("too many slabs");
+    return fail(TSDF_HIP_E_INVALID);
   }
   v->packed = m->slab[0]->packed;
   v->kmax = m->slab[0]->kmax;
@@ -163,13 +201,19 @@ extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *device
         }
       }
   m->ev.resize(n_devices, nullptr);
+  m->ev2.resize(n_devices, nullptr);
   m->uploaded[0].resize(n_devices, nullptr);
   m->uploaded[1].resize(n_devices, nullptr);
-  m->ray_state.resize(n_devices, nullptr);
-  m->ray_delta.resize(n_devices, nullptr);
+  m->ray_list.resize(n_devices, nullptr);
+  m->ray_outbox.resize(n_devices, nullptr);
+  m->ray_finbox.resize(n_devices, nullptr);
+  m->ray_counters.resize(n_devices, nullptr);
+  m->t_ev.resize(n_devices);
+  m->t_used.resize(n_devices, 0);
   for (int k = 0; k < n_devices; ++k) {
     TsdfDeviceScope scope(devices[k]);
     if (hipEventCreateWithFlags(&m->ev[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev2[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->uploaded[0][k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->uploaded[1][k], hipEventDisableTiming) != hipSuccess) {
       tsdf_set_error("hipEventCreate failed");
@@ -231,20 +275,68 @@ int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance) {
 static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed) {
   tsdf_hip_multi *m = h->multi;
   m->halo1_fresh = m->halo_all_fresh = false;
-  unsigned long long total = 0, changed = 0;
-  for (tsdf_handle s : m->slab) {
-    uint64_t n = 0;
-    const int rc = tsdf_hip_integrate_device(s, s->frame_depth, s->p.integrate_color ? s->frame_bgra : nullptr, T,
-                                             n_observed ? &n : nullptr);
+  // every slab's launch is queued before any count is read back: the slabs (GPUs) integrate concurrently whether or
+  // not the caller asked for n_observed
+  for (size_t k = 0; k < m->slab.size(); ++k) {
+    tsdf_handle s = m->slab[k];
+    TSDF_ON_DEVICE(s->device);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (m->timing) {
+      std::vector<hipEvent_t> &ev = m->t_ev[k];
+      while (ev.size() < m->t_used[k] + 2) {
+        hipEvent_t e = nullptr;
+        TSDF_HIP_TRY(hipEventCreate(&e));
+        ev.push_back(e);
+      }
+      t0 = ev[m->t_used[k]], t1 = ev[m->t_used[k] + 1];
+      m->t_used[k] += 2;
+      TSDF_HIP_TRY(hipEventRecord(t0, s->stream));
+    }
+    const int rc = tsdf_integrate_launch(s, s->frame_depth, s->p.integrate_color ? s->frame_bgra : nullptr, T, n_observed != nullptr);
     if (rc) return rc;
-    total += n;
-    changed += s->last_changed_bytes;
+    if (t1) TSDF_HIP_TRY(hipEventRecord(t1, s->stream));
   }
   if (n_observed) {
+    unsigned long long total = 0, changed = 0;
+    for (tsdf_handle s : m->slab) {
+      TSDF_ON_DEVICE(s->device);
+      uint64_t n = 0;
+      const int rc = tsdf_integrate_collect(s, &n);
+      if (rc) return rc;
+      total += n;
+      changed += s->last_changed_bytes;
+    }
     *n_observed = total;
     h->last_observed = total;
     h->last_changed_bytes = changed;
   }
+  return TSDF_HIP_OK;
+}
+
+// Per-slab k_integrate time (bench.py --host inprocess): while enabled, every slab's launches are bracketed by HIP events
+// on the slab's own stream.  tsdf_hip_multi_kernel_ms synchronises and returns the summed milliseconds and the
+// number of launches of slab k since timing was enabled (or last read), then forgets them.
+extern "C" int tsdf_hip_multi_timing(tsdf_handle h, int enable) {
+  if (!h || !h->multi) return TSDF_HIP_E_INVALID;
+  h->multi->timing = enable != 0;
+  for (size_t k = 0; k < h->multi->t_used.size(); ++k) h->multi->t_used[k] = 0;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_multi_kernel_ms(tsdf_handle h, int k, float *ms_sum, int32_t *launches) {
+  if (!h || !h->multi || k < 0 || k >= (int)h->multi->slab.size() || !ms_sum) return TSDF_HIP_E_INVALID;
+  tsdf_hip_multi *m = h->multi;
+  TSDF_ON_DEVICE(m->slab[k]->device);
+  TSDF_HIP_TRY(hipStreamSynchronize(m->slab[k]->stream));
+  float sum = 0.f;
+  for (size_t i = 0; i + 1 < m->t_used[k]; i += 2) {
+    float ms = 0.f;
+    TSDF_HIP_TRY(hipEventElapsedTime(&ms, m->t_ev[k][i], m->t_ev[k][i + 1]));
+    sum += ms;
+  }
+  *ms_sum = sum;
+  if (launches) *launches = (int32_t)(m->t_used[k] / 2);
+  m->t_used[k] = 0;
   return TSDF_HIP_OK;
 }
 
@@ -304,8 +396,10 @@ int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
 }
 
 // Device frame (anywhere on the node) -> every slab's staging buffer by peer copy, ordered on the receiving slab's
-// stream.  The frame must be complete when the call is made unless it lives in slab `src`'s own staging buffer
-// (tsdf_hip_organize), in which case the copies wait for that slab's stream.
+// stream.  A frame in slab `src`'s own staging buffer (tsdf_hip_organize) is ordered both ways by events: the copies
+// wait for that slab's stream, and that slab's later work waits for the copies.  A CALLER's buffer (src_slab < 0) must
+// be complete when the call is made and stay untouched until tsdf_hip_synchronize (or any synchronising call): the
+// library cannot order a stream it does not know.
 static int fan_out_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, int src_slab) {
   tsdf_hip_multi *m = h->multi;
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
@@ -344,6 +438,14 @@ static int fan_out_device(tsdf_handle h, const float *d_depth, const uint32_t *d
       TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_depth, s->device, d_depth, src_dev, npx * 4, s->stream));
       if (color) TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_bgra, s->device, d_bgra, src_dev, npx * 4, s->stream));
     }
+    // ... and the source after the receivers: whatever the source slab queues next (the next tsdf_hip_organize, the
+    // next upload into its staging buffer) must not overwrite the frame while another GPU is still copying it
+    if (src_slab >= 0) TSDF_HIP_TRY(hipEventRecord(m->ev2[k], s->stream));
+  }
+  if (src_slab >= 0) {
+    TSDF_ON_DEVICE(m->slab[src_slab]->device);
+    for (size_t k = 0; k < m->slab.size(); ++k)
+      if ((int)k != src_slab) TSDF_HIP_TRY(hipStreamWaitEvent(m->slab[src_slab]->stream, m->ev2[k], 0));
   }
   return TSDF_HIP_OK;
 }
@@ -410,6 +512,21 @@ static int copy_planes(tsdf_hip_multi *m, int src, int dst, int z0, int nz) {
   return TSDF_HIP_OK;
 }
 
+// Every slab's stream waits for what every other slab has queued so far.
+static int all_wait_all(tsdf_hip_multi *m) {
+  const int n = (int)m->slab.size();
+  for (int k = 0; k < n; ++k) {
+    TSDF_ON_DEVICE(m->slab[k]->device);
+    TSDF_HIP_TRY(hipEventRecord(m->ev2[k], m->slab[k]->stream));
+  }
+  for (int k = 0; k < n; ++k) {
+    TSDF_ON_DEVICE(m->slab[k]->device);
+    for (int j = 0; j < n; ++j)
+      if (j != k) TSDF_HIP_TRY(hipStreamWaitEvent(m->slab[k]->stream, m->ev2[j], 0));
+  }
+  return TSDF_HIP_OK;
+}
+
 // Refresh `planes` halo planes above every slab (and below, with `both`) from their owners.
 static int exchange_halo(tsdf_handle h, int planes, bool both) {
   tsdf_hip_multi *m = h->multi;
@@ -433,15 +550,7 @@ static int exchange_halo(tsdf_handle h, int planes, bool both) {
   }
   // the owners must not run ahead and change planes that are still being read: receivers' copies are ordered after
   // the owners' streams above; order the owners' NEXT work after the copies
-  for (int k = 0; k < n; ++k) {
-    TSDF_ON_DEVICE(m->slab[k]->device);
-    TSDF_HIP_TRY(hipEventRecord(m->ev[k], m->slab[k]->stream));
-  }
-  for (int k = 0; k < n; ++k) {
-    TSDF_ON_DEVICE(m->slab[k]->device);
-    for (int j = 0; j < n; ++j)
-      if (j != k) TSDF_HIP_TRY(hipStreamWaitEvent(m->slab[k]->stream, m->ev[j], 0));
-  }
+  if (int rc = all_wait_all(m)) return rc;
   m->halo1_fresh = true;
   if (both && planes >= m->halo) m->halo_all_fresh = true;
   return TSDF_HIP_OK;
@@ -512,8 +621,18 @@ int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rg
   return TSDF_HIP_OK;
 }
 
-// ---- renderView: ray hand-off between the slabs ------------------------------------------------------------------------
-int tsdf_ray_merge(hipStream_t stream, int *state, const int *delta, int64_t n, unsigned *suspended);  // tsdf_query.hip
+// ---- renderView: ray hand-off between the slabs, compact lists -----------------------------------------------------------
+// Every slab holds only the rays it is responsible for (at the start: pixel index = slab (mod n_slab); later: the
+// owner of the plane the ray's loop needs next).  A round = every slab, concurrently on its own stream: advance its
+// list (k_raycast<true>), sort the records by destination (tsdf_ray_list_route), copy the n_slab + 2 counters to a
+// pinned table.  The host waits for the tables (one event per slab, the slabs having run in parallel), then queues
+// the point-to-point copies: suspended records to the owner of their next plane (96 B each), finished rays to the
+// first slab (36 B each), where k_ray_deliver writes them into the image and applies :422.  No image-sized buffer
+// crosses a link and no stream is synchronised inside a round.
+static hipError_t copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream) {
+  if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+  return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
+}
 
 int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv, float *out) {
   tsdf_hip_multi *m = h->multi;
@@ -521,79 +640,122 @@ int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3],
   if (downsample < 1) return TSDF_HIP_E_INVALID;
   const int nw = h->p.image_width / downsample, nh = h->p.image_height / downsample;
   const int64_t n = (int64_t)nw * nh;
-  if (n <= 0) return TSDF_HIP_E_INVALID;
+  if (n <= 0 || n >= (1ll << 31)) return TSDF_HIP_E_INVALID;
   int rc = exchange_halo(h, m->halo, true);
   if (rc) return rc;
-  const size_t words = (size_t)n * TSDF_HIP_RAY_RECORD_INTS, bytes = words * sizeof(int);
-  if (words > m->ray_cap) {
+  const int cols = n_slab + 2;  // table row of a slab: records per destination slab, finished, incomplete
+  if ((size_t)n > m->ray_cap) {
+    if ((rc = tsdf_multi_synchronize(h))) return rc;
     for (int k = 0; k < n_slab; ++k) {
       TSDF_ON_DEVICE(m->slab[k]->device);
-      if (m->ray_state[k]) (void)hipFree(m->ray_state[k]);
-      if (m->ray_delta[k]) (void)hipFree(m->ray_delta[k]);
-      m->ray_state[k] = m->ray_delta[k] = nullptr;
-      TSDF_HIP_TRY(hipMalloc(&m->ray_state[k], bytes));
-      TSDF_HIP_TRY(hipMalloc(&m->ray_delta[k], bytes));
+      for (int **p : {&m->ray_list[k], &m->ray_outbox[k], &m->ray_finbox[k]}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+      }
+      TSDF_HIP_TRY(hipMalloc(&m->ray_list[k], (size_t)n * TSDF_HIP_RAY_RECORD_INTS * sizeof(int)));
+      TSDF_HIP_TRY(hipMalloc(&m->ray_outbox[k], (size_t)n * TSDF_HIP_RAY_RECORD_INTS * sizeof(int)));
+      TSDF_HIP_TRY(hipMalloc(&m->ray_finbox[k], (size_t)n * TSDF_RAY_FIN_INTS * sizeof(int)));
+      if (!m->ray_counters[k]) TSDF_HIP_TRY(hipMalloc(&m->ray_counters[k], (2 * (size_t)(n_slab + 1) + 1) * sizeof(unsigned)));
     }
     TSDF_ON_DEVICE(m->slab[0]->device);
-    if (m->ray_tmp) (void)hipFree(m->ray_tmp);
-    m->ray_tmp = nullptr;
-    TSDF_HIP_TRY(hipMalloc(&m->ray_tmp, bytes));
-    if (!m->ray_count) TSDF_HIP_TRY(hipMalloc(&m->ray_count, sizeof(unsigned)));
-    m->ray_cap = words;
+    if (m->ray_fin_in) (void)hipFree(m->ray_fin_in);
+    if (m->ray_image) (void)hipFree(m->ray_image);
+    m->ray_fin_in = nullptr, m->ray_image = nullptr;
+    TSDF_HIP_TRY(hipMalloc(&m->ray_fin_in, (size_t)n * TSDF_RAY_FIN_INTS * sizeof(int)));
+    TSDF_HIP_TRY(hipMalloc(&m->ray_image, (size_t)n * 8 * sizeof(float)));
+    if (!m->ray_table) TSDF_HIP_TRY(hipHostMalloc((void **)&m->ray_table, (size_t)n_slab * cols * sizeof(unsigned), hipHostMallocPortable));
+    m->ray_cap = (size_t)n;
   }
-  tsdf_handle s0 = m->slab[0];
-  int *master = m->ray_state[0];
-  if ((rc = tsdf_hip_raycast_begin(s0, rot, origin, downsample, master))) return rc;
-  TSDF_ON_DEVICE(s0->device);
-  unsigned suspended = 1;
-  for (int round = 0; suspended && round < n_slab + 4; ++round) {
-    for (int k = 0; k < n_slab; ++k) {  // every slab advances its rays from the same snapshot of the records
+  std::vector<int> z_end(n_slab);
+  for (int k = 0; k < n_slab; ++k) z_end[k] = m->slab[k]->z_end;
+  std::vector<unsigned> cnt(n_slab, 0), next(n_slab, 0);
+  uint64_t rounds = 0, handed = 0, bytes_between = 0, host_waits = 0;
+  for (int k = 0; k < n_slab; ++k) {
+    tsdf_handle s = m->slab[k];
+    TSDF_ON_DEVICE(s->device);
+    unsigned *inc = m->ray_counters[k] + 2 * (n_slab + 1);
+    TSDF_HIP_TRY(hipMemsetAsync(inc, 0, sizeof(unsigned), s->stream));
+    if ((rc = tsdf_ray_list_begin(s, rot, origin, downsample, k, n_slab, m->ray_list[k], &cnt[k]))) return rc;
+  }
+  bool done = false;
+  for (int round = 0; !done && round < 2 * n_slab + 4; ++round, ++rounds) {
+    for (int k = 0; k < n_slab; ++k) {  // every slab: advance, sort by destination, report the counts
       tsdf_handle s = m->slab[k];
-      if (k > 0) {
-        TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
-        if (s->device == s0->device)
-          TSDF_HIP_TRY(hipMemcpy(m->ray_state[k], master, bytes, hipMemcpyDeviceToDevice));
-        else
-          TSDF_HIP_TRY(hipMemcpyPeer(m->ray_state[k], s->device, master, s0->device, bytes));
-      }
-      if ((rc = tsdf_hip_raycast_advance(s, rot, origin, downsample, k, n_slab, m->ray_state[k], m->ray_delta[k]))) return rc;
+      TSDF_ON_DEVICE(s->device);
+      unsigned *ctr = m->ray_counters[k], *inc = ctr + 2 * (n_slab + 1);
+      if ((rc = tsdf_ray_list_advance(s, rot, origin, downsample, k, n_slab, m->ray_list[k], cnt[k], inc))) return rc;
+      if ((rc = tsdf_ray_list_route(s, m->ray_list[k], cnt[k], n_slab, z_end.data(), ctr, m->ray_outbox[k], m->ray_finbox[k]))) return rc;
+      unsigned *row = m->ray_table + (size_t)k * cols;
+      TSDF_HIP_TRY(hipMemcpyAsync(row, ctr, (size_t)(n_slab + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+      TSDF_HIP_TRY(hipMemcpyAsync(row + n_slab + 1, inc, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+      TSDF_HIP_TRY(hipEventRecord(m->ev[k], s->stream));
     }
-    TSDF_HIP_TRY(hipMemsetAsync(m->ray_count, 0, sizeof(unsigned), s0->stream));
-    for (int k = 0; k < n_slab; ++k) {  // exactly one slab touched a ray: overwrite the touched records
-      const int *delta = m->ray_delta[k];
-      if (k > 0) {
-        tsdf_handle s = m->slab[k];
-        TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
-        if (s->device == s0->device)
-          TSDF_HIP_TRY(hipMemcpy(m->ray_tmp, m->ray_delta[k], bytes, hipMemcpyDeviceToDevice));
-        else
-          TSDF_HIP_TRY(hipMemcpyPeer(m->ray_tmp, s0->device, m->ray_delta[k], s->device, bytes));
-        delta = m->ray_tmp;
+    for (int k = 0; k < n_slab; ++k) {  // (the slabs ran concurrently: this waits for the slowest, once)
+      TSDF_HIP_TRY(hipEventSynchronize(m->ev[k]));
+      ++host_waits;
+      if (m->ray_table[(size_t)k * cols + n_slab + 1]) {
+        tsdf_set_error("ray hand-off: the refinement walk / trilinear samples left a slab's halo planes "
+                       "(tsdf_hip_render_halo too small for this volume)");
+        return TSDF_HIP_E_UNSUPPORTED;
       }
-      if ((rc = tsdf_ray_merge(s0->stream, master, delta, n, k == n_slab - 1 ? m->ray_count : nullptr))) return rc;
     }
-    TSDF_HIP_TRY(hipMemcpyAsync(&suspended, m->ray_count, sizeof suspended, hipMemcpyDeviceToHost, s0->stream));
-    TSDF_HIP_TRY(hipStreamSynchronize(s0->stream));
+    auto table = [&](int src, int dst) { return m->ray_table[(size_t)src * cols + dst]; };
+    // suspended records: from every slab's outbox (segments in destination order) into the owner's list
+    uint64_t still = 0;
+    for (int d = 0; d < n_slab; ++d) {
+      tsdf_handle sd = m->slab[d];
+      TSDF_ON_DEVICE(sd->device);
+      unsigned at = 0;
+      for (int k = 0; k < n_slab; ++k) {
+        const unsigned c = table(k, d);
+        if (!c) continue;
+        unsigned first = 0;
+        for (int e = 0; e < d; ++e) first += table(k, e);
+        if (k != d) TSDF_HIP_TRY(hipStreamWaitEvent(sd->stream, m->ev[k], 0));
+        const size_t rec = TSDF_HIP_RAY_RECORD_INTS * sizeof(int);
+        TSDF_HIP_TRY(copy_between(m->ray_list[d] + (size_t)at * TSDF_HIP_RAY_RECORD_INTS, sd->device,
+                                  m->ray_outbox[k] + (size_t)first * TSDF_HIP_RAY_RECORD_INTS, m->slab[k]->device, c * rec, sd->stream));
+        if (k != d) handed += c, bytes_between += (uint64_t)c * rec;
+        at += c;
+      }
+      next[d] = at;
+      still += at;
+    }
+    // finished rays: to the first slab, into the image
+    {
+      tsdf_handle s0 = m->slab[0];
+      TSDF_ON_DEVICE(s0->device);
+      unsigned at = 0;
+      for (int k = 0; k < n_slab; ++k) {
+        const unsigned c = table(k, n_slab);
+        if (!c) continue;
+        if (k != 0) TSDF_HIP_TRY(hipStreamWaitEvent(s0->stream, m->ev[k], 0));
+        const size_t rec = TSDF_RAY_FIN_INTS * sizeof(int);
+        TSDF_HIP_TRY(copy_between(m->ray_fin_in + (size_t)at * TSDF_RAY_FIN_INTS, s0->device, m->ray_finbox[k], m->slab[k]->device,
+                                  c * rec, s0->stream));
+        if (k != 0) bytes_between += (uint64_t)c * rec;
+        at += c;
+      }
+      if ((rc = tsdf_ray_deliver(s0, m->ray_fin_in, at, m->ray_image, n, inv))) return rc;
+    }
+    // a slab's boxes are rewritten by its next round: that must follow the copies the other slabs just queued
+    if ((rc = all_wait_all(m))) return rc;
+    cnt.swap(next);
+    done = still == 0;
   }
-  if (suspended) {
-    tsdf_set_error("ray hand-off did not converge (rays still suspended after slabs + 4 rounds)");
+  m->rv_stats[0] = rounds, m->rv_stats[1] = handed, m->rv_stats[2] = bytes_between, m->rv_stats[3] = host_waits;
+  if (!done) {
+    tsdf_set_error("ray hand-off did not converge (rays still suspended after 2 * slabs + 4 rounds)");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  std::vector<int> host(words);
-  if ((rc = tsdf_to_host(s0, host.data(), master, bytes))) return rc;
-  for (int64_t i = 0; i < n; ++i) {
-    float o[8];
-    memcpy(o, &host[(size_t)i * TSDF_HIP_RAY_RECORD_INTS + 16], sizeof o);
-    // :422 transformPointCloudWithNormals(trans^-1), the arithmetic of k_raycast's to_camera branch
-    if (inv && std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2])) {
-      const double px = o[0], py = o[1], pz = o[2], nx = o[3], ny = o[4], nz = o[5];
-      for (int r = 0; r < 3; ++r) {
-        o[r] = (float)(px * inv[4 * r] + (py * inv[4 * r + 1] + (pz * inv[4 * r + 2] + inv[4 * r + 3])));
-        o[3 + r] = (float)(nx * inv[4 * r] + (ny * inv[4 * r + 1] + nz * inv[4 * r + 2]));
-      }
-    }
-    memcpy(out + 8 * i, o, sizeof o);
-  }
+  return tsdf_to_host(m->slab[0], out, m->ray_image, (size_t)n * 8 * sizeof(float));  // (synchronises the first slab's stream)
+}
+
+// Report-only: rounds, records handed from one slab to another, bytes that moved between slabs (hand-offs + finished rays
+// to the first slab) and host waits of the last renderView on this multi handle.
+extern "C" int tsdf_hip_multi_render_stats(tsdf_handle h, uint64_t out[4]) {
+  if (!h || !h->multi || !out) return TSDF_HIP_E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = h->multi->rv_stats[i];
   return TSDF_HIP_OK;
 }
 

@@ -564,24 +564,188 @@ extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], 
   return TSDF_HIP_OK;
 }
 
-// Merge of one slab's delta into the record array (multi-GPU renderView in one process, tsdf_multi.hip): a record the
-// slab touched (status word non-zero) replaces the old one; `suspended` (optional) counts the rays still waiting
-// for another slab afterwards.
+// ---------------------------------------------------------------------------------------------
+// Compact ray lists for the one-process multi-GPU renderView (tsdf_multi.hip).  Every slab keeps ONLY the records it is
+// responsible for; after a round of k_raycast<true> in list mode a record is either finished -- its pixel index and 8
+// output floats go to the image on the first slab -- or suspended for the owner of its next plane, and travels there
+// point-to-point.  The kernels below are the device side of that routing: nothing image-sized ever crosses a link.
+#define RAY_FIN_INTS TSDF_RAY_FIN_INTS
+struct RayRoute {
+  int n_slab;
+  int z_end[TSDF_MAX_SLABS];  // owner of plane z = first slab whose z_end exceeds it
+};
+
+// The start records of the rays with pixel index = rank (mod world), as a compact list (:305-313).
 static __global__ void __launch_bounds__(256)
-k_ray_merge(int *__restrict__ state, const int *__restrict__ delta, int64_t n, unsigned *__restrict__ suspended) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int *s = state + RAY_REC * i;
-  const int *d = delta + RAY_REC * i;
-  if (d[0] != 0) {
+k_ray_begin_list(const RayArgs a, int *__restrict__ list, int rank, int world, unsigned count) {
+  const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= count) return;
+  const int64_t i = (int64_t)slot * world + rank;
+  float du[3];
+  ray_direction(a, i, du);
+  int *r = list + RAY_REC * (size_t)slot;
+  const float t = a.zmin;
+  r[0] = 1;
+  r[1] = -1;
+  r[2] = 0;
+  r[3] = 0;
+  r[4] = __float_as_int(t);
 #pragma unroll
-    for (int k = 0; k < RAY_REC; ++k) s[k] = d[k];
+  for (int k = 0; k < 3; ++k) {
+    float pt = a.org[k];
+    pt += t * du[k];
+    r[5 + k] = __float_as_int(pt);
   }
-  if (suspended && s[0] == 1) atomicAdd(suspended, 1u);
+  r[8] = r[9] = 0;
+  r[10] = __float_as_int(a.min_step);
+  r[11] = (int)i;
+  for (int k = 12; k < RAY_REC; ++k) r[k] = 0;
 }
 
-int tsdf_ray_merge(hipStream_t stream, int *state, const int *delta, int64_t n, unsigned *suspended) {
-  hipLaunchKernelGGL(k_ray_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, delta, n, suspended);
+static __device__ __forceinline__ int ray_dest(const RayRoute &rt, const int *r) {
+  if (r[0] == 2) return rt.n_slab;  // finished: to the image
+  int d = 0;
+  while (d < rt.n_slab - 1 && r[1] >= rt.z_end[d]) ++d;
+  return d;
+}
+
+// counters[0 .. n_slab] = records per destination (n_slab = finished)
+static __global__ void __launch_bounds__(256)
+k_ray_route_count(const int *__restrict__ list, unsigned count, const RayRoute rt, unsigned *__restrict__ counters) {
+  __shared__ unsigned hist[TSDF_MAX_SLABS + 1];
+  for (int k = threadIdx.x; k <= rt.n_slab; k += 256) hist[k] = 0;
+  __syncthreads();
+  const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < count) atomicAdd(&hist[ray_dest(rt, list + RAY_REC * (size_t)slot)], 1u);
+  __syncthreads();
+  for (int k = threadIdx.x; k <= rt.n_slab; k += 256)
+    if (hist[k]) atomicAdd(&counters[k], hist[k]);
+}
+
+// cursors[d] = first outbox slot of destination d (exclusive prefix over the slabs); the finished rays have their own box
+static __global__ void k_ray_route_offsets(const unsigned *__restrict__ counters, unsigned *__restrict__ cursors, int n_slab) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned run = 0;
+  for (int k = 0; k < n_slab; ++k) {
+    cursors[k] = run;
+    run += counters[k];
+  }
+  cursors[n_slab] = 0;
+}
+
+// Records sorted by destination into `outbox` (suspended, whole records) and `finbox` (finished, RAY_FIN_INTS words);
+// one atomic per wave and destination.
+static __global__ void __launch_bounds__(256)
+k_ray_route_scatter(const int *__restrict__ list, unsigned count, const RayRoute rt, unsigned *__restrict__ cursors,
+                    int *__restrict__ outbox, int *__restrict__ finbox) {
+  const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = slot < count;
+  const int *r = list + RAY_REC * (size_t)(valid ? slot : 0);
+  const int dest = valid ? ray_dest(rt, r) : -1;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned pos = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int d = __shfl(dest, leader);
+    const unsigned long long same = __ballot(valid && dest == d);
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cursors[d], (unsigned)__popcll(same));
+    base = __shfl(base, leader);
+    if (valid && dest == d) pos = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (!valid) return;
+  if (dest == rt.n_slab) {
+    int *o = finbox + RAY_FIN_INTS * (size_t)pos;
+    o[0] = r[11];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[1 + k] = r[16 + k];
+  } else {
+    int *o = outbox + RAY_REC * (size_t)pos;
+#pragma unroll
+    for (int k = 0; k < RAY_REC; ++k) o[k] = r[k];
+  }
+}
+
+// Finished rays into the image (8 floats per pixel), with renderView's last line (:422) applied as k_raycast does.
+struct RayDeliver {
+  int to_camera;
+  double inv[12];
+};
+static __global__ void __launch_bounds__(256)
+k_ray_deliver(const int *__restrict__ fin, unsigned count, float *__restrict__ out, int64_t n_pix, const RayDeliver dl) {
+  const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= count) return;
+  const int *f = fin + RAY_FIN_INTS * (size_t)slot;
+  const int64_t pix = f[0];
+  if (pix < 0 || pix >= n_pix) return;
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = __int_as_float(f[1 + k]);
+  if (dl.to_camera && isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2])) {
+    const double px = o[0], py = o[1], pz = o[2], nx = o[3], ny = o[4], nz = o[5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[r] = (float)(px * dl.inv[4 * r] + (py * dl.inv[4 * r + 1] + (pz * dl.inv[4 * r + 2] + dl.inv[4 * r + 3])));
+      o[3 + r] = (float)(nx * dl.inv[4 * r] + (ny * dl.inv[4 * r + 1] + nz * dl.inv[4 * r + 2]));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[8 * pix + k] = o[k];
+}
+
+// Host side of the above, all asynchronous on the slab's stream (the caller is on the slab's device).
+unsigned tsdf_ray_list_share(int64_t n_rays, int rank, int world) {  // rays with index = rank (mod world)
+  return n_rays > rank ? (unsigned)((n_rays - rank + world - 1) / world) : 0u;
+}
+
+int tsdf_ray_list_begin(tsdf_handle s, const float rot[9], const float origin[3], int downsample, int rank, int world,
+                        int32_t *d_list, unsigned *count) {
+  RayArgs a;
+  if (make_ray_args(s, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  *count = tsdf_ray_list_share((int64_t)a.nw * a.nh, rank, world);
+  if (!*count) return TSDF_HIP_OK;
+  hipLaunchKernelGGL(k_ray_begin_list, dim3((*count + 255u) / 256u), dim3(256), 0, s->stream, a, (int *)d_list, rank, world, *count);
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
+int tsdf_ray_list_advance(tsdf_handle s, const float rot[9], const float origin[3], int downsample, int rank, int world,
+                          int32_t *d_list, unsigned count, unsigned *d_incomplete) {
+  if (!count) return TSDF_HIP_OK;
+  RayArgs a;
+  if (make_ray_args(s, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
+  hipLaunchKernelGGL(k_raycast<true>, dim3((count + 255u) / 256u), dim3(256), 0, s->stream, make_view(s), a, (float *)nullptr,
+                     d_incomplete, (const int *)d_list, (int *)d_list, RaySlab{rank, world, s->z_begin, s->z_end, (int)count});
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
+// d_counters: 2 * (n_slab + 1) words -- counts per destination, then the scatter cursors.
+int tsdf_ray_list_route(tsdf_handle s, const int32_t *d_list, unsigned count, int n_slab, const int *z_end,
+                        unsigned *d_counters, int32_t *d_outbox, int32_t *d_finbox) {
+  if (n_slab < 1 || n_slab > TSDF_MAX_SLABS) return TSDF_HIP_E_INVALID;
+  TSDF_HIP_TRY(hipMemsetAsync(d_counters, 0, 2 * (size_t)(n_slab + 1) * sizeof(unsigned), s->stream));
+  if (!count) return TSDF_HIP_OK;
+  RayRoute rt;
+  rt.n_slab = n_slab;
+  for (int k = 0; k < TSDF_MAX_SLABS; ++k) rt.z_end[k] = k < n_slab ? z_end[k] : INT_MAX;
+  const dim3 grid((count + 255u) / 256u), block(256);
+  hipLaunchKernelGGL(k_ray_route_count, grid, block, 0, s->stream, (const int *)d_list, count, rt, d_counters);
+  hipLaunchKernelGGL(k_ray_route_offsets, dim3(1), dim3(64), 0, s->stream, (const unsigned *)d_counters, d_counters + n_slab + 1, n_slab);
+  hipLaunchKernelGGL(k_ray_route_scatter, grid, block, 0, s->stream, (const int *)d_list, count, rt, d_counters + n_slab + 1,
+                     (int *)d_outbox, (int *)d_finbox);
+  TSDF_HIP_TRY(hipGetLastError());
+  return TSDF_HIP_OK;
+}
+
+int tsdf_ray_deliver(tsdf_handle s, const int32_t *d_fin, unsigned count, float *d_out, int64_t n_pix, const double *inv) {
+  if (!count) return TSDF_HIP_OK;
+  RayDeliver dl;
+  dl.to_camera = inv ? 1 : 0;
+  for (int i = 0; i < 12; ++i) dl.inv[i] = inv ? inv[i] : 0.0;
+  hipLaunchKernelGGL(k_ray_deliver, dim3((count + 255u) / 256u), dim3(256), 0, s->stream, (const int *)d_fin, count, d_out, n_pix, dl);
   TSDF_HIP_TRY(hipGetLastError());
   return TSDF_HIP_OK;
 }

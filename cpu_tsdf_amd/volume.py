@@ -126,6 +126,13 @@ class TSDFVolumeOctree:
             out.append(tuple(x.value for x in v))
         return out
 
+    def renderStats(self):
+        """Multi-GPU volumes: (rounds, records handed between slabs, bytes moved between slabs, host waits) of the last
+        renderView / renderColoredView."""
+        out = (C.c_uint64 * 4)()
+        capi.check(capi.load().tsdf_hip_multi_render_stats(self._need(), out), "multi_render_stats")
+        return tuple(int(v) for v in out)
+
     def setStream(self, stream_ptr):
         self._stream = stream_ptr
         if self._h:

@@ -122,16 +122,30 @@ int tsdf_hip_destroy(tsdf_handle h);
  *                   crosses a link.  n_observed is the sum over the slabs.
  *   march / fetch   one plane of halo per slab from its upper neighbour (peer copy), the slabs mesh concurrently, the
  *                   triangle lists are merged by the reference's order; the merged mesh lives on the host.
- *   raycast*        ray hand-off between the slabs (tsdf_hip_raycast_begin / _advance underneath).
+ *   raycast*        ray hand-off between the slabs on COMPACT lists: each slab keeps only the rays it is responsible
+ *                   for and advances them on its own stream; a ray that needs another slab's voxel travels there
+ *                   point-to-point (96 B), a finished ray goes to the first slab (36 B), which assembles the image
+ *                   and applies the camera transform; tsdf_hip_multi_render_stats reports what moved.
  *   sample, lookup_rgb, download, upload, save, reset, synchronize, set_weighting, centers, layout: as for one handle.
  * Not available on such a handle (TSDF_HIP_E_UNSUPPORTED): set_stream, device_planes, get/set_planes_device,
  * raycast_begin/advance*, march_fetch_device -- they expose ONE device's memory.
- * p->z_begin / z_end must be 0 (the whole grid); p->device is ignored.  Results are bit-identical to one handle
- * holding the whole grid (tests/test_multi_gpu.py).  cpu_tsdf::TSDFVolumeOctree::setDevices() is the C++ face of it;
+ * p->z_begin / z_end must be 0 (the whole grid); p->device is ignored.  Every slab works on its own non-blocking
+ * stream (also when ordinals repeat), every cross-slab dependency is an event.  Results are bit-identical to one
+ * handle holding the whole grid -- tested with repeated ordinals on one GPU and, where more than one GPU is visible,
+ * with distinct ordinals (tests/test_multi_gpu.py); the latter has not run on this project's one-GPU test boxes.  cpu_tsdf::TSDFVolumeOctree::setDevices() is the C++ face of it;
  * cpu_tsdf_amd/zslab.py is the multi-PROCESS form of the same partition (one rank per GPU, RCCL). */
 int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *devices, int n_devices, tsdf_handle *out);
 /* Number of Z-slab handles behind h (1 for an ordinary handle) and the device / owned planes / halo of slab k. */
 int tsdf_hip_slab_count(tsdf_handle h);
+/* Report-only, multi-GPU handles: of the last tsdf_hip_raycast* call -- out[0] rounds, out[1] ray records handed from one
+ * slab to another, out[2] bytes that moved between slabs (hand-offs + finished rays to the first slab), out[3] host
+ * waits (one per slab and round: the slabs of a round run concurrently). */
+int tsdf_hip_multi_render_stats(tsdf_handle h, uint64_t out[4]);
+/* Report-only, multi-GPU handles: per-slab k_integrate time.  While enabled, every slab's integrate launch is bracketed
+ * by HIP events on that slab's stream; tsdf_hip_multi_kernel_ms synchronises slab k and returns the summed milliseconds
+ * and the number of launches since timing was enabled (or last read). */
+int tsdf_hip_multi_timing(tsdf_handle h, int enable);
+int tsdf_hip_multi_kernel_ms(tsdf_handle h, int k, float *ms_sum, int32_t *launches);
 int tsdf_hip_slab_info(tsdf_handle h, int k, int32_t *device, int32_t *z_begin, int32_t *z_end, int32_t *halo);
 
 /* Host memory and the boundary.  Every entry point that takes or returns HOST arrays moves them through a pinned
@@ -154,7 +168,9 @@ int tsdf_hip_synchronize(tsdf_handle h);
  *   n_observed   optional: number of voxels that reached addObservation this frame.
  * The host variant copies the frame to the device and synchronises; the device variant takes
  * device pointers, is asynchronous on the handle's stream and only synchronises when
- * n_observed != NULL. */
+ * n_observed != NULL.  The caller's device buffers must be complete when the call is made and stay untouched until
+ * the work has finished (tsdf_hip_synchronize or any synchronising call): on a multi-GPU handle the other GPUs copy
+ * the frame from them on their own streams. */
 int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
                        const float cam_from_vol[12], uint64_t *n_observed);
 int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
@@ -443,7 +459,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 10
+#define TSDF_HIP_ABI_VERSION 11
 
 #ifdef __cplusplus
 }

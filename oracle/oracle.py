@@ -71,6 +71,9 @@ def lib():
         L.oracle_march.restype = C.c_uint64
         L.oracle_march.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, C.c_float, C.c_int, _f, _u8,
                                    C.POINTER(C.c_uint64), C.c_uint64]
+        L.oracle_march_box.restype = C.c_uint64
+        L.oracle_march_box.argtypes = [C.POINTER(OracleParams)] + [C.POINTER(C.c_int)] * 4 + [_f, _f, _u8, C.c_float, C.c_int, _f, _u8,
+                                       C.POINTER(C.c_uint64), C.c_uint64]
         L.oracle_trilinear.restype = C.c_float
         L.oracle_trilinear.argtypes = [C.POINTER(OracleParams), _f, _f, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_int)]
@@ -236,6 +239,37 @@ class OracleVolume:
             if n <= cap:
                 return verts[:n].reshape(n * 3, 3), rgb[:n].reshape(n * 3, 3), cells[:n]
             cap = n
+
+
+def march_box(params, org, d, w, rgb, clo, chi, w_min, color_mode=0):
+    """Marching cubes of the cells with base voxel in [clo, chi) (x, y, z) of the grid `params` describes, from arrays
+    d / w / rgb ([z][y][x]) that hold only the voxels starting at `org` (x, y, z): the triangles the whole-grid mesh
+    has for those cells, in its order.  How full-size GPU volumes are compared box by box."""
+    p = params if isinstance(params, OracleParams) else params_from(params)
+    d = np.ascontiguousarray(d, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    rgb = np.ascontiguousarray(rgb, np.uint8) if rgb is not None else None
+    dim = (C.c_int * 3)(d.shape[2], d.shape[1], d.shape[0])
+    i3 = lambda v: (C.c_int * 3)(*[int(x) for x in v])
+    cap = 1 << 16
+    while True:
+        verts = np.empty((cap, 9), np.float32)
+        col = np.empty((cap, 9), np.uint8)
+        cells = np.empty(cap, np.uint64)
+        n = int(lib().oracle_march_box(C.byref(p), i3(org), dim, i3(clo), i3(chi), _fp(d), _fp(w), _bp(rgb) if rgb is not None else None,
+                                       w_min, color_mode, _fp(verts), _bp(col), cells.ctypes.data_as(C.POINTER(C.c_uint64)), cap))
+        if n == 2 ** 64 - 1:
+            raise ValueError("march_box: the arrays do not cover the requested cells")
+        if n <= cap:
+            return verts[:n].reshape(n * 3, 3), col[:n].reshape(n * 3, 3), cells[:n]
+        cap = n
+
+
+def cells_in_box(cells, clo, chi):
+    """Mask of the mesh's per-triangle cell keys (x<<42 | y<<21 | z) whose base voxel lies in [clo, chi)."""
+    x, y, z = (cells >> np.uint64(42)).astype(np.int64), ((cells >> np.uint64(21)) & np.uint64(0x1fffff)).astype(np.int64), \
+        (cells & np.uint64(0x1fffff)).astype(np.int64)
+    return (x >= clo[0]) & (x < chi[0]) & (y >= clo[1]) & (y < chi[1]) & (z >= clo[2]) & (z < chi[2])
 
 
 class SlabOracle:

@@ -853,9 +853,20 @@ static int cmp_cell(const void *a, const void *b) {
   return ka < kb ? -1 : ka > kb;
 }
 
+/* The voxel arrays may hold only a BOX of the grid: voxels [org, org + dim) per axis, x fastest (the whole grid is
+ * org = 0, dim = res).  Full-size volumes are checked box by box (tests/test_fullsize_gpu.py). */
+typedef struct {
+  int org[3], dim[3];
+} mc_window;
+
+static size_t win_index(const mc_window *win, int x, int y, int z) {
+  return ((size_t)(z - win->org[2]) * win->dim[1] + (size_t)(y - win->org[1])) * win->dim[0] + (size_t)(x - win->org[0]);
+}
+
 /* getGridValue, marching_cubes_tsdf_octree.cpp:91-106 */
-static float grid_value(const oracle_params *p, const float *d, const float *w, float w_min, int x, int y, int z) {
-  const size_t vi = ((size_t)z * p->res[1] + y) * p->res[0] + x;
+static float grid_value(const oracle_params *p, const mc_window *win, const float *d, const float *w, float w_min, int x, int y,
+                        int z) {
+  const size_t vi = win_index(win, x, y, z);
   if (w[vi] < w_min || fabs(d[vi]) >= 1) return NAN;
   return d[vi] * p->max_dist_neg;
 }
@@ -863,9 +874,9 @@ static float grid_value(const oracle_params *p, const float *d, const float *w, 
 /* Returns the number of triangles; writes at most cap triangles (9 floats each, volume frame, before
  * the global transform), rgb 9 bytes per triangle (color_mode 1: setColorByRGB, 2:
  * setColorByConfidence), cell keys (x<<42 | y<<21 | z) per triangle.  Order = octree pre-order. */
-uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, const uint8_t *rgb, float w_min,
-                      int color_mode, float *verts, uint8_t *rgb_out, uint64_t *cell_out, uint64_t cap) {
-  const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
+static uint64_t march_window(const oracle_params *p, const mc_window *win, const int clo[3], const int chi[3], const float *d,
+                             const float *w, const uint8_t *rgb, float w_min, int color_mode, float *verts, uint8_t *rgb_out,
+                             uint64_t *cell_out, uint64_t cap) {
   /* setInputTSDF :44-83: the two +- terms at :64-66 cancel, so the bounding box is
    * [centre(voxel 0), centre(voxel res)]; size_voxel_ = (upper - lower) * (1 / res) in float */
   float lower[3], size_voxel[3];
@@ -878,10 +889,17 @@ uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, co
   size_t n_cells = 0, cap_cells = 1 << 16;
   mc_cell *cells = (mc_cell *)malloc(cap_cells * sizeof(mc_cell));
   /* reconstructVoxel :179-207 candidate test */
-  for (int z = 1; z < nz - 1; ++z)
-    for (int y = 1; y < ny - 1; ++y)
-      for (int x = 1; x < nx - 1; ++x) {
-        const size_t vi = ((size_t)z * ny + y) * nx + x;
+  /* (the reference walks every leaf and keeps those 0 < index < res - 1, :186-191; a window keeps the base voxels in
+   * [clo, chi) of them) */
+  int lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = clo[a] > 1 ? clo[a] : 1;
+    hi[a] = chi[a] < p->res[a] - 1 ? chi[a] : p->res[a] - 1;
+  }
+  for (int z = lo[2]; z < hi[2]; ++z)
+    for (int y = lo[1]; y < hi[1]; ++y)
+      for (int x = lo[0]; x < hi[0]; ++x) {
+        const size_t vi = win_index(win, x, y, z);
         if (!(w[vi] >= w_min && fabs(d[vi]) < 1)) continue;
         if (n_cells == cap_cells) {
           cap_cells *= 2;
@@ -902,7 +920,7 @@ uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, co
     float leaf[8];
     int ok = 1;
     for (int k = 0; k < 8 && ok; ++k) { /* getValidNeighborList1D :145-177 */
-      leaf[k] = grid_value(p, d, w, w_min, x + off[k][0], y + off[k][1], z + off[k][2]);
+      leaf[k] = grid_value(p, win, d, w, w_min, x + off[k][0], y + off[k][1], z + off[k][2]);
       if (isnan(leaf[k])) ok = 0;
     }
     if (!ok) continue;
@@ -929,7 +947,7 @@ uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, co
         for (int k = 0; k < 3; ++k) vl[e][k] = pc[a][k] + mu * (pc[b][k] - pc[a][k]);
       }
     uint8_t col[3] = {0, 0, 0};
-    const size_t vi = ((size_t)z * ny + y) * nx + x;
+    const size_t vi = win_index(win, x, y, z);
     if (color_mode == 2) { /* :217-224 */
       const float std_dev = (100. - w[vi]) / 100.;
       col[0] = (uint8_t)fmax(0., fmin((1 - std_dev) * 255., 255.));
@@ -954,4 +972,27 @@ uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, co
   }
   free(cells);
   return n_tri;
+}
+
+uint64_t oracle_march(const oracle_params *p, const float *d, const float *w, const uint8_t *rgb, float w_min,
+                      int color_mode, float *verts, uint8_t *rgb_out, uint64_t *cell_out, uint64_t cap) {
+  const mc_window win = {{0, 0, 0}, {p->res[0], p->res[1], p->res[2]}};
+  const int clo[3] = {1, 1, 1}, chi[3] = {p->res[0] - 1, p->res[1] - 1, p->res[2] - 1};
+  return march_window(p, &win, clo, chi, d, w, rgb, w_min, color_mode, verts, rgb_out, cell_out, cap);
+}
+
+/* The same for the cells whose base voxel lies in [clo, chi) of a grid of which only the voxels [org, org + dim) are in
+ * the arrays (org <= clo and chi + 1 <= org + dim per axis, or -1 is returned): the triangles the whole-grid mesh holds
+ * for those cells, in the whole-grid order restricted to them. */
+uint64_t oracle_march_box(const oracle_params *p, const int org[3], const int dim[3], const int clo[3], const int chi[3],
+                          const float *d, const float *w, const uint8_t *rgb, float w_min, int color_mode, float *verts,
+                          uint8_t *rgb_out, uint64_t *cell_out, uint64_t cap) {
+  mc_window win;
+  for (int a = 0; a < 3; ++a) {
+    win.org[a] = org[a];
+    win.dim[a] = dim[a];
+    const int hi = chi[a] < p->res[a] - 1 ? chi[a] : p->res[a] - 1;
+    if (org[a] < 0 || dim[a] < 2 || org[a] > clo[a] || hi + 1 > org[a] + dim[a] || org[a] + dim[a] > p->res[a]) return (uint64_t)-1;
+  }
+  return march_window(p, &win, clo, chi, d, w, rgb, w_min, color_mode, verts, rgb_out, cell_out, cap);
 }

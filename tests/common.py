@@ -74,3 +74,36 @@ def write_vol_from_arrays(path, params, d, w, rgb, global_transform=None, chunk=
     finally:
         if chunk:
             capi.set_tuning("vol_chunk", 256)
+
+
+def assert_mesh_boxes_equal_oracle(vol, mesh, boxes, w_min, mode, min_triangles=1000):
+    """Full-size meshes (VERDICT r02 missing #6): for every box [clo, chi) of base voxels, the product's triangles whose
+    cell key falls inside must equal -- count, order, vertex bits, colours -- the oracle's marching cubes of that box run
+    on the very voxels the GPU holds (downloaded box + one voxel on the high side).  mesh = reconstruct(want_cells=True)."""
+    from oracle.oracle import cells_in_box, march_box
+    res = vol.getResolution()
+    tri_v = mesh["vertices"].reshape(-1, 3, 3)
+    tri_c = mesh["rgb"].reshape(-1, 3, 3) if mode else None
+    seen = 0
+    for clo, chi in boxes:
+        org = [max(0, c) for c in clo]
+        end = [min(res[a], chi[a] + 1) for a in range(3)]
+        d, w, rgb = vol.download(org[0], org[1], org[2], end[0] - org[0], end[1] - org[1], end[2] - org[2])
+        v2, c2, k2 = march_box(vol._p, org, d, w, rgb if mode == 1 else None, clo, chi, w_min, mode)
+        m = cells_in_box(mesh["cells"], clo, chi)
+        assert np.array_equal(mesh["cells"][m], k2), f"box {clo}..{chi}: {int(m.sum())} product triangles, {len(k2)} oracle triangles"
+        assert_same_f32(tri_v[m].reshape(-1, 3), v2, f"mesh vertices in box {clo}..{chi}")
+        if mode:
+            assert np.array_equal(tri_c[m].reshape(-1, 3), c2), f"mesh colours in box {clo}..{chi}"
+        seen += len(k2)
+    assert seen >= min_triangles, seen
+    return seen
+
+
+def boxes_2048():
+    """Sub-boxes of a 2048^3 Scene-A grid: the sphere's near pole, one column along each axis through the whole grid
+    (sphere, walls, 2048-long index ranges, every 4 GB plane span of the classify kernel), two opposite corners of the
+    outer shell (three walls meeting; border cells the reference skips)."""
+    return [((944, 944, 432), (1104, 1104, 592)),
+            ((1000, 1008, 0), (1064, 1040, 2048)), ((0, 1100, 1400), (2048, 1132, 1464)), ((1400, 0, 1100), (1464, 2048, 1132)),
+            ((0, 0, 0), (260, 260, 260)), ((1790, 1790, 1790), (2048, 2048, 2048))]

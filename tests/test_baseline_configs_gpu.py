@@ -20,7 +20,7 @@ from cpu_tsdf_amd import capi, synth  # noqa: E402
 from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree, transform_cloud_with_normals  # noqa: E402
 from oracle import refbind  # noqa: E402
 from oracle.oracle import OracleVolume, SlabOracle  # noqa: E402
-from tests.common import assert_same_f32  # noqa: E402
+from tests.common import assert_mesh_boxes_equal_oracle, assert_same_f32, boxes_2048  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 W, H = 640, 480
@@ -161,9 +161,13 @@ def test_config3_2048_cubed_colour_through_weight_saturation_then_mesh(gpu):
     mc.setInputTSDF(v)
     mc.setMinWeight(2.0)
     mc.setColorByRGB(True)
-    mesh = mc.reconstruct()
+    mesh = mc.reconstruct(want_cells=True)
     vert = mesh["vertices"]
     assert len(vert) > 3 * 10 ** 7 and mesh["rgb"].shape == vert.shape
+    # north_star: "MC case indices / triangle topology bit-exact" AT the headline size -- count, order, vertex bits and
+    # colours of six sub-boxes (sphere pole, a column along each axis, two shell corners) against the oracle
+    n_checked = assert_mesh_boxes_equal_oracle(v, mesh, boxes_2048(), 2.0, 1, min_triangles=100000)
+    print(f"2048^3 mesh: {len(vert) // 3} triangles, {n_checked} of them compared bit for bit with the oracle")
     r = np.linalg.norm(vert[::97].astype(np.float64), axis=1)
     box = np.abs(np.abs(vert[::97]).max(1) - sc.h)
     resid = np.minimum(np.abs(r - sc.r), box)

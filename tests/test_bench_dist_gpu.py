@@ -63,3 +63,41 @@ def test_bench_two_ranks_one_gpu_over_gloo(gpu, overlap):
     assert j["multi_gpu"]["planes_per_gpu"] == 128 and len(j["multi_gpu"]["per_rank_kernel_ms"]) == 2
     # every voxel is observed by exactly one slab: the two ranks' counts add up to the single-handle count
     assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+
+
+def test_bench_plain_command_line_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher (VERDICT r02 missing #4): bench.py re-executes itself under
+    torch.distributed.run, one rank per GPU, and prints ONE line with n_gpus == 2."""
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", TSDF_BENCH_ONE_DEVICE="1", TSDF_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    check_contract(j, 2)
+    assert j["multi_gpu"]["world_size"] == 2 and j["multi_gpu"]["backend"] == "gloo"
+    assert len(j["multi_gpu"]["per_rank_kernel_ms"]) == 2 and j["multi_gpu"]["frame_broadcast_ms_isolated"] > 0
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_inprocess_host(gpu, n):
+    """--host inprocess: the tsdf_hip_create_multi path the C++ drop-in uses, N slabs on the one GPU."""
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    j = run([sys.executable, "bench.py", "--gpus", str(n), "--host", "inprocess"] + COMMON, {"TSDF_BENCH_ONE_DEVICE": "1"})
+    assert j["n_gpus"] == n and j["steps"] == 4 and j["unit"] == "Mvoxels/s" and j["value"] > 0
+    assert j["config"]["parallelism"] == f"zslab{n}-inprocess" and j["config"]["grid"] == [256, 256, 256]
+    mg = j["multi_gpu"]
+    assert len(mg["per_slab_kernel_ms"]) == n and all(ms > 0 for ms in mg["per_slab_kernel_ms"])
+    assert mg["slabs"][0]["z_begin"] == 0 and mg["slabs"][-1]["z_end"] == 256
+    assert 0 < j["roofline"]["frac"] <= 1
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+
+
+def test_bench_single_gpu_line_carries_the_host_path_rate(gpu):
+    j = run([sys.executable, "bench.py"] + COMMON, {})
+    hp = j["host_path"]
+    assert hp["frames_per_s_sync_calls"] > 0 and hp["frames_per_s_async_ring"] > 0 and "error" not in hp

@@ -203,3 +203,110 @@ def test_single_device_entry_points_refuse_a_multi_handle(gpu):
     assert lib.tsdf_hip_get_planes_device(h, 0, 1, None, None, None) == capi.E_UNSUPPORTED
     assert b"multi-GPU set" in lib.tsdf_hip_last_error()
     multi.close()
+
+
+def _devices(n):
+    """Device lists for n slabs: ordinal 0 repeated (always), plus distinct ordinals round-robin where the box has more
+    than one GPU (cross-DEVICE ordering -- peer copies, events between devices -- has only ever run with
+    repeated ordinals on this project's one-GPU boxes; this variant runs wherever it can)."""
+    out = [[0] * n]
+    ndev = capi.load().tsdf_hip_device_count()
+    if ndev > 1:
+        out.append([k % ndev for k in range(n)])
+    return out
+
+
+@pytest.mark.parametrize("n_slabs", [2, 8])
+def test_render_view_hands_rays_over_in_compact_lists(gpu, n_slabs):
+    """renderView on a multi handle moves hand-off records (96 B per seam crossing) and finished rays (36 B each, to the
+    first slab), never the image; and equals one handle at 8 slabs as well, at an image larger than the volume test's."""
+    for devices in _devices(n_slabs):
+        multi, sc = make(devices)
+        one, _ = make(None)
+        for i in range(3):
+            tr = synth.turntable_pose(i, 8, sc.size)
+            for v in (multi, one):
+                v.integrateCloud(sc.depth(tr), sc.bgra(i), tr)
+        n_rays = W * H
+        for tr in (synth.look_at_pose((0.02, 0.01, -0.9 * sc.size)), synth.turntable_pose(1, 8, sc.size, tilt=0.3),
+                   synth.look_at_pose((-0.9 * sc.size, 0.0, 0.013), target=(0.0, 0.01, -0.02))):
+            for camera in (False, True):
+                got, want = multi.renderView(tr, 1, camera_frame=camera), one.renderView(tr, 1, camera_frame=camera)
+                assert_same_f32(got, want, f"renderView {devices}")
+            rounds, handed, moved, waits = multi.renderStats()
+            assert 1 <= rounds <= 2 * n_slabs + 4 and waits == n_slabs * rounds
+            assert 96 * handed <= moved <= 96 * handed + 36 * n_rays and (moved - 96 * handed) % 36 == 0
+            # the full-image protocol this replaced moved 2 (n - 1) images of 96 B records PER ROUND
+            assert moved < 2 * (n_slabs - 1) * n_rays * 96
+        assert multi.renderStats()[1] > 0  # the last view runs along the seams: rays do change slabs
+        multi.close()
+        one.close()
+
+
+def test_device_frames_back_to_back_without_counts(gpu):
+    """with n_observed == NULL nothing synchronises between frames, so the source of the frame
+    fan-out (slab 0's staging buffer after tsdf_hip_organize, or the caller's device buffer) must be ordered AFTER the
+    other slabs' copies of the previous frame by events.  Every slab has its own stream (also on one device), so a
+    missing dependency shows up here as a torn frame: 24 frames back to back, slabs of unequal work."""
+    import torch
+    for devices in _devices(4):
+        multi, sc = make(devices)
+        one, _ = make(None)
+        u, vv = np.meshgrid(np.arange(W), np.arange(H))
+        n = 24
+        for i in range(n):  # the ingest path: z-buffer on slab 0, fan-out, integrate; no count, no synchronisation
+            tr = synth.turntable_pose(i, n, sc.size, tilt=0.1)
+            dep = sc.depth(tr, noise_seed=100 + i)
+            z = np.where(np.isfinite(dep), dep, 0).astype(np.float32)
+            xyz = np.stack([(u - sc.cx) / sc.fx * z, (vv - sc.cy) / sc.fy * z, z], -1).reshape(-1, 3).astype(np.float32)
+            col = sc.bgra(i).reshape(-1, 4)
+            for v in (multi, one):
+                v.organize(xyz, col, zero_nans=True, fetch=False)
+                v.integrateStaged(tr)
+        a, b = multi.download(), one.download()
+        assert_same_f32(a[0], b[0], f"d after {n} staged frames, devices {devices}")
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # caller-owned device frames (one buffer per frame, all complete before the first call)
+        multi.reset()
+        one.reset()
+        frames = torch.empty((n, 2, H, W), dtype=torch.float32, device="cuda:0")
+        poses = [synth.turntable_pose(i, n, sc.size, tilt=-0.1) for i in range(n)]
+        for i, tr in enumerate(poses):
+            frames[i, 0].copy_(torch.from_numpy(sc.depth(tr, noise_seed=300 + i)))
+            frames[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
+        torch.cuda.synchronize()
+        for i, tr in enumerate(poses):
+            for v in (multi, one):
+                v.integrateCloudDevice(frames[i, 0].data_ptr(), frames[i, 1].data_ptr(), tr)
+        multi.synchronize()
+        one.synchronize()
+        a, b = multi.download(), one.download()
+        assert_same_f32(a[0], b[0], f"d after {n} device frames, devices {devices}")
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        multi.close()
+        one.close()
+
+
+def test_counts_are_reduced_after_every_slab_has_launched(gpu):
+    """n_observed on a multi handle = the sum over the slabs, each slab's counters read after ALL slabs were launched;
+    tsdf_hip_last_count_detail reports the set's totals; the per-slab kernel timing hook brackets every launch."""
+    import ctypes as C
+    multi, sc = make([0, 0, 0])
+    one, _ = make(None)
+    lib = capi.load()
+    capi.check(lib.tsdf_hip_multi_timing(multi._need(), 1), "timing")
+    for i in range(3):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        a = multi.integrateCloud(sc.depth(tr), sc.bgra(i), tr, count=True)
+        b = one.integrateCloud(sc.depth(tr), sc.bgra(i), tr, count=True)
+        da, db = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        capi.check(lib.tsdf_hip_last_count_detail(multi._need(), da), "detail")
+        capi.check(lib.tsdf_hip_last_count_detail(one._need(), db), "detail")
+        assert a == b == da[0] == db[0] and da[1] == db[1] > 0
+    for k in range(3):
+        ms, cnt = C.c_float(0), C.c_int32(0)
+        capi.check(lib.tsdf_hip_multi_kernel_ms(multi._need(), k, C.byref(ms), C.byref(cnt)), "kernel_ms")
+        assert cnt.value == 3 and ms.value > 0
+    assert lib.tsdf_hip_multi_timing(one._need(), 1) == capi.E_INVALID
+    multi.close()
+    one.close()
