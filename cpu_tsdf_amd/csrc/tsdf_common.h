@@ -62,6 +62,7 @@ struct tsdf_hip_volume {
   size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
   unsigned long long last_observed = 0, last_changed_bytes = 0;  // tsdf_hip_last_count_detail
+  int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
   bool count_ran = false;  // that launch really ran (finite pose, something observable)
   hipStream_t stream = nullptr;
@@ -196,7 +197,7 @@ int tsdf_to_device(tsdf_hip_volume *v, void *dev_dst, const void *src, size_t by
 void tsdf_pipeline_destroy(tsdf_hip_volume *v);
 
 // Launch-shape knobs, overridable from the environment for A/B runs (TSDF_HIP_ROWS_PER_BLOCK,
-// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL, TSDF_HIP_VOL_CHUNK); read once, changeable
+// TSDF_HIP_BLOCKS_PER_CU, TSDF_HIP_FAST_PROJECTION, TSDF_HIP_MC_FLUSH_AT, TSDF_HIP_CULL, TSDF_HIP_VOL_CHUNK, TSDF_HIP_ALLIN); read once, changeable
 // through tsdf_hip_set_tuning.
 struct TsdfTuning {
   int rows_per_block;  // voxel rows (of up to 1024 voxels) each integrate block walks
@@ -207,6 +208,7 @@ struct TsdfTuning {
   int vol_chunk;       // edge of the voxel blocks save / load stream through host memory
   int plain_kernel;    // F32W volumes integrate through the plain per-voxel kernel (the weight_by_depth one, w_new = 1)
   int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
+  int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
 };
 const TsdfTuning &tsdf_tuning();
 

@@ -52,7 +52,7 @@ static TsdfTuning &tuning_storage() {
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
-                         env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3)};
+                         env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1)};
   return t;
 }
 
@@ -80,6 +80,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.plain_kernel = value;
   else if (n == "alloc_tries")
     t.alloc_tries = std::max(1, value);
+  else if (n == "allin")
+    t.allin = value;
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;

@@ -29,6 +29,8 @@ struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
   float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path); cxf/cyf carry the +band shift
   float hb_u, hb_v;          // certificate threshold: fract(R~) > 2 * band
+  float hb_max;              // max(hb_u, hb_v): the ALLIN instance certifies a quad with ONE compare of min(fract) against it
+  unsigned kcap, kinc;       // PACKED count after an observation, byte 3 of a word: min(k, kcap) + kinc == min(k + 1, kmax)
   int hinge_fixed;           // PACKED: (p*w + p)/(w + 1) == p for every stored weight w, p = pos_over_neg (host-checked)
   int neg_in_window;         // max_dist_pos/neg inside the scale-free divider's window
   unsigned kmax;             // PACKED layout: saturation count ceil(max_weight)
@@ -73,13 +75,25 @@ static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, cons
 //   * R~ far outside the image  =>  R is outside too, and so is trunc(R~) (or the point is flagged below).
 // Anything else (an R~ sitting on an integer, a non-finite R~ whose fract is 0 or NaN) is flagged ambiguous and
 // recomputed by project_exact.  One multiply, one fma, one fract, one compare and one conversion per coordinate.
+template <bool ALLIN = false>
 static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float gx, float gy, float gz,
-                                                   bool &ambiguous) {
+                                                   bool &ambiguous, uint32_t *margin = nullptr) {
   const float y = __builtin_amdgcn_rcpf(gz);
   const float ru = __builtin_fmaf(gx * a.fxf, y, a.cxf);
   const float rv = __builtin_fmaf(gy * a.fyf, y, a.cyf);
-  const bool cert = __builtin_amdgcn_fractf(ru) > a.hb_u && __builtin_amdgcn_fractf(rv) > a.hb_v;  // false for NaN
   const int u = (int)ru, v = (int)rv;  // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+  // ALLIN: the host has proved that every voxel of the launch projects at least a pixel inside the image border and
+  // has 1e-3 <= g.z (launch_integrate, `all_inside`), so R~ is finite and positive, a certified (u, v) needs no bounds
+  // test, and the certificate is handed back as ONE number -- min(fract(ru), fract(rv)), to be compared against
+  // max(hb_u, hb_v): slightly stricter than the two separate tests -- so that the caller can certify a whole quad
+  // with one compare.  The fractions lie in [0, 1): their bit patterns order like the values, and integer minima
+  // (v_min3_u32) need no NaN canonicalisation.
+  if (ALLIN) {
+    *margin = min(__float_as_uint(__builtin_amdgcn_fractf(ru)), __float_as_uint(__builtin_amdgcn_fractf(rv)));
+    ambiguous = false;
+    return (int)__umul24((unsigned)v, (unsigned)a.W) + u;
+  }
+  const bool cert = __builtin_amdgcn_fractf(ru) > a.hb_u && __builtin_amdgcn_fractf(rv) > a.hb_v;  // false for NaN
   // an uncertified point far outside the image is recomputed needlessly, never wrongly
   ambiguous = !cert;
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
@@ -194,11 +208,33 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #ifndef TSDF_SKIP_FIXED_HINGE
 #define TSDF_SKIP_FIXED_HINGE 1  // PACKED: waves whose observed voxels all stay at the hinge value skip the d ladder
 #endif
+// Timing-only experiment switches (WRONG results; tools/ab_bound.sh builds them to find what binds the kernel):
+//   TSDF_EXP_NO_STORE   no voxel plane is written back          TSDF_EXP_NO_GATHER  the frame is not read (constant far depth)
+//   TSDF_EXP_NO_VLOAD   no voxel plane is read (hinge / zero)   TSDF_WPE_MAX        cap on resident waves per SIMD
+#ifndef TSDF_EXP_NO_STORE
+#define TSDF_EXP_NO_STORE 0
+#endif
+#ifndef TSDF_EXP_NO_GATHER
+#define TSDF_EXP_NO_GATHER 0
+#endif
+#ifndef TSDF_EXP_NO_VLOAD
+#define TSDF_EXP_NO_VLOAD 0
+#endif
+#ifndef TSDF_WPE_MAX
+#define TSDF_WPE_MAX 8
+#endif
+#ifndef TSDF_RECOMPUTE_PX
+#define TSDF_RECOMPUTE_PX 1  // 72 instead of 80 VGPRs: 7 waves per SIMD (A/B on the GPU: 17.3-17.5 against 17.8-17.9 ms)
+#endif
 #ifndef TSDF_WPE_PACKED
 #define TSDF_WPE_PACKED 6  // waves per SIMD the PACKED / colourless instances ask for (80 VGPRs: 7 waves = 72 VGPRs spills since the result-side guard)
 #endif
-template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6, 8)))
+// ALLIN (only with FASTPROJ): the host has proved (launch_integrate, `all_inside`: the slab's eight corner voxels, a
+// convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
+// with a pixel to spare, and nx is a multiple of 4: the per-voxel range compares, the image-bounds compares and the
+// "nothing in range" exits go away -- the turntable / object-in-front-of-the-camera case the headline is quoted on.
+template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false>
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) < TSDF_WPE_MAX ? ((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
@@ -231,17 +267,20 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   const rsrc_t rsK = make_rsrc(PACKED && !COLOR ? K8 + e0 : (uint8_t *)D, PACKED && !COLOR ? span : 0u);
   const unsigned npix = (unsigned)a.W * (unsigned)a.H;
   const rsrc_t rsF = make_rsrc(depth, COLOR ? a.bgra_off + npix * 4u : npix * 4u);  // [depth ... bgra]
+  // ALLIN: every pixel index is valid, so the gather can address the frame by INDEX (stride 4, `idxen`): no shift per
+  // pixel, and no range check is wanted (NUM_RECORDS at its maximum, whichever unit the hardware counts it in)
+  const i4_rsrc rsFi = make_rsrc_2d(depth, 4u, 0xffffffffu);
   if (xq < a.qpr) {
     const int x4 = xq * 4;
     const float cz = ctrz[a.z_global0 + zl];
     const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
     const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
     // ---- pcl::transformPoint (hpp:145): the x products and the z part, once per thread -------------------
-    float px[4][3], zt[3];
+    float px_[4][3], zt[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) px[j][r] = cxs[j] * a.m[4 * r];  // == m * cx bit for bit
+      for (int j = 0; j < 4; ++j) px_[j][r] = cxs[j] * a.m[4 * r];  // == m * cx bit for bit
       zt[r] = ORDER == TSDF_XFORM_PCL_SSE ? cz * a.m[4 * r + 2] + a.m[4 * r + 3] : a.m[4 * r + 2] * cz;
     }
     const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;  // byte offset inside the row group
@@ -255,6 +294,22 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * a.m[4 * q + 1] + zt[q] : a.m[4 * q + 1] * cy;
+#if TSDF_RECOMPUTE_PX
+      // the x products are redone per row (12 multiplies, six packed) instead of living in 12 registers across the
+      // loop: the kernel waits for memory, not for the VALU, and registers are what limits the waves in flight
+      float px[4][3];
+      {
+        float cxr[4] = {cxs[0], cxs[1], cxs[2], cxs[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cxr[j]));  // (keeps LLVM from hoisting the products back out)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) px[j][q] = cxr[j] * a.m[4 * q];
+      }
+#else
+      const float (&px)[4][3] = px_;
+#endif
       auto transform = [&](int j, int q) -> float {
         if (ORDER == TSDF_XFORM_PCL_SSE) return px[j][q] + yt[q];
         return ((px[j][q] + yt[q]) + zt[q]) + a.m[4 * q + 3];
@@ -263,19 +318,20 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       int pix[4];
       float gzs[4];
       unsigned amb_mask = 0;
+      uint32_t margin[4] = {0u, 0u, 0u, 0u};  // ALLIN: bits of min(fract(ru), fract(rv)) per voxel
       bool any = false, lowz = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
         // hpp:146 + .cpp:616: !(gz < zmin || gz > zmax) && gz > 0, as two compares: zlo is the largest float every
         // accepted gz exceeds (the float below zmin when zmin > 0, else 0; a NaN gz fails, as there)
-        const bool in = gz > a.zlo && !(gz > a.zmax);
+        const bool in = ALLIN || (gz > a.zlo && !(gz > a.zmax));
         gzs[j] = gz;
-        lowz |= in && gz < 0x1p-14f;
+        if (!ALLIN) lowz |= in && gz < 0x1p-14f;  // (ALLIN: the host checked g.z > 1e-3 for the whole slab)
         int p;
         if (FASTPROJ) {
           bool amb;
-          p = project_fast(a, gx, gy, gz, amb);  // garbage in, garbage out: masked by `in` below
+          p = project_fast<ALLIN>(a, gx, gy, gz, amb, &margin[j]);  // garbage in, garbage out: masked by `in` below
           if (amb && in) amb_mask |= 1u << j;
         } else {
           p = project_exact(a, cam, gx, gy, in ? gz : 1.f);
@@ -283,7 +339,15 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         pix[j] = in ? p : -1;
         any |= in;
       }
-      if (!any) continue;
+      if (!ALLIN && !any) continue;
+      if (ALLIN && FASTPROJ) {  // one compare certifies the quad; which voxels failed is only worked out off the hot path
+        const uint32_t hb = __float_as_uint(a.hb_max);
+        if (!(min(min(margin[0], margin[1]), min(margin[2], margin[3])) > hb)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (!(margin[j] > hb)) amb_mask |= 1u << j;
+        }
+      }
       // Voxels whose fp32 projection could not be certified: redo them exactly, one at a time through a
       // single copy of the fp64 code (rare: a fraction ~4*band of the voxels).
       while (FASTPROJ && amb_mask) {
@@ -317,8 +381,16 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       for (int j = 0; j < 4; ++j) {
         // a valid pixel offset is < npix*4; -1 becomes 0xfffffffc, beyond the descriptor with or without the
         // colour image's scalar offset
-        zs[j] = __uint_as_float(bload32(rsF, (unsigned)pix[j] << 2, 0u));
-        if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
+        if (TSDF_EXP_NO_GATHER) {
+          zs[j] = 1e3f + (float)(pix[j] & 1);
+          cs[j] = 0x00406080u + (unsigned)pix[j];
+        } else if (ALLIN) {
+          zs[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, 0, 0));
+          if (COLOR) cs[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, (int)a.bgra_off, 0);
+        } else {
+          zs[j] = __uint_as_float(bload32(rsF, (unsigned)pix[j] << 2, 0u));
+          if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
+        }
       }
       // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
       // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
@@ -333,7 +405,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         raw[j] = zs[j] - gzs[j];                                        // hpp:159
         // hpp:152, :193-196: pcl_isnan(pt.z) and raw < -neg both reject; gz is finite here, so a NaN depth is a NaN
         // raw, and "raw >= -neg" is false for it and for every raw below -neg: one compare for both tests
-        act[j] = pix[j] >= 0 && raw[j] >= -a.neg;
+        act[j] = (ALLIN || pix[j] >= 0) && raw[j] >= -a.neg;
         dn[j] = a.pos_over_neg;                                         // hpp:189-192: raw > pos clamps
         any |= act[j];
         any_div |= act[j] && !(raw[j] > a.pos);
@@ -353,7 +425,12 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (act[j] && !(raw[j] > a.pos)) dn[j] = raw[j] / a.neg;
       }
       // ---- read-modify-write -----------------------------------------------------------------------------
-#if !TSDF_EARLY_VOXEL_LOADS
+#if TSDF_EXP_NO_VLOAD
+      const uint32_t hb_ = __float_as_uint(a.pos_over_neg);
+      const u4 d4 = {hb_, hb_, hb_, hb_};
+      u4 w4 = {0u, 0u, 0u, 0u}, c4 = {(unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24};
+      uint32_t k4 = 0u;
+#elif !TSDF_EARLY_VOXEL_LOADS
       const u4 d4 = bload128(rsD, voff, soff);
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
@@ -373,15 +450,18 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         kw[j] = 0u;
         if (PACKED) {
           kw[j] = COLOR ? c0[j] : (k4 << (24 - 8 * j));
-          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);  // tsdf_decode_w (neither is NaN here)
+          // tsdf_decode_w (neither is NaN here).  (With an integer max_weight the min is the identity, but leaving it
+          // out lets LLVM turn the colour sums into integer multiplies and byte shuffles: +70 instructions, measured.)
+          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
         }
       }
       float dv[4], wv[4];
       uint32_t cv[4], k1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)  // PACKED: the count after this observation, k' = min(k + 1, kmax), as byte 3 of a word
-        // (saturate BEFORE adding: with kmax == 255 an in-place add would wrap byte 3 to zero)
-        k1[j] = !PACKED ? 0u : (kw[j] >> 24) >= a.kmax ? (a.kmax << 24) : (kw[j] & 0xff000000u) + 0x01000000u;
+        // (saturate BEFORE adding: with kmax == 255 an in-place add would wrap byte 3 to zero; kcap = (kmax - 1) << 24
+        // and kinc = 1 << 24, both 0 when kmax == 0)
+        k1[j] = !PACKED ? 0u : min(kw[j] & 0xff000000u, a.kcap) + a.kinc;  // == min(k + 1, kmax) << 24
       // F32W: the fast update is exact if update_is_safe().  PACKED: the divisor k + 1 is an integer in
       // [1, 256] (unless the weight sits at a non-integer max_weight), for which the scale-free ladder is
       // exact whenever its RESULT is a normal number (residuals of a normal numerator against an integer
@@ -406,11 +486,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #if TSDF_SKIP_FIXED_HINGE
       if (PACKED && a.hinge_fixed) {
         bool off_hinge = any_div;
+        // (ALLIN: without the `observed` mask -- a quad with an unobserved voxel off the hinge just takes the general
+        // path, which is always right)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) off_hinge |= act[j] && d0u[j] != __float_as_uint(a.pos_over_neg);
-        d_moves = __ballot(off_hinge) != 0ull;  // wave-uniform: one scalar branch
+        for (int j = 0; j < 4; ++j) off_hinge |= (ALLIN || act[j]) && d0u[j] != __float_as_uint(a.pos_over_neg);
+        d_moves = __builtin_amdgcn_ballot_w64(off_hinge) != 0ull;  // wave-uniform: one scalar branch
       }
 #endif
+      bool d_touched = false;  // this lane's distances went through an update (else dv == d0 and nothing is compared or stored)
       if (safe) {
         Rcp32 rs[4];
 #pragma unroll
@@ -427,6 +510,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
         }
         if (d_moves) {  // distance
+          d_touched = true;
 #pragma unroll
           for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
 #if TSDF_GUARD_ON_RESULT
@@ -436,12 +520,13 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             // at a non-integer max_weight, whose divisor is no count -- sends the quad through the IEEE path below
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              safe &= !act[j] || ((a.wmax_is_int || kw[j] < (a.kmax << 24)) && __builtin_amdgcn_classf(dv[j], 0x108));
+              safe &= !act[j] || ((ALLIN || a.wmax_is_int || kw[j] < (a.kmax << 24)) && __builtin_amdgcn_classf(dv[j], 0x108));
           }
 #endif
         }
       }
       if (!safe) {
+        d_touched = true;
         asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -452,27 +537,36 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cv[j] |= k1[j];  // both flavours return the colour with the new count in byte 3
         }
       }
-      uint32_t diff_d = 0u, diff_w = 0u, diff_c = 0u, k4n = 0u;
-      uint32_t dn_u[4], wn_u[4];
+      uint32_t diff_w = 0u, diff_c = 0u, k4n = 0u;
+      uint32_t wn_u[4];
       const uint32_t c_before[4] = {c0[0], c0[1], c0[2], c0[3]};
+      if (d_touched) {  // (free space resting at the hinge never gets here: wave-uniform skip)
+        uint32_t diff_d = 0u, dn_u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
+          diff_d |= dn_u[j] ^ d0u[j];
+          if (COUNT) chg += dn_u[j] != d0u[j] ? 4u : 0u;
+        }
+        if (diff_d && !TSDF_EXP_NO_STORE) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (PACKED && !COLOR) k4n |= (act[j] ? k1[j] : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
-        dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
         wn_u[j] = act[j] ? __float_as_uint(wv[j]) : w0u[j];
         cv[j] = act[j] ? cv[j] : c0[j];
-        diff_d |= dn_u[j] ^ d0u[j];
         diff_w |= wn_u[j] ^ w0u[j];
         diff_c |= cv[j] ^ c0[j];
         cnt += act[j] ? 1u : 0u;
         if (COUNT)  // bytes of voxel words whose VALUE changed: what any layout-preserving kernel has to write
-          chg += (dn_u[j] != d0u[j] ? 4u : 0u) + (!PACKED && wn_u[j] != w0u[j] ? 4u : 0u) +
-                 (COLOR && cv[j] != c_before[j] ? 4u : 0u);
+          chg += (!PACKED && wn_u[j] != w0u[j] ? 4u : 0u) + (COLOR && cv[j] != c_before[j] ? 4u : 0u);
       }
       if (COUNT && PACKED && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
                                                             ((k4n ^ k4) >> 4) | ((k4n ^ k4) >> 5) | ((k4n ^ k4) >> 6) | ((k4n ^ k4) >> 7)) & 0x01010101u);
-      if (diff_d) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
       if (!PACKED && diff_w) bstore128(rsW, voff, soff, (u4){wn_u[0], wn_u[1], wn_u[2], wn_u[3]});
+      if (TSDF_EXP_NO_STORE) {  // keep the results alive without touching memory
+        if ((cv[0] ^ cv[1] ^ cv[2] ^ cv[3]) == 0x12345678u) bstore32(rsD, voff, soff, cv[0] ^ diff_w);
+      } else
       if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
       if (PACKED && !COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
     }
@@ -594,6 +688,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
     a.cyf = (float)(p.cy + (double)hh.band_v);
     a.hb_u = nextafterf(2.f * hh.band_u, INFINITY);  // rounded toward the conservative side
     a.hb_v = nextafterf(2.f * hh.band_v, INFINITY);
+    a.hb_max = std::max(a.hb_u, a.hb_v);
   }
   a.zmin = p.min_sensor_dist;
   // !(gz < zmin) && gz > 0 for a non-NaN gz: gz >= zmin when zmin > 0 (<=> gz > the float just below zmin), else gz > 0
@@ -604,6 +699,8 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.neg = p.max_dist_neg;
   a.wmax = p.max_weight;
   a.kmax = h->kmax;
+  a.kcap = h->kmax ? (h->kmax - 1u) << 24 : 0u;
+  a.kinc = h->kmax ? 0x01000000u : 0u;
   a.wmax_is_int = p.max_weight == floorf(p.max_weight);
   a.pos_over_neg = p.max_dist_pos / p.max_dist_neg;
   {
@@ -953,6 +1050,25 @@ static bool observable_index_box(const tsdf_hip_volume *h, const float T[12], in
   return true;
 }
 
+// ALLIN's margins (1e-3 m in depth, one pixel in the image) must dwarf the float transform's rounding: |g| <= ~1e3 m
+// keeps that below 1e-4 m, and a depth of at least 0.05 m keeps its image below 0.01 * f pixels ... so require both,
+// scaled by the focal length.
+static bool zlo_margin_ok(const float T[12], const tsdf_hip_volume *h) {
+  double big = 0, zmin = 1e300;
+  for (int k = 0; k < 8; ++k) {
+    const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
+                 z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
+    for (int r = 0; r < 3; ++r) {
+      const double g = fabs((double)T[4 * r] * x) + fabs((double)T[4 * r + 1] * y) + fabs((double)T[4 * r + 2] * z) + fabs((double)T[4 * r + 3]);
+      big = std::max(big, g);
+    }
+    zmin = std::min(zmin, (double)T[8] * x + (double)T[9] * y + (double)T[10] * z + (double)T[11]);
+  }
+  const double err = 8.0 * 6e-8 * big;                                   // float transform, 8x margin
+  const double f = std::max(fabs(h->p.fx), fabs(h->p.fy));
+  return err < 1e-4 && zmin > 0.05 && f * err * (1.0 + big / zmin) / zmin < 0.05;  // < 1/20 pixel
+}
+
 // Asynchronous half: queues the launch on the handle's stream.  `count` selects the counting instance, whose striped
 // counters stay in h->counter until tsdf_integrate_collect reads them (a multi-GPU set launches every slab first and
 // collects afterwards, so the slabs count concurrently).
@@ -1091,6 +1207,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   uint8_t *K8 = h->k8;
   const float *ctrx = h->ctr[0], *ctry = h->ctr[1];
   bool nothing_observable = false;
+  bool allin = false;  // every voxel of the launch in sensor range and a pixel inside the image: the ALLIN instance
   if (tsdf_tuning().cull) {
     bool all_inside = tsdf_tuning().cull != 2;
     for (int k = 0; k < 8 && all_inside; ++k) {
@@ -1103,6 +1220,11 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       all_inside = g[2] > zlo + 1e-3 && g[2] > 1e-3 && g[2] < p.max_sensor_dist - 1e-3 && u > 1 && u < p.image_width - 2 && v > 1 &&
                    v < p.image_height - 2;
     }
+    // The eight corner voxels lie inside the convex set {range, image minus a border}; so does every voxel centre in
+    // exact arithmetic, and the margins (1e-3 m, one pixel) cover the float transform (~1e-7 relative) and the
+    // projection's sensitivity to it as long as the coordinates stay moderate.
+    allin = all_inside && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
+            (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
     if (!all_inside) {
       int lo[3], hi[3];
       bool empty = false;
@@ -1165,17 +1287,29 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   bool pose_ok = true;
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
   const bool fastproj = fast_projection_ok(hh, p.integrate_color != 0);
+  h->last_launch[0] = h->last_launch[1] = h->last_launch[2] = h->last_launch[3] = 0;
   if (pose_ok && !nothing_observable) {
     const dim3 grid(gx, gy, gz), block(256);
-#define LAUNCH(ORDER, COLOR, FP, COUNT, PK)                                                                  \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
+    h->last_launch[0] = fastproj && allin && !live;
+    h->last_launch[1] = fastproj;
+    h->last_launch[2] = live != nullptr;
+    h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
+#define LAUNCH(ORDER, COLOR, FP, COUNT, PK, AI)                                                                  \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK, AI>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
                      d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live)
-#define L5(ORDER, COLOR, FP, COUNT) \
-  do {                              \
-    if (h->packed)                  \
-      LAUNCH(ORDER, COLOR, FP, COUNT, true);  \
-    else                            \
-      LAUNCH(ORDER, COLOR, FP, COUNT, false); \
+#define L5(ORDER, COLOR, FP, COUNT)                    \
+  do {                                                 \
+    if (h->packed) {                                   \
+      if (FP && allin && !live)                        \
+        LAUNCH(ORDER, COLOR, FP, COUNT, true, FP);     \
+      else                                             \
+        LAUNCH(ORDER, COLOR, FP, COUNT, true, false);  \
+    } else {                                           \
+      if (FP && allin && !live)                        \
+        LAUNCH(ORDER, COLOR, FP, COUNT, false, FP);    \
+      else                                             \
+        LAUNCH(ORDER, COLOR, FP, COUNT, false, false); \
+    }                                                  \
   } while (0)
 #define L4(ORDER, COLOR, FP) \
   do {                       \
@@ -1250,6 +1384,14 @@ extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
   if (h->multi) return tsdf_multi_last_count_detail(h, out);
   out[0] = h->last_observed;
   out[1] = h->last_changed_bytes;
+  return TSDF_HIP_OK;
+}
+
+// Test / report hook: which instance the last integrate launch on this handle (slab 0 of a set) went through.
+extern "C" int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  if (h->multi) h = tsdf_multi_first(h);
+  for (int i = 0; i < 4; ++i) out[i] = h->last_launch[i];
   return TSDF_HIP_OK;
 }
 

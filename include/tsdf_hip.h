@@ -446,11 +446,18 @@ int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
 
+/* Test / report hook: the last integrate launch on this handle -- out[0] = 1 if it ran the ALLIN instance of k_integrate
+ * (the host proved from the slab's eight corner voxels that EVERY voxel is inside the sensor range and projects inside
+ * the image with a pixel to spare -- the camera-outside-the-volume case -- so the per-voxel range / image-bounds tests are
+ * compiled out; results are identical, tuning knob "allin" = 0 turns it off), out[1] = 1 with the certified fp32
+ * projection, out[2] = 1 with brick-cull flags, out[3] = blocks launched (0: nothing could be observed). */
+int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]);
+
 /* Test / tuning hook: 256-thread blocks per CU the runtime admits for k_mc_classify (out[0]) and k_mc_emit (out[1]). */
 int tsdf_hip_selftest_occupancy_mc(int out[2]);
 
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
- * "mc_flush_at", "cull", "vol_chunk", "plain_kernel", "alloc_tries" -- the TSDF_HIP_* environment variables) at run time.  No knob
+ * "mc_flush_at", "cull", "vol_chunk", "plain_kernel", "alloc_tries", "allin" -- the TSDF_HIP_* environment variables) at run time.  No knob
  * changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 

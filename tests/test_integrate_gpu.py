@@ -468,3 +468,70 @@ def test_integrate_fuzz_equals_the_oracle(gpu):
         if color:
             assert np.array_equal(rgb, ov.rgb), f"case {case}: rgb"
         vol.close()
+
+
+def launch_info(vol):
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    capi.check(capi.load().tsdf_hip_last_launch_info(vol._need(), out), "last_launch_info")
+    return list(out)
+
+
+@pytest.mark.parametrize("color,layout,wmax", [(True, capi.LAYOUT_AUTO, 100.0), (False, capi.LAYOUT_AUTO, 4.0),
+                                               (True, capi.LAYOUT_F32W, 100.0), (True, capi.LAYOUT_AUTO, 2.5)])
+def test_all_inside_instance_equals_general_instance_and_oracle(gpu, color, layout, wmax):
+    """k_integrate's ALLIN instance (every voxel provably in range and in the image: no per-voxel range / bounds tests,
+    one certificate compare per quad, indexed frame gather) against the general instance and the oracle: same frames,
+    knob "allin" on and off, noisy depth with NaN holes so that unobserved / in-band / free-space quads all occur, enough
+    frames to pass the weight limit.  A non-integer max_weight in the PACKED layout must fall back to the general one."""
+    vols = []
+    try:
+        for allin in (1, 0):
+            capi.set_tuning("allin", allin)
+            vol, sc = make_volume(96, color=color, max_weight=wmax)
+            vol.setLayout(layout)
+            vol.reset()
+            ov = OracleVolume(vol._p)
+            used = []
+            for i, tr, dep, col in frames(sc, 7, 9, noise=True):
+                dep = dep.copy()
+                dep[(i * 7) % 50::53, ::3] = np.nan
+                n_gpu = vol.integrateCloud(dep, col if color else None, tr, count=(i % 2 == 0))
+                used.append(launch_info(vol)[0])
+                n_cpu = ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+                assert n_gpu is True or n_gpu == n_cpu
+            packed = vol.getLayout() == capi.LAYOUT_PACKED
+            expect = int(allin == 1 and not (packed and wmax != int(wmax)))
+            assert used == [expect] * 7, (used, expect)
+            compare(vol, ov)
+            vols.append(vol.download())
+            vol.close()
+    finally:
+        capi.set_tuning("allin", 1)
+    assert_same_f32(vols[0][0], vols[1][0], "d: ALLIN vs general")
+    assert np.array_equal(vols[0][1], vols[1][1])
+
+
+def test_all_inside_instance_is_not_chosen_when_a_voxel_may_leave_the_image_or_the_range(gpu):
+    """The host's proof obligation: eight corner voxels inside {sensor range, image minus a one-pixel border}.  A camera
+    close enough that a corner leaves the image, a sensor range that cuts the volume, a camera inside the volume and a
+    grid whose x resolution is not a multiple of 4 must all take the general instance -- and still equal the oracle."""
+    cases = []
+    vol, sc = make_volume(64)
+    cases.append(("turntable", vol, sc, synth.turntable_pose(1, 8, sc.size), 1))
+    vol, sc = make_volume(64)
+    cases.append(("close: corners outside the image", vol, sc, synth.turntable_pose(1, 8, sc.size, radius_factor=0.9), 0))
+    vol, sc = make_volume(64, zmax=0.5)
+    cases.append(("far plane cuts the volume", vol, sc, synth.turntable_pose(1, 8, sc.size), 0))
+    vol, sc = make_volume(64)
+    cases.append(("camera inside", vol, sc, synth.look_at_pose((0.01, 0.0, -0.02), target=(0.0, 0.0, 1.0)), 0))
+    vol, sc = make_volume(64, res3=(66, 64, 64))
+    cases.append(("nx not a multiple of 4", vol, sc, synth.turntable_pose(1, 8, sc.size), 0))
+    for name, vol, sc, tr, want in cases:
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        dep = sc.depth(tr)
+        assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate(dep, None, synth.cam_from_vol_f32(tr)), name
+        assert launch_info(vol)[0] == want, (name, launch_info(vol))
+        compare(vol, ov)
+        vol.close()
