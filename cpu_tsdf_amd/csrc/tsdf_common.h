@@ -58,6 +58,14 @@ struct tsdf_hip_volume {
   double *cam64 = nullptr;         // fx, fy, cx, cy on the device
   tsdf_hip_pipeline *pipe = nullptr;
   int frame_staged = 0;            // tsdf_hip_organize left a frame in [frame_depth | frame_bgra]
+  // "Band seen" flags, one byte per cell of 64 x 4 x 1 voxels (x, y, z) of the allocated planes: set by the integrate
+  // kernels when a voxel of the cell is observed INSIDE the truncation band -- the only way a distance becomes negative,
+  // and marching cubes only emits where one corner is negative, so k_mc_classify skips what no set flag is near.
+  // band_exact: the flags describe the planes (true from reset while only the flag-keeping kernels have written them;
+  // an upload, a plane copy or handing out raw pointers clears it, and classify then reads everything).
+  uint8_t *band = nullptr;
+  int band_fx = 0, band_fy = 0;
+  bool band_exact = false;
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
@@ -75,6 +83,8 @@ struct tsdf_hip_volume {
   bool mc_has_rgb = false;
   uint64_t *mc_keys = nullptr, *mc_vals = nullptr;  // active-cell list (Morton key, packed cell)
   size_t mc_cells_cap = 0;
+  uint8_t *mc_need = nullptr;  // k_mc_need's per-wave-plane and per-block verdicts (tsdf_march.hip)
+  size_t mc_need_cap = 0;
   hipEvent_t mc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // tsdf_hip_march_timing
   float mc_ms[3] = {0.f, 0.f, 0.f};                            // classify, sort + scan, emit of the last call
   uint64_t mc_ncells = 0;
@@ -204,6 +214,7 @@ struct TsdfTuning {
   int blocks_per_cu;   // grid-stride helper kernels: grid = 256 CUs x this
   int fast_projection; // certified fp32 pixel projection with exact fp64 fallback: 0 off, anything else on
   int mc_flush_at;     // marching-cubes classify: wave-private list flush threshold (tests lower it)
+  int mc_skip;         // marching-cubes classify: skip what the band flags rule out (1)
   int cull;            // brick-level frustum cull in integrate: 1 when useful (default), 0 never, 2 always
   int vol_chunk;       // edge of the voxel blocks save / load stream through host memory
   int plain_kernel;    // F32W volumes integrate through the plain per-voxel kernel (the weight_by_depth one, w_new = 1)

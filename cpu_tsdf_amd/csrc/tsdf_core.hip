@@ -50,7 +50,7 @@ static int env_int(const char *name, int dflt) {
 static TsdfTuning &tuning_storage() {
   static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
-                         env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512),
+                         env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1)};
   return t;
@@ -72,6 +72,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.fast_projection = value;
   else if (n == "mc_flush_at")
     t.mc_flush_at = value;
+  else if (n == "mc_skip")
+    t.mc_skip = value;
   else if (n == "cull")
     t.cull = value;
   else if (n == "vol_chunk")
@@ -325,12 +327,14 @@ static void free_volume(tsdf_hip_volume *v) {
     if (v->bounce_ev[i]) (void)hipEventDestroy(v->bounce_ev[i]);
   if (v->cam64) (void)hipFree(v->cam64);
   if (v->live) (void)hipFree(v->live);
+  if (v->band) (void)hipFree(v->band);
   if (v->counter) (void)hipFree(v->counter);
   if (v->mc_verts) (void)hipFree(v->mc_verts);
   if (v->mc_rgb) (void)hipFree(v->mc_rgb);
   if (v->mc_cell) (void)hipFree(v->mc_cell);
   if (v->mc_keys) (void)hipFree(v->mc_keys);
   if (v->mc_vals) (void)hipFree(v->mc_vals);
+  if (v->mc_need) (void)hipFree(v->mc_need);
   for (int i = 0; i < 4; ++i)
     if (v->mc_ev[i]) (void)hipEventDestroy(v->mc_ev[i]);
   if (v->scratch) (void)hipFree(v->scratch);
@@ -565,6 +569,9 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     TRY_OR_BAIL(hipMalloc(&v->cam64, sizeof cam));
     TRY_OR_BAIL(hipMemcpy(v->cam64, cam, sizeof cam, hipMemcpyHostToDevice));
   }
+  v->band_fx = (v->nx + 63) / 64;
+  v->band_fy = (v->ny + 3) / 4;
+  TRY_OR_BAIL(hipMalloc(&v->band, (size_t)v->band_fx * v->band_fy * v->nz_alloc));
   TRY_OR_BAIL(hipMalloc(&v->counter, 2048 * sizeof(unsigned long long)));
   TRY_OR_BAIL(hipMemset(v->counter, 0, 2048 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL
@@ -594,6 +601,8 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
   for (int c = 0; c < 4 && !rc; ++c)  // RGBNormalized starts at r_n = g_n = b_n = i = 0 (octree.h:217-222)
     if (h->cn[c]) rc = fill_u32(h, h->cn[c], 0u, n);
   if (rc) return rc;
+  TSDF_HIP_TRY(hipMemsetAsync(h->band, 0, (size_t)h->band_fx * h->band_fy * h->nz_alloc, h->stream));
+  h->band_exact = true;  // every distance is -1: no voxel inside the band
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }
@@ -646,6 +655,7 @@ extern "C" int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint3
                                       int32_t *z_first, int32_t *nz_alloc) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_device_planes");
+  h->band_exact = false;  // the caller may write through these pointers
   if (d) *d = h->d;
   if (w) *w = h->w;
   if (rgb) *rgb = h->rgb;
@@ -859,6 +869,7 @@ extern "C" int tsdf_hip_upload(tsdf_handle h, int x0, int y0, int z0, int nx, in
   if (h && h->multi)
     return tsdf_multi_block(h, false, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
                             const_cast<uint8_t *>(rgb));
+  if (h) h->band_exact = false;  // arbitrary distances arrive: the "band seen" flags no longer describe the planes
   return block_transfer<false>(h, x0, y0, z0, nx, ny, nz, const_cast<float *>(d), const_cast<float *>(w),
                                const_cast<uint8_t *>(rgb));
 }
@@ -971,5 +982,8 @@ extern "C" int tsdf_hip_get_planes_device(tsdf_handle h, int z0, int nz, float *
 extern "C" int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const float *d, const float *w,
                                           const uint32_t *rgb) {
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_set_planes_device");
+  // halo planes are always read by marching cubes (their flags are never consulted); owned planes written from outside
+  // invalidate the flags
+  if (h && z0 < h->z_end && z0 + nz > h->z_begin) h->band_exact = false;
   return planes_device<false>(h, z0, nz, const_cast<float *>(d), const_cast<float *>(w), const_cast<uint32_t *>(rgb));
 }

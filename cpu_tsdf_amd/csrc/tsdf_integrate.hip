@@ -49,6 +49,8 @@ struct IntegrateArgs {
   int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
   int rpb;            // row groups (of TY rows) per block
   unsigned bgra_off;  // byte offset of the colour image from the depth image (same buffer descriptor)
+  int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
+  int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
   int64_t pitch;
 };
 
@@ -223,27 +225,38 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #ifndef TSDF_WPE_MAX
 #define TSDF_WPE_MAX 8
 #endif
+#ifndef TSDF_NO_BAND
+#define TSDF_NO_BAND 0  // A/B: compile the "band seen" flag store out of k_integrate
+#endif
 #ifndef TSDF_RECOMPUTE_PX
 #define TSDF_RECOMPUTE_PX 1  // 72 instead of 80 VGPRs: 7 waves per SIMD (A/B on the GPU: 17.3-17.5 against 17.8-17.9 ms)
 #endif
 #ifndef TSDF_WPE_PACKED
-#define TSDF_WPE_PACKED 6  // waves per SIMD the PACKED / colourless instances ask for (80 VGPRs: 7 waves = 72 VGPRs spills since the result-side guard)
+#define TSDF_WPE_PACKED 7  // waves per SIMD the ALLIN instances of the PACKED / colourless kernels ask for: 72 VGPRs, reachable since the x
+                           // products are redone per row (TSDF_RECOMPUTE_PX).  The general and the counting instances stay at 6: at 7 they spill two dozen
+                           // SGPRs into VGPR lanes, and the build with that AND the band flags gave wrong voxels on the GPU
+                           // (tests/evidence/diag_allin.py; cause not found in the ISA, so the configuration is avoided)
 #endif
 // ALLIN (only with FASTPROJ): the host has proved (launch_integrate, `all_inside`: the slab's eight corner voxels, a
 // convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
 // with a pixel to spare, and nx is a multiple of 4: the per-voxel range compares, the image-bounds compares and the
 // "nothing in range" exits go away -- the turntable / object-in-front-of-the-camera case the headline is quoted on.
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) < TSDF_WPE_MAX ? ((PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
-            unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live) {
+            unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live, uint8_t *__restrict__ band) {
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
   if (live && !live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)]) return;
   const unsigned tid = threadIdx.x;
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
   __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
+  // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
+  // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
+  // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
+  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
+  if (!TSDF_NO_BAND) reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
   if (PACKED) s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
   {
     const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
@@ -511,6 +524,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         }
         if (d_moves) {  // distance
           d_touched = true;
+          // a voxel of this quad was observed inside the truncation band: its distance may turn negative, which is what
+          // marching cubes looks for (see s_band)
+          // (the host only passes `band` when every block's first row is a multiple of 4: local row groups == global ones)
+          if (!TSDF_NO_BAND && any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
 #pragma unroll
           for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
 #if TSDF_GUARD_ON_RESULT
@@ -527,6 +544,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       }
       if (!safe) {
         d_touched = true;
+        if (!TSDF_NO_BAND && any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
         asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -569,6 +587,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       } else
       if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
       if (PACKED && !COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
+    }
+  }
+  if (!TSDF_NO_BAND && band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
+    __syncthreads();
+    const int fxb = max(1, a.TX >> 4);
+    const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
+    const int xc0 = (a.x_abs0 + (int)blockIdx.x * a.TX * 4) >> 6;
+    const int n_fl = (yg1 - yg0 + 1) * fxb;
+    for (int i = (int)tid; i < n_fl; i += 256) {
+      const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
   if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes
@@ -734,6 +763,9 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.TY = 256 / a.TX;
   a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);  // rpb * TY <= 256: the block's row centres sit in LDS
   a.pitch = h->pitch;
+  a.band_fx = h->band_fx;
+  a.band_fy = h->band_fy;
+  a.x_abs0 = a.y_abs0 = 0;
   return hh;
 }
 
@@ -1096,6 +1128,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     return TSDF_HIP_E_UNSUPPORTED;
   }
   const int plain_mode = h->weight_by_depth ? 2 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  if (plain_mode || h->cn[0]) h->band_exact = false;  // the plain kernels keep no "band seen" flags: marching cubes reads everything
   if (plain_mode) {  // weight_by_depth_ (or the test knob "plain_kernel"): the plain per-voxel kernel, float weights
     if (h->packed || h->cn[0]) {
       tsdf_set_error("weight_by_depth needs the F32W layout and TSDF_COLOR_RGB");
@@ -1246,6 +1279,8 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
           ctry += y_off;
           a.qpr -= x_off / 4;
           a.ny -= y_off;
+          a.x_abs0 = x_off;
+          a.y_abs0 = y_off;
           a.z_global0 += z_off;
           a.zl0 += z_off;
           gx = (unsigned)(bx1 - bx0 + 1);
@@ -1288,6 +1323,11 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   for (int i = 0; i < 12; ++i) pose_ok &= std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f;
   const bool fastproj = fast_projection_ok(hh, p.integrate_color != 0);
   h->last_launch[0] = h->last_launch[1] = h->last_launch[2] = h->last_launch[3] = 0;
+  // the kernel keeps the "band seen" flags per block in LDS with block-local row groups: they are the volume's row groups
+  // only if every block starts on a multiple of 4 rows (always, unless the rows_per_block knob was turned below 4);
+  // otherwise this launch keeps no flags and marching cubes reads everything until the next reset
+  uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 && (a.y_abs0 & 3) == 0 ? h->band : nullptr;
+  if (!band_arg) h->band_exact = false;
   if (pose_ok && !nothing_observable) {
     const dim3 grid(gx, gy, gz), block(256);
     h->last_launch[0] = fastproj && allin && !live;
@@ -1296,7 +1336,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
 #define LAUNCH(ORDER, COLOR, FP, COUNT, PK, AI)                                                                  \
   hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK, AI>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
-                     d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live)
+                     d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live, band_arg)
 #define L5(ORDER, COLOR, FP, COUNT)                    \
   do {                                                 \
     if (h->packed) {                                   \

@@ -40,6 +40,12 @@ struct McArgs {
   int qpr;                       // quads per row = ceil(nx / 4)
   int check_w;                   // the weight test can fail (0: PACKED layout and w_min <= 0, every count passes)
   int zb;                        // cell planes a classify block marches (<= MC_ZB; zb + 1 planes must span < 4 GB)
+  // What k_mc_need derived from the "band seen" flags (NULL: read everything).  need[(z - z_lo) * need_rows + wave row]
+  // [x-chunk] = bits 0-3: the wave's four 16-lane groups (64 voxels each) must load their quads of plane z, bit 4: the
+  // one column beyond the wave's last quad; need_blk[(blockIdx.z * grid.y + block row) * grid.x + x-chunk] != 0: the
+  // block has anything to do at all.
+  const uint8_t *need, *need_blk;
+  int need_gx, need_rows, need_by;
 };
 
 static __device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> every third bit
@@ -90,6 +96,63 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
 #endif
 #define MC_COL0 0x0108421u  // bit 0 of each of the five 5-bit row groups
 
+// Which parts of which planes can a classify wave skip?  Marching cubes emits a cell only if one of its eight corners
+// is negative (cube index != 0), and a distance only turns negative through an observation inside the truncation
+// band, which the integrate kernels record per cell of 64 x 4 x 1 voxels (tsdf_hip_volume::band).  A voxel is a
+// corner of a cell that may emit only if a flagged voxel lies within one step of it along every axis, so a wave needs
+// the quads of a 16-lane group (64 voxels x its MC_R + 1 rows, plane z) only if a flag is set among the flag cells
+// that touch that box grown by one voxel.  Planes outside the handle's own slab (halo planes, filled by copies) have
+// no flags and count as set.  One thread per (x-chunk, wave row, plane); all 32-bit-safe sizes.
+struct NeedArgs {
+  const uint8_t *band;
+  int fx, fy;                 // flag cells along x / y
+  int z_first, nz_alloc;      // allocated planes
+  int z_begin, z_end;         // owned planes: only these have flags
+  int z_lo, n_planes;         // planes z_lo .. z_lo + n_planes - 1 are classified (cells z_lo .. z_hi - 1 read one more)
+  int nx, ny;
+  int gx, rows, by;           // x-chunks, wave rows (4 per block row), block rows
+  int zb;
+};
+
+static __global__ void __launch_bounds__(256)
+k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ need_blk) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n.gx * n.rows * n.n_planes;
+  if (t >= total) return;
+  const int bx = (int)(t % n.gx), wrow = (int)((t / n.gx) % n.rows), zi = (int)(t / ((int64_t)n.gx * n.rows));
+  const int z = n.z_lo + zi;
+  const int yw = 1 + wrow * MC_R;                      // the wave's rows yw .. yw + MC_R (the last one is its halo row)
+  const int fy0 = max(0, (yw - 1) >> 2), fy1 = min(n.fy - 1, (yw + MC_R + 1) >> 2);
+  auto flagged = [&](int xa, int xb) -> bool {         // any flag near voxels [xa, xb] x rows x plane z
+    const int fx0 = max(0, (xa - 1) >> 6), fx1 = min(n.fx - 1, (xb + 1) >> 6);
+    if (fx0 > fx1 || fy0 > fy1) return false;
+    for (int zz = z - 1; zz <= z + 1; ++zz) {
+      if (zz < n.z_first || zz >= n.z_first + n.nz_alloc) continue;
+      if (zz < n.z_begin || zz >= n.z_end) return true;  // a halo plane: unknown, so needed
+      const uint8_t *pl = n.band + (int64_t)(zz - n.z_first) * n.fy * n.fx;
+      for (int fy = fy0; fy <= fy1; ++fy)
+        for (int fx = fx0; fx <= fx1; ++fx)
+          if (pl[fy * n.fx + fx]) return true;
+    }
+    return false;
+  };
+  unsigned bits = 0u;
+  if (yw < n.ny) {
+    for (int g = 0; g < 4; ++g) {
+      const int xa = bx * 256 + g * 64;
+      if (xa < n.nx && flagged(xa, min(n.nx - 1, xa + 63))) bits |= 1u << g;
+    }
+    const int xe = bx * 256 + 256;
+    if (xe < n.nx && flagged(xe, xe)) bits |= 16u;
+  }
+  need[t] = (uint8_t)bits;
+  if (bits) {  // (every writer stores the same 1); a cell plane z of block zb-index k reads planes up to z + 1
+    const int brow = wrow >> 2;
+    const int k_hi = min((n.n_planes - 2) / n.zb, zi / n.zb), k_lo = max(0, (zi - 1) / n.zb);
+    for (int k = k_lo; k <= k_hi; ++k) need_blk[((int64_t)k * n.by + brow) * n.gx + bx] = 1;
+  }
+}
+
 template <int WL>  // 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3), 2 = PACKED count plane
 static __device__ __forceinline__ float mc_load_w(const PlaneView &pv, int64_t i) {
   if (WL == 0) return pv.w[i];
@@ -120,6 +183,8 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
   const int x4 = xq * 4;
   const int yw = 1 + ((int)by * 4 + (int)wave) * MC_R;  // first cell row of this wave
   if (1 + (int)by * 4 * MC_R >= a.ny - 1) return;  // the whole BLOCK lies past the last cell row (block-uniform)
+  // nothing near this block was ever observed inside the truncation band: no negative distance, no triangle
+  if (a.need_blk && !a.need_blk[((int64_t)blockIdx.z * a.need_by + by) * a.need_gx + bx]) return;
   const int zs = a.z_lo + (int)blockIdx.z * a.zb;
   const int ze = min(zs + a.zb, a.z_hi);                       // cell planes [zs, ze); plane ze is read
   s_xkey[tid] = (uint32_t)(spread3((uint64_t)tid) << 2);
@@ -227,13 +292,24 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     const rsrc_t rsD = make_rsrc(a.d + ((int64_t)(z - a.z_first) * a.ny + yw) * a.pitch, rows_here * row_bytes);
     u4 q[MC_R + 1];
     float e[MC_R + 1];
+    const u4 outside = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};  // 1.f: outside the band, not negative
+    // the band flags' verdict on this wave's part of plane z (k_mc_need): quads no flagged voxel is near cannot be a
+    // corner of an emitting cell, and read as "outside the band" without being loaded
+    unsigned nd = 31u;
+    if (a.need)
+      nd = (unsigned)__builtin_amdgcn_readfirstlane(
+          (int)a.need[((int64_t)(z - a.z_lo) * a.need_rows + (int)(by * 4u + wave)) * a.need_gx + (int)bx]);
+    const bool ld = ((nd >> (lane >> 4)) & 1u) != 0u;
 #pragma unroll
-    for (int r = 0; r < MC_R; ++r) q[r] = bload128(rsD, voff, (unsigned)r * row_bytes);
-    q[MC_R] = (u4){0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};  // 1.f: outside the band, not negative
-    if (n_load > MC_R) q[MC_R] = bload128(rsD, voff, (unsigned)MC_R * row_bytes);
+    for (int r = 0; r <= MC_R; ++r) q[r] = outside;
+    if (ld) {
+#pragma unroll
+      for (int r = 0; r < MC_R; ++r) q[r] = bload128(rsD, voff, (unsigned)r * row_bytes);
+      if (n_load > MC_R) q[MC_R] = bload128(rsD, voff, (unsigned)MC_R * row_bytes);
+    }
 #pragma unroll
     for (int r = 0; r <= MC_R; ++r) e[r] = 1.f;
-    if (edge_lane) {
+    if (edge_lane && (nd & 16u)) {
 #pragma unroll
       for (int r = 0; r < MC_R; ++r) e[r] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)r * row_bytes));
       if (n_load > MC_R) e[MC_R] = __uint_as_float(bload32(rsD, voff + 16u, (unsigned)MC_R * row_bytes));
@@ -530,6 +606,37 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   const dim3 block(256), grid((unsigned)((a.qpr + 63) / 64), (unsigned)(((cell_rows + 4 * MC_R - 1) / (4 * MC_R) + 7) / 8 * 8),
                               (unsigned)((a.z_hi - a.z_lo + a.zb - 1) / a.zb));
   if (grid.y > 65535u || grid.z > 65535u) return TSDF_HIP_E_UNSUPPORTED;
+  // What the "band seen" flags allow classify to skip (only while they describe the planes: tsdf_hip_volume::band_exact)
+  NeedArgs need_args;
+  size_t need_elems = 0, need_blocks = 0;
+  a.need = a.need_blk = nullptr;
+  a.need_gx = (int)grid.x;
+  a.need_by = (int)grid.y;
+  a.need_rows = 4 * (int)grid.y;
+  if (h->band_exact && tsdf_tuning().mc_skip) {
+    NeedArgs n;
+    n.band = h->band;
+    n.fx = h->band_fx, n.fy = h->band_fy;
+    n.z_first = h->z_first, n.nz_alloc = h->nz_alloc;
+    n.z_begin = h->z_begin, n.z_end = h->z_end;
+    n.z_lo = a.z_lo, n.n_planes = a.z_hi - a.z_lo + 1;
+    n.nx = a.nx, n.ny = a.ny;
+    n.gx = a.need_gx, n.rows = a.need_rows, n.by = a.need_by;
+    n.zb = a.zb;
+    const size_t n_need = (size_t)n.gx * n.rows * n.n_planes, n_blk = (size_t)grid.x * grid.y * grid.z;
+    if (n_need + n_blk > h->mc_need_cap) {
+      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->mc_need) (void)hipFree(h->mc_need);
+      h->mc_need = nullptr, h->mc_need_cap = 0;
+      TSDF_HIP_TRY(hipMalloc(&h->mc_need, n_need + n_blk));
+      h->mc_need_cap = n_need + n_blk;
+    }
+    a.need = h->mc_need;
+    a.need_blk = h->mc_need + n_need;
+    need_args = n;
+    need_elems = n_need;
+    need_blocks = n_blk;
+  }
   unsigned long long counts[2] = {0, 0};
   for (int i = 0; i < 4; ++i)
     if (!h->mc_ev[i]) TSDF_HIP_TRY(hipEventCreate(&h->mc_ev[i]));
@@ -540,6 +647,12 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     const size_t cap = h->mc_cells_cap;
     TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2 * sizeof(unsigned long long), h->stream));
     TSDF_HIP_TRY(hipEventRecord(h->mc_ev[0], h->stream));
+    if (a.need && attempt == 0) {  // (inside the classify phase's timing)
+      TSDF_HIP_TRY(hipMemsetAsync(const_cast<uint8_t *>(a.need_blk), 0, need_blocks, h->stream));
+      hipLaunchKernelGGL(k_mc_need, dim3((unsigned)((need_elems + 255) / 256)), dim3(256), 0, h->stream, need_args,
+                         const_cast<uint8_t *>(a.need), const_cast<uint8_t *>(a.need_blk));
+      TSDF_HIP_TRY(hipGetLastError());
+    }
     if (!h->packed)
       hipLaunchKernelGGL(k_mc_classify<0>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
     else if (h->rgb)

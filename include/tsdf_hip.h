@@ -457,7 +457,7 @@ int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]);
 int tsdf_hip_selftest_occupancy_mc(int out[2]);
 
 /* Test / A-B hook: set a launch-shape knob ("rows_per_block", "blocks_per_cu", "fast_projection",
- * "mc_flush_at", "cull", "vol_chunk", "plain_kernel", "alloc_tries", "allin" -- the TSDF_HIP_* environment variables) at run time.  No knob
+ * "mc_flush_at", "mc_skip", "cull", "vol_chunk", "plain_kernel", "alloc_tries", "allin" -- the TSDF_HIP_* environment variables) at run time.  No knob
  * changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 

@@ -409,3 +409,85 @@ def test_pinned_caller_memory_takes_the_direct_dma_path(gpu):
     for x in (pd, pw, up):
         x.free()
     vol.close()
+
+
+def _mesh(vol, wmin=2.0, mode=1):
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(vol)
+    mc.setMinWeight(wmin)
+    mc.setColorByRGB(mode == 1)
+    mc.setColorByConfidence(mode == 2)
+    return mc.reconstruct(want_cells=True)
+
+
+def _same_mesh(a, b, what):
+    assert np.array_equal(a["cells"], b["cells"]), what
+    assert_same_f32(a["vertices"], b["vertices"], what)
+    if a["rgb"] is not None:
+        assert np.array_equal(a["rgb"], b["rgb"]), what
+
+
+@pytest.mark.parametrize("res3,trunc,pose_kind", [((128, 128, 128), (0.03, 0.03), "turntable"), ((200, 72, 150), (0.02, 0.05), "turntable"),
+                                                  ((130, 128, 128), (0.03, 0.03), "inside"), ((320, 96, 64), (0.06, 0.03), "turntable")])
+def test_marching_cubes_skips_what_no_band_observation_is_near(gpu, res3, trunc, pose_kind):
+    """k_mc_classify reads only what the integrate kernels' "band seen" flags are near (cells of 64 x 4 x 1 voxels, grown
+    by one voxel: a triangle needs a negative corner, a negative distance needs an observation inside the truncation
+    band).  With the skip on and off the mesh is the same and equals the oracle's: cubic / flat / wide grids (several
+    x-chunks, rows that are no multiple of 4 or 64), a hinge value below 1 (pos < neg: free space is INSIDE the band),
+    launches restricted to a sub-box of the grid (camera inside the volume: flag coordinates offset), noise."""
+    S = max(res3) * 2.0 ** -8
+    vol, sc = make_volume(64, color=True, trunc=trunc, size=S, zmax=4 * S, res3=res3, size3=tuple(r * 2.0 ** -8 for r in res3))
+    sc.h = np.array([0.47 * r * 2.0 ** -8 for r in res3])
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i in range(5):
+        tr = synth.turntable_pose(i, 7, S, radius_factor=1.6) if pose_kind == "turntable" else \
+            synth.look_at_pose((0.02 * i - 0.04, 0.01, -0.12), target=(0.0, 0.0, 0.3))
+        dep, col = sc.depth(tr, noise_seed=31 + i), sc.bgra(i)
+        vol.integrateCloud(dep, col, tr)
+        ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+    meshes = {}
+    try:
+        for skip in (1, 0):
+            capi.set_tuning("mc_skip", skip)
+            meshes[skip] = _mesh(vol)
+    finally:
+        capi.set_tuning("mc_skip", 1)
+    _same_mesh(meshes[1], meshes[0], "skip on vs off")
+    v2, c2, cells2 = ov.march(2.0, 1)
+    assert len(cells2) > 300
+    assert np.array_equal(meshes[1]["cells"], cells2)
+    assert_same_f32(meshes[1]["vertices"], v2, "mesh vs oracle")
+    assert np.array_equal(meshes[1]["rgb"], c2)
+    vol.close()
+
+
+def test_band_flags_are_dropped_when_voxels_arrive_from_outside(gpu):
+    """An upload can put a surface where nothing was ever observed: the flags stop describing the planes and marching
+    cubes must read everything again (until the next reset)."""
+    vol, sc = make_volume(64, color=False)
+    vol.reset()
+    for i, tr, dep, col in frames(sc, 3, 8):
+        vol.integrateCloud(dep, None, tr)
+    before = _mesh(vol, 1.0, 0)
+    d, w, _ = vol.download()
+    z, y, x = np.mgrid[0:64, 0:64, 0:64]
+    blob = (np.sqrt((x - 12.0) ** 2 + (y - 50.0) ** 2 + (z - 9.0) ** 2) - 4.0) / 8.0  # a small sphere in a never-observed corner
+    region = np.abs(blob) < 0.9
+    d2, w2 = d.copy(), w.copy()
+    d2[region] = blob[region].astype(np.float32)
+    w2[region] = 3.0
+    vol.upload(d2, w2, None)
+    ov = OracleVolume(vol._p, adopt=(d2, w2, None))
+    after = _mesh(vol, 1.0, 0)
+    v2, _, cells2 = ov.march(1.0, 0)
+    assert len(cells2) > len(before["cells"]) + 50
+    assert np.array_equal(after["cells"], cells2)
+    assert_same_f32(after["vertices"], v2, "mesh after upload")
+    # ... and exact again after a reset
+    vol.reset()
+    assert len(_mesh(vol, 1.0, 0)["cells"]) == 0
+    for i, tr, dep, col in frames(sc, 3, 8):
+        vol.integrateCloud(dep, None, tr)
+    _same_mesh(_mesh(vol, 1.0, 0), before, "after reset + the same frames")
+    vol.close()
