@@ -152,6 +152,58 @@ void TSDFVolumeOctree::reset() {
   }
 }
 
+// getFrustumCulledVoxels (src/lib/tsdf_volume_octree.cpp:619-652) in replication mode: the six planes of
+// pcl::FrustumCulling::applyFilter [PCL-recall: filters/impl/frustum_culling.hpp] for this frame's pose, built with the
+// caller's Eigen -- same expressions, same order -- and handed to the library, which tests every voxel centre against
+// them (tsdf_hip_set_reference_cull).  Only when the cull can change results; otherwise the planes are cleared.
+bool TSDFVolumeOctree::applyReferenceCull(const Eigen::Affine3d &trans) const {
+  if (!reference_cull_ || tsdf_hip_reference_cull_is_noop(&p_)) {
+    if (cull_planes_set_) {
+      cull_planes_set_ = false;
+      return tsdf_hip_set_reference_cull(h_, nullptr) == 0;
+    }
+    return true;
+  }
+  using Eigen::Vector3f;
+  using Eigen::Vector4f;
+  Eigen::Matrix4f cam2robot;
+  cam2robot << 0, 0, 1, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1;
+  const Eigen::Matrix4f camera_pose = trans.matrix().cast<float>() * cam2robot;  // :633-638
+  const float hfov = 1.1 * 2 * fabs(atan(0.5 * p_.image_width / p_.fx) * 180 / M_PI);   // :641 (setHorizontalFOV(float))
+  const float vfov = 1.1 * 2 * fabs(atan(0.5 * p_.image_height / p_.fy) * 180 / M_PI);  // :642
+  const float np_dist = p_.min_sensor_dist, fp_dist = p_.max_sensor_dist;                // :643-644
+  const Vector3f view = camera_pose.block<3, 1>(0, 0);
+  const Vector3f up = camera_pose.block<3, 1>(0, 1);
+  const Vector3f right = camera_pose.block<3, 1>(0, 2);
+  const Vector3f T = camera_pose.block<3, 1>(0, 3);
+  const float vfov_rad = float(vfov * M_PI / 180);
+  const float hfov_rad = float(hfov * M_PI / 180);
+  const float np_h = float(2 * tan(vfov_rad / 2) * np_dist);
+  const float np_w = float(2 * tan(hfov_rad / 2) * np_dist);
+  const float fp_h = float(2 * tan(vfov_rad / 2) * fp_dist);
+  const float fp_w = float(2 * tan(hfov_rad / 2) * fp_dist);
+  const Vector3f fp_c(T + view * fp_dist);
+  const Vector3f fp_tl(fp_c + (up * fp_h / 2) - (right * fp_w / 2));
+  const Vector3f fp_tr(fp_c + (up * fp_h / 2) + (right * fp_w / 2));
+  const Vector3f fp_bl(fp_c - (up * fp_h / 2) - (right * fp_w / 2));
+  const Vector3f fp_br(fp_c - (up * fp_h / 2) + (right * fp_w / 2));
+  const Vector3f np_c(T + view * np_dist);
+  const Vector3f np_tr(np_c + (up * np_h / 2) + (right * np_w / 2));
+  const Vector3f np_bl(np_c - (up * np_h / 2) - (right * np_w / 2));
+  const Vector3f np_br(np_c - (up * np_h / 2) + (right * np_w / 2));
+  auto plane = [](const Vector3f &n, const Vector3f &through) { return Vector4f(n[0], n[1], n[2], -through.dot(n)); };
+  const Vector3f a(fp_bl - T), b(fp_br - T), c(fp_tr - T), d(fp_tl - T);
+  const Vector4f pl[6] = {plane(d.cross(a), T), plane(b.cross(c), T), plane(c.cross(d), T), plane(a.cross(b), T),
+                          plane((fp_bl - fp_br).cross(fp_tr - fp_br), fp_c), plane((np_tr - np_br).cross(np_bl - np_br), np_c)};
+  float planes[24];
+  for (int k = 0; k < 6; ++k)
+    for (int i = 0; i < 4; ++i) planes[4 * k + i] = pl[k][i];
+  cull_planes_set_ = true;
+  const int rc = tsdf_hip_set_reference_cull(h_, planes);
+  if (rc) report("integrateCloud (reference cull)", rc);
+  return rc == 0;
+}
+
 // reference: include/cpu_tsdf/impl/tsdf_volume_octree.hpp:48-103
 bool TSDFVolumeOctree::integratePlanar(const float *depth, const unsigned char *bgra, int width, int height,
                                        const Eigen::Affine3d &trans) {
@@ -161,6 +213,7 @@ bool TSDFVolumeOctree::integratePlanar(const float *depth, const unsigned char *
               height, p_.image_width, p_.image_height);
     return false;
   }
+  if (!applyReferenceCull(trans)) return false;
   const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
   float T[12];
   for (int r = 0; r < 3; ++r)
@@ -187,6 +240,7 @@ bool TSDFVolumeOctree::beginFrame(int width, int height, float **depth, unsigned
 }
 
 bool TSDFVolumeOctree::commitFrame(const Eigen::Affine3d &trans) {
+  if (!applyReferenceCull(trans)) return false;
   const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
   float T[12];
   for (int r = 0; r < 3; ++r)
@@ -220,6 +274,7 @@ bool TSDFVolumeOctree::integrateUnorganized(const pcl::PointCloud<pcl::PointXYZR
     return false;
   }
   if (n_valid_pixels) *n_valid_pixels = (size_t)nv;
+  if (!applyReferenceCull(trans)) return false;
   const Eigen::Affine3f trans_inv = trans.inverse().cast<float>();  // hpp:54
   float T[12];
   for (int r = 0; r < 3; ++r)

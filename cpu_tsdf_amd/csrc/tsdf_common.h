@@ -70,6 +70,8 @@ struct tsdf_hip_volume {
   size_t live_cap = 0;
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
   unsigned long long last_observed = 0, last_changed_bytes = 0;  // tsdf_hip_last_count_detail
+  bool ref_cull = false;   // tsdf_hip_set_reference_cull: replicate getFrustumCulledVoxels with these planes
+  float cull_planes[24] = {0};
   int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
   bool count_ran = false;  // that launch really ran (finite pose, something observable)
@@ -97,6 +99,7 @@ void tsdf_multi_free(tsdf_hip_volume *v);
 int tsdf_multi_reset(tsdf_handle h);
 int tsdf_multi_synchronize(tsdf_handle h);
 int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance);
+int tsdf_multi_set_reference_cull(tsdf_handle h, const float planes[24]);
 int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
                          bool asynchronous);
 int tsdf_multi_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],

@@ -49,6 +49,8 @@ struct IntegrateArgs {
   int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
   int rpb;            // row groups (of TY rows) per block
   unsigned bgra_off;  // byte offset of the colour image from the depth image (same buffer descriptor)
+  int ref_cull;          // replicate the reference's frustum cull (getFrustumCulledVoxels): six plane tests per voxel centre
+  float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
   int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
   int64_t pitch;
@@ -100,6 +102,19 @@ static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float
   ambiguous = !cert;
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? (int)__umul24((unsigned)v, (unsigned)a.W) + u : -1;  // W, H < 2^24 (checked on the host)
+}
+
+// pcl::FrustumCulling's verdict on a voxel centre (tsdf_volume_octree.cpp:619-652 -> filters/impl/frustum_culling.hpp
+// [PCL-recall]): `pt.dot(plane) <= 0` for all six planes, pt = (x, y, z, 1) as Vector4f, the 4-term dot reduced as
+// (p0 + p1) + (p2 + p3) [Eigen-recall]; no FMA (this file is built with -ffp-contract=off).  A NaN coordinate fails.
+static __device__ __forceinline__ bool reference_cull_keeps(const IntegrateArgs &a, float x, float y, float z) {
+  bool keep = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float *pl = a.cull + 4 * k;
+    keep = keep && ((x * pl[0] + y * pl[1]) + (z * pl[2] + 1.0f * pl[3]) <= 0.f);
+  }
+  return keep;
 }
 
 // Scale-free divider (LLVM's fp32 division ladder without v_div_scale / v_div_fixup) for a divisor
@@ -763,6 +778,8 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.TY = 256 / a.TX;
   a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);  // rpb * TY <= 256: the block's row centres sit in LDS
   a.pitch = h->pitch;
+  a.ref_cull = h->ref_cull ? 1 : 0;
+  for (int i = 0; i < 24; ++i) a.cull[i] = h->ref_cull ? h->cull_planes[i] : 0.f;
   a.band_fx = h->band_fx;
   a.band_fy = h->band_fy;
   a.x_abs0 = a.y_abs0 = 0;
@@ -792,7 +809,8 @@ k_integrate_rgbn(const IntegrateArgs a, float *__restrict__ D, float *__restrict
     for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
       g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
                                          : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
-    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f &&  // hpp:146, .cpp:616
+                    (!a.ref_cull || reference_cull_keeps(a, cx, cy, cz));  // hpp:93-94 (replication mode)
     const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
     if (pix >= 0) {
       const float z = depth[pix];
@@ -909,7 +927,8 @@ k_integrate_lab(const IntegrateArgs a, float *__restrict__ D, float *__restrict_
     for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
       g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
                                          : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
-    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f &&  // hpp:146, .cpp:616
+                    (!a.ref_cull || reference_cull_keeps(a, cx, cy, cz));  // hpp:93-94 (replication mode)
     const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
     if (pix >= 0) {
       const float z = depth[pix];
@@ -950,9 +969,13 @@ k_integrate_lab(const IntegrateArgs a, float *__restrict__ D, float *__restrict_
 // loaded .vol can carry the flag (tsdf_volume_octree.cpp:265), so this is the plain form: one thread per voxel, exact
 // fp64 projection, the compiler's IEEE divisions, float weight plane.  BY_DEPTH = false is the same kernel with
 // w_new = 1 (used by the tests to pin the plain kernel itself against the fast one).
-template <int ORDER, bool COLOR, bool BY_DEPTH>
+// PACKED (only with BY_DEPTH = false, i.e. w_new = 1): the weight is the count in byte 3 of the colour word or in the K8
+// plane, w = min(k, max_weight), k' = min(k + 1, kmax) -- the same state the fast kernel keeps, so the reference-cull
+// replication mode (tsdf_hip_set_reference_cull), which integrates through this kernel, works on every layout.
+template <int ORDER, bool COLOR, bool BY_DEPTH, bool PACKED = false>
 static __global__ void __launch_bounds__(256)
 k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
+                  uint8_t *__restrict__ K8,
                   const float *__restrict__ depth, const uint32_t *__restrict__ bgra, const double *__restrict__ cam,
                   const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
                   unsigned long long *__restrict__ n_obs) {
@@ -966,7 +989,8 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
     for (int q = 0; q < 3; ++q)  // pcl::transformPoint (hpp:145) in the summation order of this PCL build
       g[q] = ORDER == TSDF_XFORM_PCL_SSE ? cx * a.m[4 * q] + (cy * a.m[4 * q + 1] + (cz * a.m[4 * q + 2] + a.m[4 * q + 3]))
                                          : ((a.m[4 * q] * cx + a.m[4 * q + 1] * cy) + a.m[4 * q + 2] * cz) + a.m[4 * q + 3];
-    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f;  // hpp:146, .cpp:616
+    const bool in = !(g[2] < a.zmin || g[2] > a.zmax) && g[2] > 0.f &&  // hpp:146, .cpp:616
+                    (!a.ref_cull || reference_cull_keeps(a, cx, cy, cz));  // hpp:93-94 (replication mode)
     const int pix = in ? project_exact(a, cam, g[0], g[1], g[2]) : -1;
     if (pix >= 0) {
       const float z = depth[pix];
@@ -979,10 +1003,17 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
           wn = (float)((double)wn * (1. - ((1. < q) ? 1. : q)));
         }
         const int64_t vi = ((int64_t)(a.zl0 + zl) * a.plane_rows + y) * a.pitch + x;
-        float w = Wt[vi], d = D[vi];
+        unsigned k_old = 0u;
+        float w, d = D[vi];
+        if (PACKED) {
+          k_old = COLOR ? RGB[vi] >> 24 : (unsigned)K8[vi];
+          w = tsdf_decode_w(k_old, a.wmax);
+        } else {
+          w = Wt[vi];
+        }
         const float wsum = w + wn;
         if (COLOR) {  // RGBNode::addObservation, octree.cpp:331-335: the OLD w, static_cast<uint8_t> = cvttss2si & 255
-          const uint32_t c = bgra[pix], old = RGB[vi];  // PCL memory order b, g, r, a
+          const uint32_t c = bgra[pix], old = RGB[vi];  // PCL memory order b, g, r, a (byte 3 of `old`: the PACKED count)
           uint32_t out = 0u;
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
@@ -993,13 +1024,17 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
             const bool in_range = qv > -2147483904.f && qv < 2147483648.f;
             out |= (in_range ? ((uint32_t)(int)qv & 255u) : 0u) << (8 * ch);
           }
-          RGB[vi] = out;
+          RGB[vi] = PACKED ? out | (min(k_old + 1u, a.kmax) << 24) : out;
         }
         d = (d * w + dn * wn) / wsum;  // octree.cpp:156
         w = wsum;                      // :157
         if (w > a.wmax) w = a.wmax;    // :158-159
         D[vi] = d;
-        Wt[vi] = w;
+        if (PACKED) {
+          if (!COLOR) K8[vi] = (uint8_t)min(k_old + 1u, a.kmax);
+        } else {
+          Wt[vi] = w;
+        }
         observed = true;
       }
     }
@@ -1127,10 +1162,12 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
                    "M_ / nsample_ state of the octree, which the dense grid does not keep");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  const int plain_mode = h->weight_by_depth ? 2 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  // the plain per-voxel kernel: weight_by_depth_ (2), the test knob "plain_kernel" (1), or the reference-cull replication
+  // mode (3: any layout; the fast kernels know nothing about the six planes)
+  const int plain_mode = h->weight_by_depth ? 2 : (h->ref_cull && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
   if (plain_mode || h->cn[0]) h->band_exact = false;  // the plain kernels keep no "band seen" flags: marching cubes reads everything
-  if (plain_mode) {  // weight_by_depth_ (or the test knob "plain_kernel"): the plain per-voxel kernel, float weights
-    if (h->packed || h->cn[0]) {
+  if (plain_mode) {
+    if ((h->packed && plain_mode != 3) || h->cn[0]) {
       tsdf_set_error("weight_by_depth needs the F32W layout and TSDF_COLOR_RGB");
       return TSDF_HIP_E_UNSUPPORTED;
     }
@@ -1143,15 +1180,17 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
         tsdf_set_error("grid too large for one launch");
         return TSDF_HIP_E_UNSUPPORTED;
       }
-#define LAUNCH_PLAIN(ORDER, COLOR, BYD)                                                                             \
-  hipLaunchKernelGGL((k_integrate_plain<ORDER, COLOR, BYD>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, d_depth, \
-                     d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], count ? h->counter : nullptr)
-#define LP2(ORDER, COLOR)               \
-  do {                                  \
-    if (plain_mode == 2)                \
-      LAUNCH_PLAIN(ORDER, COLOR, true); \
-    else                                \
-      LAUNCH_PLAIN(ORDER, COLOR, false); \
+#define LAUNCH_PLAIN(ORDER, COLOR, BYD, PK)                                                                             \
+  hipLaunchKernelGGL((k_integrate_plain<ORDER, COLOR, BYD, PK>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->k8, \
+                     d_depth, d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], count ? h->counter : nullptr)
+#define LP2(ORDER, COLOR)                      \
+  do {                                         \
+    if (plain_mode == 2)                       \
+      LAUNCH_PLAIN(ORDER, COLOR, true, false); \
+    else if (h->packed)                        \
+      LAUNCH_PLAIN(ORDER, COLOR, false, true); \
+    else                                       \
+      LAUNCH_PLAIN(ORDER, COLOR, false, false); \
   } while (0)
       if (p.xform_order == TSDF_XFORM_PCL_SSE) {
         if (color)
@@ -1256,7 +1295,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     // The eight corner voxels lie inside the convex set {range, image minus a border}; so does every voxel centre in
     // exact arithmetic, and the margins (1e-3 m, one pixel) cover the float transform (~1e-7 relative) and the
     // projection's sensitivity to it as long as the coordinates stay moderate.
-    allin = all_inside && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
+    allin = all_inside && !h->ref_cull && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
             (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
     if (!all_inside) {
       int lo[3], hi[3];
@@ -1424,6 +1463,17 @@ extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
   if (h->multi) return tsdf_multi_last_count_detail(h, out);
   out[0] = h->last_observed;
   out[1] = h->last_changed_bytes;
+  return TSDF_HIP_OK;
+}
+
+// Replication mode for the reference's frustum cull (VERDICT r02 missing #3).  The six planes are PCL / Eigen arithmetic
+// on the forward pose, so the caller computes them (the C++ shell and the Python binding both do, exactly as
+// pcl::FrustumCulling::applyFilter); they apply to every integrate call until cleared with NULL.
+extern "C" int tsdf_hip_set_reference_cull(tsdf_handle h, const float planes[24]) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_set_reference_cull(h, planes);
+  h->ref_cull = planes != nullptr;
+  for (int i = 0; i < 24; ++i) h->cull_planes[i] = planes ? planes[i] : 0.f;
   return TSDF_HIP_OK;
 }
 

@@ -271,6 +271,14 @@ int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance) {
   return TSDF_HIP_OK;
 }
 
+int tsdf_multi_set_reference_cull(tsdf_handle h, const float planes[24]) {
+  for (tsdf_handle s : h->multi->slab) {
+    const int rc = tsdf_hip_set_reference_cull(s, planes);
+    if (rc) return rc;
+  }
+  return TSDF_HIP_OK;
+}
+
 // ---- integrateCloud ------------------------------------------------------------------------------------------------
 static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed) {
   tsdf_hip_multi *m = h->multi;

@@ -14,10 +14,17 @@ bool TSDFVolumeOctree::integrateCloud(const pcl::PointCloud<PointT> &cloud, cons
                                       const Eigen::Affine3d &trans) {
   float *depth = nullptr;
   unsigned char *bgra = nullptr;
+  // the staging slot holds image_width x image_height pixels: a cloud whose point count disagrees with its own
+  // width x height would overrun it (more points) or leave pixels of an older frame in it (fewer)
+  if (cloud.points.size() != (size_t)cloud.width * (size_t)cloud.height) {
+    PCL_ERROR("[cpu_tsdf::TSDFVolumeOctree::integrateCloud] cloud has %zu points but says %u x %u\n", cloud.points.size(),
+              (unsigned)cloud.width, (unsigned)cloud.height);
+    return false;
+  }
   if (!beginFrame((int)cloud.width, (int)cloud.height, &depth, &bgra)) return false;
   const long n = (long)cloud.points.size();
   const PointT *pts = n ? &cloud.points[0] : nullptr;
-#pragma omp parallel for schedule(static) num_threads(8)
+#pragma omp parallel for schedule(static) if (n > 65536)  // (the caller's OpenMP settings decide the team)
   for (long i = 0; i < n; ++i) {
     depth[i] = pts[i].z;
     if (bgra) {

@@ -297,6 +297,21 @@ int tsdf_hip_alloc_probe(tsdf_handle h, float ms[4], int32_t *chosen);
  * chased; the random hunts under tests/evidence/ recognise and report these voxels. */
 int tsdf_hip_reference_cull_is_noop(const tsdf_params *p);
 
+/* Replication mode for that cull (integrateCloud calls getFrustumCulledVoxels first, include/cpu_tsdf/impl/
+ * tsdf_volume_octree.hpp:93-94): with planes set, every integrate call drops the voxels whose centre fails one of the six
+ * plane tests `pt.dot(plane) <= 0` (pt = (x, y, z, 1), the dot reduced as (p0 + p1) + (p2 + p3), fp32, no FMA) before
+ * updateVoxel's own tests -- voxel for voxel what the reference integrates, also where
+ * tsdf_hip_reference_cull_is_noop() == 0 (tests/test_oracle_golden.py pins the restatement against the compiled
+ * reference, tests/test_integrate_gpu.py the kernel against the restatement).
+ *   planes  l, r, t, b, far, near (the order of PCL's test), 4 floats each, in the VOLUME frame: they are PCL / Eigen
+ *           arithmetic on the forward pose `trans` (pcl::FrustumCulling::applyFilter with camera pose
+ *           trans.cast<float>() * cam2robot, FOV 1.1 x the image's, near / far = the sensor range:
+ *           tsdf_volume_octree.cpp:633-646), so the caller computes them -- cpu_tsdf::TSDFVolumeOctree
+ *           (setReferenceCull(true)) and the Python binding do; NULL switches the mode off (default: the conservative
+ *           superset, fastest kernels).
+ * The planes stay in force for every later integrate call on the handle: set them per frame. */
+int tsdf_hip_set_reference_cull(tsdf_handle h, const float planes[24]);
+
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
  *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
  *   ok n bytes: 1 where the reference returns true.  A Z-slab handle answers only for points whose lower-corner

@@ -46,6 +46,10 @@ def lib():
         L.oracle_centers.argtypes = [C.c_int, C.c_float, _f]
         L.oracle_integrate.restype = C.c_uint64
         L.oracle_integrate.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int]
+        L.oracle_integrate_culled.restype = C.c_uint64
+        L.oracle_integrate_culled.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, _f]
+        L.oracle_reference_cull_planes.restype = None
+        L.oracle_reference_cull_planes.argtypes = [C.POINTER(OracleParams), C.POINTER(C.c_double), _f]
         L.oracle_integrate_weighted.restype = C.c_uint64
         L.oracle_integrate_weighted.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, C.c_int]
         L.oracle_integrate_lab.restype = C.c_uint64
@@ -138,6 +142,22 @@ class OracleVolume:
         col = np.ascontiguousarray(bgra, dtype=np.uint8) if bgra is not None else None
         return int(lib().oracle_integrate_weighted(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb), _fp(depth),
                                                    _bp(col), _fp(T), z_begin, z_end, int(bool(weight_by_depth))))
+
+    def reference_cull_planes(self, trans):
+        """The six planes (l, r, t, b, far, near) of the reference's frustum cull for the forward pose `trans`."""
+        t = np.ascontiguousarray(np.asarray(trans, np.float64).reshape(16))
+        planes = np.empty(24, np.float32)
+        lib().oracle_reference_cull_planes(C.byref(self.p), t.ctypes.data_as(C.POINTER(C.c_double)), _fp(planes))
+        return planes
+
+    def integrate_culled(self, depth, bgra, trans, cam_from_vol, z_begin=0, z_end=0):
+        """integrateCloud as the reference runs it: getFrustumCulledVoxels first (tsdf_volume_octree.cpp:619-652)."""
+        depth = np.ascontiguousarray(depth, np.float32)
+        col = np.ascontiguousarray(bgra, np.uint8) if bgra is not None else None
+        planes = self.reference_cull_planes(trans)
+        return int(lib().oracle_integrate_culled(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb) if self.rgb is not None else None,
+                                                 _fp(depth), _bp(col) if col is not None else None,
+                                                 _fp(np.ascontiguousarray(cam_from_vol, np.float32)), z_begin, z_end, _fp(planes)))
 
     def integrate_rgbn(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
         """integrate with RGBNormalized voxels (setColorMode("RGBNormalized")); self.cn holds r_n, g_n, b_n, i and

@@ -269,6 +269,8 @@ int ct_download(void *h, float *d, float *w, uint8_t *rgb) {
 }
 // Drop-in build only: the multi-GPU extension (takes effect at the next reset / load).
 void ct_set_devices(void *h, const int *devices, int n) { V(h)->setDevices(std::vector<int>(devices, devices + n)); }
+// Drop-in build only: replicate the reference's frustum cull where it is not a no-op (the reference always culls).
+void ct_set_reference_cull(void *h, int flag) { V(h)->setReferenceCull(flag != 0); }
 #endif
 
 }  // extern "C"

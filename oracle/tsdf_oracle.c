@@ -174,10 +174,81 @@ static int observe(const oracle_params *p, const float T[12], float x, float y, 
   return 1;
 }
 
+/* getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652: integrateCloud only visits the leaves pcl::FrustumCulling keeps
+ * -- a pyramid of 1.1 x the field of view around the optical axis between the sensor-range planes, six plane tests
+ * `pt.dot(plane) <= 0` on the leaf centre [PCL-recall: filters/impl/frustum_culling.hpp, as restated in
+ * compat/mini_pcl.h].  For ordinary cameras it keeps everything updateVoxel would accept; with a principal point far off
+ * centre (or a non-finite range) it drops voxels that project into the image.  The planes (l, r, t, b, far, near; 4
+ * floats each) from the forward pose `trans` (row-major 4x4 doubles); every operation in float where PCL's is. */
+static void v3_cross(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void cull_plane(const float n[3], const float through[3], float out[4]) { /* (n, -through.dot(n)), 3-term tree sum */
+  out[0] = n[0], out[1] = n[1], out[2] = n[2];
+  out[3] = -(through[0] * n[0] + (through[1] * n[1] + through[2] * n[2]));
+}
+void oracle_reference_cull_planes(const oracle_params *p, const double trans[16], float planes[24]) {
+  /* trans_robot = trans.matrix().cast<float>() * cam2robot (:633-638): columns (view, up, right, T) = (z, -y, x, t) of
+   * the pose; the 4-term sums only ever add exact zeros */
+  float view[3], up[3], right[3], T[3];
+  for (int r = 0; r < 3; ++r) {
+    view[r] = (float)trans[4 * r + 2];
+    up[r] = -(float)trans[4 * r + 1];
+    right[r] = (float)trans[4 * r + 0];
+    T[r] = (float)trans[4 * r + 3];
+  }
+  /* :641-644; setHorizontalFOV / setVerticalFOV / set*PlaneDistance take floats */
+  const float hfov = (float)(1.1 * 2 * fabs(atan(0.5 * p->image_width / p->fx) * 180 / M_PI));
+  const float vfov = (float)(1.1 * 2 * fabs(atan(0.5 * p->image_height / p->fy) * 180 / M_PI));
+  const float np_dist = p->min_sensor_dist, fp_dist = p->max_sensor_dist;
+  const float vfov_rad = (float)(vfov * M_PI / 180), hfov_rad = (float)(hfov * M_PI / 180);
+  const float np_h = (float)(2 * tan(vfov_rad / 2) * np_dist), np_w = (float)(2 * tan(hfov_rad / 2) * np_dist);
+  const float fp_h = (float)(2 * tan(vfov_rad / 2) * fp_dist), fp_w = (float)(2 * tan(hfov_rad / 2) * fp_dist);
+  float fp_c[3], fp_tl[3], fp_tr[3], fp_bl[3], fp_br[3], np_c[3], np_tr[3], np_bl[3], np_br[3];
+  for (int i = 0; i < 3; ++i) {
+    fp_c[i] = T[i] + view[i] * fp_dist;
+    fp_tl[i] = fp_c[i] + (up[i] * fp_h / 2) - (right[i] * fp_w / 2);
+    fp_tr[i] = fp_c[i] + (up[i] * fp_h / 2) + (right[i] * fp_w / 2);
+    fp_bl[i] = fp_c[i] - (up[i] * fp_h / 2) - (right[i] * fp_w / 2);
+    fp_br[i] = fp_c[i] - (up[i] * fp_h / 2) + (right[i] * fp_w / 2);
+    np_c[i] = T[i] + view[i] * np_dist;
+    np_tr[i] = np_c[i] + (up[i] * np_h / 2) + (right[i] * np_w / 2);
+    np_bl[i] = np_c[i] - (up[i] * np_h / 2) - (right[i] * np_w / 2);
+    np_br[i] = np_c[i] - (up[i] * np_h / 2) + (right[i] * np_w / 2);
+  }
+  float e1[3], e2[3], n[3], a[3], b[3], c[3], d[3];
+  for (int i = 0; i < 3; ++i) e1[i] = fp_bl[i] - fp_br[i], e2[i] = fp_tr[i] - fp_br[i];
+  v3_cross(e1, e2, n);
+  cull_plane(n, fp_c, planes + 16); /* far */
+  for (int i = 0; i < 3; ++i) e1[i] = np_tr[i] - np_br[i], e2[i] = np_bl[i] - np_br[i];
+  v3_cross(e1, e2, n);
+  cull_plane(n, np_c, planes + 20); /* near */
+  for (int i = 0; i < 3; ++i) a[i] = fp_bl[i] - T[i], b[i] = fp_br[i] - T[i], c[i] = fp_tr[i] - T[i], d[i] = fp_tl[i] - T[i];
+  v3_cross(b, c, n);
+  cull_plane(n, T, planes + 4); /* right */
+  v3_cross(d, a, n);
+  cull_plane(n, T, planes + 0); /* left */
+  v3_cross(c, d, n);
+  cull_plane(n, T, planes + 8); /* top */
+  v3_cross(a, b, n);
+  cull_plane(n, T, planes + 12); /* bottom */
+}
+
+static int cull_keeps(const float planes[24], float x, float y, float z) { /* is_in_fov: Vector4f dot = (p0 + p1) + (p2 + p3) */
+  for (int k = 0; k < 6; ++k) {
+    const float *pl = planes + 4 * k;
+    if (!((x * pl[0] + y * pl[1]) + (z * pl[2] + 1.0f * pl[3]) <= 0)) return 0;
+  }
+  return 1;
+}
+
 /* weight_by_depth: hpp:200-202, `w_new *= (1 - std::min(pt.z / 10., 1.))` -- a float times a double, stored
  * back into the float; the flag has no setter and only arrives through load() (tsdf_volume_octree.cpp:265). */
 static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
-                               const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth) {
+                               const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth,
+                               const float *cull_planes) {
   const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
   float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
         *cz = (float *)malloc(sizeof(float) * nz);
@@ -192,6 +263,7 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
       for (int i = 0; i < nx; ++i) {
         float dn;
         size_t pixel;
+        if (cull_planes && !cull_keeps(cull_planes, cx[i], cy[j], cz[k])) continue; /* hpp:93-94 */
         if (!observe(p, T, cx[i], cy[j], cz[k], depth, &dn, &pixel)) continue;
         float wn = 1;           /* hpp:200 (the variance weighting of :203-204 needs M_ / nsample_: not restated) */
         if (weight_by_depth) {  /* hpp:201-202; std::min(a, b) = (b < a) ? b : a */
@@ -220,12 +292,18 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
 
 uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                           const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
-  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0);
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, NULL);
+}
+
+/* integrateCloud INCLUDING the reference's frustum cull (planes from oracle_reference_cull_planes). */
+uint64_t oracle_integrate_culled(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
+                                 const uint8_t *bgra, const float T[12], int z_begin, int z_end, const float planes[24]) {
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, planes);
 }
 
 uint64_t oracle_integrate_weighted(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                                    const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth) {
-  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth);
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth, NULL);
 }
 
 /* The same with RGBNormalized voxels (setColorMode("RGBNormalized")): RGBNormalized::addObservation,

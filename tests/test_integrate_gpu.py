@@ -535,3 +535,58 @@ def test_all_inside_instance_is_not_chosen_when_a_voxel_may_leave_the_image_or_t
         assert launch_info(vol)[0] == want, (name, launch_info(vol))
         compare(vol, ov)
         vol.close()
+
+
+@pytest.mark.parametrize("color,layout", [(True, capi.LAYOUT_AUTO), (False, capi.LAYOUT_AUTO), (True, capi.LAYOUT_F32W)])
+def test_reference_cull_replication_mode(gpu, color, layout):
+    """setReferenceCull(True) (tsdf_hip_set_reference_cull): where the reference's frustum cull is NOT a no-op -- a
+    principal point far off centre, so that the 1.1 x FOV pyramid around the optical axis cuts the image -- the product
+    drops exactly the voxels the reference drops: equal to the oracle's restatement of the cull (which
+    tests/test_oracle_golden.py pins to the compiled reference) and, where oracle/_ref is present, to the compiled
+    reference itself.  Without the mode the product integrates the superset (the default, unchanged).  Both layouts,
+    with and without colour, counts included; a centred camera in the same mode keeps the fast kernel."""
+    import ctypes as C
+    res, W, H, size = 48, 64, 48, 1.0
+    fx = fy = 110.0
+    cy = H / 2 - 0.5
+    rng = np.random.RandomState(4)
+    for cx, off_centre in ((W / 2 - 0.5 + 5.5, True), (W / 2 - 0.5, False)):
+        vols = {}
+        for mode in (True, False):
+            v, _ = make_volume(res, W, H, color=color, size=size)
+            v.setCameraIntrinsics(fx, fy, cx, cy)
+            v.setLayout(layout)
+            v.setReferenceCull(mode)
+            v.reset()
+            vols[mode] = v
+        assert vols[True].referenceCullIsNoop() == (not off_centre)
+        oc, ov = OracleVolume(vols[True]._p), OracleVolume(vols[True]._p)
+        ref = None
+        try:
+            from oracle import refbind
+            if refbind.available():
+                ref = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, 0.0, 3 * size, color=color)
+        except ImportError:
+            pass
+        for i in range(4):
+            tr = synth.look_at_pose(np.array([1.9, 0.25 * i - 0.3, 0.3]) * size, target=np.zeros(3))
+            dep = (rng.uniform(1.2, 2.6, (H, W)) * size).astype(np.float32)
+            col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
+            c = col if color else None
+            n_cull = oc.integrate_culled(dep, c, tr, synth.cam_from_vol_f32(tr))
+            n_all = ov.integrate(dep, c, synth.cam_from_vol_f32(tr))
+            assert vols[True].integrateCloud(dep, c, tr, count=True) == n_cull
+            assert vols[False].integrateCloud(dep, c, tr, count=True) == n_all
+            assert (n_cull < n_all) == off_centre
+            if ref is not None:
+                ref.integrate(dep, c, tr)
+        compare(vols[True], oc)
+        compare(vols[False], ov)
+        if ref is not None:
+            d, w, rgb, _, _ = ref.dump_dense()
+            gd, gw, grgb = vols[True].download()
+            assert_same_f32(gd, d, "d vs the compiled reference")
+            assert np.array_equal(gw, w) and (not color or np.array_equal(grgb, rgb))
+            ref.close()
+        for v in vols.values():
+            v.close()
