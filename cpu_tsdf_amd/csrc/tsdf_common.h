@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -194,6 +195,43 @@ static inline void tsdf_lab_curve(float lut[256]) {
     lut[v] = f;
   }
 }
+
+// LAB2RGB (src/lib/octree.cpp:483-527) on the HOST: the cubes and the 1/2.4 powers go through std::pow there, so the bytes
+// LABNode::getRGB shows are the host libm's -- the libm the reference would call on this machine -- by construction.
+// Every result a caller can see (downloads, mesh colours, renderColoredView) is finished here from the voxels' float
+// L, A, B state (tsdf_lab_exact_colors); the device's own lab_to_rgb only fills a cache nothing user-visible reads.
+// static_cast<uint8_t>(float) is cvttss2si and the low byte on x86-64.
+static inline uint8_t tsdf_u8_of_float(float v) {
+  const int i = (v > -2147483904.f && v < 2147483648.f) ? (int)v : (int)0x80000000;
+  return (uint8_t)(i & 255);
+}
+static inline uint32_t tsdf_lab2rgb_host(float L, float A, float B) {
+  float Y = (L + 16) / 116.;
+  float X = A / 500. + Y;
+  float Z = Y - (B / 200.);
+  if (std::pow((double)X, 3.0) > 0.008856) X = std::pow((double)X, 3.0); else X = (X - 16 / 116.) / 7.787;
+  if (std::pow((double)Y, 3.0) > 0.008856) Y = std::pow((double)Y, 3.0); else Y = (Y - 16 / 116.) / 7.787;
+  if (std::pow((double)Z, 3.0) > 0.008856) Z = std::pow((double)Z, 3.0); else Z = (Z - 16 / 116.) / 7.787;
+  X *= 95.047;
+  Y *= 100.;
+  Z *= 108.883;
+  X /= 100;
+  Y /= 100;
+  Z /= 100;
+  float rf = X * +3.2406 + Y * -1.5372 + Z * -0.4986;
+  float gf = X * -0.9689 + Y * +1.8758 + Z * +0.0415;
+  float bf = X * +0.0557 + Y * -0.2040 + Z * +1.0570;
+  if (rf > 0.0031308) rf = 1.055 * std::pow(static_cast<double>(rf), 1. / 2.4) - 0.055; else rf *= 12.92;
+  if (gf > 0.0031308) gf = 1.055 * std::pow(static_cast<double>(gf), 1. / 2.4) - 0.055; else gf *= 12.92;
+  if (bf > 0.0031308) bf = 1.055 * std::pow(static_cast<double>(bf), 1. / 2.4) - 0.055; else bf *= 12.92;
+  return (uint32_t)tsdf_u8_of_float(rf * 255) | ((uint32_t)tsdf_u8_of_float(gf * 255) << 8) | ((uint32_t)tsdf_u8_of_float(bf * 255) << 16);
+}
+// n LAB triples (planar: L[n], A[n], B[n]) -> r | g << 8 | b << 16, on all host threads (tsdf_core.hip)
+void tsdf_lab2rgb_host_many(const float *L, const float *A, const float *B, size_t n, uint32_t *out);
+// TSDF_COLOR_LAB volumes: the exact getRGB() of n voxels given by their element indices (a DEVICE array; a negative index
+// is skipped and yields 0).  host_rgb (n words, optional) receives them; write_plane also stores them into the rgb plane
+// (what marching cubes' emit kernel reads).  Synchronises the stream.
+int tsdf_lab_exact_colors(tsdf_hip_volume *v, const int64_t *d_idx, size_t n, uint32_t *host_rgb, bool write_plane);
 
 static inline float tsdf_node_size(const tsdf_params &p, int axis) {
   const int r = p.res[0];

@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <thread>
 #include <string.h>
 
 #include <mutex>
@@ -212,6 +213,71 @@ int tsdf_ensure_scratch(tsdf_hip_volume *v, size_t bytes) {
   TSDF_HIP_TRY(hipMalloc(&v->scratch, bytes));
   v->scratch_bytes = bytes;
   return TSDF_HIP_OK;
+}
+
+// ---- exact LAB colours (host finish) ------------------------------------------------------------------------------------
+void tsdf_lab2rgb_host_many(const float *L, const float *A, const float *B, size_t n, uint32_t *out) {
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned nt = n < 4096 ? 1u : hw;
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) out[i] = tsdf_lab2rgb_host(L[i], A[i], B[i]);
+  };
+  if (nt == 1) return work(0, n);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+  for (auto &t : th) t.join();
+}
+
+static __global__ void __launch_bounds__(256)
+k_lab_gather(const int64_t *__restrict__ idx, size_t n, const float *__restrict__ L, const float *__restrict__ A,
+             const float *__restrict__ B, float *__restrict__ out) {  // out: planar L[n] A[n] B[n]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  out[i] = v >= 0 ? L[v] : 0.f;
+  out[n + i] = v >= 0 ? A[v] : 0.f;
+  out[2 * n + i] = v >= 0 ? B[v] : 0.f;
+}
+
+static __global__ void __launch_bounds__(256)
+k_rgb_scatter(const int64_t *__restrict__ idx, size_t n, const uint32_t *__restrict__ words, uint32_t *__restrict__ plane) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v >= 0) plane[v] = (plane[v] & 0xff000000u) | (words[i] & 0xffffffu);  // several entries may name one voxel: same value
+}
+
+int tsdf_lab_exact_colors(tsdf_hip_volume *v, const int64_t *d_idx, size_t n, uint32_t *host_rgb, bool write_plane) {
+  if (!n) return TSDF_HIP_OK;
+  if (!v->lab_img || !v->cn[0] || !v->cn[1] || !v->cn[2]) return TSDF_HIP_E_INVALID;
+  const size_t chunk = (size_t)16 << 20;  // voxels per round trip (192 MB of floats)
+  float *d_lab = nullptr;
+  uint32_t *d_words = nullptr;
+  const size_t m = std::min(n, chunk);
+  TSDF_HIP_TRY(hipMalloc(&d_lab, m * 3 * sizeof(float)));
+  if (write_plane && hipMalloc(&d_words, m * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipFree(d_lab);
+    return tsdf_hip_fail(hipErrorOutOfMemory, "hipMalloc", __FILE__, __LINE__);
+  }
+  std::vector<float> lab(m * 3);
+  std::vector<uint32_t> words(m);
+  int rc = TSDF_HIP_OK;
+  for (size_t off = 0; off < n && !rc; off += chunk) {
+    const size_t c = std::min(chunk, n - off);
+    hipLaunchKernelGGL(k_lab_gather, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, v->stream, d_idx + off, c, v->cn[0], v->cn[1],
+                       v->cn[2], d_lab);
+    if ((rc = tsdf_to_host(v, lab.data(), d_lab, c * 3 * sizeof(float)))) break;
+    tsdf_lab2rgb_host_many(lab.data(), lab.data() + c, lab.data() + 2 * c, c, words.data());
+    if (host_rgb) memcpy(host_rgb + off, words.data(), c * sizeof(uint32_t));
+    if (write_plane) {
+      if ((rc = tsdf_to_device(v, d_words, words.data(), c * sizeof(uint32_t)))) break;
+      hipLaunchKernelGGL(k_rgb_scatter, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, v->stream, d_idx + off, c, d_words, v->rgb);
+      if (hipStreamSynchronize(v->stream) != hipSuccess) rc = TSDF_HIP_E_HIP;
+    }
+  }
+  (void)hipFree(d_lab);
+  if (d_words) (void)hipFree(d_words);
+  return rc;
 }
 
 // Host <-> device transfers of caller memory.  A hipMemcpy straight from / into pageable memory makes the
@@ -811,7 +877,23 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
         }
       }
     }
-    if (rgb) {
+    if (rgb && DOWN && h->lab_img) {
+      // TSDF_COLOR_LAB: getRGB() is LAB2RGB of the voxel's float means through the HOST's pow (tsdf_lab2rgb_host)
+      uint8_t *hp = rgb + (int64_t)zc * plane * 3;
+      std::vector<float> lab((size_t)n * 3);
+      for (int c = 0; c < 3; ++c) {
+        hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, h->cn[c], (float *)h->scratch);
+        TSDF_HIP_TRY(hipGetLastError());
+        if ((rc = tsdf_to_host(h, lab.data() + (size_t)c * n, h->scratch, n * sizeof(float)))) return rc;
+      }
+      std::vector<uint32_t> words((size_t)n);
+      tsdf_lab2rgb_host_many(lab.data(), lab.data() + n, lab.data() + 2 * n, (size_t)n, words.data());
+      for (int64_t i = 0; i < n; ++i) {
+        hp[3 * i] = (uint8_t)(words[i] & 255u);
+        hp[3 * i + 1] = (uint8_t)((words[i] >> 8) & 255u);
+        hp[3 * i + 2] = (uint8_t)((words[i] >> 16) & 255u);
+      }
+    } else if (rgb) {
       uint8_t *hp = rgb + (int64_t)zc * plane * 3;
       if (DOWN) {
         hipLaunchKernelGGL(k_block_rgb<true>, dim3(blocks), dim3(256), 0, h->stream, a, h->rgb,

@@ -123,27 +123,34 @@ k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ ne
   const int z = n.z_lo + zi;
   const int yw = 1 + wrow * MC_R;                      // the wave's rows yw .. yw + MC_R (the last one is its halo row)
   const int fy0 = max(0, (yw - 1) >> 2), fy1 = min(n.fy - 1, (yw + MC_R + 1) >> 2);
-  auto flagged = [&](int xa, int xb) -> bool {         // any flag near voxels [xa, xb] x rows x plane z
-    const int fx0 = max(0, (xa - 1) >> 6), fx1 = min(n.fx - 1, (xb + 1) >> 6);
-    if (fx0 > fx1 || fy0 > fy1) return false;
+  // One pass over the <= 6 x 2 x 3 flag cells that can matter: m6 bit c = "a flag is set in x cell 4 bx - 1 + c" (over
+  // the row groups and the three planes).  A 16-lane group g (x cells 4 bx + g) grown by one voxel touches cells
+  // g - 1 .. g + 1 -> m6 bits g, g + 1, g + 2; the halo column (voxel 256 bx + 256) touches cells 4 bx + 3, 4 bx + 4.
+  unsigned m6 = 0u;
+  bool halo_plane = false;
+  if (yw < n.ny && fy0 <= fy1) {
     for (int zz = z - 1; zz <= z + 1; ++zz) {
       if (zz < n.z_first || zz >= n.z_first + n.nz_alloc) continue;
-      if (zz < n.z_begin || zz >= n.z_end) return true;  // a halo plane: unknown, so needed
+      if (zz < n.z_begin || zz >= n.z_end) {  // a halo plane: unknown, so everything near it is needed
+        halo_plane = true;
+        continue;
+      }
       const uint8_t *pl = n.band + (int64_t)(zz - n.z_first) * n.fy * n.fx;
       for (int fy = fy0; fy <= fy1; ++fy)
-        for (int fx = fx0; fx <= fx1; ++fx)
-          if (pl[fy * n.fx + fx]) return true;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int fx = 4 * bx - 1 + c;
+          if (fx >= 0 && fx < n.fx && pl[fy * n.fx + fx]) m6 |= 1u << c;
+        }
     }
-    return false;
-  };
+  }
   unsigned bits = 0u;
   if (yw < n.ny) {
-    for (int g = 0; g < 4; ++g) {
-      const int xa = bx * 256 + g * 64;
-      if (xa < n.nx && flagged(xa, min(n.nx - 1, xa + 63))) bits |= 1u << g;
-    }
-    const int xe = bx * 256 + 256;
-    if (xe < n.nx && flagged(xe, xe)) bits |= 16u;
+    if (halo_plane) m6 = 63u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (bx * 256 + g * 64 < n.nx && ((m6 >> g) & 7u)) bits |= 1u << g;
+    if (bx * 256 + 256 < n.nx && ((m6 >> 4) & 3u)) bits |= 16u;
   }
   need[t] = (uint8_t)bits;
   if (bits) {  // (every writer stores the same 1); a cell plane z of block zb-index k reads planes up to z + 1
@@ -422,6 +429,16 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     for (int s = 32; s > 0; s >>= 1) tri_sum += __shfl_xor(tri_sum, s);
     if (lane == 0) atomicAdd(&counters[1], (unsigned long long)tri_sum);
   }
+}
+
+// element index of every active cell's base voxel (TSDF_COLOR_LAB: the voxels whose exact colour the mesh shows)
+static __global__ void __launch_bounds__(256)
+k_mc_cell_index(const McArgs a, const uint64_t *__restrict__ vals, uint64_t n, int64_t *__restrict__ idx) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t v = vals[i];
+  const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
+  idx[i] = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
 }
 
 static __global__ void __launch_bounds__(256)
@@ -728,6 +745,16 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     TSDF_HIP_TRY(hipMalloc(&h->mc_rgb, cap * 9));
     TSDF_HIP_TRY(hipMalloc(&h->mc_cell, cap * sizeof(uint64_t)));
     h->mc_cap = cap;
+  }
+  if (color_mode == 1 && h->lab_img) {
+    // setColorByRGB on LABNode voxels (:226-231 -> LABNode::getRGB): the emit kernel reads the rgb plane; put the EXACT
+    // bytes there for the cells it is about to read (host pow, tsdf_lab_exact_colors)
+    int64_t *d_idx = nullptr;
+    TSDF_HIP_TRY(hipMalloc(&d_idx, (size_t)n_cells * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_mc_cell_index, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, n_cells, d_idx);
+    const int rcx = tsdf_lab_exact_colors(h, d_idx, (size_t)n_cells, nullptr, true);
+    (void)hipFree(d_idx);
+    if (rcx) return rcx;
   }
   TSDF_HIP_TRY(hipEventRecord(h->mc_ev[2], h->stream));
   hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts, tri_rgb,

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <vector>
 
 #include <string.h>
 
@@ -784,10 +785,48 @@ k_lookup_rgb(const GridView g, const int own_lo, const int own_hi, const float *
   found[t] = hit ? 1 : 0;
 }
 
+// the same, but the voxel's element index instead of its cached colour (-1 where not found): TSDF_COLOR_LAB volumes
+// finish the colour on the host (tsdf_lab_exact_colors)
+static __global__ void __launch_bounds__(256)
+k_lookup_index(const GridView g, const int own_lo, const int own_hi, const float *__restrict__ xyz, size_t n,
+               int64_t *__restrict__ idx) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int64_t vi;
+  bool local;
+  int k;
+  const bool hit = containing(g, xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], vi, local, k) && local && k >= own_lo && k < own_hi;
+  idx[t] = hit ? vi : -1;
+}
+
 extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
   if (!h || !xyz || !n || !rgb || !found) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_lookup_rgb(h, xyz, n, rgb, found);
   TSDF_ON_DEVICE(h->device);
+  if (h->lab_img) {  // LABNode::getRGB: exact bytes through the host's pow
+    int rc = tsdf_ensure_scratch(h, n * 12);
+    if (rc) return rc;
+    float *d_xyz = (float *)h->scratch;
+    if ((rc = tsdf_to_device(h, d_xyz, xyz, n * 12))) return rc;
+    int64_t *d_idx = nullptr;
+    TSDF_HIP_TRY(hipMalloc(&d_idx, n * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_lookup_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, make_view(h), h->z_begin, h->z_end,
+                       d_xyz, n, d_idx);
+    std::vector<int64_t> idx(n);
+    std::vector<uint32_t> words(n);
+    rc = tsdf_to_host(h, idx.data(), d_idx, n * sizeof(int64_t));
+    if (!rc) rc = tsdf_lab_exact_colors(h, d_idx, n, words.data(), false);
+    (void)hipFree(d_idx);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+      const bool hit = idx[i] >= 0;
+      found[i] = hit ? 1 : 0;
+      rgb[3 * i] = hit ? (uint8_t)(words[i] & 255u) : 0;
+      rgb[3 * i + 1] = hit ? (uint8_t)((words[i] >> 8) & 255u) : 0;
+      rgb[3 * i + 2] = hit ? (uint8_t)((words[i] >> 16) & 255u) : 0;
+    }
+    return TSDF_HIP_OK;
+  }
   int rc = tsdf_ensure_scratch(h, n * 16);
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;

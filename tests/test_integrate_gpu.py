@@ -545,8 +545,7 @@ def test_reference_cull_replication_mode(gpu, color, layout):
     tests/test_oracle_golden.py pins to the compiled reference) and, where oracle/_ref is present, to the compiled
     reference itself.  Without the mode the product integrates the superset (the default, unchanged).  Both layouts,
     with and without colour, counts included; a centred camera in the same mode keeps the fast kernel."""
-    import ctypes as C
-    res, W, H, size = 48, 64, 48, 1.0
+    res, W, H, size = 64, 64, 48, 1.0  # (a power of two: the compiled reference is an octree)
     fx = fy = 110.0
     cy = H / 2 - 0.5
     rng = np.random.RandomState(4)

@@ -67,8 +67,8 @@ def main():
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     out[key] = {
         "tag": tag, "kernel_sha16": bf["roofline"]["kernel_sha16"], "git_head_when_summarised": head,
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 "
-                   f"--steps {bf['steps']} --calib 2",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 --host-path 0 "
+                   f"--steps {bf['steps']} --calib 2" + (" " + sys.argv[2] if len(sys.argv) > 2 else ""),
         "kernel_instance": inst, "timed_launches_averaged": fetch[inst]["dispatches"],
         "hbm_bytes_per_launch": rd + wr,
         "read_bytes": rd, "written_bytes": wr,
