@@ -150,6 +150,9 @@ SIGNATURES = {
     "tsdf_hip_last_error": (C.c_char_p, []),
     "tsdf_hip_device_count": (C.c_int, []),
     "tsdf_hip_abi_version": (C.c_int, []),
+    "tsdf_hip_download_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
+    "tsdf_hip_upload_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
+    "tsdf_hip_selftest_expf": (C.c_int, [_f32p, C.c_size_t, _f32p]),
     "tsdf_hip_set_reference_cull": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),

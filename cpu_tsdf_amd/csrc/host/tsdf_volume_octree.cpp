@@ -134,7 +134,7 @@ void TSDFVolumeOctree::reset() {
     h_ = nullptr;
   }
   // weight_by_depth_ / weight_by_variance_ (set only by load(), as in the reference) survive a reset there too
-  if (weight_by_depth_ && p_.layout == TSDF_LAYOUT_AUTO) p_.layout = TSDF_LAYOUT_F32W;
+  if ((weight_by_depth_ || weight_by_variance_) && p_.layout == TSDF_LAYOUT_AUTO) p_.layout = TSDF_LAYOUT_F32W;
   int rc;
   if (devices_.empty()) {
     rc = tsdf_hip_create(&p_, &h_);

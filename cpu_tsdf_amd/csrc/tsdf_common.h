@@ -38,6 +38,10 @@ struct tsdf_hip_volume {
   float *cn[4] = {nullptr, nullptr, nullptr, nullptr};
   float *lab_lut = nullptr;
   float4 *lab_img = nullptr;
+  // weight_by_variance_ (hpp:203-204): OctreeNode::M_ and nsample_ per voxel (octree.cpp:160-161), allocated when the
+  // flag arrives (tsdf_hip_set_weighting; only a loaded .vol can carry it) on F32W / TSDF_COLOR_RGB volumes
+  float *vm = nullptr;
+  int32_t *vn = nullptr;
   // placement selection at create (tsdf_core.hip): probe sweep of each candidate allocation, which one was kept
   float alloc_probe_ms[4] = {-1.f, -1.f, -1.f, -1.f};
   int alloc_tried = 0, alloc_chosen = 0;
@@ -101,6 +105,7 @@ int tsdf_multi_reset(tsdf_handle h);
 int tsdf_multi_synchronize(tsdf_handle h);
 int tsdf_multi_set_weighting(tsdf_handle h, int by_depth, int by_variance);
 int tsdf_multi_set_reference_cull(tsdf_handle h, const float planes[24]);
+int tsdf_multi_variance_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *M, int32_t *nsample);
 int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
                          bool asynchronous);
 int tsdf_multi_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],

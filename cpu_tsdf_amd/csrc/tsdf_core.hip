@@ -383,6 +383,8 @@ static void free_volume(tsdf_hip_volume *v) {
   if (v->k8) (void)hipFree(v->k8);
   for (int c = 0; c < 4; ++c)
     if (v->cn[c]) (void)hipFree(v->cn[c]);
+  if (v->vm) (void)hipFree(v->vm);
+  if (v->vn) (void)hipFree(v->vn);
   if (v->lab_lut) (void)hipFree(v->lab_lut);
   if (v->lab_img) (void)hipFree(v->lab_img);
   for (int a = 0; a < 3; ++a)
@@ -667,6 +669,9 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
   for (int c = 0; c < 4 && !rc; ++c)  // RGBNormalized starts at r_n = g_n = b_n = i = 0 (octree.h:217-222)
     if (h->cn[c]) rc = fill_u32(h, h->cn[c], 0u, n);
   if (rc) return rc;
+  if (h->vm) rc = fill_u32(h, reinterpret_cast<float *>(h->vm), 0u, n);  // OctreeNode(): M_ (0), nsample_ (0)
+  if (!rc && h->vn) rc = fill_u32(h, reinterpret_cast<float *>(h->vn), 0u, n);
+  if (rc) return rc;
   TSDF_HIP_TRY(hipMemsetAsync(h->band, 0, (size_t)h->band_fx * h->band_fy * h->nz_alloc, h->stream));
   h->band_exact = true;  // every distance is -1: no voxel inside the band
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -916,6 +921,57 @@ extern "C" int tsdf_hip_download(tsdf_handle h, int x0, int y0, int z0, int nx, 
                                  float *w, uint8_t *rgb) {
   if (h && h->multi) return tsdf_multi_block(h, true, x0, y0, z0, nx, ny, nz, d, w, rgb);
   return block_transfer<true>(h, x0, y0, z0, nx, ny, nz, d, w, rgb);
+}
+
+// OctreeNode::M_ / nsample_ of a block of voxels ([z][y][x]; either pointer may be NULL): the state weight_by_variance_
+// integrates with (hpp:203-204, octree.cpp:160-161,281-287).  Only volumes that weight by variance keep it.
+template <bool DOWN>
+static int variance_block(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *M, int32_t *ns) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_variance_block(h, DOWN, x0, y0, z0, nx, ny, nz, M, ns);
+  int rc = check_block(h, x0, y0, z0, nx, ny, nz);
+  if (rc) return rc;
+  if (!h->vm || !h->vn) {
+    tsdf_set_error("this volume keeps no M_ / nsample_ state (only volumes loaded with weight_by_variance do)");
+    return TSDF_HIP_E_INVALID;
+  }
+  TSDF_ON_DEVICE(h->device);
+  const int64_t plane = (int64_t)nx * ny;
+  const int64_t max_planes = std::max<int64_t>(1, (int64_t)(64 << 20) / plane);
+  rc = tsdf_ensure_scratch(h, (size_t)std::min<int64_t>(max_planes, nz) * plane * sizeof(float));
+  if (rc) return rc;
+  float *planes[2] = {h->vm, reinterpret_cast<float *>(h->vn)};  // (the int32 counts move as 4-byte words)
+  float *hosts[2] = {M, reinterpret_cast<float *>(ns)};
+  for (int zc = 0; zc < nz; zc += (int)max_planes) {
+    const int bz = (int)std::min<int64_t>(max_planes, nz - zc);
+    const int64_t n = plane * bz;
+    BlockArgs a{x0, y0, z0 + zc - h->z_first, nx, ny, bz, h->ny, h->pitch};
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    for (int k = 0; k < 2; ++k) {
+      if (!hosts[k]) continue;
+      float *hp = hosts[k] + (int64_t)zc * plane, *dev = (float *)h->scratch;
+      if (DOWN) {
+        hipLaunchKernelGGL(k_block_f32<true>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k], dev);
+        TSDF_HIP_TRY(hipGetLastError());
+        if ((rc = tsdf_to_host(h, hp, dev, n * sizeof(float)))) return rc;
+      } else {
+        if ((rc = tsdf_to_device(h, dev, hp, n * sizeof(float)))) return rc;
+        hipLaunchKernelGGL(k_block_f32<false>, dim3(blocks), dim3(256), 0, h->stream, a, planes[k], dev);
+        TSDF_HIP_TRY(hipGetLastError());
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      }
+    }
+  }
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_download_variance_state(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *M,
+                                                int32_t *nsample) {
+  return variance_block<true>(h, x0, y0, z0, nx, ny, nz, M, nsample);
+}
+extern "C" int tsdf_hip_upload_variance_state(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *M,
+                                              const int32_t *nsample) {
+  return variance_block<false>(h, x0, y0, z0, nx, ny, nz, const_cast<float *>(M), const_cast<int32_t *>(nsample));
 }
 
 // The float colour state of RGB_NORMALIZED (planes r_n, g_n, b_n, i) and LAB (planes L, A, B) voxels, which no

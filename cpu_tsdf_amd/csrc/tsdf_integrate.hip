@@ -975,7 +975,7 @@ k_integrate_lab(const IntegrateArgs a, float *__restrict__ D, float *__restrict_
 template <int ORDER, bool COLOR, bool BY_DEPTH, bool PACKED = false>
 static __global__ void __launch_bounds__(256)
 k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
-                  uint8_t *__restrict__ K8,
+                  uint8_t *__restrict__ K8, float *__restrict__ VM, int32_t *__restrict__ VN,
                   const float *__restrict__ depth, const uint32_t *__restrict__ bgra, const double *__restrict__ cam,
                   const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
                   unsigned long long *__restrict__ n_obs) {
@@ -1005,13 +1005,29 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
         const int64_t vi = ((int64_t)(a.zl0 + zl) * a.plane_rows + y) * a.pitch + x;
         unsigned k_old = 0u;
         float w, d = D[vi];
+        // weight_by_variance_ (hpp:203-204; VM / VN = OctreeNode::M_ / nsample_, non-NULL only then): once a voxel has
+        // more than five samples, w_new *= std::exp(logNormal(d_new, d_, getVariance())) with logNormal (hpp:106-110)
+        // = -std::pow(x - mean, 2) / (2 * var) -- the double pow of a float difference (an exact square), a double
+        // quotient stored in a float -- getVariance (octree.cpp:281-287) = (M_ / w_) * (nsample_ / (nsample_ - 1)) with
+        // an INTEGER quotient, and std::exp(float) = expf, here the fp64 exp rounded to float (equal to glibc's expf on
+        // every float of the range that matters: tests/test_wvar_gpu.py sweeps it)
+        int ns_old = 0;
+        if (!PACKED && VM) {
+          ns_old = VN[vi];
+          if (ns_old > 5) {
+            const float var = (VM[vi] / Wt[vi]) * (float)(ns_old / (ns_old - 1));
+            const double dx = (double)(dn - d);
+            const float ln = (float)(-(dx * dx) / (double)(2 * var));
+            wn *= (float)exp((double)ln);
+          }
+        }
         if (PACKED) {
           k_old = COLOR ? RGB[vi] >> 24 : (unsigned)K8[vi];
           w = tsdf_decode_w(k_old, a.wmax);
         } else {
           w = Wt[vi];
         }
-        const float wsum = w + wn;
+        const float wsum = w + wn;  // (wn: after both weightings)
         if (COLOR) {  // RGBNode::addObservation, octree.cpp:331-335: the OLD w, static_cast<uint8_t> = cvttss2si & 255
           const uint32_t c = bgra[pix], old = RGB[vi];  // PCL memory order b, g, r, a (byte 3 of `old`: the PACKED count)
           uint32_t out = 0u;
@@ -1026,10 +1042,15 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
           }
           RGB[vi] = PACKED ? out | (min(k_old + 1u, a.kmax) << 24) : out;
         }
+        const float d_old = d;
         d = (d * w + dn * wn) / wsum;  // octree.cpp:156
         w = wsum;                      // :157
         if (w > a.wmax) w = a.wmax;    // :158-159
         D[vi] = d;
+        if (!PACKED && VM) {
+          VM[vi] += wn * (dn - d) * (dn - d_old);  // octree.cpp:160
+          VN[vi] = ns_old + 1;                      // :161
+        }
         if (PACKED) {
           if (!COLOR) K8[vi] = (uint8_t)min(k_old + 1u, a.kmax);
         } else {
@@ -1157,17 +1178,16 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
   }
-  if (h->weight_by_variance) {
-    tsdf_set_error("this volume was saved with weight_by_variance_ (hpp:203-204): integrating it needs the per-voxel "
-                   "M_ / nsample_ state of the octree, which the dense grid does not keep");
+  if (h->weight_by_variance && (!h->vm || !h->vn || h->packed || h->cn[0])) {
+    tsdf_set_error("weight_by_variance_ (hpp:203-204) needs the per-voxel M_ / nsample_ planes: F32W layout, TSDF_COLOR_RGB");
     return TSDF_HIP_E_UNSUPPORTED;
   }
   // the plain per-voxel kernel: weight_by_depth_ (2), the test knob "plain_kernel" (1), or the reference-cull replication
   // mode (3: any layout; the fast kernels know nothing about the six planes)
-  const int plain_mode = h->weight_by_depth ? 2 : (h->ref_cull && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  const int plain_mode = h->weight_by_depth ? 2 : h->weight_by_variance ? 4 : (h->ref_cull && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
   if (plain_mode || h->cn[0]) h->band_exact = false;  // the plain kernels keep no "band seen" flags: marching cubes reads everything
   if (plain_mode) {
-    if ((h->packed && plain_mode != 3) || h->cn[0]) {
+    if ((h->packed && plain_mode != 3) || h->cn[0]) {  // (2 and 4 need float weights)
       tsdf_set_error("weight_by_depth needs the F32W layout and TSDF_COLOR_RGB");
       return TSDF_HIP_E_UNSUPPORTED;
     }
@@ -1182,7 +1202,8 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       }
 #define LAUNCH_PLAIN(ORDER, COLOR, BYD, PK)                                                                             \
   hipLaunchKernelGGL((k_integrate_plain<ORDER, COLOR, BYD, PK>), grid, block, 0, h->stream, a, h->d, h->w, h->rgb, h->k8, \
-                     d_depth, d_bgra, h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], count ? h->counter : nullptr)
+                     h->weight_by_variance ? h->vm : nullptr, h->weight_by_variance ? h->vn : nullptr, d_depth, d_bgra,   \
+                     h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], count ? h->counter : nullptr)
 #define LP2(ORDER, COLOR)                      \
   do {                                         \
     if (plain_mode == 2)                       \
@@ -1492,8 +1513,39 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
     tsdf_set_error("weight_by_depth makes weights non-integer: it needs the F32W layout (and TSDF_COLOR_RGB)");
     return TSDF_HIP_E_UNSUPPORTED;
   }
+  if (weight_by_variance && (h->packed || h->cn[0])) {
+    tsdf_set_error("weight_by_variance needs float weights and TSDF_COLOR_RGB: create / load the volume with TSDF_LAYOUT_F32W");
+    return TSDF_HIP_E_UNSUPPORTED;
+  }
+  if (weight_by_variance && !h->vm) {  // OctreeNode::M_ / nsample_ per voxel, zero like a fresh octree's
+    TSDF_ON_DEVICE(h->device);
+    const size_t n = (size_t)(h->pitch * h->ny * h->nz_alloc);
+    TSDF_HIP_TRY(hipMalloc(&h->vm, n * sizeof(float)));
+    TSDF_HIP_TRY(hipMalloc(&h->vn, n * sizeof(int32_t)));
+    TSDF_HIP_TRY(hipMemsetAsync(h->vm, 0, n * sizeof(float), h->stream));
+    TSDF_HIP_TRY(hipMemsetAsync(h->vn, 0, n * sizeof(int32_t), h->stream));
+  }
   h->weight_by_depth = weight_by_depth != 0;
   h->weight_by_variance = weight_by_variance != 0;
+  return TSDF_HIP_OK;
+}
+
+// Test hook: the device's std::exp(float) of the variance weighting, (float)exp((double)x), on n floats.
+static __global__ void k_selftest_expf(const float *__restrict__ in, float *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)exp((double)in[i]);
+}
+extern "C" int tsdf_hip_selftest_expf(const float *in, size_t n, float *out) {
+  if (!in || !out || !n) return TSDF_HIP_E_INVALID;
+  float *di = nullptr, *dout = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&di, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&dout, n * 4));
+  TSDF_HIP_TRY(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, n);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(di);
+  (void)hipFree(dout);
   return TSDF_HIP_OK;
 }
 

@@ -587,6 +587,25 @@ int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, i
   return TSDF_HIP_OK;
 }
 
+int tsdf_multi_variance_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *M, int32_t *ns) {
+  tsdf_hip_multi *m = h->multi;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || z0 < 0 || z0 + nz > h->nz) {
+    tsdf_set_error("block outside the grid");
+    return TSDF_HIP_E_INVALID;
+  }
+  const size_t per_plane = (size_t)nx * ny;
+  for (int z = z0; z < z0 + nz;) {
+    const int o = owner_of(m, z);
+    const int run = std::min(z0 + nz, m->slab[o]->z_end) - z;
+    const size_t off = (size_t)(z - z0) * per_plane;
+    const int rc = down ? tsdf_hip_download_variance_state(m->slab[o], x0, y0, z, nx, ny, run, M ? M + off : nullptr, ns ? ns + off : nullptr)
+                        : tsdf_hip_upload_variance_state(m->slab[o], x0, y0, z, nx, ny, run, M ? M + off : nullptr, ns ? ns + off : nullptr);
+    if (rc) return rc;
+    z += run;
+  }
+  return TSDF_HIP_OK;
+}
+
 // ---- getFxn / getGradient / getHessian, renderColoredView's lookup -------------------------------------------------------
 int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok) {
   tsdf_hip_multi *m = h->multi;

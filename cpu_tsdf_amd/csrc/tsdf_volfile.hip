@@ -63,8 +63,11 @@ static void header_to(const VolHeader &f, tsdf_params &p, tsdf_vol_meta &m) {
   for (int i = 0; i < 16; ++i) m.global_transform[i] = f.global_transform[i];
 }
 
-extern "C" int tsdf_hip_save_blocks(const tsdf_params *p, const tsdf_vol_meta *meta, const char *filename,
-                                    tsdf_block_fn fetch, void *user) {
+// the optional M_ / nsample_ side channel of a block (vol_format.h VarFn), C style like tsdf_block_fn
+typedef int (*tsdf_var_fn)(void *user, int x0, int y0, int z0, int edge, float *M, int32_t *nsample);
+
+static int save_blocks_impl(const tsdf_params *p, const tsdf_vol_meta *meta, const char *filename, tsdf_block_fn fetch,
+                            tsdf_var_fn var, void *user) {
   if (!p || !filename || !fetch) return TSDF_HIP_E_INVALID;
   if (cpu_tsdf::volfmt::log2_exact(p->res[0]) < 0 || p->res[1] != p->res[0] || p->res[2] != p->res[0]) {
     tsdf_set_error("the .vol octree format needs a cubic power-of-two resolution");
@@ -85,15 +88,25 @@ extern "C" int tsdf_hip_save_blocks(const tsdf_params *p, const tsdf_vol_meta *m
         rc = fetch(user, x0, y0, z0, c, d, w, rgb);
         return rc == 0;
       },
-      &err);
+      &err,
+      var ? cpu_tsdf::volfmt::VarFn([&](int x0, int y0, int z0, int c, float *M, int32_t *ns) {
+        rc = var(user, x0, y0, z0, c, M, ns);
+        return rc == 0;
+      })
+          : cpu_tsdf::volfmt::VarFn());
   if (ok) return TSDF_HIP_OK;
   if (rc) return rc;  // (the callback's own code; its message, if any, is already set)
   tsdf_set_error(err);
   return TSDF_HIP_E_IO;
 }
 
-extern "C" int tsdf_hip_load_blocks(const char *filename, const tsdf_params *defaults, tsdf_header_fn on_header,
-                                    tsdf_block_fn store, void *user) {
+extern "C" int tsdf_hip_save_blocks(const tsdf_params *p, const tsdf_vol_meta *meta, const char *filename,
+                                    tsdf_block_fn fetch, void *user) {
+  return save_blocks_impl(p, meta, filename, fetch, nullptr, user);
+}
+
+static int load_blocks_impl(const char *filename, const tsdf_params *defaults, tsdf_header_fn on_header, tsdf_block_fn store,
+                            tsdf_var_fn var, void *user) {
   if (!filename || (!on_header && !store)) return TSDF_HIP_E_INVALID;
   tsdf_params p;
   if (defaults)
@@ -117,16 +130,30 @@ extern "C" int tsdf_hip_load_blocks(const char *filename, const tsdf_params *def
         rc = store(user, x0, y0, z0, c, d, w, rgb);
         return rc == 0;
       },
-      &err);
+      &err,
+      var ? cpu_tsdf::volfmt::VarFn([&](int x0, int y0, int z0, int c, float *M, int32_t *ns) {
+        rc = var(user, x0, y0, z0, c, M, ns);
+        return rc == 0;
+      })
+          : cpu_tsdf::volfmt::VarFn());
   if (ok || header_only) return TSDF_HIP_OK;
   if (rc) return rc;
   tsdf_set_error(err);
   return TSDF_HIP_E_IO;
 }
 
+extern "C" int tsdf_hip_load_blocks(const char *filename, const tsdf_params *defaults, tsdf_header_fn on_header,
+                                    tsdf_block_fn store, void *user) {
+  return load_blocks_impl(filename, defaults, on_header, store, nullptr, user);
+}
+
 // ---- one handle ---------------------------------------------------------------------------------------------
 static int fetch_from_handle(void *user, int x0, int y0, int z0, int c, float *d, float *w, uint8_t *rgb) {
   return tsdf_hip_download((tsdf_handle)user, x0, y0, z0, c, c, c, d, w, rgb);
+}
+
+static int fetch_var_from_handle(void *user, int x0, int y0, int z0, int c, float *M, int32_t *ns) {
+  return tsdf_hip_download_variance_state((tsdf_handle)user, x0, y0, z0, c, c, c, M, ns);
 }
 
 extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol_meta *meta) {
@@ -140,7 +167,9 @@ extern "C" int tsdf_hip_save(tsdf_handle h, const char *filename, const tsdf_vol
                    "octree.cpp:417-433)");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  return tsdf_hip_save_blocks(&h->p, meta, filename, fetch_from_handle, h);
+  // a volume that weights by variance carries its M_ / nsample_ state in the file, like the reference's octree nodes
+  const bool var = (h->multi ? tsdf_multi_first(h) : h)->weight_by_variance != 0;
+  return save_blocks_impl(&h->p, meta, filename, fetch_from_handle, var ? fetch_var_from_handle : nullptr, h);
 }
 
 namespace {
@@ -158,13 +187,16 @@ int load_header(void *user, const tsdf_params *p, const tsdf_vol_meta *m) {
   s->m = *m;
   if (s->force_f32w) s->p.layout = TSDF_LAYOUT_F32W;
   // a depth-weighted volume (hpp:201-202) holds weights that are not counts, and keeps integrating that way
-  if (m->weight_by_depth && s->p.layout == TSDF_LAYOUT_AUTO) s->p.layout = TSDF_LAYOUT_F32W;
+  if ((m->weight_by_depth || m->weight_by_variance) && s->p.layout == TSDF_LAYOUT_AUTO) s->p.layout = TSDF_LAYOUT_F32W;
   const int rc = s->devices ? tsdf_hip_create_multi(&s->p, s->devices, s->n_devices, &s->h) : tsdf_hip_create(&s->p, &s->h);
   if (rc) return rc;
   return tsdf_hip_set_weighting(s->h, m->weight_by_depth, m->weight_by_variance);
 }
 int load_store(void *user, int x0, int y0, int z0, int c, float *d, float *w, uint8_t *rgb) {
   return tsdf_hip_upload(((LoadState *)user)->h, x0, y0, z0, c, c, c, d, w, rgb);
+}
+int load_store_var(void *user, int x0, int y0, int z0, int c, float *M, int32_t *ns) {  // (only called for files that weight by variance)
+  return tsdf_hip_upload_variance_state(((LoadState *)user)->h, x0, y0, z0, c, c, c, M, ns);
 }
 }  // namespace
 
@@ -178,7 +210,7 @@ static int load_impl(const char *filename, const tsdf_params *defaults, const in
     s.force_f32w = attempt == 1;
     s.devices = devices;
     s.n_devices = n_devices;
-    const int rc = tsdf_hip_load_blocks(filename, defaults, load_header, load_store, &s);
+    const int rc = load_blocks_impl(filename, defaults, load_header, load_store, load_store_var, &s);
     if (rc == TSDF_HIP_OK) {
       *out = s.h;
       if (params_out) {

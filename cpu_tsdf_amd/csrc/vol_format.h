@@ -12,8 +12,9 @@
 //
 // Writing synthesises an octree from the flat grid: a subtree whose voxels all hold the same (d, w, rgb)
 // collapses into one leaf (lossless for every reader that looks voxels up by position, which is all the
-// reference does); M_ and nsample_ -- only used by the reference's unreachable variance weighting -- are
-// written as 0.  Reading rasterises every leaf over the voxels it covers.  Needs a cubic power-of-two
+// reference does); M_ and nsample_ -- only used by the reference's variance weighting, which only a loaded file can
+// switch on -- are written as 0 unless the caller supplies them through the optional VarFn side channel (volumes whose
+// header says weight_by_variance: tsdf_hip_save / tsdf_hip_load do), in which case they also take part in "same".  Reading rasterises every leaf over the voxels it covers.  Needs a cubic power-of-two
 // grid (the only kind the reference's octree represents faithfully).
 //
 // Both directions stream: the grid is visited in cubic chunks (edge `chunk`, a power of two) through a
@@ -81,6 +82,8 @@ struct Grid {
   int n, L;
   const float *d, *w;
   const unsigned char *rgb;
+  const float *M = nullptr;     // optional: OctreeNode::M_ / nsample_ per voxel (variance weighting)
+  const int32_t *ns = nullptr;
   // uniform[l][node] for levels 0..L-1 (level l has (2^l)^3 nodes); a node is uniform when all voxels
   // below it are bit-identical
   std::vector<std::vector<unsigned char> > uniform;
@@ -90,7 +93,8 @@ struct Grid {
   size_t vox(int x, int y, int z) const { return ((size_t)z * n + y) * n + x; }
   bool same(size_t a, size_t b) const {
     return std::memcmp(d + a, d + b, 4) == 0 && std::memcmp(w + a, w + b, 4) == 0 &&
-           (!rgb || std::memcmp(rgb + 3 * a, rgb + 3 * b, 3) == 0);
+           (!rgb || std::memcmp(rgb + 3 * a, rgb + 3 * b, 3) == 0) &&
+           (!M || (std::memcmp(M + a, M + b, 4) == 0 && ns[a] == ns[b]));
   }
 };
 
@@ -148,7 +152,7 @@ struct NodeSink {
 };
 
 inline void put_node(NodeSink &f, bool color, const unsigned char *rgb, float d, float w, float cx, float cy,
-                     float cz, float size, bool leaf) {
+                     float cz, float size, bool leaf, float M = 0.f, int32_t ns = 0) {
   char *p = f.room(color ? 43 : 40);
   if (color) {
     const unsigned char zero[3] = {0, 0, 0};
@@ -158,9 +162,11 @@ inline void put_node(NodeSink &f, bool color, const unsigned char *rgb, float d,
   if (!leaf) {
     d = -1.f;
     w = 0.f;
+    M = 0.f;
+    ns = 0;
   }
-  const float rec[7] = {d, w, cx, cy, cz, size, 0.f};  // ..., M
-  const int32_t nsample = 0;
+  const float rec[7] = {d, w, cx, cy, cz, size, M};
+  const int32_t nsample = ns;
   const size_t nchild = leaf ? 0 : 8;
   std::memcpy(p, rec, 28);
   std::memcpy(p + 28, &nsample, 4);
@@ -172,7 +178,8 @@ inline void write_node(NodeSink &f, const Grid &g, int level, int kx, int ky, in
   const int span = g.n >> level;
   const bool leaf = level == g.L || g.uniform[level][((size_t)kz * (1 << level) + ky) * (1 << level) + kx];
   const size_t v0 = g.vox(kx * span, ky * span, kz * span);
-  put_node(f, g.rgb != nullptr, g.rgb ? g.rgb + 3 * v0 : nullptr, g.d[v0], g.w[v0], cx, cy, cz, size, leaf);
+  put_node(f, g.rgb != nullptr, g.rgb ? g.rgb + 3 * v0 : nullptr, g.d[v0], g.w[v0], cx, cy, cz, size, leaf, g.M ? g.M[v0] : 0.f,
+           g.ns ? g.ns[v0] : 0);
   if (leaf) return;
   const float off = size / 4, ns = size / 2;
   for (int c = 0; c < 8; ++c) {
@@ -230,6 +237,9 @@ struct NodeSource {  // the reading counterpart of NodeSink
 // One cubic block of voxels, edge c, origin (x0,y0,z0): d, w [c^3] and rgb [3 c^3] (null without colour),
 // x fastest.  fetch fills the buffers from the volume, store writes them into it; both return false on error.
 typedef std::function<bool(int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb)> BlockFn;
+// Optional side channel next to a BlockFn: OctreeNode::M_ / nsample_ of the same block ([z][y][x] like d), fetched right
+// after the writer fetched the block, stored right after the reader stored it.  Empty = not carried (written as 0).
+typedef std::function<bool(int x0, int y0, int z0, int c, float *M, int32_t *nsample)> VarFn;
 
 struct ReadCtx {
   int n, C, Lc;  // grid edge, chunk edge, tree level whose nodes are chunks
@@ -237,9 +247,16 @@ struct ReadCtx {
   bool color;
   std::vector<float> d, w;  // the chunk being assembled
   std::vector<unsigned char> rgb;
+  std::vector<float> M;       // only with `var`
+  std::vector<int32_t> ns;
   int ox, oy, oz;  // its origin; ox < 0: none open
   BlockFn store;
+  VarFn var;
   std::string err;
+  bool store_block(int x, int y, int z) {
+    if (!store(x, y, z, C, d.data(), w.data(), color ? rgb.data() : nullptr)) return false;
+    return !var || var(x, y, z, C, M.data(), ns.data());
+  }
 };
 
 inline bool node_box(const ReadCtx &c, float cx, float cy, float cz, float size, int &x0, int &y0, int &z0, int &span) {
@@ -250,7 +267,8 @@ inline bool node_box(const ReadCtx &c, float cx, float cy, float cz, float size,
   return x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + span <= c.n && y0 + span <= c.n && z0 + span <= c.n;
 }
 
-inline void fill_chunk(ReadCtx &c, int x0, int y0, int z0, int span, float d, float w, const unsigned char *col) {
+inline void fill_chunk(ReadCtx &c, int x0, int y0, int z0, int span, float d, float w, const unsigned char *col, float M = 0.f,
+                       int32_t ns = 0) {
   for (int z = z0; z < z0 + span; ++z)
     for (int y = y0; y < y0 + span; ++y) {
       const size_t row = ((size_t)z * c.C + y) * c.C + x0;
@@ -258,6 +276,11 @@ inline void fill_chunk(ReadCtx &c, int x0, int y0, int z0, int span, float d, fl
         c.d[row + x] = d;
         c.w[row + x] = w;
       }
+      if (c.var)
+        for (int x = 0; x < span; ++x) {
+          c.M[row + x] = M;
+          c.ns[row + x] = ns;
+        }
       if (c.color)
         for (int x = 0; x < span; ++x) std::memcpy(&c.rgb[3 * (row + x)], col, 3);
     }
@@ -274,11 +297,13 @@ inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
     std::memcpy(col, p, 3);
     p += 3;
   }
-  float rec[6];  // d, w, centre, size (then M and nsample, unused)
+  float rec[7];  // d, w, centre, size, M; then nsample
+  int32_t nsample;
   size_t nchild;
-  std::memcpy(rec, p, 24);
+  std::memcpy(rec, p, 28);
+  std::memcpy(&nsample, p + 28, 4);
   std::memcpy(&nchild, p + 32, 8);
-  const float d = rec[0], w = rec[1], cx = rec[2], cy = rec[3], cz = rec[4], size = rec[5];
+  const float d = rec[0], w = rec[1], cx = rec[2], cy = rec[3], cz = rec[4], size = rec[5], Mv = rec[6];
   int x0, y0, z0, span;
   if (nchild == 0) {  // leaf: fill the voxels it covers
     if (!node_box(c, cx, cy, cz, size, x0, y0, z0, span)) {
@@ -291,18 +316,18 @@ inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
         c.err = "leaf outside its parent node";
         return false;
       }
-      fill_chunk(c, x0 - c.ox, y0 - c.oy, z0 - c.oz, span, d, w, col);
+      fill_chunk(c, x0 - c.ox, y0 - c.oy, z0 - c.oz, span, d, w, col, Mv, nsample);
       return true;
     }
     if (span < c.C || x0 % c.C || y0 % c.C || z0 % c.C || span % c.C) {
       c.err = "octree nodes are not aligned with their depth";
       return false;
     }
-    fill_chunk(c, 0, 0, 0, c.C, d, w, col);  // one constant chunk, stored over every chunk the leaf covers
+    fill_chunk(c, 0, 0, 0, c.C, d, w, col, Mv, nsample);  // one constant chunk, stored over every chunk the leaf covers
     for (int z = z0; z < z0 + span; z += c.C)
       for (int y = y0; y < y0 + span; y += c.C)
         for (int x = x0; x < x0 + span; x += c.C)
-          if (!c.store(x, y, z, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr)) {
+          if (!c.store_block(x, y, z)) {
             c.err = "storing a block failed";
             return false;
           }
@@ -329,7 +354,7 @@ inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
   for (int k = 0; k < 8; ++k)
     if (!read_node(f, c, depth + 1)) return false;
   if (opens) {
-    const bool ok = c.store(c.ox, c.oy, c.oz, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr);
+    const bool ok = c.store_block(c.ox, c.oy, c.oz);
     c.ox = -1;
     if (!ok) {
       c.err = "storing a block failed";
@@ -353,8 +378,15 @@ struct WriteCtx {
   Grid top;       // one voxel per chunk (its first voxel) + the chunk-uniform table
   std::vector<float> d, w;
   std::vector<unsigned char> rgb;
+  std::vector<float> M;  // only with `var`
+  std::vector<int32_t> ns;
   BlockFn fetch;
+  VarFn var;
   std::string err;
+  bool fetch_block(int x, int y, int z) {
+    if (!fetch(x, y, z, C, d.data(), w.data(), color ? rgb.data() : nullptr)) return false;
+    return !var || var(x, y, z, C, M.data(), ns.data());
+  }
 };
 
 inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, float cy, float cz, float size) {
@@ -363,7 +395,8 @@ inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, 
   const size_t v0 = c.top.vox(kx * span, ky * span, kz * span);
   const bool leaf = level == c.Lc ? (*c.top.leaf_ok)[v0] != 0 : c.top.uniform[level][((size_t)kz * m + ky) * m + kx] != 0;
   if (leaf || level < c.Lc) {
-    put_node(*c.f, c.color, c.color ? c.top.rgb + 3 * v0 : nullptr, c.top.d[v0], c.top.w[v0], cx, cy, cz, size, leaf);
+    put_node(*c.f, c.color, c.color ? c.top.rgb + 3 * v0 : nullptr, c.top.d[v0], c.top.w[v0], cx, cy, cz, size, leaf,
+             c.top.M ? c.top.M[v0] : 0.f, c.top.ns ? c.top.ns[v0] : 0);
     if (leaf) return true;
     const float off = size / 4, ns = size / 2;
     for (int k = 0; k < 8; ++k) {
@@ -375,7 +408,7 @@ inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, 
     return true;
   }
   // a non-uniform chunk: fetch it again and write its subtree
-  if (!c.fetch(kx * c.C, ky * c.C, kz * c.C, c.C, c.d.data(), c.w.data(), c.color ? c.rgb.data() : nullptr)) {
+  if (!c.fetch_block(kx * c.C, ky * c.C, kz * c.C)) {
     c.err = "fetching a block failed";
     return false;
   }
@@ -385,6 +418,8 @@ inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, 
   g.d = c.d.data();
   g.w = c.w.data();
   g.rgb = c.color ? c.rgb.data() : nullptr;
+  g.M = c.var ? c.M.data() : nullptr;
+  g.ns = c.var ? c.ns.data() : nullptr;
   build_pyramid(g);
   write_node(*c.f, g, 0, 0, 0, 0, cx, cy, cz, size);
   return true;
@@ -412,7 +447,7 @@ inline bool all_same(const Grid &g) {
 
 // Writes the volume `fetch` serves into `filename`, visiting it in blocks of edge <= chunk.
 inline bool vol_write_stream(const std::string &filename, const VolHeader &h, int chunk, const volfmt::BlockFn &fetch,
-                             std::string *err) {
+                             std::string *err, const volfmt::VarFn &var = volfmt::VarFn()) {
   const int L = volfmt::log2_exact(h.res[0]);
   if (L < 0 || h.res[1] != h.res[0] || h.res[2] != h.res[0]) {
     if (err) *err = "the .vol octree format needs a cubic power-of-two resolution";
@@ -460,13 +495,17 @@ inline bool vol_write_stream(const std::string &filename, const VolHeader &h, in
   c.LC = volfmt::log2_exact(c.C);
   c.Lc = L - c.LC;
   c.fetch = fetch;
+  c.var = var;
   const size_t cv = (size_t)c.C * c.C * c.C;
   c.d.resize(cv);
   c.w.resize(cv);
   c.rgb.resize(h.color ? 3 * cv : 0);
+  c.M.resize(var ? cv : 0);
+  c.ns.resize(var ? cv : 0);
   // pass 1: one voxel and one "uniform" flag per chunk
   const int m = 1 << c.Lc;
-  std::vector<float> td((size_t)m * m * m), tw((size_t)m * m * m);
+  std::vector<float> td((size_t)m * m * m), tw((size_t)m * m * m), tM(var ? td.size() : 0);
+  std::vector<int32_t> tns(var ? td.size() : 0);
   std::vector<unsigned char> trgb(h.color ? 3 * td.size() : 0), tok(td.size());
   volfmt::Grid blk;
   blk.n = c.C;
@@ -474,10 +513,12 @@ inline bool vol_write_stream(const std::string &filename, const VolHeader &h, in
   blk.d = c.d.data();
   blk.w = c.w.data();
   blk.rgb = h.color ? c.rgb.data() : nullptr;
+  blk.M = var ? c.M.data() : nullptr;
+  blk.ns = var ? c.ns.data() : nullptr;
   for (int kz = 0; kz < m; ++kz)
     for (int ky = 0; ky < m; ++ky)
       for (int kx = 0; kx < m; ++kx) {
-        if (!fetch(kx * c.C, ky * c.C, kz * c.C, c.C, c.d.data(), c.w.data(), h.color ? c.rgb.data() : nullptr)) {
+        if (!c.fetch_block(kx * c.C, ky * c.C, kz * c.C)) {
           if (err) *err = "fetching a block failed";
           return false;
         }
@@ -485,6 +526,7 @@ inline bool vol_write_stream(const std::string &filename, const VolHeader &h, in
         td[t] = c.d[0];
         tw[t] = c.w[0];
         if (h.color) std::memcpy(&trgb[3 * t], c.rgb.data(), 3);
+        if (var) tM[t] = c.M[0], tns[t] = c.ns[0];
         tok[t] = volfmt::all_same(blk) ? 1 : 0;
       }
   c.top.n = m;
@@ -492,6 +534,8 @@ inline bool vol_write_stream(const std::string &filename, const VolHeader &h, in
   c.top.d = td.data();
   c.top.w = tw.data();
   c.top.rgb = h.color ? trgb.data() : nullptr;
+  c.top.M = var ? tM.data() : nullptr;
+  c.top.ns = var ? tns.data() : nullptr;
   c.top.leaf_ok = &tok;
   volfmt::build_pyramid(c.top);
   // pass 2: nodes in pre-order
@@ -512,7 +556,7 @@ inline bool vol_write_stream(const std::string &filename, const VolHeader &h, in
 // voxels, handed to `store` in blocks of edge min(chunk, res).  Every voxel is stored exactly once.
 inline bool vol_read_stream(const std::string &filename, VolHeader &h, int chunk,
                             const std::function<bool(const VolHeader &)> &on_header, const volfmt::BlockFn &store,
-                            std::string *err) {
+                            std::string *err, const volfmt::VarFn &var = volfmt::VarFn()) {
   std::ifstream f(filename.c_str(), std::ios::binary);
   if (!f) {
     if (err) *err = "cannot open " + filename;
@@ -574,6 +618,9 @@ inline bool vol_read_stream(const std::string &filename, VolHeader &h, int chunk
   c.rgb.resize(h.color ? 3 * cv : 0);
   c.ox = c.oy = c.oz = -1;
   c.store = store;
+  c.var = (var && h.weight_by_variance) ? var : volfmt::VarFn();  // only a file that weights by variance carries meaningful values
+  c.M.resize(c.var ? cv : 0);
+  c.ns.resize(c.var ? cv : 0);
   volfmt::NodeSource src(f);
   if (!volfmt::read_node(src, c, 0)) {
     if (err) *err = c.err;

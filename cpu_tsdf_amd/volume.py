@@ -150,12 +150,18 @@ class TSDFVolumeOctree:
             self._h = None
         h = C.c_void_p()
         devs = getattr(self, "_devices", None)
+        # weight_by_depth_ / weight_by_variance_ (only load() sets them, as in the reference) survive a reset there too
+        weighting = tuple(int(v) for v in getattr(self, "_weighting", (0, 0)))
+        if any(weighting) and self._p.layout == capi.LAYOUT_AUTO:
+            self._p.layout = capi.LAYOUT_F32W
         if devs:
             arr = (C.c_int32 * len(devs))(*devs)
             capi.check(lib.tsdf_hip_create_multi(C.byref(self._p), arr, len(devs), C.byref(h)), "create_multi")
         else:
             capi.check(lib.tsdf_hip_create(C.byref(self._p), C.byref(h)), "create")
         self._h = h
+        if any(weighting):
+            capi.check(lib.tsdf_hip_set_weighting(h, *weighting), "set_weighting")
         if self._stream is not None and not getattr(self, "_devices", None):  # (a stream belongs to one device)
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
         self._is_empty = True
@@ -426,6 +432,26 @@ class TSDFVolumeOctree:
         for c in range(planes):
             capi.check(capi.load().tsdf_hip_download_color_state(h, c, z0, nz, capi.as_f32p(out[c])), "colour state")
         return out
+
+    def setWeighting(self, by_depth=False, by_variance=False):
+        """Not in the reference (its two flags only arrive through load()): hpp:200-204 on this volume from the next
+        reset() on -- F32W layout, plain kernel; tests use it."""
+        self._weighting = (bool(by_depth), bool(by_variance))
+
+    def downloadVarianceState(self):
+        """(M, nsample) of every voxel: OctreeNode::M_ / nsample_ (octree.h:164-165), kept by volumes that weight by variance."""
+        rx, ry, rz = self._p.res
+        M, ns = np.empty((rz, ry, rx), np.float32), np.empty((rz, ry, rx), np.int32)
+        capi.check(capi.load().tsdf_hip_download_variance_state(self._need(), 0, 0, 0, rx, ry, rz, capi.as_f32p(M),
+                                                                ns.ctypes.data_as(C.POINTER(C.c_int32))), "download_variance_state")
+        return M, ns
+
+    def uploadVarianceState(self, M, nsample):
+        rx, ry, rz = self._p.res
+        M, ns = np.ascontiguousarray(M, np.float32), np.ascontiguousarray(nsample, np.int32)
+        assert M.shape == ns.shape == (rz, ry, rx)
+        capi.check(capi.load().tsdf_hip_upload_variance_state(self._need(), 0, 0, 0, rx, ry, rz, capi.as_f32p(M),
+                                                              ns.ctypes.data_as(C.POINTER(C.c_int32))), "upload_variance_state")
 
     def upload(self, d=None, w=None, rgb=None, x0=0, y0=0, z0=0):
         h = self._need()

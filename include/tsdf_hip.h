@@ -219,11 +219,22 @@ int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]);
  *                       picks F32W by itself) and TSDF_COLOR_RGB.  Integrated by a plain per-voxel kernel (exact
  *                       fp64 projection, IEEE divisions), every operation in the reference's order.
  *   weight_by_variance  w_new *= exp(logNormal(d_new, d, variance)) once a voxel has more than 5 samples (:203-204),
- *                       from OctreeNode::M_ / nsample_ (src/lib/octree.cpp:160-161,281-287), which the dense grid
- *                       does not keep: the flag is remembered (save writes it back, queries and marching cubes
- *                       work), and every integrate entry point then FAILS with TSDF_HIP_E_UNSUPPORTED rather than
- *                       integrating unweighted. */
+ *                       from OctreeNode::M_ / nsample_ (src/lib/octree.cpp:160-161,281-287): two more planes per voxel
+ *                       (float M, int32 nsample), allocated when the flag is set, zero like a fresh octree's, updated by
+ *                       every observation from then on, carried by tsdf_hip_save / tsdf_hip_load in the node records the
+ *                       reference keeps them in, and readable / writable through tsdf_hip_*_variance_state.  Needs
+ *                       the F32W layout and TSDF_COLOR_RGB like weight_by_depth (tsdf_hip_load with AUTO picks F32W);
+ *                       integrated by the same plain kernel.  std::exp(float) is evaluated as the fp64 exp rounded to
+ *                       float, which equals the host's expf on every float of the range the weighting can produce
+ *                       (tests/test_wvar_gpu.py sweeps it). */
 int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance);
+
+/* OctreeNode::M_ / nsample_ of a block of voxels ([z][y][x]; either pointer may be NULL) -- include/cpu_tsdf/octree.h:
+ * 164-165, the state weight_by_variance integrates with.  Only volumes that weight by variance keep it (E_INVALID
+ * otherwise).  The reference exposes the members directly; tsdf_hip_save / tsdf_hip_load move them with the file. */
+int tsdf_hip_download_variance_state(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, float *M, int32_t *nsample);
+int tsdf_hip_upload_variance_state(tsdf_handle h, int x0, int y0, int z0, int nx, int ny, int nz, const float *M,
+                                   const int32_t *nsample);
 
 /* renderView -- tsdf_volume_octree.cpp:278-421 (everything except the last line).
  *   rot        3x3 row-major float:  trans.rotation().cast<float>()      (:303)
@@ -427,6 +438,9 @@ int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, u
 /* Test hook: out[i] = v_cvt_pk_u8_f32(in[i], byte 1, 0xAABBCCDD) -- the instruction the colour update packs its bytes
  * with; the tests pin its rounding (nearest even), saturation and byte selection. */
 int tsdf_hip_selftest_cvt_pk_u8(const float *in, size_t n, uint32_t *out);
+
+/* Test hook: out[i] = the device's std::exp(float) of the variance weighting, (float)exp((double)in[i]). */
+int tsdf_hip_selftest_expf(const float *in, size_t n, float *out);
 
 /* Test hooks for TSDF_COLOR_LAB: the device's RGB2LAB of n pixels (b,g,r,a bytes each -> L,A,B,0 floats each) and
  * LAB2RGB of n L,A,B triples (-> r | g<<8 | b<<16 each); references octree.cpp:436-481 and :483-527. */

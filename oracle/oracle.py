@@ -50,6 +50,11 @@ def lib():
         L.oracle_integrate_culled.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, _f]
         L.oracle_reference_cull_planes.restype = None
         L.oracle_reference_cull_planes.argtypes = [C.POINTER(OracleParams), C.POINTER(C.c_double), _f]
+        L.oracle_expf_many.restype = None
+        L.oracle_expf_many.argtypes = [_f, C.c_size_t, _f]
+        L.oracle_integrate_variance.restype = C.c_uint64
+        L.oracle_integrate_variance.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, C.POINTER(C.c_int32), _f, _u8, _f,
+                                                C.c_int, C.c_int, C.c_int]
         L.oracle_integrate_weighted.restype = C.c_uint64
         L.oracle_integrate_weighted.argtypes = [C.POINTER(OracleParams), _f, _f, _u8, _f, _u8, _f, C.c_int, C.c_int, C.c_int]
         L.oracle_integrate_lab.restype = C.c_uint64
@@ -158,6 +163,20 @@ class OracleVolume:
         return int(lib().oracle_integrate_culled(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb) if self.rgb is not None else None,
                                                  _fp(depth), _bp(col) if col is not None else None,
                                                  _fp(np.ascontiguousarray(cam_from_vol, np.float32)), z_begin, z_end, _fp(planes)))
+
+    def integrate_variance(self, depth, bgra, cam_from_vol, weight_by_depth=False, z_begin=0, z_end=0):
+        """integrateCloud with weight_by_variance_ (hpp:203-204); self.M / self.nsample = OctreeNode::M_ / nsample_
+        (created at zero on first use, or set by the caller from a loaded .vol)."""
+        if getattr(self, "M", None) is None:
+            self.M = np.zeros_like(self.d)
+            self.nsample = np.zeros(self.d.shape, np.int32)
+        depth = np.ascontiguousarray(depth, np.float32)
+        col = np.ascontiguousarray(bgra, np.uint8) if bgra is not None else None
+        return int(lib().oracle_integrate_variance(C.byref(self.p), _fp(self.d), _fp(self.w), _bp(self.rgb) if self.rgb is not None else None,
+                                                   _fp(self.M), self.nsample.ctypes.data_as(C.POINTER(C.c_int32)), _fp(depth),
+                                                   _bp(col) if col is not None else None,
+                                                   _fp(np.ascontiguousarray(cam_from_vol, np.float32)), z_begin, z_end,
+                                                   int(weight_by_depth)))
 
     def integrate_rgbn(self, depth, bgra, cam_from_vol, z_begin=0, z_end=0):
         """integrate with RGBNormalized voxels (setColorMode("RGBNormalized")); self.cn holds r_n, g_n, b_n, i and
@@ -318,6 +337,14 @@ class SlabOracle:
         return lib().oracle_integrate(C.byref(self.p), d, w, rgb, depth.ctypes.data_as(fp),
                                         col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None,
                                         T.ctypes.data_as(fp), self.zb, self.ze)
+
+
+def expf(x):
+    """The host libm's expf on a float32 array (what std::exp(float) is in the reference, hpp:204)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().oracle_expf_many(_fp(x), x.size, _fp(out))
+    return out
 
 
 def rgb2lab(rgb):

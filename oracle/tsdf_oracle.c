@@ -246,9 +246,14 @@ static int cull_keeps(const float planes[24], float x, float y, float z) { /* is
 
 /* weight_by_depth: hpp:200-202, `w_new *= (1 - std::min(pt.z / 10., 1.))` -- a float times a double, stored
  * back into the float; the flag has no setter and only arrives through load() (tsdf_volume_octree.cpp:265). */
+/* weight_by_variance: hpp:203-204, `w_new *= std::exp(logNormal(d_new, voxel->d_, voxel->getVariance()))` once the
+ * voxel has more than 5 samples.  logNormal (hpp:106-110) = -std::pow(x - mean, 2) / (2 * var): pow(float, int) is
+ * the double pow, the quotient a double, the result stored in a float; getVariance (octree.cpp:281-287) =
+ * (M_ / w_) * (nsample_ / (nsample_ - 1)) with an INTEGER quotient (1 for every count it is reached with); std::exp of
+ * a float is expf.  M_ and nsample_ (Mv, nv: per voxel, like d) are updated by every addObservation (octree.cpp:160-161). */
 static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                                const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth,
-                               const float *cull_planes) {
+                               const float *cull_planes, float *Mv, int32_t *nv) {
   const int nx = p->res[0], ny = p->res[1], nz = p->res[2];
   float *cx = (float *)malloc(sizeof(float) * nx), *cy = (float *)malloc(sizeof(float) * ny),
         *cz = (float *)malloc(sizeof(float) * nz);
@@ -271,6 +276,11 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
           wn = (float)((double)wn * (1 - ((1. < a) ? 1. : a)));
         }
         const size_t vi = ((size_t)k * ny + j) * nx + i;
+        if (Mv && nv[vi] > 5) { /* hpp:203-204 */
+          const float var = (Mv[vi] / w[vi]) * (float)(nv[vi] / (nv[vi] - 1));
+          const float ln = (float)(-pow((double)(dn - d[vi]), 2.0) / (double)(2 * var));
+          wn *= expf(ln);
+        }
         if (p->integrate_color && rgb) { /* octree.cpp:331-335 (old w, truncation) */
           const uint8_t *px = bgra + 4 * pixel;
           const float wsum = w[vi] + wn;
@@ -279,9 +289,14 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
           rgb[3 * vi + 1] = (uint8_t)(cvtt((double)((w[vi] * rgb[3 * vi + 1] + wn * px[1]) / wsum)) & 255);
           rgb[3 * vi + 2] = (uint8_t)(cvtt((double)((w[vi] * rgb[3 * vi + 2] + wn * px[0]) / wsum)) & 255);
         }
+        const float d_old = d[vi];
         d[vi] = (d[vi] * w[vi] + dn * wn) / (w[vi] + wn); /* octree.cpp:156 */
         w[vi] += wn;                                       /* octree.cpp:157 */
         if (w[vi] > p->max_weight) w[vi] = p->max_weight;  /* octree.cpp:158-159 */
+        if (Mv) {
+          Mv[vi] += wn * (dn - d[vi]) * (dn - d_old); /* octree.cpp:160 */
+          ++nv[vi];                                   /* octree.cpp:161 */
+        }
         ++n_obs;
       }
   free(cx);
@@ -292,18 +307,32 @@ static uint64_t integrate_impl(const oracle_params *p, float *d, float *w, uint8
 
 uint64_t oracle_integrate(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                           const uint8_t *bgra, const float T[12], int z_begin, int z_end) {
-  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, NULL);
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, NULL, NULL, NULL);
 }
 
 /* integrateCloud INCLUDING the reference's frustum cull (planes from oracle_reference_cull_planes). */
 uint64_t oracle_integrate_culled(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                                  const uint8_t *bgra, const float T[12], int z_begin, int z_end, const float planes[24]) {
-  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, planes);
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, 0, planes, NULL, NULL);
 }
 
 uint64_t oracle_integrate_weighted(const oracle_params *p, float *d, float *w, uint8_t *rgb, const float *depth,
                                    const uint8_t *bgra, const float T[12], int z_begin, int z_end, int weight_by_depth) {
-  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth, NULL);
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth, NULL, NULL, NULL);
+}
+
+/* std::exp(float) as the reference calls it (hpp:204): the host libm's expf, for the GPU tests' sweep of the device's form */
+void oracle_expf_many(const float *in, size_t n, float *out) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) out[i] = expf(in[i]);
+}
+
+/* integrateCloud of a volume whose header carries weight_by_variance_ (and possibly weight_by_depth_): M / nsample are the
+ * per-voxel OctreeNode::M_ / nsample_ planes ([z][y][x] like d). */
+uint64_t oracle_integrate_variance(const oracle_params *p, float *d, float *w, uint8_t *rgb, float *M, int32_t *nsample,
+                                   const float *depth, const uint8_t *bgra, const float T[12], int z_begin, int z_end,
+                                   int weight_by_depth) {
+  return integrate_impl(p, d, w, rgb, depth, bgra, T, z_begin, z_end, weight_by_depth, NULL, M, nsample);
 }
 
 /* The same with RGBNormalized voxels (setColorMode("RGBNormalized")): RGBNormalized::addObservation,

@@ -1,0 +1,163 @@
+"""GPU tier: weight_by_variance_ (include/cpu_tsdf/impl/tsdf_volume_octree.hpp:203-204; OctreeNode::M_ / nsample_ /
+getVariance, src/lib/octree.cpp:152-163,281-287) -- the last of the reference's weightings, which only a loaded .vol
+can switch on.  The product keeps M_ / nsample_ as two more planes, integrates through the plain kernel and carries the
+state through save / load in the reference's own node records.
+
+  * the device's std::exp(float), (float)exp((double)x), equals the host libm's expf on EVERY float of the range the
+    weighting can produce and matter (-104 .. -2^-26: below, both are 0; above, both are 1), and on the specials;
+  * product == oracle (which tests/test_oracle_wvar.py pins to the compiled reference), d / w / rgb / M / nsample, with
+    and without colour, together with weight_by_depth, on a multi-slab handle;
+  * a .vol the REFERENCE wrote after 8 frames (tests/golden/reference_wvar_32_after8.vol: its M_ / nsample_ inside)
+    loaded by the product, 4 more frames integrated: equal to the reference's own volume after 12 frames;
+  * the other way: the product saves, the compiled reference loads and continues: equal again;
+  * the same through the C++ class."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from cpu_tsdf_amd import capi, synth
+from cpu_tsdf_amd.volume import TSDFVolumeOctree
+from oracle import oracle
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32, make_volume
+from tests.golden.make_golden_wvar import H, NF, RES, SAVE_AT, W, frame
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(__file__)
+GOLD = os.path.join(HERE, "golden", "reference_wvar_32.npz")
+GOLD_VOL = os.path.join(HERE, "golden", "reference_wvar_32_after8.vol")
+
+
+def device_expf(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    capi.check(capi.load().tsdf_hip_selftest_expf(capi.as_f32p(x), x.size, capi.as_f32p(out)), "selftest_expf")
+    return out
+
+
+def test_device_exp_equals_the_host_expf_on_every_float_that_matters(gpu):
+    lo, hi = np.float32(-104.0).view(np.uint32), np.float32(-2.0 ** -26).view(np.uint32)  # negative floats: larger bits = more negative
+    first, last = int(hi), int(lo)
+    assert last - first > 2.5e8
+    bad = 0
+    for a in range(first, last + 1, 1 << 26):
+        bits = np.arange(a, min(a + (1 << 26), last + 1), dtype=np.uint32)
+        x = bits.view(np.float32)
+        got, want = device_expf(x), oracle.expf(x)
+        bad += int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, f"{bad} floats where the device's exp differs from expf"
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(-200, 5, 1_000_000), -np.exp(rng.uniform(-80, 6, 1_000_000)),
+                        [0.0, -0.0, -np.inf, np.inf, np.nan, -103.97, -103.98, -87.3, -88.8, 1e-30, -1e-30]]).astype(np.float32)
+    got, want = device_expf(x), oracle.expf(x)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), x[~same][:10]
+
+
+def variance_volume(color=True, by_depth=False, devices=None):
+    vol, sc = make_volume(RES, W, H, color=color)
+    vol.setWeighting(by_depth, True)
+    if devices:
+        vol.setDevices(devices)
+    vol.reset()
+    assert vol.getLayout() == capi.LAYOUT_F32W
+    return vol, sc
+
+
+def compare_all(vol, ov, color, what):
+    d, w, rgb = vol.download()
+    assert_same_f32(d, ov.d, f"d {what}")
+    assert_same_f32(w, ov.w, f"w {what}")
+    if color:
+        assert np.array_equal(rgb, ov.rgb), f"rgb {what}"
+    M, ns = vol.downloadVarianceState()
+    assert_same_f32(M, ov.M, f"M {what}")
+    assert np.array_equal(ns, ov.nsample), f"nsample {what}"
+
+
+@pytest.mark.parametrize("color,by_depth,devices", [(True, False, None), (False, False, None), (True, True, None), (True, False, [0, 0, 0])])
+def test_weight_by_variance_equals_the_oracle(gpu, color, by_depth, devices):
+    vol, sc = variance_volume(color, by_depth, devices)
+    ov = OracleVolume(vol._p)
+    for i in range(NF):
+        tr, dep, col = frame(sc, i)
+        n_gpu = vol.integrateCloud(dep, col if color else None, tr, count=True)
+        n_cpu = ov.integrate_variance(dep, col if color else None, synth.cam_from_vol_f32(tr), weight_by_depth=by_depth)
+        assert n_gpu == n_cpu
+        if i in (5, 6, NF - 1):
+            compare_all(vol, ov, color, f"after frame {i}")
+    assert ((ov.w % 1) != 0).mean() > 0.05 and ov.nsample.max() == NF
+    # reset keeps the weighting (as the reference's members survive reset()) and clears the state
+    vol.reset()
+    M, ns = vol.downloadVarianceState()
+    assert (M == 0).all() and (ns == 0).all()
+    vol.close()
+
+
+def test_reference_written_vol_is_continued_by_the_product(gpu):
+    """The reference saved after frame 8 with weight_by_variance_ on; M_ / nsample_ travel in the node records."""
+    gold = np.load(GOLD)
+    sc = synth.scene_a(RES, W, H)
+    for devices in (None, [0, 0]):
+        vol = TSDFVolumeOctree()
+        if devices:
+            vol.setDevices(devices)
+        vol.load(GOLD_VOL)
+        assert vol._weighting == (False, True) and vol.getLayout() == capi.LAYOUT_F32W
+        d, w, rgb = vol.download()
+        assert_same_f32(d, gold[f"d{SAVE_AT - 1}"], "d as loaded")
+        assert_same_f32(w, gold[f"w{SAVE_AT - 1}"], "w as loaded")
+        M, ns = vol.downloadVarianceState()
+        assert ns.max() == SAVE_AT and (M != 0).mean() > 0.3
+        for i in range(SAVE_AT, NF):
+            tr, dep, col = frame(sc, i)
+            vol.integrateCloud(dep, col, tr)
+            d, w, rgb = vol.download()
+            assert_same_f32(d, gold[f"d{i}"], f"d after frame {i}")
+            assert_same_f32(w, gold[f"w{i}"], f"w after frame {i}")
+            assert np.array_equal(rgb, gold[f"rgb{i}"])
+        vol.close()
+
+
+def test_product_written_vol_is_continued_by_the_compiled_reference(gpu, tmp_path):
+    from oracle import refbind
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    vol, sc = variance_volume(True)
+    for i in range(SAVE_AT):
+        tr, dep, col = frame(sc, i)
+        vol.integrateCloud(dep, col, tr)
+    path = str(tmp_path / "product_wvar.vol")
+    vol.save(path)
+    rv = refbind.RefVolume(RES, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True, dense=True)
+    rv.load(path)
+    for i in range(SAVE_AT, NF):
+        tr, dep, col = frame(sc, i)
+        vol.integrateCloud(dep, col, tr)
+        rv.integrate(dep, col, tr)
+    d, w, rgb = vol.download()
+    rd, rw, rrgb, _, _ = rv.dump_dense()
+    assert_same_f32(d, rd, "d")
+    assert_same_f32(w, rw, "w")
+    assert np.array_equal(rgb, rrgb)
+    rv.close()
+    vol.close()
+
+
+def test_dropin_class_loads_and_continues_a_variance_weighted_volume(gpu):
+    from oracle import refbind
+    dropin = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
+    gold = np.load(GOLD)
+    sc = synth.scene_a(RES, W, H)
+    v = refbind.RefVolume(RES, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True, lib_path=dropin)
+    v.load(GOLD_VOL)
+    for i in range(SAVE_AT, NF):
+        tr, dep, col = frame(sc, i)
+        v.integrate(dep, col, tr)
+    d, w, rgb = v.download()
+    assert_same_f32(d, gold[f"d{NF - 1}"], "d")
+    assert_same_f32(w, gold[f"w{NF - 1}"], "w")
+    assert np.array_equal(rgb, gold[f"rgb{NF - 1}"])
+    v.close()
