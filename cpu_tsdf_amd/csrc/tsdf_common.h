@@ -42,6 +42,7 @@ struct tsdf_hip_volume {
   // flag arrives (tsdf_hip_set_weighting; only a loaded .vol can carry it) on F32W / TSDF_COLOR_RGB volumes
   float *vm = nullptr;
   int32_t *vn = nullptr;
+  int expf_fused_r = 0;  // which expf the host's libm runs (tsdf_integrate.hip tsdf_expf_glibc)
   // placement selection at create (tsdf_core.hip): probe sweep of each candidate allocation, which one was kept
   float alloc_probe_ms[4] = {-1.f, -1.f, -1.f, -1.f};
   int alloc_tried = 0, alloc_chosen = 0;

@@ -49,6 +49,7 @@ struct IntegrateArgs {
   int log2TX, TX, TY; // thread tile: TX quads along x, TY rows along y (TX*TY == 256)
   int rpb;            // row groups (of TY rows) per block
   unsigned bgra_off;  // byte offset of the colour image from the depth image (same buffer descriptor)
+  int expf_fused_r;      // the host libm's expf fuses r = InvLn2N * x - k (tsdf_expf_glibc; probed by tsdf_hip_set_weighting)
   int ref_cull;          // replicate the reference's frustum cull (getFrustumCulledVoxels): six plane tests per voxel centre
   float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
@@ -102,6 +103,49 @@ static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float
   ambiguous = !cert;
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? (int)__umul24((unsigned)v, (unsigned)a.W) + u : -1;  // W, H < 2^24 (checked on the host)
+}
+
+// std::exp(float) as the reference's host evaluates it (hpp:204): glibc's expf (sysdeps/ieee754/flt-32/e_expf.c, the 2017
+// table-driven algorithm [glibc-recall], NOT correctly rounded: it differs from the rounded fp64 exp on 0.035 % of the
+// floats).  Restated operation by operation: z = x * 32/ln2 in double, k = nearest integer through the 1.5 * 2^52 shift,
+// r = z - k, 2^(k/32) from a 32-entry table, a cubic in r.  One operation depends on how the host's libm was compiled:
+// x86-64 glibc selects an FMA build on CPUs that have it, and that build fuses `r = InvLn2N * x - k`; `fused_r` says
+// which one this host runs (probed with the one float the two forms disagree on, tsdf_hip_set_weighting).  Pinned
+// against the host's expf on every float in +-(2^-26 .. 104) by tests/test_wvar_gpu.py.
+static __device__ const uint64_t k_exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+static __device__ float tsdf_expf_glibc(float x, bool fused_r) {
+  const uint32_t ix = __float_as_uint(x), abstop = (ix >> 20) & 0x7ffu;
+  if (abstop >= (0x42b00000u >> 20)) {  // |x| >= 88 or NaN
+    if (ix == 0xff800000u) return 0.f;                 // -inf
+    if (abstop >= (0x7f800000u >> 20)) return x + x;   // inf, NaN
+    if (x > 0x1.62e42ep6f) return INFINITY;            // overflow
+    if (x < -0x1.9fe368p6f) return 0.f;                // underflow
+    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;          // __math_may_uflowf: 0x1.4p-75f * 0x1.4p-75f rounds to the least subnormal
+  }
+  const double N = 32., InvLn2N = 0x1.71547652b82fep+0 * N, SHIFT = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+  const double xd = (double)x;
+  double z = InvLn2N * xd;
+  double kd = z + SHIFT;
+  const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+  kd -= SHIFT;
+  const double r = fused_r ? __builtin_fma(InvLn2N, xd, -kd) : z - kd;
+  const uint64_t t = k_exp2f_tab[ki & 31u] + (ki << 47);
+  const double s = __longlong_as_double((long long)t);
+  z = C0 * r + C1;
+  const double r2 = r * r;
+  double y = C2 * r + 1.;
+  y = z * r2 + y;
+  y = y * s;
+  return (float)y;
 }
 
 // pcl::FrustumCulling's verdict on a voxel centre (tsdf_volume_octree.cpp:619-652 -> filters/impl/frustum_culling.hpp
@@ -778,6 +822,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.TY = 256 / a.TX;
   a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);  // rpb * TY <= 256: the block's row centres sit in LDS
   a.pitch = h->pitch;
+  a.expf_fused_r = h->expf_fused_r;
   a.ref_cull = h->ref_cull ? 1 : 0;
   for (int i = 0; i < 24; ++i) a.cull[i] = h->ref_cull ? h->cull_planes[i] : 0.f;
   a.band_fx = h->band_fx;
@@ -1009,8 +1054,7 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
         // more than five samples, w_new *= std::exp(logNormal(d_new, d_, getVariance())) with logNormal (hpp:106-110)
         // = -std::pow(x - mean, 2) / (2 * var) -- the double pow of a float difference (an exact square), a double
         // quotient stored in a float -- getVariance (octree.cpp:281-287) = (M_ / w_) * (nsample_ / (nsample_ - 1)) with
-        // an INTEGER quotient, and std::exp(float) = expf, here the fp64 exp rounded to float (equal to glibc's expf on
-        // every float of the range that matters: tests/test_wvar_gpu.py sweeps it)
+        // an INTEGER quotient, and std::exp(float) = the host libm's expf (tsdf_expf_glibc)
         int ns_old = 0;
         if (!PACKED && VM) {
           ns_old = VN[vi];
@@ -1018,7 +1062,7 @@ k_integrate_plain(const IntegrateArgs a, float *__restrict__ D, float *__restric
             const float var = (VM[vi] / Wt[vi]) * (float)(ns_old / (ns_old - 1));
             const double dx = (double)(dn - d);
             const float ln = (float)(-(dx * dx) / (double)(2 * var));
-            wn *= (float)exp((double)ln);
+            wn *= tsdf_expf_glibc(ln, a.expf_fused_r != 0);
           }
         }
         if (PACKED) {
@@ -1506,6 +1550,13 @@ extern "C" int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]) {
   return TSDF_HIP_OK;
 }
 
+// Which expf does this host's libm run?  glibc's FMA build (picked by ifunc on CPUs with FMA) fuses r = InvLn2N * x - k;
+// the two builds disagree on exactly one float of +-(2^-26 .. 104) (exhaustive search on the build host), which is the probe.
+static int host_expf_fuses_r() {
+  volatile float probe = -0x1.f8cbb2p+5f;
+  return expf(probe) == 0x1.f45326p-92f ? 1 : 0;  // the unfused form (and the correctly rounded value) is 0x1.f45324p-92
+}
+
 extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance) {
   if (!h) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_set_weighting(h, weight_by_depth, weight_by_variance);
@@ -1527,21 +1578,23 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
   }
   h->weight_by_depth = weight_by_depth != 0;
   h->weight_by_variance = weight_by_variance != 0;
+  h->expf_fused_r = host_expf_fuses_r();
   return TSDF_HIP_OK;
 }
 
-// Test hook: the device's std::exp(float) of the variance weighting, (float)exp((double)x), on n floats.
-static __global__ void k_selftest_expf(const float *__restrict__ in, float *__restrict__ out, size_t n) {
+// Test hook: the device's std::exp(float) of the variance weighting (tsdf_expf_glibc in this host's flavour) on n floats.
+static __global__ void k_selftest_expf(const float *__restrict__ in, float *__restrict__ out, size_t n, int fused_r) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)exp((double)in[i]);
+  if (i < n) out[i] = tsdf_expf_glibc(in[i], fused_r != 0);
 }
 extern "C" int tsdf_hip_selftest_expf(const float *in, size_t n, float *out) {
   if (!in || !out || !n) return TSDF_HIP_E_INVALID;
+  const int fused_r = host_expf_fuses_r();
   float *di = nullptr, *dout = nullptr;
   TSDF_HIP_TRY(hipMalloc(&di, n * 4));
   TSDF_HIP_TRY(hipMalloc(&dout, n * 4));
   TSDF_HIP_TRY(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_selftest_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, n);
+  hipLaunchKernelGGL(k_selftest_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, n, fused_r);
   TSDF_HIP_TRY(hipGetLastError());
   TSDF_HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
   (void)hipFree(di);

@@ -224,9 +224,9 @@ int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]);
  *                       every observation from then on, carried by tsdf_hip_save / tsdf_hip_load in the node records the
  *                       reference keeps them in, and readable / writable through tsdf_hip_*_variance_state.  Needs
  *                       the F32W layout and TSDF_COLOR_RGB like weight_by_depth (tsdf_hip_load with AUTO picks F32W);
- *                       integrated by the same plain kernel.  std::exp(float) is evaluated as the fp64 exp rounded to
- *                       float, which equals the host's expf on every float of the range the weighting can produce
- *                       (tests/test_wvar_gpu.py sweeps it). */
+ *                       integrated by the same plain kernel.  std::exp(float) is the host libm's expf restated on the
+ *                       device (glibc's table algorithm, in the FMA or the plain build's form, whichever this host
+ *                       runs): equal on every float in +-(2^-26 .. 104), which tests/test_wvar_gpu.py sweeps. */
 int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance);
 
 /* OctreeNode::M_ / nsample_ of a block of voxels ([z][y][x]; either pointer may be NULL) -- include/cpu_tsdf/octree.h:
@@ -439,7 +439,7 @@ int tsdf_hip_selftest_div_count(const float *a, const uint32_t *k, float *out, u
  * with; the tests pin its rounding (nearest even), saturation and byte selection. */
 int tsdf_hip_selftest_cvt_pk_u8(const float *in, size_t n, uint32_t *out);
 
-/* Test hook: out[i] = the device's std::exp(float) of the variance weighting, (float)exp((double)in[i]). */
+/* Test hook: out[i] = the device's std::exp(float) of the variance weighting (the host libm's expf restated). */
 int tsdf_hip_selftest_expf(const float *in, size_t n, float *out);
 
 /* Test hooks for TSDF_COLOR_LAB: the device's RGB2LAB of n pixels (b,g,r,a bytes each -> L,A,B,0 floats each) and

@@ -2,8 +2,7 @@
 
 weight_by_depth_ has no setter in the reference; a volume only gets it from a .vol whose header says so.  The
 product follows: load() (Python binding and the C++ class alike) switches the handle to the depth-weighted plain
-kernel and float weights; weight_by_variance_ needs octree state the dense grid does not keep, so integrating such a
-volume fails loudly instead of silently integrating unweighted (missing #1)."""
+kernel and float weights; weight_by_variance_ (round 3: M_ / nsample_ planes, tests/test_wvar_gpu.py) likewise."""
 import os
 
 import numpy as np
@@ -82,17 +81,17 @@ def test_weight_by_depth_without_colour_and_mid_range_weights(gpu, tmp_path):
     v.close()
 
 
-def test_weight_by_variance_refuses_to_integrate(gpu, tmp_path):
+def test_weight_by_variance_integrates_and_keeps_its_flag(gpu, tmp_path):
+    """Round 3: a header with weight_by_variance_ no longer makes integrate refuse (tests/test_wvar_gpu.py pins the
+    results); the flag still survives save."""
     sc = synth.scene_a(RES, W, H)
     v = weighted_product(sc, tmp_path, by_depth=0, by_variance=1)
     tr, dep, col = frame(sc, 0)
-    with pytest.raises(capi.TsdfHipError) as e:
-        v.integrateCloud(dep, col, tr)
-    assert e.value.code == capi.E_UNSUPPORTED and "weight_by_variance" in str(e.value)
-    d, w, _ = v.download()
-    assert (d == -1).all() and (w == 0).all()  # nothing was integrated
+    assert v.integrateCloud(dep, col, tr, count=True) > 1000
+    M, ns = v.downloadVarianceState()
+    assert ns.max() == 1 and (ns > 0).sum() > 1000
     path = str(tmp_path / "again.vol")
-    v.save(path)  # queries / save still work and keep the flag
+    v.save(path)
     assert open(path, "rb").read().split(b"\n", 14)[12:14] == [b"0", b"1"]
     v.close()
 

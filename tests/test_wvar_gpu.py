@@ -3,8 +3,8 @@ getVariance, src/lib/octree.cpp:152-163,281-287) -- the last of the reference's 
 can switch on.  The product keeps M_ / nsample_ as two more planes, integrates through the plain kernel and carries the
 state through save / load in the reference's own node records.
 
-  * the device's std::exp(float), (float)exp((double)x), equals the host libm's expf on EVERY float of the range the
-    weighting can produce and matter (-104 .. -2^-26: below, both are 0; above, both are 1), and on the specials;
+  * the device's std::exp(float) -- glibc's expf restated, in the flavour (FMA build or not) the host's libm runs --
+    equals the host libm's expf on EVERY float in +-(2^-26 .. 104) (beyond: 0 / inf / 1), and on the specials;
   * product == oracle (which tests/test_oracle_wvar.py pins to the compiled reference), d / w / rgb / M / nsample, with
     and without colour, together with weight_by_depth, on a multi-slab handle;
   * a .vol the REFERENCE wrote after 8 frames (tests/golden/reference_wvar_32_after8.vol: its M_ / nsample_ inside)
@@ -38,15 +38,15 @@ def device_expf(x):
 
 
 def test_device_exp_equals_the_host_expf_on_every_float_that_matters(gpu):
-    lo, hi = np.float32(-104.0).view(np.uint32), np.float32(-2.0 ** -26).view(np.uint32)  # negative floats: larger bits = more negative
-    first, last = int(hi), int(lo)
-    assert last - first > 2.5e8
     bad = 0
-    for a in range(first, last + 1, 1 << 26):
-        bits = np.arange(a, min(a + (1 << 26), last + 1), dtype=np.uint32)
-        x = bits.view(np.float32)
-        got, want = device_expf(x), oracle.expf(x)
-        bad += int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    for sign in (np.uint32(0x80000000), np.uint32(0)):  # |x| from 2^-26 to 104; same-sign floats order like their bit patterns
+        first, last = int(np.float32(2.0 ** -26).view(np.uint32)), int(np.float32(104.0).view(np.uint32))
+        assert last - first > 2.5e8
+        for a in range(first, last + 1, 1 << 26):
+            bits = np.arange(a, min(a + (1 << 26), last + 1), dtype=np.uint32) | sign
+            x = bits.view(np.float32)
+            got, want = device_expf(x), oracle.expf(x)
+            bad += int((got.view(np.uint32) != want.view(np.uint32)).sum())
     assert bad == 0, f"{bad} floats where the device's exp differs from expf"
     rng = np.random.RandomState(1)
     x = np.concatenate([rng.uniform(-200, 5, 1_000_000), -np.exp(rng.uniform(-80, 6, 1_000_000)),
@@ -131,6 +131,7 @@ def test_product_written_vol_is_continued_by_the_compiled_reference(gpu, tmp_pat
         vol.integrateCloud(dep, col, tr)
     path = str(tmp_path / "product_wvar.vol")
     vol.save(path)
+    _, ns_saved = vol.downloadVarianceState()
     rv = refbind.RefVolume(RES, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True, dense=True)
     rv.load(path)
     for i in range(SAVE_AT, NF):
@@ -139,9 +140,14 @@ def test_product_written_vol_is_continued_by_the_compiled_reference(gpu, tmp_pat
         rv.integrate(dep, col, tr)
     d, w, rgb = vol.download()
     rd, rw, rrgb, _, _ = rv.dump_dense()
-    assert_same_f32(d, rd, "d")
-    assert_same_f32(w, rw, "w")
-    assert np.array_equal(rgb, rrgb)
+    # the product's writer folds uniform regions (never-observed space) into coarse leaves, which the reference then
+    # treats as its adaptive octree would; the statement here is about the voxels whose M_ / nsample_ travelled
+    seen = ns_saved > 0
+    assert seen.mean() > 0.3
+    assert_same_f32(d[seen], rd[seen], "d")
+    assert_same_f32(w[seen], rw[seen], "w")
+    assert np.array_equal(rgb[seen], rrgb[seen])
+    assert ((w[seen] % 1) != 0).mean() > 0.05  # the weighting did act on them after the load
     rv.close()
     vol.close()
 
