@@ -173,12 +173,19 @@ def extras(vol, pose, W, H):
             out["reconstruct_Mvoxels_per_s"] = vox / dt / 1e6
             out["reconstruct_phase_ms"] = {"classify": ms[0], "sort_scan": ms[1], "emit": ms[2]}
             # PHYSICAL bytes (what the kernels must move in the shipped layout), not SURVEY's 8/12 B record:
-            #  classify streams the distance plane once (4 B per voxel) and gathers 8 weight words per listed cell;
-            #  emit reads 8 corners (d + weight word) per active cell and writes 36 B of vertices + 9 B of colour +
-            #  8 B of cell key per triangle; 16 B (key, cell) per active cell go out of classify and through the sort.
-            classify_bytes = 4.0 * vox + (32.0 + 16.0) * cells.value
+            #  classify reads the distance quads the band flags of integrateCloud leave it (tsdf_hip_march_stats:
+            #  requested bytes, counted on the device; the whole plane when the flags are not in use) and gathers 8
+            #  weight words per listed cell; emit reads 8 corners (d + weight word) per active cell and writes 36 B of
+            #  vertices + 9 B of colour + 8 B of cell key per triangle; 16 B (key, cell) per active cell go out of
+            #  classify and through the sort.
+            st = (C.c_uint64 * 4)()
+            lib.tsdf_hip_march_stats(vol._need(), st)
+            classify_bytes = float(st[2]) + (32.0 + 16.0) * cells.value
             emit_bytes = 64.0 * cells.value + (36.0 + (9.0 if color else 0.0) + 8.0) * n.value
             out["reconstruct_classify_bytes"] = classify_bytes
+            out["reconstruct_classify_d_bytes_requested"] = int(st[2])
+            out["reconstruct_classify_d_plane_bytes"] = 4.0 * vox
+            out["reconstruct_classify_skips_unobserved_space"] = bool(st[3])
             out["reconstruct_classify_GBps"] = classify_bytes / (ms[0] * 1e-3) / 1e9 if ms[0] > 0 else None
             out["reconstruct_classify_frac_of_hbm_peak"] = (classify_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else None
             out["reconstruct_emit_GBps"] = emit_bytes / (ms[2] * 1e-3) / 1e9 if ms[2] > 0 else None
@@ -250,26 +257,27 @@ def scene_b_leg(res, color, cpu_seconds):
     return out
 
 
-def host_path_leg(vol, sc, poses, color, n_host=6, calls=24):
+def host_path_leg(vol, sc, poses, color, first, last):
     """Report-only: the reference's integrateCloud takes a HOST cloud, so this is the PCIe-inclusive rate of the same
-    workload -- `calls` frames handed over as host pointers, back to back, through tsdf_hip_integrate (upload + kernel +
-    synchronise per call) and through tsdf_hip_integrate_async (pinned two-slot ring, upload under the previous kernel).
-    Never `value`: the headline is timed with frames resident in HBM."""
+    workload -- the SAME frames the timed region integrated (poses[first:last]), handed over as host pointers, back to
+    back, through tsdf_hip_integrate (upload + kernel + synchronise per call) and through tsdf_hip_integrate_async
+    (pinned two-slot ring, upload under the previous kernel).  Never `value`: the headline is timed with frames
+    resident in HBM."""
     out = {}
     try:
-        frames = [(np.ascontiguousarray(sc.depth(poses[i])), np.ascontiguousarray(sc.bgra(i)) if color else None) for i in range(n_host)]
+        idx = list(range(first, last))
+        frames = [(np.ascontiguousarray(sc.depth(poses[i])), np.ascontiguousarray(sc.bgra(i)) if color else None) for i in idx]
         for name, pipelined in (("frames_per_s_sync_calls", False), ("frames_per_s_async_ring", True)):
-            vol.integrateCloud(frames[0][0], frames[0][1], poses[0], pipelined=pipelined)
+            vol.integrateCloud(frames[0][0], frames[0][1], poses[idx[0]], pipelined=pipelined)
             vol.synchronize()
             t0 = time.perf_counter()
-            for i in range(calls):
-                d, c = frames[i % n_host]
-                vol.integrateCloud(d, c, poses[i % n_host], pipelined=pipelined)
+            for (d, c), i in zip(frames, idx):
+                vol.integrateCloud(d, c, poses[i], pipelined=pipelined)
             vol.synchronize()
-            out[name] = calls / (time.perf_counter() - t0)
-        out["calls"] = calls
-        out["note"] = ("host-pointer entry points, 2.4 MB frame per call over PCIe; report-only, the headline `value` is timed "
-                       "with frames resident in HBM")
+            out[name] = len(idx) / (time.perf_counter() - t0)
+        out["calls"] = len(idx)
+        out["note"] = ("host-pointer entry points, the timed region's own frames, one 2.4 MB-class frame per call over PCIe; "
+                       "report-only, the headline `value` is timed with frames resident in HBM")
     except Exception as e:  # never let a report-only leg break the bench line
         out["error"] = repr(e)
     return out
@@ -383,7 +391,7 @@ def main():
     vol.reset()
     lib = capi.load()
     h = vol._need()
-    probe_ms, chosen = (C.c_float * 4)(), C.c_int32(0)
+    probe_ms, chosen = (C.c_float * 8)(), C.c_int32(0)
     n_tried = lib.tsdf_hip_alloc_probe(h, probe_ms, C.byref(chosen))
     placement = {"candidates_tried": int(n_tried), "probe_sweep_ms": [round(float(x), 3) for x in probe_ms[:max(1, n_tried)]],
                  "kept": int(chosen.value)}
@@ -394,7 +402,13 @@ def main():
         for _ in range(args.calib):
             capi.check(lib.tsdf_hip_selftest_sweep(h, C.byref(br), C.byref(bw)), "sweep")
         calibration = {"kernel": "k_calib_rmw", "launches": args.calib, "known_read_bytes": br.value,
-                       "known_written_bytes": bw.value}
+                       "known_written_bytes": bw.value, "narrow_reads": []}
+        # ... and what FETCH_SIZE tallies for narrow reads (one dword per 4 / 64 / 128 bytes of the distance plane)
+        for stride in (4, 64, 128):
+            span, words = C.c_uint64(), C.c_uint64()
+            capi.check(lib.tsdf_hip_selftest_read_sweep(h, stride, C.byref(span), C.byref(words)), "read_sweep")
+            calibration["narrow_reads"].append({"kernel": f"k_calib_read<{stride}>", "stride_bytes": stride,
+                                                "span_bytes": span.value, "dwords_read": words.value})
 
     # ---- synthetic frames, resident in HBM before the timed region ---------------------------------
     n_total = args.warmup + args.steps
@@ -582,7 +596,7 @@ def main():
             if args.scene_b:
                 out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and not use_dist and args.host_path:
-            out["host_path"] = host_path_leg(vol, sc, poses, bool(args.color))
+            out["host_path"] = host_path_leg(vol, sc, poses, bool(args.color), args.warmup, n_total)
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)

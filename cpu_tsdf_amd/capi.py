@@ -104,6 +104,7 @@ SIGNATURES = {
     "tsdf_hip_frame_commit": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
+    "tsdf_hip_march_stats": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
     "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
     "tsdf_hip_selftest_cvt_pk_u8": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
@@ -138,6 +139,7 @@ SIGNATURES = {
     "tsdf_hip_selftest_project": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]),
     "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
+    "tsdf_hip_selftest_read_sweep": (C.c_int, [C.c_void_p, C.c_int, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "tsdf_hip_selftest_block_flags": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.c_int, C.c_int, _u8p]),
     "tsdf_hip_selftest_index_box": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

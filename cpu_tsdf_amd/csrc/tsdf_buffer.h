@@ -14,6 +14,19 @@
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
+// Cache-policy bits of the voxel STREAM accesses (128-bit loads, all stores): on gfx94x / gfx950 bit 0 = sc0, bit 1 = nt,
+// bit 4 = sc1.  The voxel planes are touched once per frame and never again before 69 GB of other planes went by, so
+// they are marked non-temporal (nt) on BOTH sides: measured on MI355X, 2048^3 + colour, k_integrate 17.6-17.7 ms with the
+// default policy, 17.6-18.0 with nt on the loads only, 17.6-17.7 on the stores only, **16.4-16.6 with both**
+// (profiles/r03_ab_k_integrate_cache_policy.txt; sc0 / sc1 on top change nothing).  The frame gather keeps the default
+// policy: the 2.4 MB frame is what the L2 should hold.  A/B knobs: tools/build_variant.py NAME -DTSDF_STREAM_LD_AUX=0 ...
+#ifndef TSDF_STREAM_LD_AUX
+#define TSDF_STREAM_LD_AUX 2
+#endif
+#ifndef TSDF_STREAM_ST_AUX
+#define TSDF_STREAM_ST_AUX 2
+#endif
+
 static __device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
 }
@@ -21,16 +34,16 @@ static __device__ __forceinline__ uint32_t bload32(rsrc_t r, unsigned voff, unsi
   return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
 }
 static __device__ __forceinline__ u4 bload128(rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, TSDF_STREAM_LD_AUX);
 }
 static __device__ __forceinline__ void bstore32(rsrc_t r, unsigned voff, unsigned soff, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, TSDF_STREAM_ST_AUX);
 }
 static __device__ __forceinline__ uint32_t bload8(rsrc_t r, unsigned voff, unsigned soff) {
   return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, 0) & 0xffu;
 }
 static __device__ __forceinline__ void bstore128(rsrc_t r, unsigned voff, unsigned soff, u4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, TSDF_STREAM_ST_AUX);
 }
 
 // Structured (2-D) buffer access: the descriptor carries a row stride and a row count, the instruction a row index

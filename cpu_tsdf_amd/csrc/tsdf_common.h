@@ -44,7 +44,7 @@ struct tsdf_hip_volume {
   int32_t *vn = nullptr;
   int expf_fused_r = 0;  // which expf the host's libm runs (tsdf_integrate.hip tsdf_expf_glibc)
   // placement selection at create (tsdf_core.hip): probe sweep of each candidate allocation, which one was kept
-  float alloc_probe_ms[4] = {-1.f, -1.f, -1.f, -1.f};
+  float alloc_probe_ms[8] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
   int alloc_tried = 0, alloc_chosen = 0;
   int packed = 0;
   unsigned kmax = 0;
@@ -96,6 +96,8 @@ struct tsdf_hip_volume {
   hipEvent_t mc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // tsdf_hip_march_timing
   float mc_ms[3] = {0.f, 0.f, 0.f};                            // classify, sort + scan, emit of the last call
   uint64_t mc_ncells = 0;
+  uint64_t mc_d_bytes = 0;   // distance bytes the last classify pass requested (tsdf_hip_march_stats)
+  bool mc_skipped = false;   // ... with the band flags deciding what to read
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
 };
@@ -123,6 +125,7 @@ int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3],
 int tsdf_multi_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri);
 int tsdf_multi_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell);
 int tsdf_multi_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
+int tsdf_multi_march_stats(tsdf_handle h, uint64_t out[4]);
 tsdf_handle tsdf_multi_first(tsdf_handle h);
 #define TSDF_NOT_ON_MULTI(h, what)                                                                          \
   do {                                                                                                      \

@@ -425,20 +425,23 @@ struct PlaneSet {
 
 static __global__ void __launch_bounds__(256)
 k_probe_rmw(uint4 *__restrict__ a, uint4 *__restrict__ b, uint4 *__restrict__ c, int64_t n4, unsigned zero) {
-  // reads every word of the planes and writes it back unchanged (`zero` is 0, but only at run time)
+  // reads every word of the planes and writes it back unchanged (`zero` is 0, but only at run time), non-temporal on
+  // both sides like k_integrate's voxel stream (tsdf_buffer.h)
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u *pa = reinterpret_cast<v4u *>(a), *pb = reinterpret_cast<v4u *>(b), *pc = reinterpret_cast<v4u *>(c);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    uint4 x = a[i];
-    x.x ^= zero;
-    a[i] = x;
+    v4u x = __builtin_nontemporal_load(pa + i);
+    x ^= zero;  // (every component: an untouched one would let the compiler drop its load and store)
+    __builtin_nontemporal_store(x, pa + i);
     if (b) {
-      uint4 y = b[i];
-      y.x ^= zero;
-      b[i] = y;
+      v4u y = __builtin_nontemporal_load(pb + i);
+      y ^= zero;
+      __builtin_nontemporal_store(y, pb + i);
     }
     if (c) {
-      uint4 z = c[i];
-      z.x ^= zero;
-      c[i] = z;
+      v4u z = __builtin_nontemporal_load(pc + i);
+      z ^= zero;
+      __builtin_nontemporal_store(z, pc + i);
     }
   }
 }
@@ -585,7 +588,15 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     float best_ms = tries > 1 ? probe_planes(best, n, v->stream) : -1.f;
     v->alloc_probe_ms[0] = best_ms;
     v->alloc_tried = 1;
-    for (int t = 1; t < tries && best_ms > 0.f; ++t) {
+    // A sweep moves every plane byte once each way.  Placements fall into classes (2 x 68.7 GB: 26.0-26.6, 27.2-28.3 and
+    // 29.9-30.1 ms on MI355X); one that streams at >= 5.15 TB/s is in the fast class and ends the search, and while none
+    // has reached 4.95 TB/s the search goes on for up to `tries` more candidates (round 3: a volume whose three
+    // candidates were all slow integrated at 17.6 instead of 16.5 ms).
+    const double swept = (double)n * (4 + (v->packed ? 0 : 4) + (p->integrate_color ? 4 : 0));  // (the probe leaves a count-byte plane alone)
+    auto rate_tbps = [&](float ms) { return ms > 0.f ? 2.0 * swept / ((double)ms * 1e9) : 0.0; };
+    for (int t = 1; t < std::min(8, 2 * tries) && best_ms > 0.f && tries > 1; ++t) {
+      if (rate_tbps(best_ms) >= 5.15) break;
+      if (t >= tries && rate_tbps(best_ms) >= 4.95) break;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < plane_bytes + ((size_t)2 << 30)) break;
       PlaneSet cand;
@@ -594,7 +605,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
         break;
       }
       const float ms = probe_planes(cand, n, v->stream);
-      v->alloc_probe_ms[t < 4 ? t : 3] = ms;
+      v->alloc_probe_ms[t < 8 ? t : 7] = ms;
       v->alloc_tried = t + 1;
       if (ms > 0.f && ms < best_ms) {
         release_planes(best);
@@ -707,13 +718,13 @@ extern "C" int tsdf_hip_centers(tsdf_handle h, int axis, float *out) {
   return TSDF_HIP_OK;
 }
 
-// Which placement tsdf_hip_create kept: ms[i] = probe sweep of candidate i (up to 4; negative = not probed), *chosen = its
+// Which placement tsdf_hip_create kept: ms[i] = probe sweep of candidate i (up to 8; negative = not probed), *chosen = its
 // index, return value = candidates tried (1 for small volumes, for alloc_tries = 1 and for multi handles' slabs in turn).
-extern "C" int tsdf_hip_alloc_probe(tsdf_handle h, float ms[4], int32_t *chosen) {
+extern "C" int tsdf_hip_alloc_probe(tsdf_handle h, float ms[8], int32_t *chosen) {
   if (!h) return 0;
   const tsdf_hip_volume *s = h->multi ? tsdf_multi_first(h) : h;
   if (ms)
-    for (int i = 0; i < 4; ++i) ms[i] = s->alloc_probe_ms[i];
+    for (int i = 0; i < 8; ++i) ms[i] = s->alloc_probe_ms[i];
   if (chosen) *chosen = s->alloc_chosen;
   return s->alloc_tried;
 }

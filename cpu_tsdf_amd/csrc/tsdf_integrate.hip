@@ -1795,33 +1795,62 @@ extern "C" int tsdf_hip_selftest_div_f64(const double *a, const double *b, doubl
 // WRITE_SIZE on a known byte count in your own access pattern).
 static __global__ void __launch_bounds__(256)
 k_calib_rmw(float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB, uint8_t *__restrict__ K8,
-            int64_t first4, int64_t n4, float addv /* 0 at run time */, uint32_t xorv /* 0 at run time */) {
+            int64_t first4, int64_t n4, uint32_t xorv /* 0 at run time */) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    // run-time zeros keep the stores alive without changing any value
-    float4 *pd = reinterpret_cast<float4 *>(D) + first4 + i;
-    float4 d4 = *pd;
-    d4.x += addv;
-    d4.y += addv;
-    *pd = d4;
+    // a run-time zero xor-ed into EVERY component keeps the loads and stores alive without changing a bit (an untouched
+    // component would let the compiler drop its load and store); non-temporal like the integrate kernel's stream
+    u4 *pd = reinterpret_cast<u4 *>(D) + first4 + i;
+    __builtin_nontemporal_store(__builtin_nontemporal_load(pd) ^ xorv, pd);
     if (Wt) {
-      float4 *pw = reinterpret_cast<float4 *>(Wt) + first4 + i;
-      float4 w4 = *pw;
-      w4.x += addv;
-      w4.y += addv;
-      *pw = w4;
+      u4 *pw = reinterpret_cast<u4 *>(Wt) + first4 + i;
+      __builtin_nontemporal_store(__builtin_nontemporal_load(pw) ^ xorv, pw);
     }
     if (RGB) {
-      uint4 *pc = reinterpret_cast<uint4 *>(RGB) + first4 + i;
-      uint4 c4 = *pc;
-      c4.x ^= xorv;
-      c4.y ^= xorv;
-      *pc = c4;
+      u4 *pc = reinterpret_cast<u4 *>(RGB) + first4 + i;
+      __builtin_nontemporal_store(__builtin_nontemporal_load(pc) ^ xorv, pc);
     }
     if (K8) {
       uint32_t *pk = reinterpret_cast<uint32_t *>(K8) + first4 + i;
-      *pk = *pk ^ xorv;
+      __builtin_nontemporal_store(__builtin_nontemporal_load(pk) ^ xorv, pk);
     }
   }
+}
+
+// Calibration of FETCH_SIZE for NARROW reads (k_calib_rmw only exercises 16 B per lane): a read-only
+// sweep of the distance plane taking ONE dword per STRIDE bytes -- STRIDE 4: a wave instruction covers 256 contiguous
+// bytes; 64 / 128: every lane touches its own 64 B / 128 B piece, the shape of marching cubes' lane-63 halo words.
+// The xor of everything read is stored only if it equals a run-time value it never equals.
+template <int STRIDE>
+static __global__ void __launch_bounds__(256)
+k_calib_read(const uint32_t *__restrict__ D, int64_t n, uint32_t *__restrict__ sink, uint32_t never) {
+  uint32_t v = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    v ^= D[i * (STRIDE / 4)];
+  if (v == never) *sink = v;
+}
+
+extern "C" int tsdf_hip_selftest_read_sweep(tsdf_handle h, int stride_bytes, uint64_t *span_bytes, uint64_t *dwords_read) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_selftest_read_sweep");
+  TSDF_ON_DEVICE(h->device);
+  const int64_t plane = h->pitch * h->ny;
+  const uint32_t *base = reinterpret_cast<const uint32_t *>(h->d) + (int64_t)(h->z_begin - h->z_first) * plane;
+  const int64_t span = (int64_t)(h->z_end - h->z_begin) * plane * 4;
+  const int64_t n = span / stride_bytes;
+  const unsigned grid = 256u * (unsigned)tsdf_tuning().blocks_per_cu;
+  uint32_t *sink = reinterpret_cast<uint32_t *>(h->counter + 2047);
+  const uint32_t never = 0x7fc5a5a5u;
+  switch (stride_bytes) {
+  case 4: hipLaunchKernelGGL(k_calib_read<4>, dim3(grid), dim3(256), 0, h->stream, base, n, sink, never); break;
+  case 64: hipLaunchKernelGGL(k_calib_read<64>, dim3(grid), dim3(256), 0, h->stream, base, n, sink, never); break;
+  case 128: hipLaunchKernelGGL(k_calib_read<128>, dim3(grid), dim3(256), 0, h->stream, base, n, sink, never); break;
+  default: tsdf_set_error("tsdf_hip_selftest_read_sweep: stride must be 4, 64 or 128"); return TSDF_HIP_E_INVALID;
+  }
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (span_bytes) *span_bytes = (uint64_t)n * (uint64_t)stride_bytes;
+  if (dwords_read) *dwords_read = (uint64_t)n;
+  return TSDF_HIP_OK;
 }
 
 // Test hook, host only (no device needed): the index box launch_integrate would restrict a frame's launch to.
@@ -1887,7 +1916,7 @@ extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint
   const int64_t first4 = (int64_t)(h->z_begin - h->z_first) * plane / 4;
   const int64_t n4 = (int64_t)(h->z_end - h->z_begin) * plane / 4;
   const unsigned grid = 256u * (unsigned)tsdf_tuning().blocks_per_cu;
-  hipLaunchKernelGGL(k_calib_rmw, dim3(grid), dim3(256), 0, h->stream, h->d, h->w, h->rgb, h->k8, first4, n4, 0.f, 0u);
+  hipLaunchKernelGGL(k_calib_rmw, dim3(grid), dim3(256), 0, h->stream, h->d, h->w, h->rgb, h->k8, first4, n4, 0u);
   TSDF_HIP_TRY(hipGetLastError());
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   const uint64_t bytes_per_quad = 16u + (h->w ? 16u : 0u) + (h->rgb ? 16u : 0u) + (h->k8 ? 4u : 0u);

@@ -103,6 +103,7 @@ static __device__ __forceinline__ int cube_index(const float leaf[8]) {
 // the quads of a 16-lane group (64 voxels x its MC_R + 1 rows, plane z) only if a flag is set among the flag cells
 // that touch that box grown by one voxel.  Planes outside the handle's own slab (halo planes, filled by copies) have
 // no flags and count as set.  One thread per (x-chunk, wave row, plane); all 32-bit-safe sizes.
+#define MC_NEED_SLOTS 64
 struct NeedArgs {
   const uint8_t *band;
   int fx, fy;                 // flag cells along x / y
@@ -115,10 +116,12 @@ struct NeedArgs {
 };
 
 static __global__ void __launch_bounds__(256)
-k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ need_blk) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ need_blk,
+          unsigned long long *__restrict__ d_bytes) {
+  const int64_t t_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)n.gx * n.rows * n.n_planes;
-  if (t >= total) return;
+  const bool live = t_raw < total;  // (the last wave's spare lanes stay for the wave-wide sum below)
+  const int64_t t = live ? t_raw : total - 1;
   const int bx = (int)(t % n.gx), wrow = (int)((t / n.gx) % n.rows), zi = (int)(t / ((int64_t)n.gx * n.rows));
   const int z = n.z_lo + zi;
   const int yw = 1 + wrow * MC_R;                      // the wave's rows yw .. yw + MC_R (the last one is its halo row)
@@ -152,8 +155,22 @@ k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ ne
       if (bx * 256 + g * 64 < n.nx && ((m6 >> g) & 7u)) bits |= 1u << g;
     if (bx * 256 + 256 < n.nx && ((m6 >> 4) & 3u)) bits |= 16u;
   }
-  need[t] = (uint8_t)bits;
-  if (bits) {  // (every writer stores the same 1); a cell plane z of block zb-index k reads planes up to z + 1
+  if (live) need[t] = (uint8_t)bits;
+  {  // bytes of the distance plane classify will request for this (wave, plane): 16 lanes x 16 B per row and group,
+     // one 4-byte word per row for the halo column; the plane a block ends on is the plane the next block starts on
+    const unsigned rows = (unsigned)max(0, min((wrow & 3) == 3 ? MC_R + 1 : MC_R, n.ny - yw));
+    const unsigned times = (zi > 0 && zi < n.n_planes - 1 && zi % n.zb == 0) ? 2u : 1u;
+    unsigned long long b = live ? (unsigned long long)(__popc(bits & 15u) * 256u + ((bits >> 4) & 1u) * 4u) * rows * times : 0ull;
+    for (int o = 32; o; o >>= 1) b += __shfl_xor(b, o);
+    // (one global atomic per block, spread over MC_NEED_SLOTS addresses: 130 k wave sums on ONE address cost 1 ms)
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0u) s_sum = 0ull;
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u && b) atomicAdd(&s_sum, b);
+    __syncthreads();
+    if (threadIdx.x == 0u && s_sum) atomicAdd(d_bytes + (blockIdx.x % MC_NEED_SLOTS), s_sum);
+  }
+  if (live && bits) {  // (every writer stores the same 1); a cell plane z of block zb-index k reads planes up to z + 1
     const int brow = wrow >> 2;
     const int k_hi = min((n.n_planes - 2) / n.zb, zi / n.zb), k_lo = max(0, (zi - 1) / n.zb);
     for (int k = k_lo; k <= k_hi; ++k) need_blk[((int64_t)k * n.by + brow) * n.gx + bx] = 1;
@@ -200,6 +217,14 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
   if (tid < (unsigned)MC_ZB) s_zkey[tid] = spread3((uint64_t)(zs + (int)tid));
   __syncthreads();
   const int64_t sz = (int64_t)a.ny * a.pitch;
+  // k_mc_need's verdicts on this wave's part of planes zs .. ze, one per lane, fetched once: a load per plane step
+  // would put a second dependent memory latency into every step of the march
+  int nd_all = 31;
+  if (a.need) {
+    nd_all = 0;
+    if ((int)lane <= ze - zs)
+      nd_all = (int)a.need[((int64_t)(zs + (int)lane - a.z_lo) * a.need_rows + (int)(by * 4u + wave)) * a.need_gx + (int)bx];
+  }
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   unsigned n_buf = 0;    // wave-uniform: entries waiting in buf
   unsigned tri_sum = 0;  // per lane
@@ -302,10 +327,7 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
     const u4 outside = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};  // 1.f: outside the band, not negative
     // the band flags' verdict on this wave's part of plane z (k_mc_need): quads no flagged voxel is near cannot be a
     // corner of an emitting cell, and read as "outside the band" without being loaded
-    unsigned nd = 31u;
-    if (a.need)
-      nd = (unsigned)__builtin_amdgcn_readfirstlane(
-          (int)a.need[((int64_t)(z - a.z_lo) * a.need_rows + (int)(by * 4u + wave)) * a.need_gx + (int)bx]);
+    const unsigned nd = a.need ? (unsigned)__builtin_amdgcn_readlane(nd_all, z - zs) : 31u;
     const bool ld = ((nd >> (lane >> 4)) & 1u) != 0u;
 #pragma unroll
     for (int r = 0; r <= MC_R; ++r) q[r] = outside;
@@ -654,7 +676,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     need_elems = n_need;
     need_blocks = n_blk;
   }
-  unsigned long long counts[2] = {0, 0};
+  unsigned long long counts[2 + MC_NEED_SLOTS] = {0};
   for (int i = 0; i < 4; ++i)
     if (!h->mc_ev[i]) TSDF_HIP_TRY(hipEventCreate(&h->mc_ev[i]));
   h->mc_ms[0] = h->mc_ms[1] = h->mc_ms[2] = 0.f;
@@ -662,12 +684,12 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   // pass 1 with the capacity we already have; if the surface turned out larger, grow and repeat
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t cap = h->mc_cells_cap;
-    TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2 * sizeof(unsigned long long), h->stream));
+    TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, (attempt == 0 ? 2 + MC_NEED_SLOTS : 2) * sizeof(unsigned long long), h->stream));
     TSDF_HIP_TRY(hipEventRecord(h->mc_ev[0], h->stream));
     if (a.need && attempt == 0) {  // (inside the classify phase's timing)
       TSDF_HIP_TRY(hipMemsetAsync(const_cast<uint8_t *>(a.need_blk), 0, need_blocks, h->stream));
       hipLaunchKernelGGL(k_mc_need, dim3((unsigned)((need_elems + 255) / 256)), dim3(256), 0, h->stream, need_args,
-                         const_cast<uint8_t *>(a.need), const_cast<uint8_t *>(a.need_blk));
+                         const_cast<uint8_t *>(a.need), const_cast<uint8_t *>(a.need_blk), h->counter + 2);
       TSDF_HIP_TRY(hipGetLastError());
     }
     if (!h->packed)
@@ -692,6 +714,25 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   const uint64_t n_cells = counts[0], ntri = counts[1];
   (void)hipEventElapsedTime(&h->mc_ms[0], h->mc_ev[0], h->mc_ev[1]);  // the last (successful) classify pass
   h->mc_ncells = n_cells;
+  // distance bytes the classify pass requested: what k_mc_need allowed, or every plane of every block
+  unsigned long long need_bytes = 0;
+  for (int i = 0; i < MC_NEED_SLOTS; ++i) need_bytes += counts[2 + i];
+  if (!a.need) {  // every wave reads its rows of every plane of its block: the same accounting as k_mc_need's
+    uint64_t per_plane = 0;
+    for (int wrow = 0; wrow < 4 * (int)grid.y; ++wrow) {
+      const int yw = 1 + wrow * MC_R;
+      if (1 + (wrow >> 2) * 4 * MC_R >= a.ny - 1) break;  // the block lies past the last cell row
+      const uint64_t rows = (uint64_t)std::max(0, std::min((wrow & 3) == 3 ? MC_R + 1 : MC_R, a.ny - yw));
+      for (int bx = 0; bx < (int)grid.x; ++bx) {
+        for (int g = 0; g < 4; ++g)
+          if (bx * 256 + g * 64 < a.nx) per_plane += 256u * rows;
+        if (bx * 256 + 256 < a.nx) per_plane += 4u * rows;
+      }
+    }
+    need_bytes = per_plane * (uint64_t)((a.z_hi - a.z_lo) + (int)grid.z);
+  }
+  h->mc_d_bytes = need_bytes;
+  h->mc_skipped = a.need != nullptr;
   if (n_cells == 0) return TSDF_HIP_OK;
   if (n_cells > 0xffffffffull || ntri > 0xffffffffull) {
     tsdf_set_error("mesh too large (more than 2^32 cells or triangles)");
@@ -791,6 +832,16 @@ extern "C" int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cel
   if (h->multi) return tsdf_multi_march_timing(h, ms, n_cells);
   for (int i = 0; i < 3; ++i) ms[i] = h->mc_ms[i];
   if (n_cells) *n_cells = h->mc_ncells;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_march_stats(tsdf_handle h, uint64_t out[4]) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_march_stats(h, out);
+  out[0] = h->mc_ncells;
+  out[1] = h->mc_ntri;
+  out[2] = h->mc_d_bytes;
+  out[3] = h->mc_skipped ? 1u : 0u;
   return TSDF_HIP_OK;
 }
 

@@ -901,4 +901,15 @@ int tsdf_multi_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells) {
   return TSDF_HIP_OK;
 }
 
+int tsdf_multi_march_stats(tsdf_handle h, uint64_t out[4]) {  // sums over the slabs; "skipped" only if every slab did
+  out[0] = out[1] = out[2] = 0, out[3] = 1;
+  for (tsdf_handle s : h->multi->slab) {
+    uint64_t o[4];
+    const int rc = tsdf_hip_march_stats(s, o);
+    if (rc) return rc;
+    out[0] += o[0], out[1] += o[1], out[2] += o[2], out[3] &= o[3];
+  }
+  return TSDF_HIP_OK;
+}
+
 tsdf_handle tsdf_multi_first(tsdf_handle h) { return h->multi->slab[0]; }

@@ -289,10 +289,11 @@ int tsdf_hip_render_halo(const tsdf_params *p);
  * fast a streaming read-modify-write of it runs (a 2048^3 volume integrates in 17.9 ms or in 18.4-19.0 ms depending on
  * the allocation), so tsdf_hip_create allocates the planes of a volume of 4 GiB or more up to
  * `alloc_tries` times (tsdf_hip_set_tuning / TSDF_HIP_ALLOC_TRIES, default 3, 1 = off; a second candidate is only
- * tried while it fits next to the first), sweeps each candidate once and keeps the fastest.  This reports what
- * happened: ms[i] = probe sweep of candidate i (negative = not probed), *chosen = the one kept; returns the number of
- * candidates tried. */
-int tsdf_hip_alloc_probe(tsdf_handle h, float ms[4], int32_t *chosen);
+ * tried while it fits next to the first), sweeps each candidate once and keeps the fastest.  The search ends early
+ * at a candidate that streams at >= 5.15 TB/s (the fast class) and goes on for up to alloc_tries more (8 at most)
+ * while none has reached 4.95 TB/s.  This reports what happened: ms[i] = probe sweep of candidate i (negative = not
+ * probed), *chosen = the one kept; returns the number of candidates tried. */
+int tsdf_hip_alloc_probe(tsdf_handle h, float ms[8], int32_t *chosen);
 
 /* 1 if the reference's frustum cull (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652: pcl::FrustumCulling with
  * 1.1 x the field of view AROUND THE OPTICAL AXIS, near = min_sensor_dist, far = max_sensor_dist) cannot change results
@@ -346,6 +347,11 @@ int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *ce
 /* Report-only: device milliseconds of the last tsdf_hip_march by phase -- ms[0] classify (k_mc_classify), ms[1] count
  * read-back + sort + scan, ms[2] emit (k_mc_emit) -- and the number of active cells. */
 int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
+/* Report-only: out[0] active cells, out[1] triangles, out[2] bytes of the distance plane the classify pass of the last
+ * tsdf_hip_march REQUESTED (with the band flags of integrateCloud deciding, it reads only the quads an in-band
+ * observation is near: src/lib/marching_cubes_tsdf_octree.cpp:179-236 visits every leaf), out[3] 1 if the flags were
+ * in use (0: every plane was read -- after an upload / load the flags say nothing until reset). */
+int tsdf_hip_march_stats(tsdf_handle h, uint64_t out[4]);
 /* The same copies into DEVICE buffers of the caller, asynchronous on the handle's stream (multi-GPU mesh merge:
  * the buffers go straight to RCCL). */
 int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell);
@@ -474,6 +480,11 @@ int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to
  * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/prof_integrate.py). */
 int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written);
+/* The same for NARROW reads: a read-only sweep of the owned distance planes that takes one 32-bit word per
+ * stride_bytes (4: a wave instruction covers 256 contiguous bytes; 64 / 128: every lane touches its own 64 B / 128 B
+ * piece).  Reports the bytes spanned and the words read; FETCH_SIZE of kernel k_calib_read<stride> says what the
+ * counter tallies for that shape (bench.py --calib, tools/make_profile_summary.py). */
+int tsdf_hip_selftest_read_sweep(tsdf_handle h, int stride_bytes, uint64_t *span_bytes, uint64_t *dwords_read);
 
 /* Test / report hook: the last integrate launch on this handle -- out[0] = 1 if it ran the ALLIN instance of k_integrate
  * (the host proved from the slab's eight corner voxels that EVERY voxel is inside the sensor range and projects inside
@@ -495,7 +506,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 11
+#define TSDF_HIP_ABI_VERSION 12
 
 #ifdef __cplusplus
 }

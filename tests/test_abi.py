@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
-    assert lib.tsdf_hip_abi_version() == 11
+    assert lib.tsdf_hip_abi_version() == 12
 
 
 def test_default_params_match_reference_constructor():

@@ -100,7 +100,7 @@ def test_4096_grid_slab_with_1280x960_frames_matches_oracle(gpu):
 
 
 def test_plane_placement_is_probed_for_large_volumes_only(gpu):
-    """tsdf_hip_create keeps the fastest of up to `alloc_tries` placements of a >= 4 GiB volume's planes and says what it
+    """tsdf_hip_create keeps the fastest of up to 2 x `alloc_tries` placements of a >= 4 GiB volume's planes and says what it
     did (tsdf_hip_alloc_probe); small volumes and alloc_tries = 1 allocate once."""
     import ctypes as C
 
@@ -108,13 +108,13 @@ def test_plane_placement_is_probed_for_large_volumes_only(gpu):
     from tests.common import make_volume
 
     def probe(vol):
-        ms, chosen = (C.c_float * 4)(), C.c_int32(-1)
+        ms, chosen = (C.c_float * 8)(), C.c_int32(-1)
         n = capi.load().tsdf_hip_alloc_probe(vol._need(), ms, C.byref(chosen))
         return n, list(ms), chosen.value
     big, _ = make_volume(1024, color=True)      # 8 GiB of planes
     big.reset()
     n, ms, chosen = probe(big)
-    assert n == 3 and 0 <= chosen < 3 and all(m > 0 for m in ms[:3]) and ms[chosen] == min(ms[:3])
+    assert 1 <= n <= 6 and 0 <= chosen < n and all(m > 0 for m in ms[:n]) and ms[chosen] == min(ms[:n])  # (ends early at a fast placement)
     big.close()
     capi.check(capi.load().tsdf_hip_set_tuning(b"alloc_tries", 1), "tuning")
     try:

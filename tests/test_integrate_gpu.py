@@ -589,3 +589,37 @@ def test_reference_cull_replication_mode(gpu, color, layout):
             ref.close()
         for v in vols.values():
             v.close()
+
+
+@pytest.mark.parametrize("color,layout", [(True, capi.LAYOUT_PACKED), (False, capi.LAYOUT_PACKED), (True, capi.LAYOUT_F32W)])
+def test_calibration_sweeps_leave_every_bit_alone(gpu, color, layout):
+    """The PMC calibration sweeps (tsdf_hip_selftest_sweep: read-modify-write of every plane; tsdf_hip_selftest_read_sweep:
+    one word per 4 / 64 / 128 bytes of the distance plane) run inside bench.py's profiled process: they must report the
+    bytes they move and change nothing -- also not a -0.0 or a NaN payload."""
+    import ctypes as C
+    vol, sc = make_volume(64, color=color)
+    vol.setLayout(layout)
+    vol.reset()
+    for i, tr, dep, col in frames(sc, 3, 8):
+        vol.integrateCloud(dep, col if color else None, tr)
+    d, w, rgb = vol.download()
+    d[3, 4, 5:9] = np.array([-0.0, np.nan, np.inf, 1e-42], dtype=np.float32)  # a denormal too
+    w[3, 4, 5:9] = 1.0
+    vol.upload(d, w, rgb)
+    lib, h = capi.load(), vol._need()
+    br, bw = C.c_uint64(), C.c_uint64()
+    capi.check(lib.tsdf_hip_selftest_sweep(h, C.byref(br), C.byref(bw)), "sweep")
+    n = 64 ** 3
+    per_voxel = 4 + (0 if layout == capi.LAYOUT_PACKED else 4) + (4 if color else (1 if layout == capi.LAYOUT_PACKED else 0))
+    assert br.value == bw.value == n * per_voxel
+    for stride in (4, 64, 128):
+        span, words = C.c_uint64(), C.c_uint64()
+        capi.check(lib.tsdf_hip_selftest_read_sweep(h, stride, C.byref(span), C.byref(words)), "read_sweep")
+        assert span.value == n * 4 and words.value == n * 4 // stride
+    assert lib.tsdf_hip_selftest_read_sweep(h, 32, None, None) == capi.E_INVALID
+    d2, w2, rgb2 = vol.download()
+    assert np.array_equal(d2.view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(w2.view(np.uint32), w.view(np.uint32))
+    if color:
+        assert np.array_equal(rgb2, rgb)
+    vol.close()

@@ -3,6 +3,7 @@ oracle and vs the committed golden outputs of the reference (tests/golden/refere
 
 Bar: marching-cubes case indices / topology / triangle order exact (north_star); positions, normals,
 sampled values: bit equality with the oracle (the kernels replay the same fp32/fp64 operation order)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -446,14 +447,26 @@ def test_marching_cubes_skips_what_no_band_observation_is_near(gpu, res3, trunc,
         dep, col = sc.depth(tr, noise_seed=31 + i), sc.bgra(i)
         vol.integrateCloud(dep, col, tr)
         ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
-    meshes = {}
+    meshes, stats = {}, {}
     try:
         for skip in (1, 0):
             capi.set_tuning("mc_skip", skip)
             meshes[skip] = _mesh(vol)
+            st = (C.c_uint64 * 4)()
+            capi.check(capi.load().tsdf_hip_march_stats(vol._need(), st), "march_stats")
+            stats[skip] = [int(v) for v in st]
     finally:
         capi.set_tuning("mc_skip", 1)
     _same_mesh(meshes[1], meshes[0], "skip on vs off")
+    # tsdf_hip_march_stats: cells / triangles as fetched; without the flags every plane is requested (the plane a block
+    # of up to 32 cell planes ends on is read again by the next one), with them strictly less
+    assert stats[1][3] == 1 and stats[0][3] == 0
+    assert stats[1][:2] == stats[0][:2] == [len(np.unique(meshes[1]["cells"])), len(meshes[1]["cells"])]
+    nx, ny, nz = res3
+    pitch = (nx + 3) // 4 * 4
+    planes_read = (nz - 2) + -(-(nz - 2) // 32)  # cell planes 1 .. nz - 2, + one plane per block
+    assert 0.9 * ny * pitch * 4 * planes_read < stats[0][2] < 1.4 * ny * pitch * 4 * planes_read  # (+ halo rows and columns)
+    assert 0 < stats[1][2] <= stats[0][2]
     v2, c2, cells2 = ov.march(2.0, 1)
     assert len(cells2) > 300
     assert np.array_equal(meshes[1]["cells"], cells2)

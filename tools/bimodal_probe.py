@@ -54,7 +54,7 @@ def one(res=2048, W=640, H=480, frames=8, hold=None):
         e1.record()
         torch.cuda.synchronize()
         sw.append(e0.elapsed_time(e1))
-    pm, ch = (C.c_float * 4)(), C.c_int32(0)
+    pm, ch = (C.c_float * 8)(), C.c_int32(0)
     nt = lib.tsdf_hip_alloc_probe(h, pm, C.byref(ch))
     v.close()
     return float(np.median(ms)), float(np.median(sw[1:])), [round(float(x), 2) for x in pm[:nt]], int(ch.value)

@@ -52,6 +52,13 @@ def main():
     cal = bf["calibration"]
     cal_r = cal["known_read_bytes"] / (fetch["k_calib_rmw"]["FETCH_SIZE"] * 1024)
     cal_w = bw["calibration"]["known_written_bytes"] / (write["k_calib_rmw"]["WRITE_SIZE"] * 1024)
+    # narrow reads: what FETCH_SIZE tallies per dword read at strides 4 / 64 / 128 (bench.py --calib runs the sweeps)
+    narrow = []
+    for e in cal.get("narrow_reads", []):
+        f = fetch.get(e["kernel"])
+        if f:
+            narrow.append({**e, "FETCH_SIZE_KiB": f["FETCH_SIZE"], "fetch_bytes_per_dword_read": f["FETCH_SIZE"] * 1024 / e["dwords_read"],
+                           "span_over_fetch": e["span_bytes"] / (f["FETCH_SIZE"] * 1024)})
     inst = timed_instance(fetch)
     assert fetch[inst]["dispatches"] == bf["steps"] and write[inst]["dispatches"] == bw["steps"], "timed instance != timed launches"
     rd = fetch[inst]["FETCH_SIZE"] * 1024 * round(cal_r)
@@ -76,7 +83,8 @@ def main():
         "calibration": {"kernel": "k_calib_rmw", "known_read_bytes": cal["known_read_bytes"],
                         "FETCH_SIZE_KiB": fetch["k_calib_rmw"]["FETCH_SIZE"], "ratio_read": cal_r,
                         "known_written_bytes": bw["calibration"]["known_written_bytes"],
-                        "WRITE_SIZE_KiB": write["k_calib_rmw"]["WRITE_SIZE"], "ratio_write": cal_w},
+                        "WRITE_SIZE_KiB": write["k_calib_rmw"]["WRITE_SIZE"], "ratio_write": cal_w,
+                        "narrow_reads": narrow},
         "algorithmic_bytes_per_launch": bf["roofline"]["algorithmic_bytes_per_launch"],
         "kernel_ms_in_profile": {"kernel_trace_avg_timed_instance": trace[timed_instance(trace)]["duration_ns"] / 1e6,
                                  "bench_line_same_run": bt["roofline"]["kernel_ms"],
