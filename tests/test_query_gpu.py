@@ -465,7 +465,7 @@ def test_marching_cubes_skips_what_no_band_observation_is_near(gpu, res3, trunc,
     nx, ny, nz = res3
     pitch = (nx + 3) // 4 * 4
     planes_read = (nz - 2) + -(-(nz - 2) // 32)  # cell planes 1 .. nz - 2, + one plane per block
-    assert 0.9 * ny * pitch * 4 * planes_read < stats[0][2] < 1.4 * ny * pitch * 4 * planes_read  # (+ halo rows and columns)
+    assert 0.9 * ny * pitch * 4 * planes_read < stats[0][2] < 2.0 * ny * pitch * 4 * planes_read  # (+ halo rows / columns, whole 64-voxel groups)
     assert 0 < stats[1][2] <= stats[0][2]
     v2, c2, cells2 = ov.march(2.0, 1)
     assert len(cells2) > 300
