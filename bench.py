@@ -277,7 +277,9 @@ def host_path_leg(vol, sc, poses, color, first, last):
             out[name] = len(idx) / (time.perf_counter() - t0)
         out["calls"] = len(idx)
         out["note"] = ("host-pointer entry points, the timed region's own frames, one 2.4 MB-class frame per call over PCIe; "
-                       "report-only, the headline `value` is timed with frames resident in HBM")
+                       "report-only, the headline `value` is timed with frames resident in HBM.  This leg runs AFTER the timed "
+                       "region on the further-fused volume (observation counts nearer saturation: fewer changed words to "
+                       "store), so its rate can exceed frames_per_s")
     except Exception as e:  # never let a report-only leg break the bench line
         out["error"] = repr(e)
     return out
