@@ -26,6 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ref-cull", type=float, default=0.0, help="fraction of the cases that keep a principal point far off "
+                    "centre (the reference's frustum cull then drops voxels that project into the image) and run the drop-in "
+                    "with setReferenceCull(true): round 3's replication mode against the reference itself")
     a = ap.parse_args()
     assert refbind.available(), "oracle/_ref missing"
     dropin = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
@@ -45,13 +48,18 @@ def main():
         color = bool(rng.randint(2))
         p = params(res, W, H, size, color)
         p.fx, p.fy, p.cx, p.cy, p.max_sensor_dist = fx, fy, cx, cy, zmax
-        while not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)):
+        ref_cull = bool(a.ref_cull > 0 and rng.rand() < a.ref_cull)
+        if ref_cull:  # push the principal point further out: the regime the mode exists for
+            cx, cy = W / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * W / 2, H / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * H / 2
+            p.cx, p.cy = cx, cy
+        while not ref_cull and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)):
             cx, cy = W / 2 - 0.5 + 0.5 * (cx - (W / 2 - 0.5)), H / 2 - 0.5 + 0.5 * (cy - (H / 2 - 0.5))
             p.cx, p.cy = cx, cy
         devices = [0] * int(rng.choice([1, 1, 2, 3]))
         kw = dict(trunc=(pos, neg), max_weight=wmax, color=color)
+        cull_active = ref_cull and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p))
         gv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, lib_path=dropin,
-                               devices=devices if len(devices) > 1 else None, **kw)
+                               devices=devices if len(devices) > 1 else None, reference_cull=ref_cull, **kw)
         rv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, **kw)
         sc = synth.Scene(size, W, H, sphere=float(rng.uniform(0.15, 0.35)), box=float(rng.uniform(0.35, 0.49)))
         sc.fx, sc.fy, sc.cx, sc.cy = fx, fy, cx, cy
@@ -115,7 +123,7 @@ def main():
             v.close()
         print(f"case {case:4d}: res {res:3d} slabs {len(devices)} size {size:5.3f} {W}x{H} f {fx:6.1f} c ({cx - (W / 2 - 0.5):+5.1f},{cy - (H / 2 - 0.5):+5.1f}) "
               f"z [{zmin:.3f},{zmax:.2f}] trunc {pos / size:.2f}/{neg / size:.2f} wmax {wmax} colour {int(color)} "
-              f"observed {int((rw > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
+              f"{'refcull ' if cull_active else ''}observed {int((rw > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
         if what:
             bad.append((case, what))
     print(f"{a.cases} cases, seed {a.seed}: {len(bad)} with differences {bad[:20]}")

@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ref-cull", type=float, default=0.0, help="fraction of the cases that run in the reference-cull "
+                    "replication mode (setReferenceCull: round 3) against the oracle's culled integrate")
     a = ap.parse_args()
     rng = np.random.RandomState(a.seed)
     bad = []
@@ -42,6 +44,7 @@ def main():
             res3 = (res, int(rng.choice([res // 2, res, res + 8])), int(rng.choice([res // 2, res + 24])))
         size3 = tuple(size * r / res for r in res3)
         n_dev = int(rng.choice([1, 1, 2, 3]))    # one volume over several slab handles (all on GPU 0 here)
+        ref_cull = bool(a.ref_cull > 0 and rng.rand() < a.ref_cull)
         v = TSDFVolumeOctree()
         v.setResolution(*res3)
         v.setGridSize(*size3)
@@ -55,7 +58,12 @@ def main():
         v.setIntegrateColor(color)
         v.setTransformOrder(order)
         v.setLayout(layout)
+        if ref_cull:
+            v.setReferenceCull(True)
         v.reset()
+        # (where the cull is a no-op the product skips it; the oracle's culled integrate would then differ only by the
+        # sensor-range-shell voxels INTEGRATION.md describes, so the plain oracle is the comparison there)
+        ref_cull = ref_cull and not v.referenceCullIsNoop()
         ov = OracleVolume(v._p)
         sc = synth.Scene(size, W, H, sphere=float(rng.uniform(0.15, 0.35)), box=float(rng.uniform(0.35, 0.49)))
         sc.fx, sc.fy, sc.cx, sc.cy = fx, fy, cx, cy
@@ -73,7 +81,8 @@ def main():
             dep[(junk >= 0.04) & (junk < 0.05)] = np.inf
             col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
             n_gpu = v.integrateCloud(dep, col if color else None, tr, count=True)
-            n_cpu = ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+            n_cpu = (ov.integrate_culled(dep, col if color else None, tr, synth.cam_from_vol_f32(tr)) if ref_cull else
+                     ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr)))
             if n_gpu != n_cpu:
                 what.append(f"count{i}")
         d, w, rgb = v.download()
@@ -109,7 +118,7 @@ def main():
         v.close()
         print(f"case {case:4d}: res {'x'.join(map(str, res3)):>11s} slabs {n_dev} size {size:5.3f} {W}x{H} f {fx:6.1f} c ({cx - (W / 2 - 0.5):+5.1f},{cy - (H / 2 - 0.5):+5.1f}) "
               f"z [{zmin:.3f},{zmax:.2f}] trunc {pos / size:.2f}/{neg / size:.2f} wmax {wmax} colour {int(color)} "
-              f"{'packed' if packed else 'f32w'} order {order} observed {int((ov.w > 0).sum()):8d}  "
+              f"{'packed' if packed else 'f32w'} order {order}{' refcull' if ref_cull else ''} observed {int((ov.w > 0).sum()):8d}  "
               f"{'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
         if what:
             bad.append((case, what))
