@@ -588,15 +588,16 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
     float best_ms = tries > 1 ? probe_planes(best, n, v->stream) : -1.f;
     v->alloc_probe_ms[0] = best_ms;
     v->alloc_tried = 1;
-    // A sweep moves every plane byte once each way.  Placements fall into classes (2 x 68.7 GB: 26.0-26.6, 27.2-28.3 and
-    // 29.9-30.1 ms on MI355X); one that streams at >= 5.15 TB/s is in the fast class and ends the search, and while none
-    // has reached 4.95 TB/s the search goes on for up to `tries` more candidates (round 3: a volume whose three
-    // candidates were all slow integrated at 17.6 instead of 16.5 ms).
+    // A sweep moves every plane byte once each way.  Placements fall into classes (2 x 68.7 GB with the non-temporal
+    // sweep: 24.4-24.8, 25.2-25.5, 26-26.5 and 29-30 ms on MI355X; k_integrate follows: 16.5 / 16.7 / 16.9-17.0 / 17.6 ms);
+    // one that streams at >= 5.55 TB/s is in the fastest class and ends the search, and while none has reached
+    // 5.15 TB/s the search goes on for up to `tries` more candidates (round 3: a volume whose three candidates were all
+    // of the slowest class integrated at 17.6 instead of 16.5 ms).
     const double swept = (double)n * (4 + (v->packed ? 0 : 4) + (p->integrate_color ? 4 : 0));  // (the probe leaves a count-byte plane alone)
     auto rate_tbps = [&](float ms) { return ms > 0.f ? 2.0 * swept / ((double)ms * 1e9) : 0.0; };
     for (int t = 1; t < std::min(8, 2 * tries) && best_ms > 0.f && tries > 1; ++t) {
-      if (rate_tbps(best_ms) >= 5.15) break;
-      if (t >= tries && rate_tbps(best_ms) >= 4.95) break;
+      if (rate_tbps(best_ms) >= 5.55) break;
+      if (t >= tries && rate_tbps(best_ms) >= 5.15) break;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < plane_bytes + ((size_t)2 << 30)) break;
       PlaneSet cand;

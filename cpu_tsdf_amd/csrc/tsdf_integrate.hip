@@ -281,6 +281,9 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #ifndef TSDF_EXP_NO_VLOAD
 #define TSDF_EXP_NO_VLOAD 0
 #endif
+#ifndef TSDF_GATHER_AUX
+#define TSDF_GATHER_AUX 0  // cache policy of the ALLIN instance's frame gather (A/B: the default keeps the frame in L2)
+#endif
 #ifndef TSDF_WPE_MAX
 #define TSDF_WPE_MAX 8
 #endif
@@ -457,8 +460,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           zs[j] = 1e3f + (float)(pix[j] & 1);
           cs[j] = 0x00406080u + (unsigned)pix[j];
         } else if (ALLIN) {
-          zs[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, 0, 0));
-          if (COLOR) cs[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, (int)a.bgra_off, 0);
+          zs[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, 0, TSDF_GATHER_AUX));
+          if (COLOR) cs[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, (int)a.bgra_off, TSDF_GATHER_AUX);
         } else {
           zs[j] = __uint_as_float(bload32(rsF, (unsigned)pix[j] << 2, 0u));
           if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);

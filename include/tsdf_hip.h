@@ -290,8 +290,8 @@ int tsdf_hip_render_halo(const tsdf_params *p);
  * the allocation), so tsdf_hip_create allocates the planes of a volume of 4 GiB or more up to
  * `alloc_tries` times (tsdf_hip_set_tuning / TSDF_HIP_ALLOC_TRIES, default 3, 1 = off; a second candidate is only
  * tried while it fits next to the first), sweeps each candidate once and keeps the fastest.  The search ends early
- * at a candidate that streams at >= 5.15 TB/s (the fast class) and goes on for up to alloc_tries more (8 at most)
- * while none has reached 4.95 TB/s.  This reports what happened: ms[i] = probe sweep of candidate i (negative = not
+ * at a candidate that streams at >= 5.55 TB/s (the fastest class) and goes on for up to alloc_tries more (8 at most)
+ * while none has reached 5.15 TB/s.  This reports what happened: ms[i] = probe sweep of candidate i (negative = not
  * probed), *chosen = the one kept; returns the number of candidates tried. */
 int tsdf_hip_alloc_probe(tsdf_handle h, float ms[8], int32_t *chosen);
 
