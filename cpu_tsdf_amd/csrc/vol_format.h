@@ -135,19 +135,42 @@ inline void put(std::ostream &f, const T &v) {
 // Node records are 40 / 43 bytes and a big volume has hundreds of millions of them: they are gathered
 // into a 4 MB block before they reach the stream.
 struct NodeSink {
-  std::ostream &f;
+  std::ostream *f;  // null: a memory sink -- the records stay in `mem`, which grows (a subtree serialised by a worker
+                    // thread; plain malloc / realloc: no zero fill, and the capacity survives reset() for the next block)
   std::vector<char> buf;
-  size_t n;
-  explicit NodeSink(std::ostream &s) : f(s), buf(4u << 20), n(0) {}
+  char *mem = nullptr;
+  size_t cap = 0, n = 0;
+  explicit NodeSink(std::ostream &s) : f(&s), buf(4u << 20) {}
+  NodeSink() : f(nullptr) {}
+  NodeSink(const NodeSink &) = delete;
+  NodeSink &operator=(const NodeSink &) = delete;
+  ~NodeSink() { std::free(mem); }
+  void reset() { n = 0; }
   void flush() {
-    if (n) f.write(buf.data(), (std::streamsize)n);
+    if (!f) return;
+    if (n) f->write(buf.data(), (std::streamsize)n);
     n = 0;
   }
   char *room(size_t bytes) {
-    if (n + bytes > buf.size()) flush();
-    char *p = buf.data() + n;
+    if (f) {
+      if (n + bytes > buf.size()) flush();
+      char *p = buf.data() + n;
+      n += bytes;
+      return p;
+    }
+    if (n + bytes > cap) {
+      const size_t want = std::max<size_t>((size_t)1 << 20, cap + cap / 2 + bytes);
+      char *m2 = static_cast<char *>(std::realloc(mem, want));
+      if (!m2) throw std::bad_alloc();
+      mem = m2, cap = want;
+    }
+    char *p = mem + n;
     n += bytes;
     return p;
+  }
+  void append(const NodeSink &part) {  // (a stream sink only) the records of a memory sink, in one write
+    flush();
+    if (part.n) f->write(part.mem, (std::streamsize)part.n);
   }
 };
 
@@ -186,6 +209,49 @@ inline void write_node(NodeSink &f, const Grid &g, int level, int kx, int ky, in
     const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
     write_node(f, g, level + 1, 2 * kx + bx, 2 * ky + by, 2 * kz + bz, bx ? cx + off : cx - off,
                by ? cy + off : cy - off, bz ? cz + off : cz - off, ns);
+  }
+}
+
+// write_node(f, g, 0, ...) for a big block, with the serialisation spread over threads: pre-order puts the records of
+// the 64 subtrees below level 2 one after another, so the workers fill one memory sink per subtree (a subtree whose
+// parent or grandparent is a uniform leaf has no records) and this thread writes the level-0 / level-1 records and
+// the parts in order.  Byte for byte what write_node writes; the centres descend by the same float operations.
+inline void write_block(NodeSink &f, const Grid &g, float cx, float cy, float cz, float size, std::vector<NodeSink> &parts) {
+  if (g.L < 5) return write_node(f, g, 0, 0, 0, 0, cx, cy, cz, size);
+  const bool color = g.rgb != nullptr;
+  auto child = [](int k, int &kx, int &ky, int &kz, float &x, float &y, float &z, float &sz) {
+    const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+    const float off = sz / 4;
+    kx = 2 * kx + bx, ky = 2 * ky + by, kz = 2 * kz + bz;
+    x = bx ? x + off : x - off, y = by ? y + off : y - off, z = bz ? z + off : z - off;
+    sz = sz / 2;
+  };
+  auto node = [&](NodeSink &s, int level, int kx, int ky, int kz, float x, float y, float z, float sz) -> bool {  // true: a leaf
+    const int span = g.n >> level;
+    const bool leaf = g.uniform[level][((size_t)kz * (1 << level) + ky) * (1 << level) + kx] != 0;
+    const size_t v0 = g.vox(kx * span, ky * span, kz * span);
+    put_node(s, color, color ? g.rgb + 3 * v0 : nullptr, g.d[v0], g.w[v0], x, y, z, sz, leaf, g.M ? g.M[v0] : 0.f, g.ns ? g.ns[v0] : 0);
+    return leaf;
+  };
+  if (parts.size() != 64) parts = std::vector<NodeSink>(64);
+  for (NodeSink &p : parts) p.reset();
+  const bool root_leaf = g.uniform[0][0] != 0;
+  if (!root_leaf)
+    par_for(64, [&](int i) {
+      int kx = 0, ky = 0, kz = 0;
+      float x = cx, y = cy, z = cz, sz = size;
+      child(i >> 3, kx, ky, kz, x, y, z, sz);
+      if (g.uniform[1][((size_t)kz * 2 + ky) * 2 + kx]) return;
+      child(i & 7, kx, ky, kz, x, y, z, sz);
+      write_node(parts[i], g, 2, kx, ky, kz, x, y, z, sz);
+    });
+  if (node(f, 0, 0, 0, 0, cx, cy, cz, size)) return;
+  for (int k1 = 0; k1 < 8; ++k1) {
+    int kx = 0, ky = 0, kz = 0;
+    float x = cx, y = cy, z = cz, sz = size;
+    child(k1, kx, ky, kz, x, y, z, sz);
+    if (node(f, 1, kx, ky, kz, x, y, z, sz)) continue;
+    for (int k2 = 0; k2 < 8; ++k2) f.append(parts[k1 * 8 + k2]);
   }
 }
 
@@ -383,6 +449,7 @@ struct WriteCtx {
   BlockFn fetch;
   VarFn var;
   std::string err;
+  std::vector<NodeSink> parts;  // write_block's per-subtree memory sinks, kept from block to block
   bool fetch_block(int x, int y, int z) {
     if (!fetch(x, y, z, C, d.data(), w.data(), color ? rgb.data() : nullptr)) return false;
     return !var || var(x, y, z, C, M.data(), ns.data());
@@ -421,7 +488,7 @@ inline bool write_top(WriteCtx &c, int level, int kx, int ky, int kz, float cx, 
   g.M = c.var ? c.M.data() : nullptr;
   g.ns = c.var ? c.ns.data() : nullptr;
   build_pyramid(g);
-  write_node(*c.f, g, 0, 0, 0, 0, cx, cy, cz, size);
+  write_block(*c.f, g, cx, cy, cz, size, c.parts);
   return true;
 }
 

@@ -88,6 +88,34 @@ def test_every_block_size_writes_the_same_file_and_reads_the_same_voxels(harness
             assert np.array_equal(rgb2, rgb)
 
 
+def test_parallel_block_writer_writes_what_the_serial_walk_writes(harness, tmp_path):
+    """Blocks of edge >= 32 are serialised by 64 worker subtrees (vol_format.h write_block); smaller ones by the plain
+    recursion.  A 128^3 grid with a uniform octant (a level-1 leaf inside every 64^3 / 128^3 block that holds it), uniform
+    level-2 cubes, single uniform voxels groups and noise: the files of block edges 128, 64, 32 (parallel, at three
+    depths) and 16 (serial) are the same bytes."""
+    n = 128
+    rng = np.random.RandomState(9)
+    d = rng.uniform(-1, 1, (n,) * 3).astype(np.float32)
+    w = rng.randint(1, 7, (n,) * 3).astype(np.float32)
+    rgb = rng.randint(0, 256, (n,) * 3 + (3,)).astype(np.uint8)
+    for box, val in (((slice(0, 64),) * 3, (-1.0, 0.0)), ((slice(64, 96), slice(0, 32), slice(32, 64)), (1.0, 3.0)),
+                     ((slice(96, 112), slice(112, 128), slice(0, 16)), (0.5, 2.0)), ((slice(64, 128), slice(64, 128), slice(64, 128)), (1.0, 5.0))):
+        d[box], w[box], rgb[box] = val[0], val[1], (val[1] * 10, 20, 30)
+    d[70, 70, 70] = 0.125  # one voxel that breaks the last uniform octant
+    raw = str(tmp_path / "in.raw")
+    write_raw(raw, d, w, rgb, True)
+    files = {}
+    for chunk in (128, 64, 32, 16):
+        out = str(tmp_path / f"c{chunk}.vol")
+        subprocess.check_call([harness, "write", raw, str(n), str(SIZE), "1", str(chunk), out], stdout=subprocess.DEVNULL)
+        files[chunk] = open(out, "rb").read()
+    assert all(files[c] == files[16] for c in files), "the parallel block writer changed the file"
+    back = str(tmp_path / "back.raw")
+    subprocess.check_call([harness, "read", str(tmp_path / "c128.vol"), "64", back], stdout=subprocess.DEVNULL)
+    d2, w2, rgb2 = read_raw(back, n, True)
+    assert np.array_equal(d2.view(np.uint32), d.view(np.uint32)) and np.array_equal(w2, w) and np.array_equal(rgb2, rgb)
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_streamed_files_cross_with_the_reference(harness, tmp_path, color):
     if not refbind.available():
