@@ -166,6 +166,24 @@ SIGNATURES = {
 RAY_RECORD_INTS = 24  # TSDF_HIP_RAY_RECORD_INTS
 
 
+def _torch_first():
+    """A process that uses BOTH this library and PyTorch-ROCm must let torch load its HIP runtime first: torch wheels
+    bundle their own copy of the ROCm libraries, libtsdf_hip.so links the system's (/opt/rocm), and when the system copy
+    is loaded first `torch.cuda` later finds no device ("No HIP GPUs are available"; seen on MI355X, ROCm 7.2 + torch
+    2.10+rocm7.0, tests/test_multi_gpu.py run on its own).  The other order works and is what bench.py and zslab.py
+    always did.  So, where torch is installed and not yet imported, import it before the library
+    (TSDF_HIP_NO_TORCH_PRELOAD=1 skips this; a process without torch is not affected)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("TSDF_HIP_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # a broken torch installation must not keep the library from loading
+        pass
+
+
 def load():
     """Load libtsdf_hip.so (once) and declare every entry point.  Raises if it is not built."""
     global _lib
@@ -175,6 +193,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    _torch_first()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

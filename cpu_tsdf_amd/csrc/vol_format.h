@@ -300,6 +300,16 @@ struct NodeSource {  // the reading counterpart of NodeSink
   }
 };
 
+struct MemSource {  // records already in memory (one subtree of an open chunk, parsed by a worker thread)
+  const char *p, *end;
+  const char *take(size_t bytes) {
+    if ((size_t)(end - p) < bytes) return nullptr;
+    const char *r = p;
+    p += bytes;
+    return r;
+  }
+};
+
 // One cubic block of voxels, edge c, origin (x0,y0,z0): d, w [c^3] and rgb [3 c^3] (null without colour),
 // x fastest.  fetch fills the buffers from the volume, store writes them into it; both return false on error.
 typedef std::function<bool(int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb)> BlockFn;
@@ -311,14 +321,29 @@ struct ReadCtx {
   int n, C, Lc;  // grid edge, chunk edge, tree level whose nodes are chunks
   float vs, half;
   bool color;
-  std::vector<float> d, w;  // the chunk being assembled
+  bool has_var = false;
+  std::vector<float> d, w;  // the chunk being assembled (owner only; the parsers write through the views below)
   std::vector<unsigned char> rgb;
   std::vector<float> M;       // only with `var`
   std::vector<int32_t> ns;
+  float *pd = nullptr, *pw = nullptr, *pM = nullptr;
+  unsigned char *prgb = nullptr;
+  int32_t *pns = nullptr;
   int ox, oy, oz;  // its origin; ox < 0: none open
   BlockFn store;
   VarFn var;
   std::string err;
+  std::vector<char> sub;  // the records of the open chunk's subtree while worker threads parse them
+  void bind() {
+    pd = d.data(), pw = w.data(), prgb = rgb.data(), pM = M.data(), pns = ns.data();
+    has_var = (bool)var;
+  }
+  // what a worker thread needs: the geometry and the views, none of the vectors
+  void view_of(const ReadCtx &o) {
+    n = o.n, C = o.C, Lc = o.Lc, vs = o.vs, half = o.half, color = o.color, has_var = o.has_var;
+    pd = o.pd, pw = o.pw, pM = o.pM, prgb = o.prgb, pns = o.pns;
+    ox = o.ox, oy = o.oy, oz = o.oz;
+  }
   bool store_block(int x, int y, int z) {
     if (!store(x, y, z, C, d.data(), w.data(), color ? rgb.data() : nullptr)) return false;
     return !var || var(x, y, z, C, M.data(), ns.data());
@@ -339,20 +364,117 @@ inline void fill_chunk(ReadCtx &c, int x0, int y0, int z0, int span, float d, fl
     for (int y = y0; y < y0 + span; ++y) {
       const size_t row = ((size_t)z * c.C + y) * c.C + x0;
       for (int x = 0; x < span; ++x) {
-        c.d[row + x] = d;
-        c.w[row + x] = w;
+        c.pd[row + x] = d;
+        c.pw[row + x] = w;
       }
-      if (c.var)
+      if (c.has_var)
         for (int x = 0; x < span; ++x) {
-          c.M[row + x] = M;
-          c.ns[row + x] = ns;
+          c.pM[row + x] = M;
+          c.pns[row + x] = ns;
         }
       if (c.color)
-        for (int x = 0; x < span; ++x) std::memcpy(&c.rgb[3 * (row + x)], col, 3);
+        for (int x = 0; x < span; ++x) std::memcpy(c.prgb + 3 * (row + x), col, 3);
     }
 }
 
-inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
+// Appends the records of ONE subtree (pre-order, `rec` bytes each) from f to c.sub without interpreting them beyond the
+// child count; `budget` = records the open chunk may still hold (bounds memory on a malformed file).
+template <class S>
+inline bool scan_subtree(S &f, ReadCtx &c, size_t rec, size_t &used, size_t &budget) {
+  size_t pending = 1;
+  while (pending) {
+    const char *p = f.take(rec);
+    if (!p) {
+      c.err = "truncated octree";
+      return false;
+    }
+    if (!budget) {
+      c.err = "octree deeper than the grid";
+      return false;
+    }
+    --budget;
+    if (used + rec > c.sub.size()) c.sub.resize(std::max<size_t>((size_t)4 << 20, 2 * c.sub.size()));
+    std::memcpy(c.sub.data() + used, p, rec);
+    used += rec;
+    size_t nchild;
+    std::memcpy(&nchild, p + rec - 8, 8);
+    if (nchild == 8) pending += 8;
+    else if (nchild != 0) {
+      c.err = "malformed octree node";
+      return false;
+    }
+    --pending;
+  }
+  return true;
+}
+
+template <class S>
+inline bool read_node(S &f, ReadCtx &c, int depth);
+
+// The eight children of a chunk node that has just been opened, parsed on worker threads: the records of the chunk's
+// subtree are copied out of the stream (structure only: child counts), split at the grandchildren -- in pre-order the
+// 64 subtrees below level 2 follow one another -- and every piece fills its own part of the chunk.  Same checks, same
+// voxels as the recursion; the first error in pre-order is the one reported.
+template <class S>
+inline bool read_open_chunk_parallel(S &f, ReadCtx &c, int depth) {
+  const size_t rec = c.color ? 43 : 40;
+  size_t used = 0, budget = 0;
+  for (int l = 1; (c.C >> l) >= 1; ++l) budget += (size_t)1 << (3 * l);  // 8 + 64 + ... + C^3: every node a chunk's subtree can hold
+  struct Piece {
+    size_t a, b;
+    int depth;
+  };
+  std::vector<Piece> pieces;
+  for (int k1 = 0; k1 < 8; ++k1) {
+    const size_t a1 = used;
+    const char *p = f.take(rec);
+    if (!p) {
+      c.err = "truncated octree";
+      return false;
+    }
+    if (!budget) {
+      c.err = "octree deeper than the grid";
+      return false;
+    }
+    --budget;
+    if (used + rec > c.sub.size()) c.sub.resize(std::max<size_t>((size_t)4 << 20, 2 * c.sub.size()));
+    std::memcpy(c.sub.data() + used, p, rec);
+    used += rec;
+    size_t nchild;
+    std::memcpy(&nchild, p + rec - 8, 8);
+    if (nchild == 0) {
+      pieces.push_back({a1, used, depth + 1});  // a leaf child: one record
+    } else if (nchild == 8) {
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const size_t a2 = used;
+        if (!scan_subtree(f, c, rec, used, budget)) return false;
+        pieces.push_back({a2, used, depth + 2});
+      }
+    } else {
+      c.err = "malformed octree node";
+      return false;
+    }
+  }
+  std::vector<std::string> errs(pieces.size());
+  std::vector<unsigned char> ok(pieces.size(), 0);
+  const char *base = c.sub.data();
+  par_for((int)pieces.size(), [&](int i) {
+    ReadCtx t;
+    t.view_of(c);
+    MemSource ms{base + pieces[i].a, base + pieces[i].b};
+    ok[i] = read_node(ms, t, pieces[i].depth) ? 1 : 0;
+    if (!ok[i]) errs[i] = t.err;
+  });
+  for (size_t i = 0; i < pieces.size(); ++i)
+    if (!ok[i]) {
+      c.err = errs[i];
+      return false;
+    }
+  return true;
+}
+
+template <class S>
+inline bool read_node(S &f, ReadCtx &c, int depth) {
   unsigned char col[3] = {0, 0, 0};
   const char *p = f.take(c.color ? 43 : 40);
   if (!p) {
@@ -417,8 +539,12 @@ inline bool read_node(NodeSource &f, ReadCtx &c, int depth) {
     c.err = "octree deeper than the grid";
     return false;
   }
-  for (int k = 0; k < 8; ++k)
-    if (!read_node(f, c, depth + 1)) return false;
+  if (opens && c.C >= 32) {
+    if (!read_open_chunk_parallel(f, c, depth)) return false;
+  } else {
+    for (int k = 0; k < 8; ++k)
+      if (!read_node(f, c, depth + 1)) return false;
+  }
   if (opens) {
     const bool ok = c.store_block(c.ox, c.oy, c.oz);
     c.ox = -1;
@@ -688,6 +814,7 @@ inline bool vol_read_stream(const std::string &filename, VolHeader &h, int chunk
   c.var = (var && h.weight_by_variance) ? var : volfmt::VarFn();  // only a file that weights by variance carries meaningful values
   c.M.resize(c.var ? cv : 0);
   c.ns.resize(c.var ? cv : 0);
+  c.bind();
   volfmt::NodeSource src(f);
   if (!volfmt::read_node(src, c, 0)) {
     if (err) *err = c.err;

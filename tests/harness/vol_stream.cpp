@@ -163,6 +163,19 @@ int main(int argc, char **argv) {
         }
       return true;
     };
+    auto digest = [&]() {  // FNV-1a over the three arrays: the read must put back exactly what was written
+      uint64_t hsh = 1469598103934665603ull;
+      auto eat = [&](const void *p, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < bytes; i += 8) {  // (every 8th byte: a digest, not a proof -- tests/test_vol_stream.py compares everything)
+          hsh ^= b[i];
+          hsh *= 1099511628211ull;
+        }
+      };
+      eat(d.data(), 4 * nv), eat(w.data(), 4 * nv), eat(rgb.data(), 3 * nv);
+      return hsh;
+    };
+    const uint64_t before = digest();
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     if (!vol_write_stream(argv[4], h, chunk, [&](int x0, int y0, int z0, int c, float *bd, float *bw, unsigned char *brgb) {
@@ -171,10 +184,13 @@ int main(int argc, char **argv) {
       return 1;
     }
     auto t1 = clk::now();
+    const double write_s = std::chrono::duration<double>(t1 - t0).count();
     if (std::string(argv[4]) == "/dev/null") {  // the serialisation alone, no file system behind it
       std::printf("write %.3f s (to /dev/null)\n", std::chrono::duration<double>(t1 - t0).count());
       return 0;
     }
+    std::fill(d.begin(), d.end(), 7.f), std::fill(w.begin(), w.end(), 7.f), std::fill(rgb.begin(), rgb.end(), (unsigned char)7);
+    t1 = clk::now();
     VolHeader h2;
     if (!vol_read_stream(argv[4], h2, chunk, [&](const VolHeader &) { return true; },
                          [&](int x0, int y0, int z0, int c, float *bd, float *bw, unsigned char *brgb) {
@@ -183,13 +199,16 @@ int main(int argc, char **argv) {
       return 1;
     }
     auto t2 = clk::now();
+    if (digest() != before) {
+      std::cerr << "the read did not restore the grid" << std::endl;
+      return 6;
+    }
     FILE *f = std::fopen(argv[4], "rb");
     std::fseek(f, 0, SEEK_END);
     const double gb = (double)std::ftell(f) / 1e9;
     std::fclose(f);
-    std::printf("write %.3f s  read %.3f s  file %.3f GB  (%.2f / %.2f GB/s of file)\n", std::chrono::duration<double>(t1 - t0).count(),
-                std::chrono::duration<double>(t2 - t1).count(), gb, gb / std::chrono::duration<double>(t1 - t0).count(),
-                gb / std::chrono::duration<double>(t2 - t1).count());
+    std::printf("write %.3f s  read %.3f s  file %.3f GB  (%.2f / %.2f GB/s of file)  restored\n", write_s,
+                std::chrono::duration<double>(t2 - t1).count(), gb, gb / write_s, gb / std::chrono::duration<double>(t2 - t1).count());
     return 0;
   }
   return 2;

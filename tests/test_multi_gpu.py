@@ -7,6 +7,7 @@ first slab's device, ownership-routed sampling / block transfer / save / load.  
 holding the whole grid, bit for bit (VERDICT r01 "Next round" #4)."""
 import numpy as np
 import pytest
+import torch  # at collection time, i.e. BEFORE libtsdf_hip.so brings in /opt/rocm's HIP runtime (see tests/conftest.py)
 
 from cpu_tsdf_amd import capi, synth
 from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree
@@ -248,7 +249,6 @@ def test_device_frames_back_to_back_without_counts(gpu):
     fan-out (slab 0's staging buffer after tsdf_hip_organize, or the caller's device buffer) must be ordered AFTER the
     other slabs' copies of the previous frame by events.  Every slab has its own stream (also on one device), so a
     missing dependency shows up here as a torn frame: 24 frames back to back, slabs of unequal work."""
-    import torch
     for devices in _devices(4):
         multi, sc = make(devices)
         one, _ = make(None)
