@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1, help="replay this case alone (same random stream) and save its inputs")
+    ap.add_argument("--culled", type=int, default=0, help="1: the oracle runs getFrustumCulledVoxels' restatement in EVERY frame "
+                    "(oracle_integrate_culled, round 3), as the reference does, and principal points go up to 40 %% off centre: "
+                    "the regime where the cull drops voxels that project into the image")
     a = ap.parse_args()
     assert refbind.available(), "build oracle/_ref first (make -C oracle ref)"
     rng = np.random.RandomState(a.seed)
@@ -55,7 +58,10 @@ def main():
         p.fx, p.fy, p.cx, p.cy = fx, fy, cx, cy
         p.min_sensor_dist, p.max_sensor_dist = zmin, zmax
         p.max_dist_pos, p.max_dist_neg, p.max_weight = pos, neg, wmax
-        while not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)):
+        if a.culled:
+            cx, cy = W / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * W / 2, H / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * H / 2
+            p.cx, p.cy = cx, cy
+        while not a.culled and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)):
             cx, cy = W / 2 - 0.5 + 0.5 * (cx - (W / 2 - 0.5)), H / 2 - 0.5 + 0.5 * (cy - (H / 2 - 0.5))
             p.cx, p.cy = cx, cy
         rv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, trunc=(pos, neg), max_weight=wmax, color=color)
@@ -76,7 +82,10 @@ def main():
             dep[(junk >= 0.04) & (junk < 0.05)] = np.inf
             col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
             rv.integrate(dep, col, tr)
-            ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+            if a.culled:
+                ov.integrate_culled(dep, col if color else None, tr, synth.cam_from_vol_f32(tr))
+            else:
+                ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
         what = []
         d, w, rgb, _, _ = rv.dump_dense()
         shell = 0
@@ -125,7 +134,7 @@ def main():
         rv.close()
         print(f"case {case:4d}: res {res:3d} size {size:5.3f} {W}x{H} f {fx:6.1f} c ({cx - (W / 2 - 0.5):+5.1f},{cy - (H / 2 - 0.5):+5.1f}) "
               f"z [{zmin:.3f},{zmax:.2f}] trunc {pos / size:.2f}/{neg / size:.2f} wmax {wmax} colour {int(color)} "
-              f"observed {int((ov.w > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}"
+              f"{'cull active ' if a.culled and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)) else ''}observed {int((ov.w > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}"
               + (f"  ({shell} voxel(s) on the sensor-range shell decided the other way by the reference's cull; derived outputs not compared)" if shell else ""), flush=True)
         if what:
             bad.append((case, what))

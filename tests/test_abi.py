@@ -29,6 +29,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.tsdf_hip_abi_version() == 12
 
 
+def test_torch_enters_the_process_before_the_library():
+    """Where PyTorch-ROCm is installed, capi.load() imports it BEFORE libtsdf_hip.so pulls in the system's ROCm runtime:
+    the other order leaves torch.cuda without devices on the GPU box.  Checked in a fresh interpreter
+    (this process has long loaded both), with and without the opt-out."""
+    import subprocess
+    import sys
+    code = ("import sys; from cpu_tsdf_amd import capi; assert 'torch' not in sys.modules; capi.load(); "
+            "print('torch' in sys.modules)")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip()
+    assert out == "True"
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(env, TSDF_HIP_NO_TORCH_PRELOAD="1"), text=True).strip()
+    assert out == "False"
+
+
 def test_default_params_match_reference_constructor():
     # src/lib/tsdf_volume_octree.cpp:54-85
     p = capi.default_params()
