@@ -274,6 +274,7 @@ class TSDFVolumeOctree:
     def integrateStaged(self, trans=None, count=False):
         """integrateCloud on the frame the last organize() left in the volume."""
         trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
+        self._apply_reference_cull(trans)  # (as integrateCloud does: the planes belong to this frame's pose)
         T = np.ascontiguousarray(cam_from_vol_f32(trans).reshape(12))
         c = C.c_uint64(0)
         capi.check(capi.load().tsdf_hip_integrate_staged(self._need(), capi.as_f32p(T), C.byref(c) if count else None),
