@@ -142,6 +142,7 @@ SIGNATURES = {
     "tsdf_hip_selftest_read_sweep": (C.c_int, [C.c_void_p, C.c_int, _u64p, _u64p]),
     "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "tsdf_hip_selftest_block_flags": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.c_int, C.c_int, _u8p]),
+    "tsdf_hip_selftest_row_intervals": (C.c_int, [C.POINTER(TsdfParams), _f32p, _f32p, C.POINTER(C.c_uint32)]),
     "tsdf_hip_selftest_index_box": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdf_hip_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_save_blocks": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta), C.c_char_p, BLOCK_FN, C.c_void_p]),
@@ -156,6 +157,7 @@ SIGNATURES = {
     "tsdf_hip_upload_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_expf": (C.c_int, [_f32p, C.c_size_t, _f32p]),
     "tsdf_hip_set_reference_cull": (C.c_int, [C.c_void_p, _f32p]),
+    "tsdf_hip_reference_cull_planes": (C.c_int, [C.POINTER(TsdfParams), _f64p, _f32p]),
     "tsdf_hip_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_multi_timing": (C.c_int, [C.c_void_p, C.c_int]),

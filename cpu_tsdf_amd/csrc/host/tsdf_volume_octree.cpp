@@ -155,9 +155,10 @@ void TSDFVolumeOctree::reset() {
 // getFrustumCulledVoxels (src/lib/tsdf_volume_octree.cpp:619-652) in replication mode: the six planes of
 // pcl::FrustumCulling::applyFilter [PCL-recall: filters/impl/frustum_culling.hpp] for this frame's pose, built with the
 // caller's Eigen -- same expressions, same order -- and handed to the library, which tests every voxel centre against
-// them (tsdf_hip_set_reference_cull).  Only when the cull can change results; otherwise the planes are cleared.
+// them (tsdf_hip_set_reference_cull) wherever they can decide one -- per launch, the library checks whether they keep the
+// whole slab anyway.  Cleared when the caller opted out (setReferenceCull(false)).
 bool TSDFVolumeOctree::applyReferenceCull(const Eigen::Affine3d &trans) const {
-  if (!reference_cull_ || tsdf_hip_reference_cull_is_noop(&p_)) {
+  if (!reference_cull_) {
     if (cull_planes_set_) {
       cull_planes_set_ = false;
       return tsdf_hip_set_reference_cull(h_, nullptr) == 0;

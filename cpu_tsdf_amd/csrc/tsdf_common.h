@@ -74,6 +74,9 @@ struct tsdf_hip_volume {
   bool band_exact = false;
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
+  uint32_t *row_iv = nullptr;      // row intervals of a LIVE launch (k_rows, tsdf_integrate.hip), one word per voxel row
+  size_t row_iv_cap = 0;
+  bool ctr_increasing[3] = {false, false, false};  // the axis' centre table strictly increases (checked at create)
   unsigned long long *counter = nullptr;  // device scratch (n_observed etc.): 2048 slots
   unsigned long long last_observed = 0, last_changed_bytes = 0;  // tsdf_hip_last_count_detail
   bool ref_cull = false;   // tsdf_hip_set_reference_cull: replicate getFrustumCulledVoxels with these planes
@@ -270,6 +273,7 @@ struct TsdfTuning {
   int plain_kernel;    // F32W volumes integrate through the plain per-voxel kernel (the weight_by_depth one, w_new = 1)
   int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
+  int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
 };
 const TsdfTuning &tsdf_tuning();
 

@@ -53,7 +53,8 @@ static TsdfTuning &tuning_storage() {
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
-                         env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1)};
+                         env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
+                         env_int("TSDF_HIP_REFCULL_PLAIN", 0)};
   return t;
 }
 
@@ -85,6 +86,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.alloc_tries = std::max(1, value);
   else if (n == "allin")
     t.allin = value;
+  else if (n == "refcull_plain")
+    t.refcull_plain = value;
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;
@@ -395,6 +398,7 @@ static void free_volume(tsdf_hip_volume *v) {
     if (v->bounce_ev[i]) (void)hipEventDestroy(v->bounce_ev[i]);
   if (v->cam64) (void)hipFree(v->cam64);
   if (v->live) (void)hipFree(v->live);
+  if (v->row_iv) (void)hipFree(v->row_iv);
   if (v->band) (void)hipFree(v->band);
   if (v->counter) (void)hipFree(v->counter);
   if (v->mc_verts) (void)hipFree(v->mc_verts);
@@ -494,6 +498,51 @@ extern "C" int tsdf_hip_reference_cull_is_noop(const tsdf_params *p) {
   return (p->cx + 1.0) / p->fx <= th && (W - p->cx) / p->fx <= th && (p->cy + 1.0) / p->fy <= tv && (H - p->cy) / p->fy <= tv;
 }
 
+// The six planes pcl::FrustumCulling::applyFilter builds for getFrustumCulledVoxels (tsdf_volume_octree.cpp:633-646) from
+// the forward pose [PCL-recall: filters/impl/frustum_culling.hpp], for callers without Eigen / PCL of their own (the
+// Python binding; cpu_tsdf::TSDFVolumeOctree builds them with the CALLER's Eigen instead): camera pose =
+// trans.cast<float>() * cam2robot, i.e. view / up / right / T = the pose's z, -y, x columns and translation; the field of
+// view 1.1 x the image's, through float setters; frustum corners, edge vectors, cross products and the plane offsets in
+// float, one rounding per operation, left to right (this file is built with -ffp-contract=off); `tan` in double.
+extern "C" int tsdf_hip_reference_cull_planes(const tsdf_params *p, const double trans[16], float planes[24]) {
+  if (!p || !trans || !planes) return TSDF_HIP_E_INVALID;
+  struct V3 { float v[3]; };
+  auto axis = [&](int col, float sign) { V3 o; for (int r = 0; r < 3; ++r) o.v[r] = sign * (float)trans[4 * r + col]; return o; };
+  const V3 view = axis(2, 1.f), up = axis(1, -1.f), right = axis(0, 1.f), T = axis(3, 1.f);
+  const float hfov = (float)(1.1 * 2 * fabs(atan((double)(0.5 * p->image_width / p->fx)) * 180 / M_PI));   // :641, setHorizontalFOV(float)
+  const float vfov = (float)(1.1 * 2 * fabs(atan((double)(0.5 * p->image_height / p->fy)) * 180 / M_PI));  // :642
+  const float vrad = (float)(vfov * M_PI / 180), hrad = (float)(hfov * M_PI / 180);
+  const float dist[2] = {p->max_sensor_dist, p->min_sensor_dist};  // far, near (:643-644)
+  V3 centre[2], corner[2][4];  // corner: tl, tr, bl, br
+  for (int f = 0; f < 2; ++f) {
+    // (`tan` of a float divided by an int, evaluated in double: the C reading of PCL's expression, which the oracle and
+    // the stand-in the reference is compiled against share)
+    const float hgt = (float)(2 * tan((double)(vrad / 2)) * dist[f]), wid = (float)(2 * tan((double)(hrad / 2)) * dist[f]);
+    for (int i = 0; i < 3; ++i) {
+      const float c = T.v[i] + view.v[i] * dist[f], u = up.v[i] * hgt / 2, r = right.v[i] * wid / 2;
+      centre[f].v[i] = c;
+      corner[f][0].v[i] = c + u - r;
+      corner[f][1].v[i] = c + u + r;
+      corner[f][2].v[i] = c - u - r;
+      corner[f][3].v[i] = c - u + r;
+    }
+  }
+  auto minus = [](const V3 &a, const V3 &b) { V3 o; for (int i = 0; i < 3; ++i) o.v[i] = a.v[i] - b.v[i]; return o; };
+  auto put = [&](int k, const V3 &e1, const V3 &e2, const V3 &through) {  // plane k: normal e1 x e2 through a point
+    const float n[3] = {e1.v[1] * e2.v[2] - e1.v[2] * e2.v[1], e1.v[2] * e2.v[0] - e1.v[0] * e2.v[2], e1.v[0] * e2.v[1] - e1.v[1] * e2.v[0]};
+    planes[4 * k] = n[0], planes[4 * k + 1] = n[1], planes[4 * k + 2] = n[2];
+    planes[4 * k + 3] = -(through.v[0] * n[0] + (through.v[1] * n[1] + through.v[2] * n[2]));  // Vector3f::dot, 3-term tree
+  };
+  const V3 a = minus(corner[0][2], T), b = minus(corner[0][3], T), c = minus(corner[0][1], T), d = minus(corner[0][0], T);
+  put(0, d, a, T);  // left
+  put(1, b, c, T);  // right
+  put(2, c, d, T);  // top
+  put(3, a, b, T);  // bottom
+  put(4, minus(corner[0][2], corner[0][3]), minus(corner[0][1], corner[0][3]), centre[0]);  // far:  (bl - br) x (tr - br)
+  put(5, minus(corner[1][1], corner[1][3]), minus(corner[1][2], corner[1][3]), centre[1]);  // near: (tr - br) x (bl - br)
+  return TSDF_HIP_OK;
+}
+
 extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   if (!p || !out) return TSDF_HIP_E_INVALID;
   *out = nullptr;
@@ -508,15 +557,6 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
       p->color_mode < TSDF_COLOR_RGB || p->color_mode > TSDF_COLOR_LAB) {
     tsdf_set_error("bad image size / truncation / halo / xform_order / layout / color_mode");
     return TSDF_HIP_E_INVALID;
-  }
-  if (!tsdf_hip_reference_cull_is_noop(p)) {
-    static bool said = false;
-    if (!said) {
-      said = true;
-      fprintf(stderr, "libtsdf_hip: note: with this principal point / sensor range the reference's frustum cull "
-                      "(tsdf_volume_octree.cpp:619-652) drops voxels that project into the image; this library "
-                      "integrates them (tsdf_hip_reference_cull_is_noop, INTEGRATION.md)\n");
-    }
   }
   const bool lab = p->integrate_color && p->color_mode == TSDF_COLOR_LAB;
   const bool rgbn = (p->integrate_color && p->color_mode == TSDF_COLOR_RGB_NORMALIZED) || lab;  // float colour state
@@ -633,6 +673,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   }
   for (int a = 0; a < 3; ++a) {
     tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v->h_ctr[a], &v->levels[a]);
+    v->ctr_increasing[a] = true;
+    for (size_t i = 1; i < v->h_ctr[a].size(); ++i) v->ctr_increasing[a] &= v->h_ctr[a][i - 1] < v->h_ctr[a][i];
     // pad the tables so float4 loads of the last (partial) quad stay in bounds; the pad is NaN, which
     // fails k_integrate's sensor-range test, so voxels of the pitch padding are never observed
     std::vector<float> padded(v->h_ctr[a]);

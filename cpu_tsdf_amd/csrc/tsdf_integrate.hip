@@ -299,21 +299,32 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
                            // SGPRs into VGPR lanes, and the build with that AND the band flags gave wrong voxels on the GPU
                            // (tests/evidence/diag_allin.py; cause not found in the ISA, so the configuration is avoided)
 #endif
+#ifndef TSDF_WPE_GENERAL
+#define TSDF_WPE_GENERAL 6  // waves per SIMD the general and the counting instances ask for (see TSDF_WPE_PACKED)
+#endif
 // ALLIN (only with FASTPROJ): the host has proved (launch_integrate, `all_inside`: the slab's eight corner voxels, a
 // convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
 // with a pixel to spare, and nx is a multiple of 4: the per-voxel range compares, the image-bounds compares and the
 // "nothing in range" exits go away -- the turntable / object-in-front-of-the-camera case the headline is quoted on.
-template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : 6) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
+// LIVE (never with ALLIN): the launch comes with the frame's ROW INTERVALS (k_rows below: per voxel row of the launch,
+// the x range [lo, lo + len) outside of which no voxel of the row can be integrated -- conservative for updateVoxel's
+// own tests, EXACT for the reference's frustum cull when it is replicated) and with k_cull's block flags.  A block no
+// row of which meets its x range leaves at once, a wave skips every row whose interval misses its 64 quads before any
+// arithmetic, and the voxels of a quad that lie outside the interval are masked like voxels out of sensor range.
+template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false, bool LIVE = false>
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
-            unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live, uint8_t *__restrict__ band) {
+            unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live, uint8_t *__restrict__ band,
+            const uint32_t *__restrict__ row_iv) {
+  static_assert(!(ALLIN && LIVE), "the ALLIN instance has nothing to cull");
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
-  if (live && !live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)]) return;
+  if (LIVE && !live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)]) return;
   const unsigned tid = threadIdx.x;
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
   __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
+  __shared__ uint32_t s_iv[LIVE ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
   // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
   // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
@@ -323,6 +334,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   {
     const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
+    if (LIVE) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
   __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
@@ -363,6 +375,12 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     for (int r = 0; r < a.rpb; ++r) {
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
+      unsigned iv_lo = 0u, iv_len = 0u;
+      if (LIVE) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
+        const uint32_t iv = s_iv[ty + r * a.TY];
+        iv_lo = iv & 0xffffu, iv_len = iv >> 16;
+        if (!((unsigned)(x4 + 3) - iv_lo < iv_len + 3u)) continue;
+      }
       const unsigned soff = (unsigned)r * row_step;
       const float cy = s_cy[ty + r * a.TY];
       float yt[3];
@@ -400,7 +418,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
         // hpp:146 + .cpp:616: !(gz < zmin || gz > zmax) && gz > 0, as two compares: zlo is the largest float every
         // accepted gz exceeds (the float below zmin when zmin > 0, else 0; a NaN gz fails, as there)
-        const bool in = ALLIN || (gz > a.zlo && !(gz > a.zmax));
+        const bool in = ALLIN || (gz > a.zlo && !(gz > a.zmax) && (!LIVE || (unsigned)(x4 + j) - iv_lo < iv_len));
         gzs[j] = gz;
         if (!ALLIN) lowz |= in && gz < 0x1p-14f;  // (ALLIN: the host checked g.z > 1e-3 for the whole slab)
         int p;
@@ -730,16 +748,145 @@ static __host__ __device__ inline bool box_may_be_observed(const CullArgs &c, do
   return true;
 }
 
+// Row intervals.  Along a voxel row (y, z fixed) both sets that decide whether a voxel is integrated are INTERVALS of x:
+//  * updateVoxel's own tests (sensor range hpp:146, pixel inside the image .cpp:616) cut the row's line g(x) = g0 + x m0
+//    with a convex pyramid.  Here conservatively: each test is a linear inequality in x once the division by g.z is
+//    multiplied out (g.z > 0), widened by the float transform's error bound eps (the same 8x-margin bound as
+//    box_may_be_observed) -- nothing outside [ob_lo, ob_hi] can be observed, so masking it changes no result.
+//  * the reference's frustum cull (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652, replicated when `rc`): PCL's
+//    verdict `(x p0 + y p1) + (z p2 + p3) <= 0` is, for finite operands, a MONOTONE function of the float x (every
+//    rounding is monotone), and the centre table increases with the index, so each plane keeps a prefix or a suffix of
+//    the row and the six planes keep an interval.  Its ends are found by bisection on the very float expression the
+//    per-voxel test evaluates (reference_cull_keeps): EXACT, voxel for voxel.
+// One thread per row of the launch; the word is lo | len << 16 in launch-relative x (an empty row: lo = 0xffff).
+struct RowArgs {
+  double m[12], fx, fy, cx, cy;
+  double zlo, zmax;
+  int W, H, nx, ny, nz, z_global0;  // the launch box: nx voxels of ctrx, ny rows of ctry, nz planes from z_global0
+  int rc;                           // replicate the reference's cull with these planes
+  float cull[24];
+};
+
+static __host__ __device__ inline bool row_plane_keeps(const float *pl, float x, float y, float z) {
+  return (x * pl[0] + y * pl[1]) + (z * pl[2] + 1.0f * pl[3]) <= 0.f;  // == reference_cull_keeps, one plane
+}
+
+static __host__ __device__ inline uint32_t row_interval(const RowArgs &c, const float *ctrx, float cyf, float czf) {
+  int lo = 0, hi = c.nx - 1;
+  // ---- conservative: what updateVoxel can accept at all ----
+  {
+    const double y = cyf, z = czf, xa = ctrx[0], xb = ctrx[c.nx - 1];
+    double g0[3], m0[3], eps = 0;
+    for (int r = 0; r < 3; ++r) {
+      m0[r] = c.m[4 * r];
+      g0[r] = c.m[4 * r + 1] * y + c.m[4 * r + 2] * z + c.m[4 * r + 3];
+      const double mag = fmax(fabs(c.m[4 * r] * xa), fabs(c.m[4 * r] * xb)) + fabs(c.m[4 * r + 1] * y) + fabs(c.m[4 * r + 2] * z) + fabs(c.m[4 * r + 3]);
+      eps = fmax(eps, 8.0 * 4.0 * 5.97e-8 * mag);
+    }
+    // a voxel needs  A x + B <= C  for each of:  -g.z <= -zlo + eps,  g.z <= zmax + eps,  and with R = fx g.x / g.z + cx
+    // (evaluated on float coordinates within eps of these) -1 < R < W, i.e. fx g.x + (cx + 1) g.z > 0 and
+    // fx g.x + (cx - W) g.z < 0, likewise for v -- each with the margin its coefficients give eps, relaxed by 1e-9 relative
+    double xlo = -1e300, xhi = 1e300;
+    bool none = !(eps < 1e300);
+    const double zlo = c.zlo > 0 ? c.zlo : 0;
+    const double A[6] = {-m0[2], m0[2], -(c.fx * m0[0] + (c.cx + 1.0) * m0[2]), c.fx * m0[0] + (c.cx - c.W) * m0[2],
+                         -(c.fy * m0[1] + (c.cy + 1.0) * m0[2]), c.fy * m0[1] + (c.cy - c.H) * m0[2]};
+    const double B[6] = {-g0[2], g0[2], -(c.fx * g0[0] + (c.cx + 1.0) * g0[2]), c.fx * g0[0] + (c.cx - c.W) * g0[2],
+                         -(c.fy * g0[1] + (c.cy + 1.0) * g0[2]), c.fy * g0[1] + (c.cy - c.H) * g0[2]};
+    const double Cm[6] = {-zlo + eps, c.zmax + eps, (fabs(c.fx) + fabs(c.cx + 1.0)) * eps, (fabs(c.fx) + fabs(c.cx - c.W)) * eps,
+                          (fabs(c.fy) + fabs(c.cy + 1.0)) * eps, (fabs(c.fy) + fabs(c.cy - c.H)) * eps};
+    bool claim = !none;
+    for (int k = 0; k < 6 && claim; ++k) {
+      const double slack = 1e-9 * (fabs(B[k]) + fabs(A[k]) * fmax(fabs(xa), fabs(xb)) + fabs(Cm[k])) + 1e-300;
+      const double rhs = Cm[k] - B[k] + slack;
+      if (!(fabs(A[k]) < 1e300) || !(fabs(rhs) < 1e300)) {
+        continue;  // non-finite (an unbounded sensor range): this test bounds nothing
+      } else if (A[k] > 0) {
+        xhi = fmin(xhi, rhs / A[k]);
+      } else if (A[k] < 0) {
+        xlo = fmax(xlo, rhs / A[k]);
+      } else if (!(0 <= rhs)) {
+        xhi = -1e300;  // the row fails this test for every x
+      }
+    }
+    if (claim && xhi < xlo) {
+      lo = 1, hi = 0;  // both bounds are conservative: nothing in this row can be observed
+    } else if (claim) {
+      // widen by the bisection's own granularity: a relative 1e-9 on the bounds and one voxel on each side
+      const double w = 1e-9 * (fabs(xlo) < 1e299 ? fabs(xlo) : 0) + 1e-9 * (fabs(xhi) < 1e299 ? fabs(xhi) : 0);
+      xlo -= w, xhi += w;
+      // first index with ctrx >= xlo, minus one; last index with ctrx <= xhi, plus one (the table increases)
+      int a = 0, b = c.nx;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if ((double)ctrx[mid] < xlo) a = mid + 1; else b = mid;
+      }
+      lo = a > 0 ? a - 1 : 0;
+      a = 0, b = c.nx;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if ((double)ctrx[mid] <= xhi) a = mid + 1; else b = mid;
+      }
+      hi = a < c.nx ? a : c.nx - 1;  // a - 1 is the last one inside; plus one
+    }
+  }
+  // ---- exact: what the reference's cull keeps ----
+  if (c.rc) {
+    for (int k = 0; k < 6 && lo <= hi; ++k) {
+      const float *pl = c.cull + 4 * k;
+      if (pl[0] > 0.f) {  // keeps a prefix: the first index in [lo, hi] that fails ends it
+        int a = lo, b = hi + 1;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (row_plane_keeps(pl, ctrx[mid], cyf, czf)) a = mid + 1; else b = mid;
+        }
+        hi = a - 1;
+      } else if (pl[0] < 0.f) {  // keeps a suffix: the first index that passes starts it
+        int a = lo, b = hi + 1;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (row_plane_keeps(pl, ctrx[mid], cyf, czf)) b = mid; else a = mid + 1;
+        }
+        lo = a;
+      } else if (!row_plane_keeps(pl, ctrx[lo], cyf, czf)) {  // +-0 (the host rejects NaN planes): the same verdict for every x
+        hi = lo - 1;
+      }
+    }
+  }
+  if (lo > hi) return 0x0000ffffu;
+  return (uint32_t)lo | ((uint32_t)(hi - lo + 1) << 16);
+}
+
+static __global__ void __launch_bounds__(256)
+k_rows(const RowArgs c, const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
+       uint32_t *__restrict__ row_iv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)c.ny * c.nz) return;
+  const int y = (int)(i % c.ny), z = (int)(i / c.ny);
+  row_iv[i] = row_interval(c, ctrx, ctry[y], ctrz[c.z_global0 + z]);
+}
+
+// One flag per k_integrate block of a LIVE launch: does any of its rows' intervals meet its x range (and can the block's
+// rectangle be observed at all)?
 static __global__ void __launch_bounds__(256)
 k_cull(const CullArgs c, const float *__restrict__ ctrx, const float *__restrict__ ctry,
-       const float *__restrict__ ctrz, uint8_t *__restrict__ live) {
+       const float *__restrict__ ctrz, const uint32_t *__restrict__ row_iv, uint8_t *__restrict__ live) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= (int64_t)c.gx * c.gy * c.gz) return;
   const int bx = (int)(b % c.gx), by = (int)((b / c.gx) % c.gy), bz = (int)(b / ((int64_t)c.gx * c.gy));
   const int xa = bx * c.bx_vox, xb = min(c.nx, xa + c.bx_vox) - 1;
   const int ya = by * c.by_rows, yb = min(c.ny, ya + c.by_rows) - 1;
   // the centre tables increase with the index, so the first and last voxel bound the block
-  live[b] = box_may_be_observed(c, ctrx[xa], ctrx[xb], ctry[ya], ctry[yb], ctrz[c.z_global0 + bz]) ? 1 : 0;
+  bool any = box_may_be_observed(c, ctrx[xa], ctrx[xb], ctry[ya], ctry[yb], ctrz[c.z_global0 + bz]);
+  if (any) {
+    any = false;
+    for (int y = ya; y <= yb && !any; ++y) {
+      const uint32_t iv = row_iv[(int64_t)bz * c.ny + y];
+      const int lo = (int)(iv & 0xffffu), len = (int)(iv >> 16);
+      any = len > 0 && lo <= xb && lo + len - 1 >= xa;
+    }
+  }
+  live[b] = any ? 1 : 0;
 }
 
 static float f32_ulp(float v) {
@@ -1204,6 +1351,39 @@ static bool zlo_margin_ok(const float T[12], const tsdf_hip_volume *h) {
   return err < 1e-4 && zmin > 0.05 && f * err * (1.0 + big / zmin) / zmin < 0.05;  // < 1/20 pixel
 }
 
+// Do the six planes of the reference's frustum cull keep EVERY voxel of this handle's slab?  Each plane's verdict is
+// `dot <= 0` of an affine function of the centre, so its maximum over the slab's box of centres sits at one of the eight
+// corner voxels; evaluated in double, plus a bound on what the per-voxel float evaluation (three products, three sums)
+// can add.  True for any ordinary camera looking at a volume inside its sensor range -- then the cull is a no-op for this
+// frame and the launch need not know about it.  Non-finite planes: false (the per-voxel test decides).
+static bool reference_cull_keeps_whole_slab(const tsdf_hip_volume *h) {
+  for (int k = 0; k < 6; ++k) {
+    const float *pl = h->cull_planes + 4 * k;
+    double worst = -1e300, mag = 0;
+    for (int c = 0; c < 8; ++c) {
+      const double x = h->h_ctr[0][(c & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(c & 2) ? h->ny - 1 : 0],
+                   z = h->h_ctr[2][(c & 4) ? h->z_end - 1 : h->z_begin];
+      const double v = (double)pl[0] * x + (double)pl[1] * y + (double)pl[2] * z + (double)pl[3];
+      if (!std::isfinite(v)) return false;
+      worst = std::max(worst, v);
+      mag = std::max(mag, fabs((double)pl[0] * x) + fabs((double)pl[1] * y) + fabs((double)pl[2] * z) + fabs((double)pl[3]));
+    }
+    if (!(worst + 8.0 * 4.0 * 5.97e-8 * mag < 0.0)) return false;
+  }
+  return true;
+}
+
+// Can a launch use row intervals (k_rows)?  The interval words hold 16-bit x indices, the bisections need an increasing
+// x centre table, and the exact half (`planes`: the reference's cull) needs finite planes of moderate size so that every
+// product and sum of the per-voxel test is finite (then each rounding is monotone in x).
+static bool row_intervals_usable(const tsdf_hip_volume *h, bool planes) {
+  if (h->pitch > 0xfff0 || !h->ctr_increasing[0]) return false;
+  if (planes)
+    for (int i = 0; i < 24; ++i)
+      if (!(fabsf(h->cull_planes[i]) < 1e30f)) return false;
+  return true;
+}
+
 // Asynchronous half: queues the launch on the handle's stream.  `count` selects the counting instance, whose striped
 // counters stay in h->counter until tsdf_integrate_collect reads them (a multi-GPU set launches every slab first and
 // collects afterwards, so the slabs count concurrently).
@@ -1231,7 +1411,14 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   }
   // the plain per-voxel kernel: weight_by_depth_ (2), the test knob "plain_kernel" (1), or the reference-cull replication
   // mode (3: any layout; the fast kernels know nothing about the six planes)
-  const int plain_mode = h->weight_by_depth ? 2 : h->weight_by_variance ? 4 : (h->ref_cull && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  // The reference's frustum cull (tsdf_hip_set_reference_cull): nothing to do when the six planes provably keep every
+  // voxel of this slab (ordinary cameras: the cull is a no-op and the launch is the usual one); otherwise the fast kernel
+  // applies it through the row intervals (k_rows), or -- planes that are not finite, a grid too wide for the interval
+  // words, the `refcull_plain` knob -- the plain per-voxel kernel tests the six planes itself.
+  const bool rc = h->ref_cull && !reference_cull_keeps_whole_slab(h);
+  const bool rc_rows = rc && !h->cn[0] && !tsdf_tuning().refcull_plain && row_intervals_usable(h, true);
+  const int plain_mode = h->weight_by_depth ? 2 : h->weight_by_variance ? 4 : (rc && !rc_rows && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
+  a.ref_cull = rc ? 1 : 0;  // (the plain kernels test the planes per voxel only when they can bite)
   if (plain_mode || h->cn[0]) h->band_exact = false;  // the plain kernels keep no "band seen" flags: marching cubes reads everything
   if (plain_mode) {
     if ((h->packed && plain_mode != 3) || h->cn[0]) {  // (2 and 4 need float weights)
@@ -1348,8 +1535,9 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   const float *ctrx = h->ctr[0], *ctry = h->ctr[1];
   bool nothing_observable = false;
   bool allin = false;  // every voxel of the launch in sensor range and a pixel inside the image: the ALLIN instance
+  bool all_inside = false;
   if (tsdf_tuning().cull) {
-    bool all_inside = tsdf_tuning().cull != 2;
+    all_inside = tsdf_tuning().cull != 2;
     for (int k = 0; k < 8 && all_inside; ++k) {
       const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
                    z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
@@ -1363,63 +1551,95 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     // The eight corner voxels lie inside the convex set {range, image minus a border}; so does every voxel centre in
     // exact arithmetic, and the margins (1e-3 m, one pixel) cover the float transform (~1e-7 relative) and the
     // projection's sensitivity to it as long as the coordinates stay moderate.
-    allin = all_inside && !h->ref_cull && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
+    allin = all_inside && !rc && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
             (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
-    if (!all_inside) {
-      int lo[3], hi[3];
-      bool empty = false;
-      if (observable_index_box(h, T, lo, hi, &empty)) {
-        lo[2] = std::max(lo[2], h->z_begin);
-        hi[2] = std::min(hi[2], h->z_end - 1);
-        if (empty || lo[2] > hi[2]) {
-          nothing_observable = true;
-        } else {
-          const int bxv = a.TX * 4, byr = a.rpb * a.TY;  // voxels / rows per block
-          const int bx0 = lo[0] / bxv, bx1 = hi[0] / bxv, by0 = lo[1] / byr, by1 = hi[1] / byr;
-          const int x_off = bx0 * bxv, y_off = by0 * byr, z_off = lo[2] - h->z_begin;
-          const int64_t e_off = (int64_t)y_off * h->pitch + x_off;
-          D += e_off;
-          if (Wt) Wt += e_off;
-          if (RGB) RGB += e_off;
-          if (K8) K8 += e_off;
-          ctrx += x_off;
-          ctry += y_off;
-          a.qpr -= x_off / 4;
-          a.ny -= y_off;
-          a.x_abs0 = x_off;
-          a.y_abs0 = y_off;
-          a.z_global0 += z_off;
-          a.zl0 += z_off;
-          gx = (unsigned)(bx1 - bx0 + 1);
-          gy = (unsigned)(by1 - by0 + 1);
-          gz = (unsigned)(hi[2] - lo[2] + 1);
-        }
+  }
+  // LIVE launch: the frame cannot see the whole slab (or the reference's cull bites): row intervals + block flags
+  const bool want_live = (tsdf_tuning().cull && !all_inside && row_intervals_usable(h, false)) || rc_rows;
+  if (want_live) {
+    // narrow blocks: 64 quads of 4 rows, so that the flags and a wave's row skip follow the frustum's outline (a block
+    // of a whole 1024-voxel row group is mostly outside it when the camera sits inside the volume)
+    if (a.TX > 64) {
+      a.TX = 64, a.log2TX = 6, a.TY = 4;
+      a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);
+      gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
+      gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
+    }
+    int lo[3], hi[3];
+    bool empty = false;
+    if (tsdf_tuning().cull && !all_inside && observable_index_box(h, T, lo, hi, &empty)) {
+      lo[2] = std::max(lo[2], h->z_begin);
+      hi[2] = std::min(hi[2], h->z_end - 1);
+      if (empty || lo[2] > hi[2]) {
+        nothing_observable = true;
+      } else {
+        const int bxv = a.TX * 4, byr = a.rpb * a.TY;  // voxels / rows per block
+        const int bx0 = lo[0] / bxv, bx1 = hi[0] / bxv, by0 = lo[1] / byr, by1 = hi[1] / byr;
+        const int x_off = bx0 * bxv, y_off = by0 * byr, z_off = lo[2] - h->z_begin;
+        const int64_t e_off = (int64_t)y_off * h->pitch + x_off;
+        D += e_off;
+        if (Wt) Wt += e_off;
+        if (RGB) RGB += e_off;
+        if (K8) K8 += e_off;
+        ctrx += x_off;
+        ctry += y_off;
+        a.qpr -= x_off / 4;
+        a.ny -= y_off;
+        a.x_abs0 = x_off;
+        a.y_abs0 = y_off;
+        a.z_global0 += z_off;
+        a.zl0 += z_off;
+        gx = (unsigned)(bx1 - bx0 + 1);
+        gy = (unsigned)(by1 - by0 + 1);
+        gz = (unsigned)(hi[2] - lo[2] + 1);
       }
-      if (!nothing_observable) {
-        CullArgs c;
-        for (int i = 0; i < 12; ++i) c.m[i] = T[i];
-        c.fx = p.fx, c.fy = p.fy, c.cx = p.cx, c.cy = p.cy;
-        c.zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
-        c.zmax = p.max_sensor_dist;
-        c.W = p.image_width, c.H = p.image_height;
-        c.nx = h->nx - (int)(ctrx - h->ctr[0]), c.ny = a.ny, c.z_global0 = a.z_global0;
-        c.bx_vox = a.TX * 4, c.by_rows = a.rpb * a.TY;
-        c.gx = (int)gx, c.gy = (int)gy, c.gz = (int)gz;
-        const size_t nb = (size_t)gx * gy * gz;
+    }
+    if (gy > 65535u) {
+      tsdf_set_error("grid too large for one launch");
+      return TSDF_HIP_E_UNSUPPORTED;
+    }
+    if (!nothing_observable) {
+      CullArgs c;
+      for (int i = 0; i < 12; ++i) c.m[i] = T[i];
+      c.fx = p.fx, c.fy = p.fy, c.cx = p.cx, c.cy = p.cy;
+      c.zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
+      c.zmax = p.max_sensor_dist;
+      c.W = p.image_width, c.H = p.image_height;
+      c.nx = h->nx - (int)(ctrx - h->ctr[0]), c.ny = a.ny, c.z_global0 = a.z_global0;
+      c.bx_vox = a.TX * 4, c.by_rows = a.rpb * a.TY;
+      c.gx = (int)gx, c.gy = (int)gy, c.gz = (int)gz;
+      // the rows the launch's blocks cover (the last row group may reach past the box, never past the grid)
+      const int rows = std::min(a.ny, (int)gy * a.rpb * a.TY);
+      a.ny = rows;
+      c.ny = rows;
+      RowArgs ra;
+      for (int i = 0; i < 12; ++i) ra.m[i] = T[i];
+      ra.fx = p.fx, ra.fy = p.fy, ra.cx = p.cx, ra.cy = p.cy;
+      ra.zlo = c.zlo, ra.zmax = c.zmax;
+      ra.W = c.W, ra.H = c.H;
+      ra.nx = std::min(c.nx, (int)gx * a.TX * 4), ra.ny = rows, ra.nz = (int)gz, ra.z_global0 = a.z_global0;
+      ra.rc = rc_rows ? 1 : 0;
+      for (int i = 0; i < 24; ++i) ra.cull[i] = rc_rows ? h->cull_planes[i] : 0.f;
+      const size_t nb = (size_t)gx * gy * gz, nrows = (size_t)rows * gz;
+      if (nb > h->live_cap || nrows > h->row_iv_cap) {
+        TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
         if (nb > h->live_cap) {
-          if (h->live) {
-            TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-            TSDF_HIP_TRY(hipFree(h->live));
-            h->live = nullptr;
-            h->live_cap = 0;
-          }
+          if (h->live) TSDF_HIP_TRY(hipFree(h->live));
+          h->live = nullptr, h->live_cap = 0;
           TSDF_HIP_TRY(hipMalloc(&h->live, nb));
           h->live_cap = nb;
         }
-        hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, ctrx, ctry, h->ctr[2], h->live);
-        TSDF_HIP_TRY(hipGetLastError());
-        live = h->live;
+        if (nrows > h->row_iv_cap) {
+          if (h->row_iv) TSDF_HIP_TRY(hipFree(h->row_iv));
+          h->row_iv = nullptr, h->row_iv_cap = 0;
+          TSDF_HIP_TRY(hipMalloc(&h->row_iv, nrows * sizeof(uint32_t)));
+          h->row_iv_cap = nrows;
+        }
       }
+      hipLaunchKernelGGL(k_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, h->stream, ra, ctrx, ctry, h->ctr[2], h->row_iv);
+      hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, ctrx, ctry, h->ctr[2], h->row_iv, h->live);
+      TSDF_HIP_TRY(hipGetLastError());
+      live = h->live;
     }
   }
   if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
@@ -1439,24 +1659,26 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     const dim3 grid(gx, gy, gz), block(256);
     h->last_launch[0] = fastproj && allin && !live;
     h->last_launch[1] = fastproj;
-    h->last_launch[2] = live != nullptr;
+    h->last_launch[2] = live ? (rc_rows ? 2 : 1) : 0;
     h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
-#define LAUNCH(ORDER, COLOR, FP, COUNT, PK, AI)                                                                  \
-  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK, AI>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
-                     d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live, band_arg)
-#define L5(ORDER, COLOR, FP, COUNT)                    \
-  do {                                                 \
-    if (h->packed) {                                   \
-      if (FP && allin && !live)                        \
-        LAUNCH(ORDER, COLOR, FP, COUNT, true, FP);     \
-      else                                             \
-        LAUNCH(ORDER, COLOR, FP, COUNT, true, false);  \
-    } else {                                           \
-      if (FP && allin && !live)                        \
-        LAUNCH(ORDER, COLOR, FP, COUNT, false, FP);    \
-      else                                             \
-        LAUNCH(ORDER, COLOR, FP, COUNT, false, false); \
-    }                                                  \
+#define LAUNCH(ORDER, COLOR, FP, COUNT, PK, AI, LV)                                                                  \
+  hipLaunchKernelGGL((k_integrate<ORDER, COLOR, FP, COUNT, PK, AI, LV>), grid, block, 0, h->stream, a, D, Wt, RGB, K8, \
+                     d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live, band_arg, h->row_iv)
+#define L6(ORDER, COLOR, FP, COUNT, PK)                  \
+  do {                                                   \
+    if (live)                                            \
+      LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, true);  \
+    else if (FP && allin)                                \
+      LAUNCH(ORDER, COLOR, FP, COUNT, PK, FP, false);    \
+    else                                                 \
+      LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, false); \
+  } while (0)
+#define L5(ORDER, COLOR, FP, COUNT)     \
+  do {                                  \
+    if (h->packed)                      \
+      L6(ORDER, COLOR, FP, COUNT, true);  \
+    else                                \
+      L6(ORDER, COLOR, FP, COUNT, false); \
   } while (0)
 #define L4(ORDER, COLOR, FP) \
   do {                       \
@@ -1486,6 +1708,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
 #undef L2
 #undef L4
 #undef L5
+#undef L6
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
   }
@@ -1908,6 +2131,31 @@ extern "C" int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float c
         flags[((size_t)bz * c.gy + by) * c.gx + bx] =
             box_may_be_observed(c, ctr[0][xa], ctr[0][xb], ctr[1][ya], ctr[1][yb], ctr[2][bz]) ? 1 : 0;
       }
+  return TSDF_HIP_OK;
+}
+
+// Test hook, host only: k_rows' row intervals (row_interval) for every voxel row of the WHOLE grid,
+// words[z * res_y + y] = lo | len << 16 (an empty row: lo = 0xffff); planes = the reference cull's six planes or NULL.
+extern "C" int tsdf_hip_selftest_row_intervals(const tsdf_params *p, const float cam_from_vol[12], const float *planes,
+                                               uint32_t *words) {
+  if (!p || !cam_from_vol || !words) return TSDF_HIP_E_INVALID;
+  std::vector<float> ctr[3];
+  for (int a = 0; a < 3; ++a) {
+    int levels;
+    if (p->res[a] <= 0 || !(p->size[a] > 0.f)) return TSDF_HIP_E_INVALID;
+    tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), ctr[a], &levels);
+  }
+  if (p->res[0] > 0xfff0) return TSDF_HIP_E_UNSUPPORTED;
+  RowArgs c;
+  for (int i = 0; i < 12; ++i) c.m[i] = cam_from_vol[i];
+  c.fx = p->fx, c.fy = p->fy, c.cx = p->cx, c.cy = p->cy;
+  c.zlo = p->min_sensor_dist > 0 ? p->min_sensor_dist : 0;
+  c.zmax = p->max_sensor_dist;
+  c.W = p->image_width, c.H = p->image_height, c.nx = p->res[0], c.ny = p->res[1], c.nz = p->res[2], c.z_global0 = 0;
+  c.rc = planes ? 1 : 0;
+  for (int i = 0; i < 24; ++i) c.cull[i] = planes ? planes[i] : 0.f;
+  for (int z = 0; z < c.nz; ++z)
+    for (int y = 0; y < c.ny; ++y) words[(size_t)z * c.ny + y] = row_interval(c, ctr[0].data(), ctr[1][y], ctr[2][z]);
   return TSDF_HIP_OK;
 }
 

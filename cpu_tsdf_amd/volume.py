@@ -188,15 +188,15 @@ class TSDFVolumeOctree:
     # -- hot path ------------------------------------------------------------------------------------
     def setReferenceCull(self, flag):
         """Not in the reference's API, but its behaviour: integrateCloud there only visits the voxels pcl::FrustumCulling
-        keeps (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652).  For ordinary cameras that changes nothing and
-        this library skips it (referenceCullIsNoop()); with flag = True the cull is replicated voxel for voxel whenever
-        it is NOT a no-op (the planes are computed here, as PCL computes them, per frame), at the price of the plain
-        per-voxel kernel.  Default False: the conservative superset, fastest kernels."""
+        keeps (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652).  Default True: every integrate call hands the six
+        planes of its pose to the library (tsdf_hip_set_reference_cull), which applies them wherever they can decide a
+        voxel -- this volume's voxels are the reference's in every regime.  False: no cull (every voxel updateVoxel
+        itself accepts; identical for ordinary cameras, see referenceCullIsNoop())."""
         self._reference_cull = bool(flag)
 
     def _apply_reference_cull(self, trans):
         lib, h = capi.load(), self._need()
-        if getattr(self, "_reference_cull", False) and not self.referenceCullIsNoop():
+        if getattr(self, "_reference_cull", True):
             planes = reference_cull_planes(self._p, trans)
             capi.check(lib.tsdf_hip_set_reference_cull(h, capi.as_f32p(planes)), "set_reference_cull")
             self._cull_set = True
@@ -568,54 +568,14 @@ class MarchingCubesTSDFOctree:
 
 def reference_cull_planes(p, trans):
     """The six planes (l, r, t, b, far, near; 4 float32 each) pcl::FrustumCulling::applyFilter builds for the reference's
-    getFrustumCulledVoxels (tsdf_volume_octree.cpp:633-646) from the forward pose `trans` [PCL-recall: filters/impl/
-    frustum_culling.hpp]: camera pose = trans.cast<float>() * cam2robot (columns view, up, right, T = z, -y, x, t of the
-    pose), FOV = 1.1 x the image's, near / far = the sensor range; every operation in float where PCL's is (numpy float32
-    scalars), `tan` in double.  Host-side Eigen / PCL arithmetic restated, like eigen_affine_inverse: what the C ABI's
-    tsdf_hip_set_reference_cull expects its caller to supply."""
-    import math
-    f = np.float32
-    tr = np.asarray(trans, dtype=np.float64)
-    view = [f(tr[r, 2]) for r in range(3)]
-    up = [-f(tr[r, 1]) for r in range(3)]
-    right = [f(tr[r, 0]) for r in range(3)]
-    T = [f(tr[r, 3]) for r in range(3)]
-    hfov = f(1.1 * 2 * abs(math.atan(0.5 * p.image_width / p.fx) * 180 / math.pi))
-    vfov = f(1.1 * 2 * abs(math.atan(0.5 * p.image_height / p.fy) * 180 / math.pi))
-    np_dist, fp_dist = f(p.min_sensor_dist), f(p.max_sensor_dist)
-    vfov_rad, hfov_rad = f(float(vfov) * math.pi / 180), f(float(hfov) * math.pi / 180)
-    two = f(2)
-    with np.errstate(all="ignore"):
-        def ext(rad, dist):  # float(2 * tan(rad / 2) * dist): rad / 2 in float, tan and the products in double
-            return f(np.float64(2 * math.tan(float(f(rad / two)))) * np.float64(dist))
-        np_h, np_w, fp_h, fp_w = ext(vfov_rad, np_dist), ext(hfov_rad, np_dist), ext(vfov_rad, fp_dist), ext(hfov_rad, fp_dist)
-
-        def corner(c, su, sr, h, w):  # c +- (up * h / 2) +- (right * w / 2), left to right
-            out = []
-            for i in range(3):
-                t = f(f(up[i] * h) / two)
-                v = f(c[i] + t) if su > 0 else f(c[i] - t)
-                t = f(f(right[i] * w) / two)
-                out.append(f(v + t) if sr > 0 else f(v - t))
-            return out
-        fp_c = [f(T[i] + f(view[i] * fp_dist)) for i in range(3)]
-        np_c = [f(T[i] + f(view[i] * np_dist)) for i in range(3)]
-        fp_tl, fp_tr = corner(fp_c, 1, -1, fp_h, fp_w), corner(fp_c, 1, 1, fp_h, fp_w)
-        fp_bl, fp_br = corner(fp_c, -1, -1, fp_h, fp_w), corner(fp_c, -1, 1, fp_h, fp_w)
-        np_tr, np_bl, np_br = corner(np_c, 1, 1, np_h, np_w), corner(np_c, -1, -1, np_h, np_w), corner(np_c, -1, 1, np_h, np_w)
-
-        def sub(a, b):
-            return [f(a[i] - b[i]) for i in range(3)]
-
-        def cross(a, b):
-            return [f(f(a[1] * b[2]) - f(a[2] * b[1])), f(f(a[2] * b[0]) - f(a[0] * b[2])), f(f(a[0] * b[1]) - f(a[1] * b[0]))]
-
-        def plane(n, through):
-            return [n[0], n[1], n[2], -f(f(through[0] * n[0]) + f(f(through[1] * n[1]) + f(through[2] * n[2])))]
-        a, b, c, d = sub(fp_bl, T), sub(fp_br, T), sub(fp_tr, T), sub(fp_tl, T)
-        planes = [plane(cross(d, a), T), plane(cross(b, c), T), plane(cross(c, d), T), plane(cross(a, b), T),
-                  plane(cross(sub(fp_bl, fp_br), sub(fp_tr, fp_br)), fp_c), plane(cross(sub(np_tr, np_br), sub(np_bl, np_br)), np_c)]
-    return np.ascontiguousarray(np.array(planes, dtype=np.float32).reshape(24))
+    getFrustumCulledVoxels (tsdf_volume_octree.cpp:633-646) from the forward pose `trans`: host-side Eigen / PCL
+    arithmetic restated, like eigen_affine_inverse -- here by the library's own helper
+    (tsdf_hip_reference_cull_planes), since Python has no Eigen to do it with."""
+    tr = np.ascontiguousarray(np.asarray(trans, dtype=np.float64).reshape(4, 4))
+    planes = np.empty(24, np.float32)
+    capi.check(capi.load().tsdf_hip_reference_cull_planes(C.byref(p), tr.ctypes.data_as(C.POINTER(C.c_double)), capi.as_f32p(planes)),
+               "reference_cull_planes")
+    return planes
 
 
 def transform_points_f64(xyz, m):

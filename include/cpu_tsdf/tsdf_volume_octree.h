@@ -118,11 +118,10 @@ class TSDFVolumeOctree : public TSDFInterface {
   const std::vector<int> &getDevices() const { return devices_; }
   // The reference's integrateCloud only visits the voxels pcl::FrustumCulling keeps (getFrustumCulledVoxels,
   // src/lib/tsdf_volume_octree.cpp:619-652): 1.1 x the field of view around the optical AXIS between the sensor-range
-  // planes.  For ordinary cameras that is a superset of what updateVoxel accepts and this class skips it; for a
-  // principal point far off centre or a non-finite range it is not (tsdf_hip_reference_cull_is_noop).  With
-  // setReferenceCull(true) the cull is replicated voxel for voxel in exactly those cases -- the planes are built here
-  // with the caller's Eigen, operation by operation as pcl::FrustumCulling::applyFilter builds them -- at the price of
-  // the plain per-voxel kernel.  Default false: the conservative superset through the fast kernels.
+  // planes.  integrateCloud here does the same: the six planes are built with the caller's Eigen, operation by operation as
+  // pcl::FrustumCulling::applyFilter builds them, and handed to the library per frame (tsdf_hip_set_reference_cull), which
+  // applies them wherever they can decide a voxel (for an ordinary camera looking at a volume inside its sensor range:
+  // nowhere, at no cost).  setReferenceCull(false) opts out: every voxel updateVoxel itself accepts is integrated.
   void setReferenceCull(bool flag) { reference_cull_ = flag; }
   bool getReferenceCull() const { return reference_cull_; }
   // TSDF_LAYOUT_* (include/tsdf_hip.h): how the weight is stored in HBM; default AUTO
@@ -139,7 +138,7 @@ class TSDFVolumeOctree : public TSDFInterface {
   bool is_empty_, weight_by_depth_, weight_by_variance_;
   std::string color_mode_;
   std::vector<int> devices_;
-  bool reference_cull_ = false;
+  bool reference_cull_ = true;
   mutable bool cull_planes_set_ = false;
   bool applyReferenceCull(const Eigen::Affine3d &trans) const;
   // pinned staging for renderView's readback (tsdf_hip_host_alloc): the GPU writes it by DMA, the conversion into the

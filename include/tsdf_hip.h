@@ -295,34 +295,36 @@ int tsdf_hip_render_halo(const tsdf_params *p);
  * probed), *chosen = the one kept; returns the number of candidates tried. */
 int tsdf_hip_alloc_probe(tsdf_handle h, float ms[8], int32_t *chosen);
 
-/* 1 if the reference's frustum cull (getFrustumCulledVoxels, tsdf_volume_octree.cpp:619-652: pcl::FrustumCulling with
- * 1.1 x the field of view AROUND THE OPTICAL AXIS, near = min_sensor_dist, far = max_sensor_dist) cannot change results
- * for these parameters, i.e. the culling pyramid contains every ray of the image: then this library's voxels equal the
- * reference's.  0 if the principal point lies so far off centre (more than ~10 % of the half-width) or max_sensor_dist
- * is so large (>= 1e15, inf) that the reference drops voxels which project into the image -- this library integrates
- * them and says so once on stderr.  tests/test_oracle_golden.py shows both regimes against the compiled reference.
- * One residue remains even in the no-op regime: the cull's near and far planes restate updateVoxel's own range test
- * (min_sensor_dist <= g.z <= max_sensor_dist) in other float arithmetic, on the forward pose, inside PCL and Eigen.
- * When such a plane cuts the volume, a voxel whose g.z lies within rounding (~1e-7 relative) of it may pass one test
- * and fail the other: about one voxel per 10^7 on the plane's cross-section per frame, one observation each.  Which
- * way it falls is not determined by the reference's own sources (it changes with the PCL / Eigen build), so it is not
- * chased; the random hunts under tests/evidence/ recognise and report these voxels. */
-int tsdf_hip_reference_cull_is_noop(const tsdf_params *p);
-
-/* Replication mode for that cull (integrateCloud calls getFrustumCulledVoxels first, include/cpu_tsdf/impl/
- * tsdf_volume_octree.hpp:93-94): with planes set, every integrate call drops the voxels whose centre fails one of the six
- * plane tests `pt.dot(plane) <= 0` (pt = (x, y, z, 1), the dot reduced as (p0 + p1) + (p2 + p3), fp32, no FMA) before
- * updateVoxel's own tests -- voxel for voxel what the reference integrates, also where
- * tsdf_hip_reference_cull_is_noop() == 0 (tests/test_oracle_golden.py pins the restatement against the compiled
- * reference, tests/test_integrate_gpu.py the kernel against the restatement).
- *   planes  l, r, t, b, far, near (the order of PCL's test), 4 floats each, in the VOLUME frame: they are PCL / Eigen
+/* The reference's integrateCloud visits only the voxels pcl::FrustumCulling keeps (getFrustumCulledVoxels,
+ * tsdf_volume_octree.cpp:619-652, called at impl/tsdf_volume_octree.hpp:93-94): a pyramid of 1.1 x the field of view
+ * AROUND THE OPTICAL AXIS between near = min_sensor_dist and far = max_sensor_dist, tested per voxel centre as
+ * `pt.dot(plane) <= 0` for six planes (pt = (x, y, z, 1), the dot reduced as (p0 + p1) + (p2 + p3), fp32, no FMA).
+ * For an ordinary camera that pyramid contains every ray of the image and the cull only removes voxels updateVoxel
+ * rejects anyway; with a principal point more than ~10 % off centre, or a range plane cutting the volume, it decides
+ * voxels.  To integrate exactly the reference's voxels in EVERY regime, hand the six planes of the frame's pose to
+ * tsdf_hip_set_reference_cull before each integrate call -- cpu_tsdf::TSDFVolumeOctree::integrateCloud and the Python
+ * binding do so by default (setReferenceCull(false) opts out).
+ *   planes  l, r, t, b, far, near (the order of PCL's test), 4 floats each, in the VOLUME frame.  They are PCL / Eigen
  *           arithmetic on the forward pose `trans` (pcl::FrustumCulling::applyFilter with camera pose
- *           trans.cast<float>() * cam2robot, FOV 1.1 x the image's, near / far = the sensor range:
- *           tsdf_volume_octree.cpp:633-646), so the caller computes them -- cpu_tsdf::TSDFVolumeOctree
- *           (setReferenceCull(true)) and the Python binding do; NULL switches the mode off (default: the conservative
- *           superset, fastest kernels).
- * The planes stay in force for every later integrate call on the handle: set them per frame. */
+ *           trans.cast<float>() * cam2robot, tsdf_volume_octree.cpp:633-646), so the caller computes them: the C++
+ *           shell with the caller's Eigen, anyone else with tsdf_hip_reference_cull_planes.  NULL = no cull (the
+ *           conservative superset: every voxel updateVoxel itself accepts).
+ * Cost: none when the planes provably keep every voxel of the slab (eight corner voxels, evaluated per launch on the
+ * host: the usual case -- the launch is then the ordinary one); otherwise the frame's ROW INTERVALS carry the cull
+ * (k_rows: per voxel row the exact x range the six planes keep, found by bisection on the very float expression of the
+ * per-voxel test) and k_integrate masks by interval -- a few per cent.  Non-finite planes and the RGB_NORMALIZED / LAB
+ * kernels test the six planes per voxel.  The planes stay in force for every later integrate call on the handle: set
+ * them per frame.  tests/test_oracle_golden.py pins the restatement against the compiled reference,
+ * tests/test_index_box.py the intervals and tests/test_integrate_gpu.py the kernels against the restatement. */
 int tsdf_hip_set_reference_cull(tsdf_handle h, const float planes[24]);
+/* Host only: those six planes from the forward pose `trans` (row-major 4x4 doubles, camera -> volume, what
+ * integrateCloud is called with) and the camera of `p` [PCL-recall: filters/impl/frustum_culling.hpp]. */
+int tsdf_hip_reference_cull_planes(const tsdf_params *p, const double trans[16], float planes[24]);
+/* 1 if that cull cannot change results for ANY pose with these parameters as far as the field of view goes (the
+ * culling pyramid contains every ray of the image and max_sensor_dist is finite and moderate); 0 for a principal point
+ * so far off centre, or a range so large (>= 1e15, inf), that the reference drops voxels which project into the image.
+ * Report-only since the planes are applied per launch. */
+int tsdf_hip_reference_cull_is_noop(const tsdf_params *p);
 
 /* getFxn / getGradient / getHessian -- tsdf_volume_octree.cpp:655-828, batched.
  *   xyz n x 3 floats; val n floats (nullable); grad n x 3 (nullable); hess n x 9 row-major (nullable);
@@ -475,6 +477,12 @@ int tsdf_hip_selftest_index_box(const tsdf_params *p, const float cam_from_vol[1
  * by_rows rows of one plane); flags[(z * gy + by) * gx + bx] with gx = ceil(nx / bx_vox), gy = ceil(ny / by_rows). */
 int tsdf_hip_selftest_block_flags(const tsdf_params *p, const float cam_from_vol[12], int bx_vox, int by_rows,
                                   uint8_t *flags);
+
+/* Test hook, host only: the row intervals of a LIVE integrate launch over the whole grid -- per voxel row (y, z) the x
+ * range outside of which no voxel is integrated: words[z * res_y + y] = lo | len << 16 (an empty row has lo = 0xffff).
+ * Conservative for updateVoxel's own tests; with `planes` (the reference cull's six planes, else NULL) additionally
+ * EXACTLY the voxels pcl::FrustumCulling keeps. */
+int tsdf_hip_selftest_row_intervals(const tsdf_params *p, const float cam_from_vol[12], const float *planes, uint32_t *words);
 
 /* Test / profiling hook: one read-modify-write sweep of the owned slab's SoA planes with the integrate
  * kernel's access shape and no other work; reports the exact bytes it read and wrote.  Used to

@@ -109,3 +109,64 @@ def test_index_box_gives_up_on_degenerate_input():
     p.max_sensor_dist = 3.0
     p.fx = 0.0
     assert index_box(p, T)[0] == 2
+
+
+def row_intervals(p, T, planes=None):
+    words = np.zeros((p.res[2], p.res[1]), np.uint32)
+    capi.check(capi.load().tsdf_hip_selftest_row_intervals(C.byref(p), capi.as_f32p(T), capi.as_f32p(planes) if planes is not None else None,
+                                                           words.ctypes.data_as(C.POINTER(C.c_uint32))), "row_intervals")
+    lo, ln = (words & 0xffff).astype(np.int64), (words >> 16).astype(np.int64)
+    x = np.arange(p.res[0])[None, None, :]
+    return (x >= lo[..., None]) & (x < (lo + ln)[..., None])  # [z, y, x] mask of the voxels a LIVE launch does not mask
+
+
+def test_row_intervals_contain_every_observable_voxel_and_replicate_the_reference_cull_exactly():
+    """k_rows (cpu_tsdf_amd/csrc/tsdf_integrate.hip: row_interval, evaluated here on the host for every voxel row): (1)
+    without planes the interval of a row is a superset of what the oracle observes with an all-valid far frame; (2) with
+    the reference cull's six planes the voxels integrated -- interval AND updateVoxel's own tests -- are EXACTLY the culled
+    oracle's (tsdf_volume_octree.cpp:619-652 restated in oracle/tsdf_oracle.c, itself pinned to the compiled reference),
+    for principal points up to 40 % off centre, range planes through the volume, sheared poses, cameras inside."""
+    rng = np.random.RandomState(47)
+    cut = kept_all = bites = 0
+    for case in range(260):
+        p = capi.default_params()
+        r = int(rng.choice([16, 32])) if case % 2 else None
+        res = [r, r, r] if r else [int(v) for v in rng.choice([16, 24, 40], 3)]
+        size = [float(rng.uniform(0.5, 4.0))] * 3 if r else [float(s) for s in rng.uniform(0.5, 4.0, 3)]
+        p.res[:], p.size[:] = res, size
+        W, H = 64, 48
+        p.image_width, p.image_height = W, H
+        f = float(rng.uniform(25.0, 90.0))
+        off = 0.4 if case % 3 == 0 else 0.05
+        p.fx, p.fy = f, f * float(rng.uniform(0.8, 1.2))
+        p.cx, p.cy = W / 2 - 0.5 + float(rng.uniform(-off, off)) * W / 2, H / 2 - 0.5 + float(rng.uniform(-off, off)) * H / 2
+        p.min_sensor_dist = float(rng.choice([0.0, 0.2]))
+        p.max_sensor_dist = float(rng.uniform(0.3, 6.0))
+        p.max_dist_pos = p.max_dist_neg = 0.03
+        ext = max(size)
+        eye = rng.uniform(-1.2 * ext, 1.2 * ext, 3) * (1.0 if case % 4 else 0.3)
+        tr = synth.look_at_pose(eye, target=rng.uniform(-0.5 * ext, 0.5 * ext, 3))
+        if case % 5 == 0:
+            tr = tr.copy()
+            tr[:3, :3] = tr[:3, :3] @ (np.eye(3) + rng.uniform(-0.15, 0.15, (3, 3)))
+        T = np.ascontiguousarray(synth.cam_from_vol_f32(tr), np.float32).reshape(12)
+        far = np.full((H, W), 1.0e6, np.float32)
+        ov = OracleVolume(p)
+        ov.integrate(far, None, T)
+        seen = ov.w > 0
+        keep = row_intervals(p, T)
+        assert not (seen & ~keep).any(), (case, int((seen & ~keep).sum()))
+        cut += int((~keep).sum())
+        kept_all += int(keep.sum())
+        # (2) the culled oracle: exactly interval-with-planes AND seen
+        oc = OracleVolume(p)
+        planes = oc.reference_cull_planes(tr)
+        if not np.isfinite(planes).all():
+            continue
+        oc.integrate_culled(far, None, tr, T)
+        keep_rc = row_intervals(p, T, planes)
+        want = oc.w > 0
+        got = keep_rc & seen
+        assert np.array_equal(got, want), (case, int((got != want).sum()), int(want.sum()), int(seen.sum()))
+        bites += int(want.sum() < seen.sum())
+    assert cut > 0.3 * (cut + kept_all) and bites > 40, (cut, kept_all, bites)
