@@ -157,6 +157,8 @@ SIGNATURES = {
     "tsdf_hip_upload_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
     "tsdf_hip_selftest_expf": (C.c_int, [_f32p, C.c_size_t, _f32p]),
     "tsdf_hip_set_reference_cull": (C.c_int, [C.c_void_p, _f32p]),
+    "tsdf_hip_integrate_device2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_void_p, _f32p, _f32p,
+                                             _u64p, C.POINTER(C.c_int32)]),
     "tsdf_hip_reference_cull_planes": (C.c_int, [C.POINTER(TsdfParams), _f64p, _f32p]),
     "tsdf_hip_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),

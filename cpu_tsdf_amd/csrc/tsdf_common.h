@@ -82,6 +82,8 @@ struct tsdf_hip_volume {
   bool ref_cull = false;   // tsdf_hip_set_reference_cull: replicate getFrustumCulledVoxels with these planes
   float cull_planes[24] = {0};
   int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
+  bool pair_fused = false;  // the last tsdf_integrate_launch2 went through k_integrate2 (else two launches)
+  unsigned long long pair_first_observed = 0, pair_first_changed = 0;  // ... of its first launch when it did not
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
   bool count_ran = false;  // that launch really ran (finite pose, something observable)
   hipStream_t stream = nullptr;
@@ -141,6 +143,9 @@ tsdf_handle tsdf_multi_first(tsdf_handle h);
 // integrateCloud in two halves (tsdf_integrate.hip): queue the launch; read the counting instance's counters later.
 int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12], bool count);
 int tsdf_integrate_collect(tsdf_handle h, uint64_t *n_observed);
+int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, const float TA[12], const float *planesA,
+                           const float *dB, const uint32_t *cB, const float TB[12], const float *planesB, bool count, bool *fused);
+int tsdf_integrate_collect2(tsdf_handle h, uint64_t n_observed[2]);
 
 // Compact ray lists of the one-process multi-GPU renderView (tsdf_query.hip; all asynchronous on the slab's stream).
 #define TSDF_MAX_SLABS 64
@@ -274,6 +279,7 @@ struct TsdfTuning {
   int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
+  int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
 };
 const TsdfTuning &tsdf_tuning();
 

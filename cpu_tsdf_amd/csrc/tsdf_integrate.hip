@@ -696,6 +696,271 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two frames per sweep.  k_integrate waits for HBM with all the requests the register file lets it
+// keep in flight: half of its time is arithmetic, the other half latency it cannot cover.  When TWO frames
+// are at hand, this kernel reads a quad's voxel words once, applies frame A's observation and then frame B's to the
+// values in registers, and writes the words back once: the bytes per frame halve and there is twice the arithmetic to
+// cover each memory round trip.  updateVoxel (hpp:113-218) is applied frame by frame in order -- the second update sees
+// exactly the words the first would have stored -- so the planes are bit-identical to two k_integrate launches.
+// Restricted to what the headline runs on: PACKED layout, certified fp32 projection, BOTH poses proved ALLIN by the
+// host (every voxel of the slab in sensor range and a pixel inside the image, see k_integrate), nx a multiple of 4.
+// Anything else takes two ordinary launches (tsdf_integrate_launch2).
+struct Frame2 {
+  float m[12];        // frame B's cam_from_vol
+  unsigned bgra_off;  // ... and the byte offset of its colour image from its depth image
+};
+#ifndef TSDF_WPE_K2
+#define TSDF_WPE_K2 5
+#endif
+
+template <int ORDER, bool COLOR, bool COUNT>
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_WPE_K2, TSDF_WPE_MAX)))
+k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint32_t *__restrict__ RGB, uint8_t *__restrict__ K8,
+             const float *__restrict__ depthA, const float *__restrict__ depthB, const double *__restrict__ cam,
+             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
+             unsigned long long *__restrict__ n_obs, uint8_t *__restrict__ band) {
+  const unsigned tid = threadIdx.x;
+  __shared__ float s_rcp[256];
+  __shared__ float s_cy[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
+  reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+  s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
+  {
+    const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
+    s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
+  }
+  __syncthreads();
+  const int tx = (int)(tid & (unsigned)(a.TX - 1));
+  const int ty = (int)(tid >> a.log2TX);
+  const int xq = (int)blockIdx.x * a.TX + tx;
+  const int zl = (int)blockIdx.z;
+  const Rcp32 rneg = rcp32_prepare(a.neg);
+  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0;
+  const int row0 = (int)blockIdx.y * a.rpb * a.TY;
+  const int rows = min(a.rpb * a.TY, a.ny - row0);
+  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
+  const unsigned span = (unsigned)rows * (unsigned)a.pitch;
+  const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
+  const rsrc_t rsC = make_rsrc(COLOR ? RGB + e0 : (uint32_t *)D, COLOR ? span * 4u : 0u);
+  const rsrc_t rsK = make_rsrc(!COLOR ? K8 + e0 : (uint8_t *)D, !COLOR ? span : 0u);
+  const i4_rsrc rsFA = make_rsrc_2d(depthA, 4u, 0xffffffffu), rsFB = make_rsrc_2d(depthB, 4u, 0xffffffffu);
+  const uint32_t hinge_bits = __float_as_uint(a.pos_over_neg);
+  if (xq < a.qpr) {
+    const int x4 = xq * 4;
+    const float cz = ctrz[a.z_global0 + zl];
+    const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
+    const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+    const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;
+    const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
+    for (int r = 0; r < a.rpb; ++r) {
+      const int y = row0 + ty + r * a.TY;
+      if (y >= a.ny) break;
+      const unsigned soff = (unsigned)r * row_step;
+      const float cy = s_cy[ty + r * a.TY];
+      // ---- one frame's side of updateVoxel up to the normalised distance (hpp:143-198), for the four voxels ------
+      // returns bit j = voxel j reaches addObservation; bit 4 = one of them lies inside the truncation band
+      auto observe = [&](const float (&m)[12], const i4_rsrc &rsF, unsigned bgra_off, float (&dn)[4], uint32_t (&cs)[4]) -> unsigned {
+        float yt[3], zt[3], gzs[4];
+        int pix[4];
+        uint32_t margin[4];
+        float cxr[4] = {cxs[0], cxs[1], cxs[2], cxs[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cxr[j]));  // (keeps the x products out of loop-carried registers)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          zt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cz * m[4 * q + 2] + m[4 * q + 3] : m[4 * q + 2] * cz;
+          yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * m[4 * q + 1] + zt[q] : m[4 * q + 1] * cy;
+        }
+        auto transform = [&](int j, int q) -> float {  // pcl::transformPoint (hpp:145) in this build's summation order
+          const float px = cxr[j] * m[4 * q];
+          if (ORDER == TSDF_XFORM_PCL_SSE) return px + yt[q];
+          return ((px + yt[q]) + zt[q]) + m[4 * q + 3];
+        };
+        unsigned amb_mask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
+          gzs[j] = gz;
+          bool amb;
+          pix[j] = project_fast<true>(a, gx, gy, gz, amb, &margin[j]);
+        }
+        {
+          const uint32_t hb = __float_as_uint(a.hb_max);
+          if (!(min(min(margin[0], margin[1]), min(margin[2], margin[3])) > hb)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!(margin[j] > hb)) amb_mask |= 1u << j;
+          }
+        }
+        while (amb_mask) {  // rare: the exact fp64 projection, one voxel at a time through one copy of the code
+          const int j = __builtin_ctz(amb_mask);
+          amb_mask &= amb_mask - 1;
+          float g[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            g[q] = j == 0 ? transform(0, q) : j == 1 ? transform(1, q) : j == 2 ? transform(2, q) : transform(3, q);
+          const int pe = project_exact(a, cam, g[0], g[1], g[2]);
+          if (j == 0) pix[0] = pe;
+          if (j == 1) pix[1] = pe;
+          if (j == 2) pix[2] = pe;
+          if (j == 3) pix[3] = pe;
+        }
+        float zs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          zs[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsF, pix[j], 0, 0, TSDF_GATHER_AUX));
+          cs[j] = COLOR ? tsdf_struct_buffer_load_u32(rsF, pix[j], 0, (int)bgra_off, TSDF_GATHER_AUX) : 0u;
+        }
+        unsigned obs = 0;
+        float raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          raw[j] = zs[j] - gzs[j];                 // hpp:159
+          const bool act = raw[j] >= -a.neg;       // hpp:152, :193-196 in one compare (a NaN depth is a NaN raw)
+          dn[j] = a.pos_over_neg;                  // hpp:189-192
+          obs |= act ? 1u << j : 0u;
+          obs |= act && !(raw[j] > a.pos) ? 16u : 0u;
+        }
+        if (obs & 16u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
+        }
+        if (!a.neg_in_window) {  // truncation limits outside the scale-free divider's window: the compiler's IEEE division
+          asm volatile("");
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((obs >> j & 1u) && !(raw[j] > a.pos)) dn[j] = raw[j] / a.neg;
+        }
+        return obs;
+      };
+      float dnA[4], dnB[4];
+      uint32_t csA[4], csB[4];
+      const unsigned obsA = observe(a.m, rsFA, a.bgra_off, dnA, csA);
+      const unsigned obsB = observe(fb.m, rsFB, fb.bgra_off, dnB, csB);
+      if (!((obsA | obsB) & 15u)) continue;
+      // ---- the quad's words, once ---------------------------------------------------------------------------
+      const u4 d4 = bload128(rsD, voff, soff);
+      u4 c4 = {0u, 0u, 0u, 0u};
+      uint32_t k4 = 0u;
+      if (COLOR) c4 = bload128(rsC, voff, soff);
+      if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+      const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
+      const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
+      uint32_t du[4], kw[4];  // the state both updates work on: distance bits; colour | count << 24 (or only the count there)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        du[j] = d0u[j];
+        kw[j] = COLOR ? c0[j] : ((k4 << (24 - 8 * j)) & 0xff000000u);
+      }
+      // ---- OctreeNode / RGBNode::addObservation (octree.cpp:152-163, 328-337) of one frame on that state ----
+      auto apply = [&](unsigned obs, const float (&dn)[4], const uint32_t (&cs)[4]) {
+        if (!(obs & 15u)) return;
+        const bool any_div = (obs & 16u) != 0u;
+        float d0[4], w0[4], dv[4], wv[4];
+        uint32_t cv[4], k1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d0[j] = __uint_as_float(du[j]);
+          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);  // tsdf_decode_w
+          k1[j] = min(kw[j] & 0xff000000u, a.kcap) + a.kinc;      // min(k + 1, kmax) << 24
+        }
+        bool d_moves = true;
+        if (a.hinge_fixed) {  // free space resting at the hinge value stays there (host-checked identity): skip the d ladder
+          bool off_hinge = any_div;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) off_hinge |= du[j] != hinge_bits;
+          d_moves = __builtin_amdgcn_ballot_w64(off_hinge) != 0ull;
+        }
+        bool safe = true, d_touched = false;
+        {
+          Rcp32 rs[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dv[j] = d0[j];
+            wv[j] = w0[j];
+            cv[j] = kw[j];
+            rs[j].nb = -(w0[j] + 1.f);
+            rs[j].y = s_rcp[kw[j] >> 24];
+            add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
+          }
+          if (d_moves) {
+            d_touched = true;
+            if (any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) safe &= !(obs >> j & 1u) || __builtin_amdgcn_classf(dv[j], 0x108);
+          }
+        }
+        if (!safe) {  // a zero / subnormal / non-finite quotient: the compiler's IEEE divisions for the quad
+          asm volatile("");
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dv[j] = d0[j];
+            wv[j] = w0[j];
+            cv[j] = kw[j] & 0xffffffu;
+            add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax);
+            if (COLOR) cv[j] |= k1[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool act = (obs >> j & 1u) != 0u;
+          if (d_touched) du[j] = act ? __float_as_uint(dv[j]) : du[j];
+          kw[j] = act ? (COLOR ? cv[j] : k1[j]) : kw[j];
+        }
+      };
+      apply(obsA, dnA, csA);
+      apply(obsB, dnB, csB);
+      // ---- write back what changed ----------------------------------------------------------------------------
+      uint32_t diff_d = 0u, diff_c = 0u, k4n = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        diff_d |= du[j] ^ d0u[j];
+        if (COLOR) diff_c |= kw[j] ^ c0[j];
+        if (!COLOR) k4n |= (kw[j] & 0xff000000u) >> (24 - 8 * j);
+        cnt += ((obsA | obsB) >> j & 1u);
+        if (COUNT) cntA += (obsA >> j & 1u), cntB += (obsB >> j & 1u);
+        if (COUNT) chg += (du[j] != d0u[j] ? 4u : 0u) + (COLOR && kw[j] != c0[j] ? 4u : 0u);
+      }
+      if (COUNT && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
+                                                   ((k4n ^ k4) >> 4) | ((k4n ^ k4) >> 5) | ((k4n ^ k4) >> 6) | ((k4n ^ k4) >> 7)) & 0x01010101u);
+      if (diff_d) bstore128(rsD, voff, soff, (u4){du[0], du[1], du[2], du[3]});
+      if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){kw[0], kw[1], kw[2], kw[3]});
+      if (!COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
+    }
+  }
+  if (band) {
+    __syncthreads();
+    const int fxb = max(1, a.TX >> 4);
+    const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
+    const int xc0 = (a.x_abs0 + (int)blockIdx.x * a.TX * 4) >> 6;
+    const int n_fl = (yg1 - yg0 + 1) * fxb;
+    for (int i = (int)tid; i < n_fl; i += 256) {
+      const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+    }
+  }
+  if (COUNT) {
+    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB;
+    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    if (chg) atomicAdd(&s_chg, chg);
+    if (cntA) atomicAdd(&s_cntA, cntA);
+    if (cntB) atomicAdd(&s_cntB, cntB);
+    __syncthreads();
+    if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes (tsdf_integrate_collect2)
+      const unsigned b = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 511u;
+      if (s_cntA) atomicAdd(n_obs + b, (unsigned long long)s_cntA);
+      if (s_cntB) atomicAdd(n_obs + 512u + b, (unsigned long long)s_cntB);
+      atomicAdd(n_obs + 1024u + b, (unsigned long long)s_cnt);
+      if (s_chg) atomicAdd(n_obs + 1536u + b, (unsigned long long)s_chg);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Brick-level frustum cull -- the dense counterpart of getFrustumCulledVoxels (tsdf_volume_octree.cpp:
 // 619-652), which lets the reference skip coarse octree cells outside a 1.1x FOV frustum.  Here the unit is
 // one k_integrate block (up to 1024 voxels of x by rpb*TY rows of one plane) and the test is CONSERVATIVE:
@@ -1356,9 +1621,9 @@ static bool zlo_margin_ok(const float T[12], const tsdf_hip_volume *h) {
 // corner voxels; evaluated in double, plus a bound on what the per-voxel float evaluation (three products, three sums)
 // can add.  True for any ordinary camera looking at a volume inside its sensor range -- then the cull is a no-op for this
 // frame and the launch need not know about it.  Non-finite planes: false (the per-voxel test decides).
-static bool reference_cull_keeps_whole_slab(const tsdf_hip_volume *h) {
+static bool reference_cull_keeps_whole_slab(const tsdf_hip_volume *h, const float *planes) {
   for (int k = 0; k < 6; ++k) {
-    const float *pl = h->cull_planes + 4 * k;
+    const float *pl = planes + 4 * k;
     double worst = -1e300, mag = 0;
     for (int c = 0; c < 8; ++c) {
       const double x = h->h_ctr[0][(c & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(c & 2) ? h->ny - 1 : 0],
@@ -1382,6 +1647,26 @@ static bool row_intervals_usable(const tsdf_hip_volume *h, bool planes) {
     for (int i = 0; i < 24; ++i)
       if (!(fabsf(h->cull_planes[i]) < 1e30f)) return false;
   return true;
+}
+
+// The host's ALLIN proof: the slab's eight corner voxels inside {sensor range, image minus a border} with 1e-3 m / one
+// pixel to spare.  The set is convex, so every voxel centre lies inside in exact arithmetic, and the margins cover the
+// float transform (~1e-7 relative) and the projection's sensitivity to it while the coordinates stay moderate
+// (zlo_margin_ok, checked separately).
+static bool slab_all_inside(const tsdf_hip_volume *h, const float T[12]) {
+  const tsdf_params &p = h->p;
+  bool all_inside = true;
+  for (int k = 0; k < 8 && all_inside; ++k) {
+    const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
+                 z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
+    double g[3];
+    for (int r = 0; r < 3; ++r) g[r] = (double)T[4 * r] * x + (double)T[4 * r + 1] * y + (double)T[4 * r + 2] * z + (double)T[4 * r + 3];
+    const double u = p.fx * g[0] / g[2] + p.cx, v = p.fy * g[1] / g[2] + p.cy;
+    const double zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
+    all_inside = g[2] > zlo + 1e-3 && g[2] > 1e-3 && g[2] < p.max_sensor_dist - 1e-3 && u > 1 && u < p.image_width - 2 && v > 1 &&
+                 v < p.image_height - 2;
+  }
+  return all_inside;
 }
 
 // Asynchronous half: queues the launch on the handle's stream.  `count` selects the counting instance, whose striped
@@ -1415,7 +1700,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   // voxel of this slab (ordinary cameras: the cull is a no-op and the launch is the usual one); otherwise the fast kernel
   // applies it through the row intervals (k_rows), or -- planes that are not finite, a grid too wide for the interval
   // words, the `refcull_plain` knob -- the plain per-voxel kernel tests the six planes itself.
-  const bool rc = h->ref_cull && !reference_cull_keeps_whole_slab(h);
+  const bool rc = h->ref_cull && !reference_cull_keeps_whole_slab(h, h->cull_planes);
   const bool rc_rows = rc && !h->cn[0] && !tsdf_tuning().refcull_plain && row_intervals_usable(h, true);
   const int plain_mode = h->weight_by_depth ? 2 : h->weight_by_variance ? 4 : (rc && !rc_rows && !h->cn[0]) ? 3 : (tsdf_tuning().plain_kernel && !h->packed && !h->cn[0] ? 1 : 0);
   a.ref_cull = rc ? 1 : 0;  // (the plain kernels test the planes per voxel only when they can bite)
@@ -1537,20 +1822,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   bool allin = false;  // every voxel of the launch in sensor range and a pixel inside the image: the ALLIN instance
   bool all_inside = false;
   if (tsdf_tuning().cull) {
-    all_inside = tsdf_tuning().cull != 2;
-    for (int k = 0; k < 8 && all_inside; ++k) {
-      const double x = h->h_ctr[0][(k & 1) ? h->nx - 1 : 0], y = h->h_ctr[1][(k & 2) ? h->ny - 1 : 0],
-                   z = h->h_ctr[2][(k & 4) ? h->z_end - 1 : h->z_begin];
-      double g[3];
-      for (int r = 0; r < 3; ++r) g[r] = (double)T[4 * r] * x + (double)T[4 * r + 1] * y + (double)T[4 * r + 2] * z + (double)T[4 * r + 3];
-      const double u = p.fx * g[0] / g[2] + p.cx, v = p.fy * g[1] / g[2] + p.cy;
-      const double zlo = p.min_sensor_dist > 0 ? p.min_sensor_dist : 0;
-      all_inside = g[2] > zlo + 1e-3 && g[2] > 1e-3 && g[2] < p.max_sensor_dist - 1e-3 && u > 1 && u < p.image_width - 2 && v > 1 &&
-                   v < p.image_height - 2;
-    }
-    // The eight corner voxels lie inside the convex set {range, image minus a border}; so does every voxel centre in
-    // exact arithmetic, and the margins (1e-3 m, one pixel) cover the float transform (~1e-7 relative) and the
-    // projection's sensitivity to it as long as the coordinates stay moderate.
+    all_inside = tsdf_tuning().cull != 2 && slab_all_inside(h, T);
     allin = all_inside && !rc && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
             (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
   }
@@ -1744,6 +2016,148 @@ static int launch_integrate(tsdf_handle h, const float *d_depth, const uint32_t 
   const int rc = tsdf_integrate_launch(h, d_depth, d_bgra, T, n_observed != nullptr);
   if (rc || !n_observed) return rc;
   return tsdf_integrate_collect(h, n_observed);
+}
+
+// Two frames in one sweep (k_integrate2) when the handle and BOTH poses qualify, else two ordinary launches in order.
+// planesA / planesB: the reference cull's planes of each frame (NULL = none), as tsdf_hip_set_reference_cull takes them;
+// the handle keeps frame B's afterwards.  *fused says which way it went.  With `count`, tsdf_integrate_collect2 reads
+// the per-frame observation counts (identical to two separate launches) and the detail of the pair.
+static bool fusable_pose(tsdf_handle h, const IntegrateHost &hh, const float T[12], const float *planes) {
+  for (int i = 0; i < 12; ++i)
+    if (!(std::isfinite(T[i]) && fabsf(T[i]) <= 1e15f)) return false;
+  if (planes && !reference_cull_keeps_whole_slab(h, planes)) return false;
+  return slab_all_inside(h, T) && zlo_margin_ok(T, h) && fast_projection_ok(hh, h->p.integrate_color != 0);
+}
+
+int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, const float TA[12], const float *planesA,
+                           const float *dB, const uint32_t *cB, const float TB[12], const float *planesB, bool count, bool *fused) {
+  const tsdf_params &p = h->p;
+  const bool color = p.integrate_color != 0;
+  if (color && (!cA || !cB)) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  const IntegrateHost hh = make_args(h, TA);
+  IntegrateArgs a = hh.a;
+  const size_t npx = (size_t)p.image_width * p.image_height;
+  auto bgra_offset = [&](const float *d, const uint32_t *c, unsigned *off) {  // the colour image behind the depth image, within 2 GB
+    *off = 0;
+    if (!color) return true;
+    const char *zd = (const char *)d, *cb = (const char *)c;
+    if (!(cb >= zd + npx * 4 && (size_t)(cb - zd) + npx * 4 < (1ull << 31))) return false;
+    *off = (unsigned)(cb - zd);
+    return true;
+  };
+  Frame2 fb;
+  for (int i = 0; i < 12; ++i) fb.m[i] = TB[i];
+  const unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX), gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY)),
+                 gz = (unsigned)hh.planes;
+  const bool ok = tsdf_tuning().fuse2 && tsdf_tuning().cull == 1 && tsdf_tuning().allin && h->packed && !h->cn[0] && !h->weight_by_depth &&
+                  !h->weight_by_variance && !tsdf_tuning().plain_kernel && (h->nx & 3) == 0 && a.wmax_is_int && (float)h->kmax == p.max_weight &&
+                  gy <= 65535u && gz <= 65535u && gz > 0 && bgra_offset(dA, cA, &a.bgra_off) && bgra_offset(dB, cB, &fb.bgra_off) &&
+                  fusable_pose(h, hh, TA, planesA) && fusable_pose(h, hh, TB, planesB);
+  if (fused) *fused = ok;
+  if (!ok) {  // two launches, each with its own planes; with `count` the first one's counters are read before the second runs
+    int rc = tsdf_hip_set_reference_cull(h, planesA);
+    if (!rc) rc = tsdf_integrate_launch(h, dA, cA, TA, count);
+    if (!rc && count) {
+      uint64_t n = 0;
+      rc = tsdf_integrate_collect(h, &n);
+      h->pair_first_observed = n, h->pair_first_changed = h->last_changed_bytes;
+    }
+    if (!rc) rc = tsdf_hip_set_reference_cull(h, planesB);
+    if (!rc) rc = tsdf_integrate_launch(h, dB, cB, TB, count);
+    h->pair_fused = false;
+    return rc;
+  }
+  h->ref_cull = planesB != nullptr;
+  for (int i = 0; i < 24; ++i) h->cull_planes[i] = planesB ? planesB[i] : 0.f;
+  h->count_slots = 0;
+  h->count_ran = false;
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
+  uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 ? h->band : nullptr;
+  if (!band_arg) h->band_exact = false;
+  h->last_launch[0] = 2, h->last_launch[1] = 1, h->last_launch[2] = 0;
+  h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
+  const dim3 grid(gx, gy, gz), block(256);
+#define LAUNCH2(ORDER, COLOR, COUNT)                                                                                    \
+  hipLaunchKernelGGL((k_integrate2<ORDER, COLOR, COUNT>), grid, block, 0, h->stream, a, fb, h->d, h->rgb, h->k8, dA, dB, \
+                     h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter, band_arg)
+#define L2B(ORDER, COLOR)         \
+  do {                            \
+    if (count)                    \
+      LAUNCH2(ORDER, COLOR, true);  \
+    else                          \
+      LAUNCH2(ORDER, COLOR, false); \
+  } while (0)
+  if (p.xform_order == TSDF_XFORM_PCL_SSE) {
+    if (color)
+      L2B(TSDF_XFORM_PCL_SSE, true);
+    else
+      L2B(TSDF_XFORM_PCL_SSE, false);
+  } else {
+    if (color)
+      L2B(TSDF_XFORM_LEFT_TO_RIGHT, true);
+    else
+      L2B(TSDF_XFORM_LEFT_TO_RIGHT, false);
+  }
+#undef L2B
+#undef LAUNCH2
+  TSDF_HIP_TRY(hipGetLastError());
+  h->count_slots = count ? 2048 : 0;
+  h->count_ran = true;
+  h->pair_fused = true;
+  return TSDF_HIP_OK;
+}
+
+// Counters of the last tsdf_integrate_launch2(count = true): n_observed[0 / 1] = voxels frame A / B brought to
+// addObservation (what two separate launches report); the handle's last_count_detail becomes the PAIR's: voxels
+// observed by at least one of the two frames, bytes of voxel words whose value changed over the pair.
+int tsdf_integrate_collect2(tsdf_handle h, uint64_t n_observed[2]) {
+  if (!h->pair_fused) {  // two launches: the second one's counters are still pending
+    uint64_t nb = 0;
+    const int rc = tsdf_integrate_collect(h, &nb);
+    if (rc) return rc;
+    n_observed[0] = h->pair_first_observed, n_observed[1] = nb;
+    h->last_observed = h->pair_first_observed + nb;  // (an upper bound of the union; the words were read twice anyway)
+    h->last_changed_bytes += h->pair_first_changed;
+    return TSDF_HIP_OK;
+  }
+  if (!h->count_slots) {
+    tsdf_set_error("tsdf_integrate_collect2 without a counting launch");
+    return TSDF_HIP_E_INVALID;
+  }
+  unsigned long long c[2048];
+  TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned long long sum[4] = {0, 0, 0, 0};  // A, B, union, changed bytes: 512 striped slots each
+  for (int i = 0; i < 2048; ++i) sum[i >> 9] += c[i];
+  n_observed[0] = sum[0], n_observed[1] = sum[1];
+  h->last_observed = sum[2];
+  h->last_changed_bytes = sum[3];
+  h->count_slots = 0;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a, const uint32_t *d_bgra_a, const float cam_from_vol_a[12],
+                                          const float *planes_a, const float *d_depth_b, const uint32_t *d_bgra_b,
+                                          const float cam_from_vol_b[12], const float *planes_b, uint64_t *n_observed, int32_t *fused) {
+  if (!h || !d_depth_a || !d_depth_b || !cam_from_vol_a || !cam_from_vol_b) return TSDF_HIP_E_INVALID;
+  if (fused) *fused = 0;
+  if (h->multi) {  // a multi-GPU set: frame by frame (every slab integrates its own planes; no pairing yet)
+    int rc = tsdf_hip_set_reference_cull(h, planes_a);
+    if (!rc) rc = tsdf_multi_integrate_device(h, d_depth_a, d_bgra_a, cam_from_vol_a, n_observed);
+    if (!rc) rc = tsdf_hip_set_reference_cull(h, planes_b);
+    if (!rc) rc = tsdf_multi_integrate_device(h, d_depth_b, d_bgra_b, cam_from_vol_b, n_observed ? n_observed + 1 : nullptr);
+    return rc;
+  }
+  TSDF_ON_DEVICE(h->device);
+  bool f = false;
+  const int rc = tsdf_integrate_launch2(h, d_depth_a, d_bgra_a, cam_from_vol_a, planes_a, d_depth_b, d_bgra_b, cam_from_vol_b, planes_b,
+                                        n_observed != nullptr, &f);
+  if (fused) *fused = f ? 1 : 0;
+  if (rc || !n_observed) return rc;
+  return tsdf_integrate_collect2(h, n_observed);
 }
 
 // The measured side of the roofline's algorithmic bytes (bench.py): of the last integrate call that asked for

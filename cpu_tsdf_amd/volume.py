@@ -247,6 +247,28 @@ class TSDFVolumeOctree:
         self._is_empty = False
         return int(n.value) if count else True
 
+    def integrateCloudDevice2(self, frame_a, frame_b, count=False):
+        """Two frames in one call (tsdf_hip_integrate_device2): each frame = (depth_ptr, bgra_ptr, trans), device pointers
+        with the colour image behind the depth image in one allocation.  The voxels are those of two integrateCloudDevice
+        calls in this order; where both poses see the whole slab one kernel sweep does both.  Returns (fused, counts):
+        counts = the two frames' observed voxels when `count`, else None."""
+        h = self._need()
+        args = []
+        for dp, cp, trans in (frame_a, frame_b):
+            trans = np.asarray(trans, dtype=np.float64)
+            planes = reference_cull_planes(self._p, trans) if getattr(self, "_reference_cull", True) else None
+            args.append((C.c_void_p(dp), C.c_void_p(cp) if cp else None, np.ascontiguousarray(cam_from_vol_f32(trans).reshape(12)), planes))
+        n = (C.c_uint64 * 2)()
+        fused = C.c_int32(0)
+        (da, ca, ta, pa), (db, cb, tb, pb) = args
+        capi.check(capi.load().tsdf_hip_integrate_device2(
+            h, da, ca, capi.as_f32p(ta), capi.as_f32p(pa) if pa is not None else None,
+            db, cb, capi.as_f32p(tb), capi.as_f32p(pb) if pb is not None else None,
+            n if count else None, C.byref(fused)), "integrate_device2")
+        self._cull_set = args[1][3] is not None
+        self._is_empty = False
+        return bool(fused.value), ([int(n[0]), int(n[1])] if count else None)
+
     def organize(self, xyz, bgra=None, cloud_units=1.0, zero_nans=False, world_to_cam=None, fetch=True):
         """The `integrate` program's per-cloud preparation (src/prog/integrate.cpp:559-618) on the GPU: scale,
         (0,0,0) -> NaN, optional world -> camera transform (4x4 = poses[i].inverse()), z-buffer reprojection

@@ -317,6 +317,20 @@ int tsdf_hip_alloc_probe(tsdf_handle h, float ms[8], int32_t *chosen);
  * them per frame.  tests/test_oracle_golden.py pins the restatement against the compiled reference,
  * tests/test_index_box.py the intervals and tests/test_integrate_gpu.py the kernels against the restatement. */
 int tsdf_hip_set_reference_cull(tsdf_handle h, const float planes[24]);
+/* Two frames in one sweep (not in the reference; its integrateCloud takes one cloud).  Integrates frame A, then frame B
+ * -- the same voxels, bit for bit, as two tsdf_hip_integrate_device calls in that order -- but where the handle and both
+ * poses allow it (PACKED layout, nx a multiple of 4, every voxel of the slab inside the sensor range and the image for
+ * BOTH poses: the camera-outside-the-volume case; the cull planes keeping the whole slab) one kernel reads each voxel's
+ * words once, applies updateVoxel for A and then for B in registers and writes them back once: half the HBM bytes per
+ * frame (k_integrate2).  Otherwise it IS two launches.  planes_a / planes_b: as
+ * tsdf_hip_set_reference_cull (NULL = none); the handle keeps frame B's.  n_observed (nullable, 2 values): per frame, as
+ * the single call reports; tsdf_hip_last_count_detail then describes the pair.  *fused (nullable): 1 if one sweep did
+ * it.  Each frame's colour image must lie behind its depth image in one allocation (as tsdf_hip_integrate_device
+ * prefers); device pointers, asynchronous unless n_observed. */
+int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a, const uint32_t *d_bgra_a, const float cam_from_vol_a[12],
+                               const float *planes_a, const float *d_depth_b, const uint32_t *d_bgra_b,
+                               const float cam_from_vol_b[12], const float *planes_b, uint64_t *n_observed, int32_t *fused);
+
 /* Host only: those six planes from the forward pose `trans` (row-major 4x4 doubles, camera -> volume, what
  * integrateCloud is called with) and the camera of `p` [PCL-recall: filters/impl/frustum_culling.hpp]. */
 int tsdf_hip_reference_cull_planes(const tsdf_params *p, const double trans[16], float planes[24]);

@@ -1,0 +1,162 @@
+"""GPU tier: two frames per sweep (tsdf_hip_integrate_device2 -> k_integrate2, cpu_tsdf_amd/csrc/tsdf_integrate.hip).
+
+The pair entry point must leave exactly the voxels of two integrateCloud calls in order -- updateVoxel applied frame by
+frame (include/cpu_tsdf/impl/tsdf_volume_octree.hpp:113-218, addObservation src/lib/octree.cpp:152-163, 328-337) -- whether
+one kernel sweep did both frames (both poses see the whole slab: the turntable) or it fell back to two launches.  Checked
+against the CPU oracle bit for bit, counts per frame included, through weight saturation, with NaN holes and noise, and
+against the band flags' consumer (marching cubes)."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_tsdf_amd import capi, synth
+from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree
+from oracle.oracle import OracleVolume
+from tests.common import assert_same_f32, frames, make_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def device_frame(dep, col):
+    """[depth | bgra] in one allocation, as tsdf_hip_integrate_device2 wants it."""
+    H, W = dep.shape
+    t = torch.empty((2, H, W), dtype=torch.float32, device="cuda")
+    t[0].copy_(torch.from_numpy(dep))
+    if col is not None:
+        t[1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(col))
+    return t
+
+
+def launch_info(vol):
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    capi.check(capi.load().tsdf_hip_last_launch_info(vol._need(), out), "last_launch_info")
+    return list(out)
+
+
+def run_pairs(vol, sc, n_pairs, color, total, expect_fused, count_every=2, poses=None):
+    ov = OracleVolume(vol._p)
+    keep = []
+    fr = list(frames(sc, 2 * n_pairs, total, noise=True))
+    for k in range(n_pairs):
+        pair = []
+        want = []
+        for i, tr, dep, col in fr[2 * k:2 * k + 2]:
+            if poses is not None:
+                tr = poses[i]
+                dep = sc.depth(tr, noise_seed=99 + i)
+            dep = dep.copy()
+            dep[(i * 7) % 50::53, ::3] = np.nan
+            c = col if color else None
+            t = device_frame(dep, c)
+            keep.append(t)
+            pair.append((t[0].data_ptr(), t[1].data_ptr() if color else 0, tr))
+            want.append(ov.integrate_culled(dep, c, tr, synth.cam_from_vol_f32(tr)))
+        fused, counts = vol.integrateCloudDevice2(pair[0], pair[1], count=(k % count_every == 0))
+        assert fused == expect_fused, (k, fused, launch_info(vol))
+        if counts is not None:
+            assert counts == want, (k, counts, want)
+    vol.synchronize()
+    return ov
+
+
+def compare(vol, ov):
+    d, w, rgb = vol.download()
+    assert_same_f32(d, ov.d, "d")
+    assert_same_f32(w, ov.w, "w")
+    if ov.rgb is not None:
+        assert np.array_equal(rgb, ov.rgb)
+    return d, w, rgb
+
+
+@pytest.mark.parametrize("color,wmax,order", [(True, 100.0, 0), (False, 100.0, 0), (True, 3.0, 1), (False, 2.0, 1), (True, 255.0, 0)])
+def test_two_frames_per_sweep_equal_two_integrate_calls_and_the_oracle(gpu, color, wmax, order):
+    vol, sc = make_volume(96, color=color, max_weight=wmax, order=order)
+    vol.reset()
+    assert vol.getLayout() == capi.LAYOUT_PACKED
+    ov = run_pairs(vol, sc, 5, color, total=11, expect_fused=True)
+    assert launch_info(vol)[0] == 2
+    d, w, _ = compare(vol, ov)
+    assert (w > 0).mean() > 0.5 and (np.abs(d) < 1).sum() > 1000 and w.max() == min(wmax, 10.0)
+    # the band flags k_integrate2 kept feed marching cubes' skip: the mesh equals the oracle's
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(vol)
+    mc.setMinWeight(0.0)
+    mc.setColorByRGB(color)
+    mesh = mc.reconstruct()
+    verts, cols = ov.march(0.0, 1 if color else 0)[:2]
+    assert len(verts) > 3000
+    assert_same_f32(mesh["vertices"], verts, "mesh after fused integration")
+    if color:
+        assert np.array_equal(mesh["rgb"], cols)
+    vol.close()
+
+
+def test_pairs_that_do_not_qualify_take_two_launches_with_the_same_result(gpu):
+    """One pose of the pair inside the volume; the F32W layout; nx not a multiple of 4; the knob off: no fused sweep, same
+    voxels, same per-frame counts."""
+    cases = []
+    vol, sc = make_volume(64, color=True)
+    inside = [synth.turntable_pose(0, 8, sc.size), synth.look_at_pose((0.01, 0.0, -0.02), target=(0.0, 0.0, 1.0)),
+              synth.turntable_pose(2, 8, sc.size), synth.turntable_pose(3, 8, sc.size)]
+    cases.append(("a camera inside", vol, sc, inside, None, [False, True]))
+    vol, sc = make_volume(64, color=True)
+    vol.setLayout(capi.LAYOUT_F32W)
+    cases.append(("F32W", vol, sc, None, None, [False, False]))
+    vol, sc = make_volume(64, color=False, res3=(66, 64, 64))
+    cases.append(("nx % 4", vol, sc, None, None, [False, False]))
+    vol, sc = make_volume(64, color=True)
+    cases.append(("knob off", vol, sc, None, ("fuse2", 0), [False, False]))
+    for name, vol, sc, poses, knob, expect in cases:
+        try:
+            if knob:
+                capi.set_tuning(*knob)
+            vol.reset()
+            ov = OracleVolume(vol._p)
+            color = bool(vol._p.integrate_color)
+            keep = []
+            for k in range(2):
+                pair, want = [], []
+                for i in (2 * k, 2 * k + 1):
+                    tr = poses[i] if poses else synth.turntable_pose(i, 8, sc.size)
+                    dep, col = sc.depth(tr, noise_seed=5 + i), sc.bgra(i) if color else None
+                    t = device_frame(dep, col)
+                    keep.append(t)
+                    pair.append((t[0].data_ptr(), t[1].data_ptr() if color else 0, tr))
+                    want.append(ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr)))
+                fused, counts = vol.integrateCloudDevice2(pair[0], pair[1], count=True)
+                assert fused == expect[k], (name, k, fused)
+                assert counts == want, (name, k, counts, want)
+            compare(vol, ov)
+            vol.close()
+        finally:
+            if knob:
+                capi.set_tuning(knob[0], 1)
+
+
+def test_fused_sweep_on_a_z_slab_and_a_wide_grid(gpu):
+    """A Z-slab handle (planes 5..29 of 64) on a grid several blocks wide: pointers and tables offset as in the
+    single-frame launch."""
+    vol, sc = make_volume(64, 160, 120, color=True, res3=(1280, 48, 64), size3=(5.0, 0.1875, 0.25), zmax=20.0)
+    vol.setZSlab(5, 29)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    keep = []
+    rng = np.random.RandomState(3)
+    for k in range(2):
+        pair = []
+        for i in (2 * k, 2 * k + 1):
+            tr = synth.look_at_pose((0.3 * i - 0.4, 0.05 * i, -6.5), target=(0.0, 0.0, 0.0))
+            dep = rng.uniform(6.3, 6.7, (120, 160)).astype(np.float32)
+            col = rng.randint(0, 256, (120, 160, 4)).astype(np.uint8)
+            t = device_frame(dep, col)
+            keep.append(t)
+            pair.append((t[0].data_ptr(), t[1].data_ptr(), tr))
+            ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr), 5, 29)
+        fused, _ = vol.integrateCloudDevice2(pair[0], pair[1])
+        assert fused, launch_info(vol)
+    d, w, rgb = vol.download(z0=5, nz=24)
+    assert_same_f32(d, ov.d[5:29], "d")
+    assert np.array_equal(w, ov.w[5:29]) and np.array_equal(rgb, ov.rgb[5:29])
+    assert (w > 0).mean() > 0.5
+    vol.close()

@@ -288,7 +288,7 @@ def test_brick_cull_is_conservative_camera_inside_volume(gpu):
                 n = vol.integrateCloud(dep, col, tr, count=True)
                 tot += n
                 if ov is not None:
-                    assert n == ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+                    assert n == ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
             d, w, rgb = vol.download()
             if ov is not None:
                 assert_same_f32(d, ov.d, "d")
@@ -460,7 +460,7 @@ def test_integrate_fuzz_equals_the_oracle(gpu):
             dep[(junk >= 0.10) & (junk < 0.11)] = 3.0e38
             col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
             n_gpu = vol.integrateCloud(dep, col if color else None, tr, count=True)
-            n_cpu = ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+            n_cpu = ov.integrate_culled(dep, col if color else None, tr, synth.cam_from_vol_f32(tr))
             assert n_gpu == n_cpu, (case, i, n_gpu, n_cpu)
         d, w, rgb = vol.download()
         assert_same_f32(d, ov.d, f"case {case}: d")
@@ -531,7 +531,7 @@ def test_all_inside_instance_is_not_chosen_when_a_voxel_may_leave_the_image_or_t
         vol.reset()
         ov = OracleVolume(vol._p)
         dep = sc.depth(tr)
-        assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate(dep, None, synth.cam_from_vol_f32(tr)), name
+        assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate_culled(dep, None, tr, synth.cam_from_vol_f32(tr)), name
         assert launch_info(vol)[0] == want, (name, launch_info(vol))
         compare(vol, ov)
         vol.close()
@@ -589,6 +589,75 @@ def test_reference_cull_replication_mode(gpu, color, layout):
             ref.close()
         for v in vols.values():
             v.close()
+
+
+@pytest.mark.parametrize("color,layout,res3", [(True, capi.LAYOUT_AUTO, (64, 64, 64)), (False, capi.LAYOUT_AUTO, (70, 45, 33)),
+                                               (True, capi.LAYOUT_F32W, (32, 32, 32)), (False, capi.LAYOUT_F32W, (384, 40, 24))])
+def test_default_path_is_the_reference_cull_through_the_row_intervals(gpu, color, layout, res3):
+    """a caller who never heard of setReferenceCull gets the reference's voxels where its frustum cull
+    decides them (tsdf_volume_octree.cpp:619-652, hpp:93-94) -- principal point up to 40 % off centre, a far plane through
+    the volume, cameras inside, sheared poses -- AND through the fast kernel: the LIVE instance of k_integrate masked by
+    k_rows' row intervals (last_launch_info[2] == 2), bit-identical to the plain per-voxel kernel applying the six planes
+    itself (knob refcull_plain) and to the culled oracle; counts included; a centred camera that sees the whole volume
+    keeps the ALLIN instance although the planes are set."""
+    rng = np.random.RandomState(hash((color, layout, res3)) % 1000)
+    W, H = 64, 48
+    size = 1.0
+    outs = {}
+    try:
+        for plain in (0, 1):
+            capi.set_tuning("refcull_plain", plain)
+            rng = np.random.RandomState(77)
+            seen_modes = set()
+            for case in range(6):
+                f = float(rng.uniform(40.0, 110.0))
+                cx = W / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * W / 2 * (case % 3 != 2)
+                cy = H / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * H / 2 * (case % 3 == 1)
+                zmax = float(rng.choice([0.9, 3.0]))
+                cubic = res3[0] == res3[1] == res3[2]
+                vol, _ = make_volume(res3[0], W, H, color=color, size=size, zmin=float(rng.choice([0.0, 0.1])), zmax=zmax,
+                                     max_weight=float(rng.choice([100.0, 2.0])), res3=res3,
+                                     size3=None if cubic else (size * res3[0] / 64, size * res3[1] / 64, size * res3[2] / 64))
+                vol.setCameraIntrinsics(f, f * float(rng.uniform(0.9, 1.1)), cx, cy)
+                vol.setLayout(layout)
+                vol.reset()
+                oc = OracleVolume(vol._p)
+                ext = max(vol.getGridSize())
+                for i in range(5):
+                    eye = rng.uniform(-1.5, 1.5, 3) * ext * (1.0 if i % 2 else 0.25)
+                    tr = synth.look_at_pose(eye, target=rng.uniform(-0.3, 0.3, 3) * ext)
+                    if i == 3:
+                        tr = tr.copy()
+                        tr[:3, :3] = tr[:3, :3] @ (np.eye(3) + rng.uniform(-0.15, 0.15, (3, 3)))
+                    dep = (rng.uniform(0.2, 2.5, (H, W)) * ext).astype(np.float32)
+                    dep[rng.rand(H, W) < 0.05] = np.nan
+                    col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
+                    c = col if color else None
+                    want = oc.integrate_culled(dep, c, tr, synth.cam_from_vol_f32(tr))
+                    got = vol.integrateCloud(dep, c, tr, count=(i % 2 == 0))
+                    assert got is True or got == want, (case, i, got, want)
+                    seen_modes.add(launch_info(vol)[2] if not plain else -1)
+                compare(vol, oc)
+                outs.setdefault(case, []).append(vol.download())
+                vol.close()
+            if not plain:
+                assert 2 in seen_modes, seen_modes  # the row intervals carried the cull at least once
+    finally:
+        capi.set_tuning("refcull_plain", 0)
+    for case, (a, b) in outs.items():
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), case
+    # the headline shape: planes set (default), camera outside, whole volume in view and in range -> ALLIN, no flags
+    vol, sc = make_volume(64, color=color)
+    vol.setLayout(layout)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    for i, tr, dep, col in frames(sc, 3, 8):
+        c = col if color else None
+        assert vol.integrateCloud(dep, c, tr, count=True) == ov.integrate_culled(dep, c, tr, synth.cam_from_vol_f32(tr))
+        assert launch_info(vol)[0] == 1 and launch_info(vol)[2] == 0, launch_info(vol)
+    compare(vol, ov)
+    vol.close()
 
 
 @pytest.mark.parametrize("color,layout", [(True, capi.LAYOUT_PACKED), (False, capi.LAYOUT_PACKED), (True, capi.LAYOUT_F32W)])
