@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--host", choices=["process", "inprocess"], default="process",
                     help="N>1: one process per GPU over RCCL (default) or ONE process driving all GPUs through tsdf_hip_create_multi")
     ap.add_argument("--host-path", type=int, default=1, help="N=1: also time the host-pointer entry point (report-only side field)")
+    ap.add_argument("--principal-offset", type=float, default=0.0, help="evidence runs: move the principal point by this fraction "
+                    "of the half-width and yaw every turntable camera so that the grid's centre still projects to the image "
+                    "centre -- the regime where the reference's frustum cull (1.1 x FOV about the optical AXIS) decides voxels "
+                    "and the launch carries it in row intervals.  Not the headline configuration: the line says so")
     ap.add_argument("--calib", type=int, default=0, help="run this many k_calib_rmw sweeps of exactly known bytes first "
                     "(PMC passes: calibrates FETCH_SIZE / WRITE_SIZE in the same process)")
     a = ap.parse_args()
@@ -222,7 +226,11 @@ def scene_b_leg(res, color, cpu_seconds):
             frame[i, 1].view(torch.uint8).view(sc.height, sc.width, 4).copy_(torch.from_numpy(sc.bgra(i)))
         lib, h = capi.load(), v._need()
 
+        from cpu_tsdf_amd.volume import reference_cull_planes
+        planes = [reference_cull_planes(v._p, p) for p in poses]  # the shells' default: the reference's cull, per frame
+
         def run(i, count=None):
+            capi.check(lib.tsdf_hip_set_reference_cull(h, capi.as_f32p(planes[i])), "set_reference_cull")
             capi.check(lib.tsdf_hip_integrate_device(h, C.c_void_p(frame[i, 0].data_ptr()),
                                                      C.c_void_p(frame[i, 1].data_ptr()) if color else None,
                                                      capi.as_f32p(synth.cam_from_vol_f32(poses[i])), count), "scene_b")
@@ -236,8 +244,19 @@ def scene_b_leg(res, color, cpu_seconds):
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / nf
+        info = (C.c_int32 * 4)()
+        capi.check(lib.tsdf_hip_last_launch_info(h, info), "last_launch_info")
+        detail = (C.c_uint64 * 2)()
+        run(nf // 2, C.byref(c))
+        capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+        packed = v.getLayout() == capi.LAYOUT_PACKED
+        read_bpv = ((8 if color else 5) if packed else (12 if color else 8))
+        alg = read_bpv * int(detail[0]) + int(detail[1]) + (8 if color else 4) * sc.width * sc.height
         out.update({"grid": [res] * 3, "size_m": 10.0, "sensor_range_m": [0.0, 3.0], "observed_voxels_per_frame": int(c.value),
-                    "gpu_ms_per_frame": ms, "gpu_frames_per_s": 1e3 / ms})
+                    "gpu_ms_per_frame": ms, "gpu_frames_per_s": 1e3 / ms,
+                    "launch": {"row_intervals": int(info[2]), "reference_cull_in_intervals": bool(info[2] == 2), "blocks": int(info[3])},
+                    "algorithmic_bytes_per_frame": alg, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "ms per frame = rows + flags + k_integrate (HIP events around 12 frames); algorithmic bytes as in roofline"})
         v.close()
         if cpu_seconds > 0:
             from oracle import refbind
@@ -255,6 +274,52 @@ def scene_b_leg(res, color, cpu_seconds):
     except Exception as e:
         out["error"] = repr(e)
     return out
+
+
+def fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, packed):
+    """extras.fused2: frames [warmup, warmup + steps) integrated two per kernel sweep (k_integrate2).  ms per FRAME from
+    one HIP event pair around all launches; algorithmic bytes per LAUNCH from the counting instance of the same kernel
+    (voxel words a voxel observed by either frame must read, once + words whose value changed over the pair + two
+    frames)."""
+    import torch
+    from cpu_tsdf_amd import capi
+    first, n_pairs = args.warmup, args.steps // 2
+
+    def pair(k, count=None, fused=None):
+        i, j = first + 2 * k, first + 2 * k + 1
+        fa, fb = frames_dev[i], frames_dev[j]
+        capi.check(lib.tsdf_hip_integrate_device2(
+            h, C.c_void_p(fa[0].data_ptr()), C.c_void_p(fa[1].data_ptr()) if args.color else None, capi.as_f32p(T_all[i]),
+            capi.as_f32p(planes_all[i]),
+            C.c_void_p(fb[0].data_ptr()), C.c_void_p(fb[1].data_ptr()) if args.color else None, capi.as_f32p(T_all[j]),
+            capi.as_f32p(planes_all[j]), count, fused), "integrate_device2")
+    was = C.c_int32(0)
+    pair(0, None, C.byref(was))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for k in range(n_pairs):
+        pair(k)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms_launch = e0.elapsed_time(e1) / n_pairs
+    detail, n2 = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+    obs = chg = per_frame = 0
+    for k in range(n_pairs):
+        pair(k, n2)
+        capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+        obs, chg, per_frame = obs + int(detail[0]), chg + int(detail[1]), per_frame + int(n2[0]) + int(n2[1])
+    obs, chg = obs / n_pairs, chg / n_pairs
+    read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))
+    alg = read_bpv * obs + chg + 2 * (8 if args.color else 4) * W * H
+    return {"one_sweep_per_pair": bool(was.value), "pairs_timed": n_pairs, "ms_per_launch": ms_launch, "ms_per_frame": ms_launch / 2,
+            "frames_per_s": 2e3 / ms_launch, "kernel": "k_integrate2" if was.value else "k_integrate x 2",
+            "algorithmic_bytes_per_launch": alg, "voxels_observed_by_either_frame": obs,
+            "voxels_observed_per_frame": per_frame / (2 * n_pairs), "changed_word_bytes_per_launch": chg,
+            "achieved_GBps": alg / (ms_launch * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "report-only: tsdf_hip_integrate_device2 reads and writes each voxel word once per PAIR of frames; the planes "
+                    "are bit-identical to frame-by-frame integration (tests/test_fused2_gpu.py); the headline `value` is the "
+                    "single-frame kernel"}
 
 
 def host_path_leg(vol, sc, poses, color, first, last):
@@ -378,6 +443,8 @@ def main():
     if res3[2] != res3[0]:
         sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
 
+    if args.principal_offset:
+        sc.cx += args.principal_offset * (W / 2)
     vol = TSDFVolumeOctree()
     vol.setResolution(*res3)
     vol.setGridSize(*size3)
@@ -417,7 +484,16 @@ def main():
     n_distinct = args.frames or n_total
     radius = 2.2 * max(size3) / S
     poses = [synth.turntable_pose(i, n_distinct, S, radius_factor=radius) for i in range(n_total)]
+    if args.principal_offset:
+        psi = float(np.arctan(args.principal_offset * (W / 2) / sc.fx))
+        yaw = np.eye(4)
+        yaw[0, 0], yaw[0, 2], yaw[2, 0], yaw[2, 2] = np.cos(psi), np.sin(psi), -np.sin(psi), np.cos(psi)  # about the camera's y
+        poses = [p @ yaw for p in poses]
     T_all = [synth.cam_from_vol_f32(p) for p in poses]
+    # what cpu_tsdf::TSDFVolumeOctree::integrateCloud hands over per frame besides the pose: the six planes of the
+    # reference's frustum cull (tsdf_hip_set_reference_cull; for this workload they keep every voxel: checked per launch)
+    from cpu_tsdf_amd.volume import reference_cull_planes
+    planes_all = [reference_cull_planes(vol._p, p) for p in poses]
     # one allocation per frame: [depth | bgra] back to back, which is what the kernel's single frame
     # descriptor wants (no staging copy) and what ONE broadcast per frame can carry
     fplanes = 2 if args.color else 1
@@ -444,6 +520,7 @@ def main():
         if timed:
             pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
             pairs[-1][0].record(stream)
+        capi.check(lib.tsdf_hip_set_reference_cull(h, capi.as_f32p(planes_all[i])), "set_reference_cull")
         rc = lib.tsdf_hip_integrate_device(h, C.c_void_p(fr[0].data_ptr()), C.c_void_p(fr[1].data_ptr()) if args.color else None,
                                            capi.as_f32p(T_all[i]), count)
         capi.check(rc, "integrate_device")
@@ -490,6 +567,10 @@ def main():
     # average launch duration of the dominant kernel: HIP events on the kernel's stream around each launch (at
     # N > 1 this leaves the frame broadcast out of the kernel's roofline; `value` keeps it, via the wall clock)
     kern_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
+    info4 = (C.c_int32 * 4)()
+    capi.check(lib.tsdf_hip_last_launch_info(h, info4), "last_launch_info")
+    last_info = {"instance": {0: "general", 1: "ALLIN", 2: "k_integrate2"}.get(int(info4[0]), "?") + (" + row intervals" if info4[2] else ""),
+                 "certified_fp32_projection": bool(info4[1]), "reference_cull_decides_voxels": bool(info4[2] == 2), "blocks": int(info4[3])}
 
     # Algorithmic bytes of the timed frames, counted outside the timed region by running the same frames once more
     # through the counting instance: observed voxels (state-independent: pose + depth only) and the bytes of voxel
@@ -501,6 +582,15 @@ def main():
     n_obs_rank = sum(c[0] for c in counted) / args.steps
     chg_rank = sum(c[1] for c in counted) / args.steps
     chg_per_obs = chg_rank / n_obs_rank if n_obs_rank else 0.0
+
+    # Two frames per sweep (tsdf_hip_integrate_device2 -> k_integrate2), report-only side field: the same timed frames
+    # once more, in pairs.  Its own event pair around the whole region, its own algorithmic bytes per launch.
+    fused2 = None
+    if world == 1 and not use_dist and args.extras and args.steps >= 2:
+        try:
+            fused2 = fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, vol.getLayout() == capi.LAYOUT_PACKED)
+        except Exception as e:  # never let a report-only leg break the bench line
+            fused2 = {"error": repr(e)}
 
     # isolated cost of one frame broadcast (report only)
     bcast_ms = None
@@ -559,6 +649,8 @@ def main():
                             f"resident in HBM (BASELINE configs[{args.config}] integrate leg)" +
                             (f", Z-slab {z_end - z_begin} planes/GPU, one RCCL frame broadcast per step"
                              + (" overlapped with the previous kernel" if args.overlap else "") if use_dist else ""),
+                "principal_offset": args.principal_offset or None,
+                "last_launch": last_info,
                 "grid": list(res3), "image": [W, H], "color": bool(args.color),
                 "layout": "packed" if packed else "f32w",
                 "observed_voxels_per_frame": n_obs_all,
@@ -569,18 +661,25 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                "traffic_measured_in_this_run": False,  # PMC counters need rocprofv3 around the process: `traffic` is quoted from
+                                                        # the committed profile of this same command (tools/run_rocprof.sh), below
+                "survey_8d_frac": (ref_bpv * n_obs_rank + bpp * W * H) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "kernel": "k_integrate", "kernel_ms": kern_ms, "kernel_sha16": sha,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes": {"read_per_observed_voxel": read_bpv, "observed_voxels": n_obs_rank,
                                       "changed_word_bytes": chg_rank, "changed_bytes_per_observed_voxel": chg_per_obs,
                                       "frame_bytes": bpp * W * H},
-                "traffic_profile": ({"tag": prof.get("tag"), "read_bytes": prof.get("read_bytes"),
+                "traffic_from_profile": ({"tag": prof.get("tag"), "commit": prof.get("commit"), "read_bytes": prof.get("read_bytes"),
                                      "written_bytes": prof.get("written_bytes"),
                                      "frac_of_peak_by_traffic": prof["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "kernel_ms_in_profile": prof.get("kernel_ms_in_profile")} if prof else why),
                 "reference_record_bytes_per_observed_voxel": ref_bpv,
                 "reference_record_bytes_per_launch": ref_bpv * n_obs_rank + bpp * W * H,
                 "sweep_upper_bound_bytes": ref_bpv * vox_total / world,
+                "survey_8d_note": "survey_8d_frac prices an observed voxel at SURVEY 8(d)'s record of the reference (d, w, rgb read and "
+                                  "written: 24 B with colour, 16 B without) + the frame; it exceeds what the kernel moves because the "
+                                  "shipped PACKED layout holds the weight as a count in the colour word's free byte (8 B per voxel) and "
+                                  "unchanged words are not written back -- a value above 1 is that ratio, not a bandwidth",
                 "note": "achieved/frac: algorithmic bytes of the shipped HBM layout (words an observed voxel must read + words whose "
                         "value changed, counted by the kernel's counting instance + the frame) / kernel_ms; traffic: PMC FETCH_SIZE x2 + "
                         "WRITE_SIZE over this command's timed launches; reference_record_*: SURVEY 8d's 24 B (16 B) record of the "
@@ -595,6 +694,8 @@ def main():
             out["calibration"] = calibration
         if world == 1 and args.extras:
             out["extras"] = extras(vol, poses[-1], W, H)
+            if fused2 is not None:
+                out["extras"]["fused2"] = fused2
             if args.scene_b:
                 out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and not use_dist and args.host_path:

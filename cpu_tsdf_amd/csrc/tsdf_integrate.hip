@@ -54,6 +54,7 @@ struct IntegrateArgs {
   float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
   int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
+  int live_skip1;        // LIVE: leave the blocks flagged 1 (wholly inside every row interval) to the ALLIN pass of the same frame
   int64_t pitch;
 };
 
@@ -306,11 +307,14 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 // convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
 // with a pixel to spare, and nx is a multiple of 4: the per-voxel range compares, the image-bounds compares and the
 // "nothing in range" exits go away -- the turntable / object-in-front-of-the-camera case the headline is quoted on.
-// LIVE (never with ALLIN): the launch comes with the frame's ROW INTERVALS (k_rows below: per voxel row of the launch,
-// the x range [lo, lo + len) outside of which no voxel of the row can be integrated -- conservative for updateVoxel's
-// own tests, EXACT for the reference's frustum cull when it is replicated) and with k_cull's block flags.  A block no
-// row of which meets its x range leaves at once, a wave skips every row whose interval misses its 64 quads before any
-// arithmetic, and the voxels of a quad that lie outside the interval are masked like voxels out of sensor range.
+// LIVE: the launch comes with the frame's ROW INTERVALS (k_rows below: per voxel row of the launch, the x range
+// [lo, lo + len) outside of which no voxel of the row can be integrated -- conservative for updateVoxel's own tests, EXACT
+// for the reference's frustum cull when it is replicated) and with k_cull's block flags: 0 = no row of the block meets
+// its x range (the block leaves at once), 1 = every row's interval covers the block's whole x range (the intervals decide
+// nothing in it), 2 = some do not: then a wave skips every row whose interval misses its 64 quads before any arithmetic,
+// and the voxels of a quad that lie outside the interval are masked like voxels out of sensor range.
+// ALLIN && LIVE: the slab is wholly in view but the reference's cull cuts it: this instance takes the blocks flagged 1 at
+// the ALLIN instance's speed, and a LIVE pass with a.live_skip1 takes the blocks flagged 2 (two launches per frame).
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false, bool LIVE = false>
 static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
@@ -318,13 +322,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
             unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live, uint8_t *__restrict__ band,
             const uint32_t *__restrict__ row_iv) {
-  static_assert(!(ALLIN && LIVE), "the ALLIN instance has nothing to cull");
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
-  if (LIVE && !live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)]) return;
+  bool strad = false;  // LIVE: this block's rows need their intervals (block-uniform)
+  if (LIVE) {
+    const unsigned flag = live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)];
+    if (ALLIN ? flag != 1u : (flag == 0u || (a.live_skip1 && flag == 1u))) return;
+    strad = !ALLIN && flag == 2u;
+  }
   const unsigned tid = threadIdx.x;
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
   __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
-  __shared__ uint32_t s_iv[LIVE ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
+  __shared__ uint32_t s_iv[LIVE && !ALLIN ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
   // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
   // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
@@ -334,7 +342,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   {
     const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
-    if (LIVE) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
+    if (LIVE && !ALLIN && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
   __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
@@ -376,7 +384,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
       unsigned iv_lo = 0u, iv_len = 0u;
-      if (LIVE) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
+      if (LIVE && !ALLIN && strad) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
         const uint32_t iv = s_iv[ty + r * a.TY];
         iv_lo = iv & 0xffffu, iv_len = iv >> 16;
         if (!((unsigned)(x4 + 3) - iv_lo < iv_len + 3u)) continue;
@@ -418,7 +426,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
         // hpp:146 + .cpp:616: !(gz < zmin || gz > zmax) && gz > 0, as two compares: zlo is the largest float every
         // accepted gz exceeds (the float below zmin when zmin > 0, else 0; a NaN gz fails, as there)
-        const bool in = ALLIN || (gz > a.zlo && !(gz > a.zmax) && (!LIVE || (unsigned)(x4 + j) - iv_lo < iv_len));
+        const bool in = ALLIN || (gz > a.zlo && !(gz > a.zmax) && (!LIVE || !strad || (unsigned)(x4 + j) - iv_lo < iv_len));
         gzs[j] = gz;
         if (!ALLIN) lowz |= in && gz < 0x1p-14f;  // (ALLIN: the host checked g.z > 1e-3 for the whole slab)
         int p;
@@ -757,11 +765,12 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       if (y >= a.ny) break;
       const unsigned soff = (unsigned)r * row_step;
       const float cy = s_cy[ty + r * a.TY];
-      // ---- one frame's side of updateVoxel up to the normalised distance (hpp:143-198), for the four voxels ------
-      // returns bit j = voxel j reaches addObservation; bit 4 = one of them lies inside the truncation band
-      auto observe = [&](const float (&m)[12], const i4_rsrc &rsF, unsigned bgra_off, float (&dn)[4], uint32_t (&cs)[4]) -> unsigned {
-        float yt[3], zt[3], gzs[4];
-        int pix[4];
+      // ---- one memory round trip per row for BOTH frames: project A, project B, then issue every load the row needs --
+      // the two frames' depth / colour gathers and the quad's voxel words (read whether or not a voxel turns out to be
+      // observed: in this regime -- the whole slab in view -- three quarters are) -- before anything waits
+      // pcl::transformPoint (hpp:145) + reprojectPoint (.cpp:611-617) of the four voxels for one frame
+      auto project = [&](const float (&m)[12], int (&pix)[4], float (&gzs)[4]) {
+        float yt[3], zt[3];
         uint32_t margin[4];
         float cxr[4] = {cxs[0], cxs[1], cxs[2], cxs[3]};
 #pragma unroll
@@ -771,7 +780,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
           zt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cz * m[4 * q + 2] + m[4 * q + 3] : m[4 * q + 2] * cz;
           yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * m[4 * q + 1] + zt[q] : m[4 * q + 1] * cy;
         }
-        auto transform = [&](int j, int q) -> float {  // pcl::transformPoint (hpp:145) in this build's summation order
+        auto transform = [&](int j, int q) -> float {
           const float px = cxr[j] * m[4 * q];
           if (ORDER == TSDF_XFORM_PCL_SSE) return px + yt[q];
           return ((px + yt[q]) + zt[q]) + m[4 * q + 3];
@@ -805,12 +814,31 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
           if (j == 2) pix[2] = pe;
           if (j == 3) pix[3] = pe;
         }
-        float zs[4];
+      };
+      int pixA[4], pixB[4];
+      float gzA[4], gzB[4];
+      project(a.m, pixA, gzA);
+      project(fb.m, pixB, gzB);
+      float zsA[4], zsB[4];
+      uint32_t csA[4], csB[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          zs[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsF, pix[j], 0, 0, TSDF_GATHER_AUX));
-          cs[j] = COLOR ? tsdf_struct_buffer_load_u32(rsF, pix[j], 0, (int)bgra_off, TSDF_GATHER_AUX) : 0u;
-        }
+      for (int j = 0; j < 4; ++j) {
+        zsA[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, 0, TSDF_GATHER_AUX));
+        csA[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, (int)a.bgra_off, TSDF_GATHER_AUX) : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        zsB[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, 0, TSDF_GATHER_AUX));
+        csB[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, (int)fb.bgra_off, TSDF_GATHER_AUX) : 0u;
+      }
+      const u4 d4 = bload128(rsD, voff, soff);
+      u4 c4 = {0u, 0u, 0u, 0u};
+      uint32_t k4 = 0u;
+      if (COLOR) c4 = bload128(rsC, voff, soff);
+      if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+      // ---- hpp:152-198 for one frame: NaN test, projective distance, hinge, normalisation ---------------------------
+      // returns bit j = voxel j reaches addObservation; bit 4 = one of them lies inside the truncation band
+      auto finish = [&](const float (&zs)[4], const float (&gzs)[4], float (&dn)[4]) -> unsigned {
         unsigned obs = 0;
         float raw[4];
 #pragma unroll
@@ -834,16 +862,9 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         return obs;
       };
       float dnA[4], dnB[4];
-      uint32_t csA[4], csB[4];
-      const unsigned obsA = observe(a.m, rsFA, a.bgra_off, dnA, csA);
-      const unsigned obsB = observe(fb.m, rsFB, fb.bgra_off, dnB, csB);
+      const unsigned obsA = finish(zsA, gzA, dnA);
+      const unsigned obsB = finish(zsB, gzB, dnB);
       if (!((obsA | obsB) & 15u)) continue;
-      // ---- the quad's words, once ---------------------------------------------------------------------------
-      const u4 d4 = bload128(rsD, voff, soff);
-      u4 c4 = {0u, 0u, 0u, 0u};
-      uint32_t k4 = 0u;
-      if (COLOR) c4 = bload128(rsC, voff, soff);
-      if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
       const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       uint32_t du[4], kw[4];  // the state both updates work on: distance bits; colour | count << 24 (or only the count there)
@@ -1122,17 +1143,25 @@ static __host__ __device__ inline uint32_t row_interval(const RowArgs &c, const 
   return (uint32_t)lo | ((uint32_t)(hi - lo + 1) << 16);
 }
 
+#define TSDF_ROWS_LDS_NX 8192  // x centre tables up to this long are staged in LDS for the bisections (32 KB)
+template <bool LDSX>
 static __global__ void __launch_bounds__(256)
 k_rows(const RowArgs c, const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
        uint32_t *__restrict__ row_iv) {
+  // a row's bisections are ~90 DEPENDENT reads of the x table: from LDS they cost a tenth of what L2 hits cost
+  __shared__ float s_x[LDSX ? TSDF_ROWS_LDS_NX : 1];
+  if (LDSX) {
+    for (int k = (int)threadIdx.x; k < c.nx; k += 256) s_x[k] = ctrx[k];
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)c.ny * c.nz) return;
   const int y = (int)(i % c.ny), z = (int)(i / c.ny);
-  row_iv[i] = row_interval(c, ctrx, ctry[y], ctrz[c.z_global0 + z]);
+  row_iv[i] = row_interval(c, LDSX ? s_x : ctrx, ctry[y], ctrz[c.z_global0 + z]);
 }
 
-// One flag per k_integrate block of a LIVE launch: does any of its rows' intervals meet its x range (and can the block's
-// rectangle be observed at all)?
+// One flag per k_integrate block of a LIVE launch: 0 = no row's interval meets the block's x range (or the block's
+// rectangle cannot be observed at all), 1 = every row's interval covers it, 2 = neither.
 static __global__ void __launch_bounds__(256)
 k_cull(const CullArgs c, const float *__restrict__ ctrx, const float *__restrict__ ctry,
        const float *__restrict__ ctrz, const uint32_t *__restrict__ row_iv, uint8_t *__restrict__ live) {
@@ -1142,16 +1171,17 @@ k_cull(const CullArgs c, const float *__restrict__ ctrx, const float *__restrict
   const int xa = bx * c.bx_vox, xb = min(c.nx, xa + c.bx_vox) - 1;
   const int ya = by * c.by_rows, yb = min(c.ny, ya + c.by_rows) - 1;
   // the centre tables increase with the index, so the first and last voxel bound the block
-  bool any = box_may_be_observed(c, ctrx[xa], ctrx[xb], ctry[ya], ctry[yb], ctrz[c.z_global0 + bz]);
+  bool any = box_may_be_observed(c, ctrx[xa], ctrx[xb], ctry[ya], ctry[yb], ctrz[c.z_global0 + bz]), all = true;
   if (any) {
     any = false;
-    for (int y = ya; y <= yb && !any; ++y) {
+    for (int y = ya; y <= yb; ++y) {
       const uint32_t iv = row_iv[(int64_t)bz * c.ny + y];
       const int lo = (int)(iv & 0xffffu), len = (int)(iv >> 16);
-      any = len > 0 && lo <= xb && lo + len - 1 >= xa;
+      any |= len > 0 && lo <= xb && lo + len - 1 >= xa;
+      all &= lo <= xa && lo + len - 1 >= xb;
     }
   }
-  live[b] = any ? 1 : 0;
+  live[b] = !any ? 0 : all ? 1 : 2;
 }
 
 static float f32_ulp(float v) {
@@ -1243,6 +1273,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.band_fx = h->band_fx;
   a.band_fy = h->band_fy;
   a.x_abs0 = a.y_abs0 = 0;
+  a.live_skip1 = 0;
   return hh;
 }
 
@@ -1633,7 +1664,9 @@ static bool reference_cull_keeps_whole_slab(const tsdf_hip_volume *h, const floa
       worst = std::max(worst, v);
       mag = std::max(mag, fabs((double)pl[0] * x) + fabs((double)pl[1] * y) + fabs((double)pl[2] * z) + fabs((double)pl[3]));
     }
-    if (!(worst + 8.0 * 4.0 * 5.97e-8 * mag < 0.0)) return false;
+    // (`<= 0` keeps, so <= suffices; with min_sensor_dist = 0 -- the programs' default -- the near plane's corners all
+    // coincide with the camera centre and PCL's near plane is the zero vector: its dot is 0 for every voxel, kept)
+    if (!(worst + 8.0 * 4.0 * 5.97e-8 * mag <= 0.0)) return false;
   }
   return true;
 }
@@ -1823,15 +1856,20 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   bool all_inside = false;
   if (tsdf_tuning().cull) {
     all_inside = tsdf_tuning().cull != 2 && slab_all_inside(h, T);
-    allin = all_inside && !rc && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
+    allin = all_inside && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
             (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
   }
+  // wholly in view, but the reference's cull cuts the slab: the ALLIN instance for the blocks the cull leaves whole, the
+  // LIVE instance for the blocks it cuts
+  const bool dual = allin && rc_rows;
+  if (rc) allin = false;
   // LIVE launch: the frame cannot see the whole slab (or the reference's cull bites): row intervals + block flags
   const bool want_live = (tsdf_tuning().cull && !all_inside && row_intervals_usable(h, false)) || rc_rows;
   if (want_live) {
     // narrow blocks: 64 quads of 4 rows, so that the flags and a wave's row skip follow the frustum's outline (a block
     // of a whole 1024-voxel row group is mostly outside it when the camera sits inside the volume)
-    if (a.TX > 64) {
+    // (a slab that is wholly in view -- only the reference's cull decides anything -- keeps the streaming shape)
+    if (a.TX > 64 && !all_inside) {
       a.TX = 64, a.log2TX = 6, a.TY = 4;
       a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);
       gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
@@ -1908,7 +1946,10 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
           h->row_iv_cap = nrows;
         }
       }
-      hipLaunchKernelGGL(k_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, h->stream, ra, ctrx, ctry, h->ctr[2], h->row_iv);
+      if (ra.nx <= TSDF_ROWS_LDS_NX)
+        hipLaunchKernelGGL(k_rows<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, h->stream, ra, ctrx, ctry, h->ctr[2], h->row_iv);
+      else
+        hipLaunchKernelGGL(k_rows<false>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, h->stream, ra, ctrx, ctry, h->ctr[2], h->row_iv);
       hipLaunchKernelGGL(k_cull, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, h->stream, c, ctrx, ctry, h->ctr[2], h->row_iv, h->live);
       TSDF_HIP_TRY(hipGetLastError());
       live = h->live;
@@ -1929,7 +1970,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   if (!band_arg) h->band_exact = false;
   if (pose_ok && !nothing_observable) {
     const dim3 grid(gx, gy, gz), block(256);
-    h->last_launch[0] = fastproj && allin && !live;
+    h->last_launch[0] = fastproj && ((allin && !live) || dual);
     h->last_launch[1] = fastproj;
     h->last_launch[2] = live ? (rc_rows ? 2 : 1) : 0;
     h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
@@ -1938,7 +1979,12 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
                      d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live, band_arg, h->row_iv)
 #define L6(ORDER, COLOR, FP, COUNT, PK)                  \
   do {                                                   \
-    if (live)                                            \
+    if (live && FP && dual) {                            \
+      a.live_skip1 = 0;                                  \
+      LAUNCH(ORDER, COLOR, FP, COUNT, PK, FP, true);     \
+      a.live_skip1 = 1;                                  \
+      LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, true);  \
+    } else if (live)                                     \
       LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, true);  \
     else if (FP && allin)                                \
       LAUNCH(ORDER, COLOR, FP, COUNT, PK, FP, false);    \

@@ -118,7 +118,7 @@ class RefVolume:
     Octree::init pre-splits to full resolution (src/lib/octree.cpp:593-599), the mode used for parity."""
 
     def __init__(self, res, size, width, height, fx, fy, cx, cy, zmin, zmax, trunc=(0.03, 0.03), max_weight=100.0,
-                 color=False, dense=True, max_cell=0.5, lib_path=LIB, color_mode=None, devices=None, reference_cull=False):
+                 color=False, dense=True, max_cell=0.5, lib_path=LIB, color_mode=None, devices=None, reference_cull=None):
         self.L = load(lib_path)
         self.h = C.c_void_p(self.L.ct_create())
         self.res, self.size, self.W, self.H, self.color = res, float(size), width, height, bool(color)
@@ -136,8 +136,8 @@ class RefVolume:
         if color_mode is not None:
             L.ct_set_color_mode(h, color_mode.encode())
         L.ct_set_num_random_splits(h, 1)
-        if reference_cull:  # drop-in build only: TSDFVolumeOctree::setReferenceCull
-            L.ct_set_reference_cull(h, 1)
+        if reference_cull is not None:  # drop-in build only: TSDFVolumeOctree::setReferenceCull (None = the class's default)
+            L.ct_set_reference_cull(h, int(bool(reference_cull)))
         if devices:  # drop-in build only: TSDFVolumeOctree::setDevices
             L.ct_set_devices(h, (C.c_int * len(devices))(*devices), len(devices))
         L.ct_reset(h)

@@ -26,9 +26,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--ref-cull", type=float, default=0.0, help="fraction of the cases that keep a principal point far off "
-                    "centre (the reference's frustum cull then drops voxels that project into the image) and run the drop-in "
-                    "with setReferenceCull(true): round 3's replication mode against the reference itself")
+    ap.add_argument("--ref-cull", type=float, default=0.0, help="fraction of the cases whose principal point is pushed up to 40 %% "
+                    "off centre (the reference's frustum cull then drops voxels that project into the image).  The drop-in is "
+                    "driven through the reference's own API only -- no call to setReferenceCull or any other method the "
+                    "reference lacks (VERDICT r03 #1): its default integrateCloud must follow the reference in every regime")
     a = ap.parse_args()
     assert refbind.available(), "oracle/_ref missing"
     dropin = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
@@ -52,14 +53,11 @@ def main():
         if ref_cull:  # push the principal point further out: the regime the mode exists for
             cx, cy = W / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * W / 2, H / 2 - 0.5 + float(rng.uniform(-0.4, 0.4)) * H / 2
             p.cx, p.cy = cx, cy
-        while not ref_cull and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p)):
-            cx, cy = W / 2 - 0.5 + 0.5 * (cx - (W / 2 - 0.5)), H / 2 - 0.5 + 0.5 * (cy - (H / 2 - 0.5))
-            p.cx, p.cy = cx, cy
         devices = [0] * int(rng.choice([1, 1, 2, 3]))
         kw = dict(trunc=(pos, neg), max_weight=wmax, color=color)
-        cull_active = ref_cull and not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p))
+        cull_active = not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p))
         gv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, lib_path=dropin,
-                               devices=devices if len(devices) > 1 else None, reference_cull=ref_cull, **kw)
+                               devices=devices if len(devices) > 1 else None, **kw)
         rv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, **kw)
         sc = synth.Scene(size, W, H, sphere=float(rng.uniform(0.15, 0.35)), box=float(rng.uniform(0.35, 0.49)))
         sc.fx, sc.fy, sc.cx, sc.cy = fx, fy, cx, cy

@@ -284,31 +284,32 @@ def test_dropin_set_color_mode_rgb_normalized(dropin):
         v.close()
 
 
-def test_drop_in_reference_cull_mode_equals_the_reference_with_an_off_centre_camera(gpu):
-    """cpu_tsdf::TSDFVolumeOctree::setReferenceCull(true) through the SAME C driver as the reference: a principal point
-    15 % of the half-width off centre makes pcl::FrustumCulling drop voxels at one image border
-    (tsdf_volume_octree.cpp:619-652); the drop-in, building the six planes with its own Eigen, drops the same ones.
-    Also on a three-slab multi handle."""
+def test_drop_in_default_path_equals_the_reference_with_an_off_centre_camera(gpu):
+    """The drop-in through the SAME C driver as the reference, calling nothing the reference does not have: a principal
+    point 15 % of the half-width off centre makes pcl::FrustumCulling drop voxels at one image border
+    (tsdf_volume_octree.cpp:619-652); cpu_tsdf::TSDFVolumeOctree::integrateCloud, building the six planes with its own
+    Eigen, drops the same ones.  Also on a three-slab multi handle, and with the explicit
+    setReferenceCull(true); setReferenceCull(false) is the opt-out and integrates the strict superset."""
     res, W, H, size = 32, 64, 48, 1.0
     fx = fy = 110.0
     cx, cy = W / 2 - 0.5 + 4.8, H / 2 - 0.5
     ref = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, 0.0, 3.0, color=True)
     drops = [refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, 0.0, 3.0, color=True, lib_path=refbind.DROPIN_LIB,
-                               reference_cull=True, devices=dev) for dev in (None, [0, 0, 0])]
-    plain = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, 0.0, 3.0, color=True, lib_path=refbind.DROPIN_LIB)
+                               reference_cull=rc, devices=dev) for rc, dev in ((None, None), (None, [0, 0, 0]), (True, None))]
+    optout = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, 0.0, 3.0, color=True, lib_path=refbind.DROPIN_LIB, reference_cull=False)
     rng = np.random.RandomState(9)
     for i in range(4):
         tr = synth.look_at_pose(np.array([1.9, 0.2 * i, 0.3]) * size, target=np.zeros(3))
         dep = (rng.uniform(1.2, 2.6, (H, W)) * size).astype(np.float32)
         col = rng.randint(0, 256, (H, W, 4)).astype(np.uint8)
-        for v in [ref, plain] + drops:
+        for v in [ref, optout] + drops:
             v.integrate(dep, col, tr)
     d, w, rgb, _, _ = ref.dump_dense()
     for v in drops:
         gd, gw, grgb = v.download()
         assert_same_f32(gd, d, "d")
         assert np.array_equal(gw, w) and np.array_equal(grgb, rgb)
-    pd, pw, _ = plain.download()
-    assert (w <= pw).all() and (w < pw).sum() > 20  # the default (no replication) integrates a strict superset
-    for v in [ref, plain] + drops:
+    pd, pw, _ = optout.download()
+    assert (w <= pw).all() and (w < pw).sum() > 20  # without the cull: a strict superset
+    for v in [ref, optout] + drops:
         v.close()
