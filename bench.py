@@ -420,6 +420,8 @@ def main():
 
     from cpu_tsdf_amd import capi, synth
     from cpu_tsdf_amd.volume import TSDFVolumeOctree
+    if args.calib:
+        capi.use_test_library()  # the calibration sweeps of exactly known bytes are test hooks (include/tsdf_hip_test.h): PMC runs only
     capi.load()  # raises if the HIP library is not built: there is no fallback
 
     res = args.res

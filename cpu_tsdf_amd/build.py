@@ -18,6 +18,9 @@ HOST = os.path.join(CSRC, "host")
 LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(_HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libtsdf_hip.so")
+# the test build: the same translation units + the hooks of include/tsdf_hip_test.h (-DTSDF_HIP_TEST_HOOKS)
+TEST_LIB = os.path.join(LIBDIR, "libtsdf_hip_test.so")
+TEST_OBJDIR = os.path.join(_HERE, "lib", "obj_test")
 SHELL_LIB = os.path.join(LIBDIR, "libcpu_tsdf_hip.so")
 PROG = os.path.join(CSRC, "prog")
 BINDIR = os.path.join(_HERE, "bin")
@@ -33,15 +36,15 @@ def sources():
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "tsdf_hip.h")]
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "tsdf_hip.h"), os.path.join(ROOT, "include", "tsdf_hip_test.h")]
 
 
 def _stale(target, deps):
     return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(p) for p in deps)
 
 
-def needs_build():
-    return _stale(LIB, sources() + _headers())
+def needs_build(test_hooks=False):
+    return _stale(TEST_LIB if test_hooks else LIB, sources() + _headers())
 
 
 def _hipcc():
@@ -51,18 +54,22 @@ def _hipcc():
     return hipcc
 
 
-def build_hip(force=False, verbose=False):
-    """Compile every HIP translation unit (in parallel) and link cpu_tsdf_amd/lib/libtsdf_hip.so."""
-    if not force and not needs_build():
-        return LIB
+def build_hip(force=False, verbose=False, test_hooks=False):
+    """Compile every HIP translation unit (in parallel) and link cpu_tsdf_amd/lib/libtsdf_hip.so -- the product: exactly
+    the entry points of include/tsdf_hip.h -- or, with test_hooks, libtsdf_hip_test.so: the same sources with
+    -DTSDF_HIP_TEST_HOOKS, which adds the hooks of include/tsdf_hip_test.h."""
+    lib, objdir = (TEST_LIB, TEST_OBJDIR) if test_hooks else (LIB, OBJDIR)
+    if not force and not needs_build(test_hooks):
+        return lib
     hipcc = _hipcc()
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    extra = ["-DTSDF_HIP_TEST_HOOKS"] if test_hooks else []
     jobs = []
     for src in sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _stale(obj, [src] + _headers()):
-            jobs.append([hipcc] + HIPCC_FLAGS + inc + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + HIPCC_FLAGS + extra + inc + ["-c", src, "-o", obj])
     if verbose:
         for j in jobs:
             print(" ".join(j))
@@ -70,12 +77,23 @@ def build_hip(force=False, verbose=False):
         for rc in ex.map(lambda c: subprocess.run(c).returncode, jobs):
             if rc:
                 raise RuntimeError("hipcc failed")
-    objs = [os.path.join(OBJDIR, os.path.basename(s) + ".o") for s in sources()]
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in sources()]
+    # -Bsymbolic: calls between the library's own entry points stay inside it, whatever else the process has loaded (the
+    # product and the test build can sit in one process: the C++ drop-in links the former, the Python tests load the latter)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
-    return LIB
+    return lib
+
+
+def clean():
+    """Remove every built artefact of this package (objects, libraries, programs): the next build starts from the sources."""
+    for d in (OBJDIR, TEST_OBJDIR, os.path.join(LIBDIR, "variants"), BINDIR):
+        shutil.rmtree(d, ignore_errors=True)
+    for f in (LIB, TEST_LIB, SHELL_LIB):
+        if os.path.exists(f):
+            os.remove(f)
 
 
 def host_include_flags():

@@ -1,6 +1,11 @@
 """ctypes binding of the C ABI in include/tsdf_hip.h (libtsdf_hip.so).
 
 Fails loudly when the library is missing -- there is no CPU / eager fallback by design.
+
+Two builds of the same sources exist (cpu_tsdf_amd/build.py): libtsdf_hip.so, the product -- exactly the entry points
+of include/tsdf_hip.h -- and libtsdf_hip_test.so, the product plus the test hooks of include/tsdf_hip_test.h (device-side
+dividers on arbitrary operands, host-side cull predicates, calibration sweeps, run-time tuning knobs).  load() binds the
+product unless use_test_library() was called first (tests/conftest.py does; bench.py does for --calib only).
 """
 import ctypes as C
 import os
@@ -9,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TSDF_HIP_LIB_PATH: an A/B build of the same library (tools/build_variant.py); still no fallback if it is missing
-LIB_PATH = os.environ.get("TSDF_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "libtsdf_hip.so")
+PRODUCT_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libtsdf_hip_test.so")
+LIB_PATH = os.environ.get("TSDF_HIP_LIB_PATH") or PRODUCT_LIB_PATH
 
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_IO = range(7)
 XFORM_PCL_SSE, XFORM_LEFT_TO_RIGHT = 0, 1
@@ -105,12 +112,6 @@ SIGNATURES = {
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_march_stats": (C.c_int, [C.c_void_p, _u64p]),
-    "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
-    "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
-    "tsdf_hip_selftest_cvt_pk_u8": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
-    "tsdf_hip_selftest_rgb2lab": (C.c_int, [_u8p, C.c_size_t, _f32p]),
-    "tsdf_hip_selftest_lab2rgb": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
-    "tsdf_hip_selftest_struct_oob": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),
     "tsdf_hip_raycast_camera": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f64p, _f32p]),
     "tsdf_hip_raycast_begin": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_void_p]),
@@ -134,16 +135,6 @@ SIGNATURES = {
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdf_hip_layout": (C.c_int, [C.c_void_p]),
     "tsdf_hip_centers": (C.c_int, [C.c_void_p, C.c_int, _f32p]),
-    "tsdf_hip_selftest_div_f32": (C.c_int, [_f32p, _f32p, _f32p, C.c_size_t]),
-    "tsdf_hip_selftest_div_f64": (C.c_int, [_f64p, _f64p, _f64p, C.c_size_t]),
-    "tsdf_hip_selftest_project": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]),
-    "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
-    "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
-    "tsdf_hip_selftest_read_sweep": (C.c_int, [C.c_void_p, C.c_int, _u64p, _u64p]),
-    "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
-    "tsdf_hip_selftest_block_flags": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.c_int, C.c_int, _u8p]),
-    "tsdf_hip_selftest_row_intervals": (C.c_int, [C.POINTER(TsdfParams), _f32p, _f32p, C.POINTER(C.c_uint32)]),
-    "tsdf_hip_selftest_index_box": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsdf_hip_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(TsdfVolMeta)]),
     "tsdf_hip_save_blocks": (C.c_int, [C.POINTER(TsdfParams), C.POINTER(TsdfVolMeta), C.c_char_p, BLOCK_FN, C.c_void_p]),
     "tsdf_hip_load_blocks": (C.c_int, [C.c_char_p, C.POINTER(TsdfParams), HEADER_FN, BLOCK_FN, C.c_void_p]),
@@ -155,7 +146,6 @@ SIGNATURES = {
     "tsdf_hip_abi_version": (C.c_int, []),
     "tsdf_hip_download_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
     "tsdf_hip_upload_variance_state": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [_f32p, C.POINTER(C.c_int32)]),
-    "tsdf_hip_selftest_expf": (C.c_int, [_f32p, C.c_size_t, _f32p]),
     "tsdf_hip_set_reference_cull": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_integrate_device2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_void_p, _f32p, _f32p,
                                              _u64p, C.POINTER(C.c_int32)]),
@@ -164,6 +154,27 @@ SIGNATURES = {
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_multi_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsdf_hip_multi_kernel_ms": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int32)]),
+}
+
+# include/tsdf_hip_test.h: only libtsdf_hip_test.so (and the A/B variants of tools/build_variant.py) export these
+TEST_SIGNATURES = {
+    "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
+    "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
+    "tsdf_hip_selftest_cvt_pk_u8": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "tsdf_hip_selftest_rgb2lab": (C.c_int, [_u8p, C.c_size_t, _f32p]),
+    "tsdf_hip_selftest_lab2rgb": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "tsdf_hip_selftest_struct_oob": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int]),
+    "tsdf_hip_selftest_div_f32": (C.c_int, [_f32p, _f32p, _f32p, C.c_size_t]),
+    "tsdf_hip_selftest_div_f64": (C.c_int, [_f64p, _f64p, _f64p, C.c_size_t]),
+    "tsdf_hip_selftest_project": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]),
+    "tsdf_hip_selftest_containing": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(C.c_int32)]),
+    "tsdf_hip_selftest_sweep": (C.c_int, [C.c_void_p, _u64p, _u64p]),
+    "tsdf_hip_selftest_read_sweep": (C.c_int, [C.c_void_p, C.c_int, _u64p, _u64p]),
+    "tsdf_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "tsdf_hip_selftest_block_flags": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.c_int, C.c_int, _u8p]),
+    "tsdf_hip_selftest_row_intervals": (C.c_int, [C.POINTER(TsdfParams), _f32p, _f32p, C.POINTER(C.c_uint32)]),
+    "tsdf_hip_selftest_index_box": (C.c_int, [C.POINTER(TsdfParams), _f32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tsdf_hip_selftest_expf": (C.c_int, [_f32p, C.c_size_t, _f32p]),
 }
 
 
@@ -188,9 +199,29 @@ def _torch_first():
         pass
 
 
+def use_test_library():
+    """Bind libtsdf_hip_test.so (the product's sources + the hooks of include/tsdf_hip_test.h) instead of the product.
+    Must be called before the first load(); TSDF_HIP_LIB_PATH, if set, still wins."""
+    global LIB_PATH
+    if _lib is not None:
+        if LIB_PATH != TEST_LIB_PATH and not os.environ.get("TSDF_HIP_LIB_PATH"):
+            raise RuntimeError("capi.use_test_library() after the product library was loaded")
+        return
+    if not os.environ.get("TSDF_HIP_LIB_PATH"):
+        LIB_PATH = TEST_LIB_PATH
+
+
+def has_test_hooks():
+    load()
+    return _has_hooks
+
+
+_has_hooks = False
+
+
 def load():
-    """Load libtsdf_hip.so (once) and declare every entry point.  Raises if it is not built."""
-    global _lib
+    """Load the library (once) and declare every entry point.  Raises if it is not built."""
+    global _lib, _has_hooks
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -203,6 +234,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    _has_hooks = hasattr(lib, "tsdf_hip_set_tuning")
+    if _has_hooks:
+        for name, (res, args) in TEST_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -215,7 +252,16 @@ def check(code, where):
 
 
 def set_tuning(name, value):
-    check(load().tsdf_hip_set_tuning(name.encode(), int(value)), f"set_tuning({name})")
+    """Launch-shape knobs at run time: a hook of the TEST library (the product reads the TSDF_HIP_* variables once).  The
+    one knob the product follows live is vol_chunk, through the environment -- so that is how it is set here, for whichever
+    library (and for the C++ drop-in, which links the product) is in the process."""
+    if name == "vol_chunk":
+        os.environ["TSDF_HIP_VOL_CHUNK"] = str(int(value))
+        return
+    lib = load()
+    if not _has_hooks:
+        raise RuntimeError(f"set_tuning({name}): {LIB_PATH} has no test hooks; call capi.use_test_library() before the first load")
+    check(lib.tsdf_hip_set_tuning(name.encode(), int(value)), f"set_tuning({name})")
 
 
 def default_params():

@@ -279,9 +279,14 @@ struct TsdfTuning {
   int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
+  int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (6: 256 voxels x 4 rows per block pass)
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
 };
 const TsdfTuning &tsdf_tuning();
+// Edge of the voxel blocks save / load stream through host memory: TSDF_HIP_VOL_CHUNK, read at EVERY call (an I/O path: a
+// getenv costs nothing there), so that a caller -- the tests, through the C++ drop-in as well -- can change it at run time
+// without an entry point for it; else the tuning value.
+int tsdf_vol_chunk();
 
 // Read-only view of the voxel planes for the gather kernels (raycast, sample, marching cubes, transfers).
 struct PlaneView {

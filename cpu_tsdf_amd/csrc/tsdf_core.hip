@@ -13,6 +13,9 @@
 #include <mutex>
 
 #include "tsdf_common.h"
+#ifdef TSDF_HIP_TEST_HOOKS
+#include "tsdf_hip_test.h"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -54,12 +57,18 @@ static TsdfTuning &tuning_storage() {
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
-                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_FUSE2", 1)};
+                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 6), env_int("TSDF_HIP_FUSE2", 1)};
   return t;
 }
 
 const TsdfTuning &tsdf_tuning() { return tuning_storage(); }
 
+int tsdf_vol_chunk() {
+  const int live = env_int("TSDF_HIP_VOL_CHUNK", 0);
+  return live > 0 ? live : tsdf_tuning().vol_chunk;
+}
+
+#ifdef TSDF_HIP_TEST_HOOKS
 // Test / A-B hook: change a launch-shape knob at run time (same names as the TSDF_HIP_* variables, lower
 // case, without the prefix).  None of them may change results; the tests use this to prove it.
 extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
@@ -90,10 +99,13 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.refcull_plain = value;
   else if (n == "fuse2")
     t.fuse2 = value;
+  else if (n == "live_log2tx")
+    t.live_log2tx = value;
   else
     return TSDF_HIP_E_INVALID;
   return TSDF_HIP_OK;
 }
+#endif  // TSDF_HIP_TEST_HOOKS
 
 extern "C" int tsdf_hip_abi_version(void) { return TSDF_HIP_ABI_VERSION; }
 

@@ -24,6 +24,9 @@
 #include "tsdf_common.h"
 #include "tsdf_div.h"
 #include "tsdf_buffer.h"
+#ifdef TSDF_HIP_TEST_HOOKS
+#include "tsdf_hip_test.h"
+#endif
 
 struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
@@ -1869,8 +1872,9 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     // narrow blocks: 64 quads of 4 rows, so that the flags and a wave's row skip follow the frustum's outline (a block
     // of a whole 1024-voxel row group is mostly outside it when the camera sits inside the volume)
     // (a slab that is wholly in view -- only the reference's cull decides anything -- keeps the streaming shape)
-    if (a.TX > 64 && !all_inside) {
-      a.TX = 64, a.log2TX = 6, a.TY = 4;
+    const int ltx = std::max(4, std::min(8, tsdf_tuning().live_log2tx));  // 64 quads by default (a knob for A/B runs: 16 .. 256)
+    if (a.TX > (1 << ltx) && !all_inside) {
+      a.TX = 1 << ltx, a.log2TX = ltx, a.TY = 256 >> ltx;
       a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);
       gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
       gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
@@ -2268,6 +2272,7 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
   return TSDF_HIP_OK;
 }
 
+#ifdef TSDF_HIP_TEST_HOOKS
 // Test hook: the device's std::exp(float) of the variance weighting (tsdf_expf_glibc in this host's flavour) on n floats.
 static __global__ void k_selftest_expf(const float *__restrict__ in, float *__restrict__ out, size_t n, int fused_r) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2287,6 +2292,7 @@ extern "C" int tsdf_hip_selftest_expf(const float *in, size_t n, float *out) {
   (void)hipFree(dout);
   return TSDF_HIP_OK;
 }
+#endif  // TSDF_HIP_TEST_HOOKS
 
 extern "C" int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra,
                                          const float cam_from_vol[12], uint64_t *n_observed) {
@@ -2431,6 +2437,7 @@ extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const
   return tsdf_hip_frame_commit(h, cam_from_vol);
 }
 
+#ifdef TSDF_HIP_TEST_HOOKS  // everything below: libtsdf_hip_test.so only (include/tsdf_hip_test.h)
 // ---------------------------------------------------------------------------------------------
 // Test hooks: run the shared-reciprocal dividers of tsdf_div.h on arbitrary operands so the tests
 // can compare them bit for bit with IEEE division done on the host.
@@ -2815,3 +2822,4 @@ extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n
   (void)hipFree(da);
   return TSDF_HIP_OK;
 }
+#endif  // TSDF_HIP_TEST_HOOKS

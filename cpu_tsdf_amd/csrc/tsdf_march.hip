@@ -22,6 +22,9 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "tsdf_common.h"
+#ifdef TSDF_HIP_TEST_HOOKS
+#include "tsdf_hip_test.h"
+#endif
 #include "tsdf_buffer.h"
 #define TSDF_MC_TABLE_QUALIFIER __device__
 #include "mc_tables.h"
@@ -817,6 +820,7 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   return TSDF_HIP_OK;
 }
 
+#ifdef TSDF_HIP_TEST_HOOKS
 // Test / tuning hook: blocks of 256 threads the runtime admits per CU for the marching-cubes kernels
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0] k_mc_classify<1>, out[1] k_mc_emit.
 extern "C" int tsdf_hip_selftest_occupancy_mc(int out[2]) {
@@ -825,6 +829,7 @@ extern "C" int tsdf_hip_selftest_occupancy_mc(int out[2]) {
   TSDF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], k_mc_emit, 256, 0));
   return TSDF_HIP_OK;
 }
+#endif  // TSDF_HIP_TEST_HOOKS
 
 // Report-only: device time of the last tsdf_hip_march by phase (HIP events on the handle's stream).
 extern "C" int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells) {

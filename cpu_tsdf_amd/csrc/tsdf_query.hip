@@ -17,6 +17,9 @@
 #include <string.h>
 
 #include "tsdf_common.h"
+#ifdef TSDF_HIP_TEST_HOOKS
+#include "tsdf_hip_test.h"
+#endif
 
 struct GridView {
   int nx, ny, nz;        // full resolution
@@ -843,6 +846,7 @@ extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, ui
 // (Measured alternatives to the level-by-level walk -- a boundary-table search and, on dyadic grids, computed
 // boundaries -- were slower inside k_raycast: 1.78 and 2.40 ms vs 1.55 ms per 640x480 view at 2048^3; the
 // fixed-trip, branch-free walk wins over shorter but divergent searches.)
+#ifdef TSDF_HIP_TEST_HOOKS
 static __global__ void __launch_bounds__(256)
 k_selftest_containing(const GridView g, const float *__restrict__ xyz, size_t n, int *__restrict__ idx) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,6 +878,7 @@ extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, siz
   TSDF_HIP_TRY(hipGetLastError());
   return tsdf_to_host(h, idx, d_idx, n * 12);
 }
+#endif  // TSDF_HIP_TEST_HOOKS
 
 // ---------------------------------------------------------------------------------------------
 // getNeighbors :796-828, getFxn :655-672, getGradient :681-700, getHessian :703-726.

@@ -83,7 +83,7 @@ static int save_blocks_impl(const tsdf_params *p, const tsdf_vol_meta *meta, con
   int rc = 0;
   std::string err;
   const bool ok = cpu_tsdf::vol_write_stream(
-      filename, hd, tsdf_tuning().vol_chunk,
+      filename, hd, tsdf_vol_chunk(),
       [&](int x0, int y0, int z0, int c, float *d, float *w, unsigned char *rgb) {
         rc = fetch(user, x0, y0, z0, c, d, w, rgb);
         return rc == 0;
@@ -119,7 +119,7 @@ static int load_blocks_impl(const char *filename, const tsdf_params *defaults, t
   bool header_only = false;
   std::string err;
   const bool ok = cpu_tsdf::vol_read_stream(
-      filename, hd, tsdf_tuning().vol_chunk,
+      filename, hd, tsdf_vol_chunk(),
       [&](const VolHeader &f) {
         header_to(f, p, m);
         if (on_header) rc = on_header(user, &p, &m);

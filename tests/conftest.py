@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The suite runs on libtsdf_hip_test.so: the product's sources and kernels + the hooks of include/tsdf_hip_test.h (knobs that
+# force a kernel instance, device-side dividers on chosen operands, host-side cull predicates).  The product library itself
+# (libtsdf_hip.so, no hooks) is what the C++ drop-in links -- tests/test_dropin_gpu.py, tests/test_programs_gpu.py -- and what
+# tests/test_product_lib_gpu.py, __graft_entry__.smoke() and bench.py load.
+from cpu_tsdf_amd import capi  # noqa: E402
+
+capi.use_test_library()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

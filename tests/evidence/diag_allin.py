@@ -1,6 +1,7 @@
 import sys, numpy as np
 sys.path.insert(0, '.')
 from cpu_tsdf_amd import capi, synth
+capi.use_test_library()  # knobs / selftest hooks live in libtsdf_hip_test.so (include/tsdf_hip_test.h)
 from oracle.oracle import OracleVolume
 from tests.common import frames, make_volume
 import ctypes as C

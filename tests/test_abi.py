@@ -12,10 +12,16 @@ from cpu_tsdf_amd import capi, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "tsdf_hip.h")).read()
+def declared_functions(header="tsdf_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(tsdf_hip_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(tsdf_hip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("tsdf_hip_"))
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -26,7 +32,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
-    assert lib.tsdf_hip_abi_version() == 12
+    assert lib.tsdf_hip_abi_version() == 13
+
+
+def test_the_product_library_exports_the_boundary_and_nothing_else():
+    """libtsdf_hip.so exports exactly what include/tsdf_hip.h declares -- no selftest hook, no tuning
+    knob; libtsdf_hip_test.so exports that plus exactly the hooks of include/tsdf_hip_test.h; the ctypes tables mirror both."""
+    product, hooks = declared_functions(), declared_functions("tsdf_hip_test.h")
+    assert not [n for n in product if "selftest" in n or n == "tsdf_hip_set_tuning"]
+    assert all("selftest" in n or n == "tsdf_hip_set_tuning" for n in hooks) and len(hooks) == 17
+    assert exported(capi.PRODUCT_LIB_PATH) == product
+    assert exported(capi.TEST_LIB_PATH) == sorted(product + hooks)
+    assert sorted(capi.SIGNATURES) == product and sorted(capi.TEST_SIGNATURES) == hooks
+    # the product binds without the hooks (a fresh interpreter: this process runs on the test build)
+    import subprocess
+    import sys
+    code = ("from cpu_tsdf_amd import capi; lib = capi.load(); assert capi.LIB_PATH == capi.PRODUCT_LIB_PATH; "
+            "assert not capi.has_test_hooks() and not hasattr(lib, 'tsdf_hip_set_tuning'); print(lib.tsdf_hip_abi_version())")
+    env = {k: v for k, v in os.environ.items() if k != "TSDF_HIP_LIB_PATH"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, PYTHONPATH=ROOT), text=True).strip() == "13"
 
 
 def test_torch_enters_the_process_before_the_library():

@@ -727,7 +727,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                                     psi = float(np.arctan(0.6 * (W / 2) / sc.fx))
                                     yaw = np.eye(4)
                                     yaw[0, 0], yaw[0, 2], yaw[2, 0], yaw[2, 2] = np.cos(psi), np.sin(psi), -np.sin(psi), np.cos(psi)
-                                    tr = synth.turntable_pose(i, 9, sc.size) @ yaw
+                                    tr = synth.turntable_pose(2 * i + 1, 8, sc.size) @ yaw  # the grid seen edge-on: its corners leave the pyramid
                                 else:
                                     tr = synth.turntable_pose(i, 9, sc.size)
                                 dep = sc.depth(tr, noise_seed=40 + i)

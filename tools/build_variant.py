@@ -19,10 +19,10 @@ def main():
     for src in b.sources():
         obj = os.path.join(out, "obj", os.path.basename(src) + ".o")
         objs.append(obj)
-        procs.append(subprocess.Popen([b._hipcc()] + b.HIPCC_FLAGS + flags + inc + ["-c", src, "-o", obj]))
+        procs.append(subprocess.Popen([b._hipcc()] + b.HIPCC_FLAGS + ["-DTSDF_HIP_TEST_HOOKS"] + flags + inc + ["-c", src, "-o", obj]))
     if any(p.wait() for p in procs):
         raise SystemExit("hipcc failed")
-    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", os.path.join(out, "libtsdf_hip.so")])
+    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", os.path.join(out, "libtsdf_hip.so")])
     print(os.path.join(out, "libtsdf_hip.so"))
 
 

@@ -1,6 +1,7 @@
 import sys, numpy as np, ctypes as C
 sys.path.insert(0,'.')
 from cpu_tsdf_amd import capi
+capi.use_test_library()  # knobs / selftest hooks live in libtsdf_hip_test.so (include/tsdf_hip_test.h)
 W,H=640,480
 img=np.arange(2*W*H,dtype=np.float32).reshape(2,H,W)+1.0
 uv=np.array([[0,0],[5,7],[W-1,H-1],[W,0],[W,3],[W+5,3],[-1,3],[3,H],[3,-1],[W,H-1],[2*W,0],[0,H+100],[-1,-1],[W-1,0],[0,H-1]],dtype=np.int32)

@@ -12,6 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpu_tsdf_amd import capi, synth  # noqa: E402
+capi.use_test_library()  # knobs / selftest hooks live in libtsdf_hip_test.so (include/tsdf_hip_test.h)
 from cpu_tsdf_amd.volume import TSDFVolumeOctree  # noqa: E402
 
 
