@@ -279,7 +279,7 @@ struct TsdfTuning {
   int alloc_tries;     // tsdf_hip_create: placements of a large volume's planes to probe before keeping the fastest
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
-  int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (6: 256 voxels x 4 rows per block pass)
+  int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (5: 128 voxels x 8 rows per block pass; Scene B at 2048^3: 0.37 ms against 0.60 at 6)
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
 };
 const TsdfTuning &tsdf_tuning();

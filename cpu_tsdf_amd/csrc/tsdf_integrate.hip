@@ -57,7 +57,6 @@ struct IntegrateArgs {
   float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
   int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
-  int live_skip1;        // LIVE: leave the blocks flagged 1 (wholly inside every row interval) to the ALLIN pass of the same frame
   int64_t pitch;
 };
 
@@ -298,13 +297,18 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 #define TSDF_RECOMPUTE_PX 1  // 72 instead of 80 VGPRs: 7 waves per SIMD (A/B on the GPU: 17.3-17.5 against 17.8-17.9 ms)
 #endif
 #ifndef TSDF_WPE_PACKED
-#define TSDF_WPE_PACKED 7  // waves per SIMD the ALLIN instances of the PACKED / colourless kernels ask for: 72 VGPRs, reachable since the x
-                           // products are redone per row (TSDF_RECOMPUTE_PX).  The general and the counting instances stay at 6: at 7 they spill two dozen
-                           // SGPRs into VGPR lanes, and the build with that AND the band flags gave wrong voxels on the GPU
-                           // (tests/evidence/diag_allin.py; cause not found in the ISA, so the configuration is avoided)
+#define TSDF_WPE_PACKED 7  // waves per SIMD the non-counting ALLIN instances ask for: 72 VGPRs, reachable since the x products are redone per
+                           // row (TSDF_RECOMPUTE_PX)
 #endif
 #ifndef TSDF_WPE_GENERAL
-#define TSDF_WPE_GENERAL 6  // waves per SIMD the general and the counting instances ask for (see TSDF_WPE_PACKED)
+#define TSDF_WPE_GENERAL 7  // ... and every other instance (general, row intervals, counting): 72 VGPRs + two dozen SGPRs spilled into
+                            // VGPR lanes + 30-60 B of scratch, 17.7 against 18.7 ms at 2048^3 + colour (round 4).  Round 3 kept these at 6
+                            // because ONE run of a 7-wave build "gave wrong voxels".  Round 4 rebuilt that configuration (and 8 waves, and
+                            // SGPR spills to scratch instead of lanes), audited its ISA (spill register only ever touched by lane
+                            // accesses; no VALU-writes-SGPR -> VMEM hazard) and ran the bisect script and the integrate / fused test
+                            // modules on it on three GPU boxes: no voxel differs (profiles/r04_wave7_bisect.txt).  Not reproducible;
+                            // tests/test_integrate_gpu.py::test_every_reachable_k_integrate_instance_equals_the_oracle now gates every
+                            // instance of the shipped build
 #endif
 // ALLIN (only with FASTPROJ): the host has proved (launch_integrate, `all_inside`: the slab's eight corner voxels, a
 // convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
@@ -316,8 +320,9 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 // its x range (the block leaves at once), 1 = every row's interval covers the block's whole x range (the intervals decide
 // nothing in it), 2 = some do not: then a wave skips every row whose interval misses its 64 quads before any arithmetic,
 // and the voxels of a quad that lie outside the interval are masked like voxels out of sensor range.
-// ALLIN && LIVE: the slab is wholly in view but the reference's cull cuts it: this instance takes the blocks flagged 1 at
-// the ALLIN instance's speed, and a LIVE pass with a.live_skip1 takes the blocks flagged 2 (two launches per frame).
+// (Never with ALLIN.  A slab wholly in view that the reference's cull cuts takes this instance for all its blocks: the
+// alternative -- an ALLIN pass over the blocks flagged 1 plus an interval pass over those flagged 2 -- was built and
+// measured slower, profiles/r04_refcull_dual_launch_measured_and_removed.txt.)
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false, bool LIVE = false>
 static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
@@ -326,16 +331,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             unsigned long long *__restrict__ n_obs, const uint8_t *__restrict__ live, uint8_t *__restrict__ band,
             const uint32_t *__restrict__ row_iv) {
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
+  static_assert(!(ALLIN && LIVE), "the ALLIN instance knows no row intervals");
   bool strad = false;  // LIVE: this block's rows need their intervals (block-uniform)
   if (LIVE) {
     const unsigned flag = live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)];
-    if (ALLIN ? flag != 1u : (flag == 0u || (a.live_skip1 && flag == 1u))) return;
-    strad = !ALLIN && flag == 2u;
+    if (flag == 0u) return;
+    strad = flag == 2u;
   }
   const unsigned tid = threadIdx.x;
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
   __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
-  __shared__ uint32_t s_iv[LIVE && !ALLIN ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
+  __shared__ uint32_t s_iv[LIVE ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
   // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
   // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
@@ -345,7 +351,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   {
     const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
-    if (LIVE && !ALLIN && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
+    if (LIVE && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
   __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
@@ -387,7 +393,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
       unsigned iv_lo = 0u, iv_len = 0u;
-      if (LIVE && !ALLIN && strad) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
+      if (LIVE && strad) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
         const uint32_t iv = s_iv[ty + r * a.TY];
         iv_lo = iv & 0xffffu, iv_len = iv >> 16;
         if (!((unsigned)(x4 + 3) - iv_lo < iv_len + 3u)) continue;
@@ -1276,7 +1282,6 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.band_fx = h->band_fx;
   a.band_fy = h->band_fy;
   a.x_abs0 = a.y_abs0 = 0;
-  a.live_skip1 = 0;
   return hh;
 }
 
@@ -1862,17 +1867,15 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     allin = all_inside && tsdf_tuning().allin && (h->nx & 3) == 0 && zlo_margin_ok(T, h) &&
             (!h->packed || (a.wmax_is_int && (float)h->kmax == p.max_weight));
   }
-  // wholly in view, but the reference's cull cuts the slab: the ALLIN instance for the blocks the cull leaves whole, the
-  // LIVE instance for the blocks it cuts
-  const bool dual = allin && rc_rows;
-  if (rc) allin = false;
+  if (rc) allin = false;  // (the ALLIN instance knows no row intervals; measured: an ALLIN pass over the blocks the cull leaves
+                          // whole + an interval pass over the rest took 16.0 + 3.8 ms where ONE interval pass takes 18 ms)
   // LIVE launch: the frame cannot see the whole slab (or the reference's cull bites): row intervals + block flags
   const bool want_live = (tsdf_tuning().cull && !all_inside && row_intervals_usable(h, false)) || rc_rows;
   if (want_live) {
     // narrow blocks: 64 quads of 4 rows, so that the flags and a wave's row skip follow the frustum's outline (a block
     // of a whole 1024-voxel row group is mostly outside it when the camera sits inside the volume)
     // (a slab that is wholly in view -- only the reference's cull decides anything -- keeps the streaming shape)
-    const int ltx = std::max(4, std::min(8, tsdf_tuning().live_log2tx));  // 64 quads by default (a knob for A/B runs: 16 .. 256)
+    const int ltx = std::max(4, std::min(8, tsdf_tuning().live_log2tx));  // 32 quads by default (a knob for A/B runs: 16 .. 256)
     if (a.TX > (1 << ltx) && !all_inside) {
       a.TX = 1 << ltx, a.log2TX = ltx, a.TY = 256 >> ltx;
       a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);
@@ -1974,7 +1977,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   if (!band_arg) h->band_exact = false;
   if (pose_ok && !nothing_observable) {
     const dim3 grid(gx, gy, gz), block(256);
-    h->last_launch[0] = fastproj && ((allin && !live) || dual);
+    h->last_launch[0] = fastproj && allin && !live;
     h->last_launch[1] = fastproj;
     h->last_launch[2] = live ? (rc_rows ? 2 : 1) : 0;
     h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
@@ -1983,12 +1986,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
                      d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, live, band_arg, h->row_iv)
 #define L6(ORDER, COLOR, FP, COUNT, PK)                  \
   do {                                                   \
-    if (live && FP && dual) {                            \
-      a.live_skip1 = 0;                                  \
-      LAUNCH(ORDER, COLOR, FP, COUNT, PK, FP, true);     \
-      a.live_skip1 = 1;                                  \
-      LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, true);  \
-    } else if (live)                                     \
+    if (live)                                            \
       LAUNCH(ORDER, COLOR, FP, COUNT, PK, false, true);  \
     else if (FP && allin)                                \
       LAUNCH(ORDER, COLOR, FP, COUNT, PK, FP, false);    \

@@ -42,7 +42,7 @@ for name, off in (("centred", 0.0), ("off-centre", 0.45)):
     d, w, rgb = vol.download()
     assert_same_f32(d, ov.d, name + ": d")
     assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
-    img = vol.renderView(poses[1], 1)
+    img = vol.renderView(poses[1], 1, camera_frame=False)
     assert_same_f32(img[..., :6], ov.raycast(poses[1], 1)[..., :6], name + ": renderView")
     mc = MarchingCubesTSDFOctree()
     mc.setInputTSDF(vol)
