@@ -85,6 +85,10 @@ def parse():
                     "of the half-width and yaw every turntable camera so that the grid's centre still projects to the image "
                     "centre -- the regime where the reference's frustum cull (1.1 x FOV about the optical AXIS) decides voxels "
                     "and the launch carries it in row intervals.  Not the headline configuration: the line says so")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, help="run the FULL N-rank control flow (rendezvous, Z-slab partition, per-step "
+                    "frame broadcast overlapped with the previous kernel, all-reduce of the results) with N ranks on ONE GPU over gloo "
+                    "(RCCL refuses two ranks per device): what an N-GPU node executes, minus the links.  Timings of such a run say "
+                    "nothing about scaling; host_us_per_step (the host-side cost of one step) is what it is for")
     ap.add_argument("--calib", type=int, default=0, help="run this many k_calib_rmw sweeps of exactly known bytes first "
                     "(PMC passes: calibrates FETCH_SIZE / WRITE_SIZE in the same process)")
     a = ap.parse_args()
@@ -381,6 +385,10 @@ def relaunch_under_torchrun(n):
 
 def main():
     args = parse()
+    if args.dry_run_ranks:
+        args.gpus = args.dry_run_ranks
+        os.environ["TSDF_BENCH_ONE_DEVICE"] = "1"
+        os.environ["TSDF_BENCH_BACKEND"] = "gloo"
     if args.gpus > 1 and args.host == "process" and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)  # does not return
     if args.host == "inprocess":
@@ -508,6 +516,20 @@ def main():
     # two receive slots: the broadcast of frame i+1 fills one while k_integrate reads frame i from the other
     recv = torch.empty((2, fplanes, H, W), dtype=torch.float32, device=dev) if use_dist else None
     pairs = []  # HIP event pairs around each timed launch, on the stream the kernel runs on
+    ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    host_t = {"launch": 0.0, "broadcast": 0.0, "events": 0.0, "steps": 0}  # host seconds spent ENQUEUEING, timed steps only
+    # everything a step hands to the C ABI is bound once, outside the timed region: per step the host makes two ctypes calls
+    # (planes, integrate) with ready-made pointer objects
+    set_cull, integ = lib.tsdf_hip_set_reference_cull, lib.tsdf_hip_integrate_device
+    bound = {}
+
+    def bound_args(i):
+        b = bound.get(i)
+        if b is None:
+            fr = frame_buf(i)
+            b = bound[i] = (capi.as_f32p(planes_all[i]), C.c_void_p(fr[0].data_ptr()), C.c_void_p(fr[1].data_ptr()) if args.color else None,
+                            capi.as_f32p(T_all[i]))
+        return b
 
     def frame_buf(i):
         return frames_dev[i] if rank == 0 else recv[i & 1]
@@ -518,16 +540,22 @@ def main():
         return dist.broadcast(frame_buf(i), src=0, async_op=async_op)
 
     def launch(i, count=None, timed=False):
-        fr = frame_buf(i)
+        pl, dp, cp, tp = bound_args(i)
         if timed:
-            pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            t0 = time.perf_counter()
+            pairs.append(ev_pool[len(pairs)])
             pairs[-1][0].record(stream)
-        capi.check(lib.tsdf_hip_set_reference_cull(h, capi.as_f32p(planes_all[i])), "set_reference_cull")
-        rc = lib.tsdf_hip_integrate_device(h, C.c_void_p(fr[0].data_ptr()), C.c_void_p(fr[1].data_ptr()) if args.color else None,
-                                           capi.as_f32p(T_all[i]), count)
-        capi.check(rc, "integrate_device")
+            t1 = time.perf_counter()
+        rc = set_cull(h, pl) or integ(h, dp, cp, tp, count)
         if timed:
+            t2 = time.perf_counter()
             pairs[-1][1].record(stream)
+            t3 = time.perf_counter()
+            host_t["events"] += (t1 - t0) + (t3 - t2)
+            host_t["launch"] += t2 - t1
+            host_t["steps"] += 1
+        if rc:
+            capi.check(rc, "integrate_device")
 
     counted = []  # (observed voxels, changed-word bytes) of every counted launch
 
@@ -538,11 +566,14 @@ def main():
         detail = (C.c_uint64 * 2)()
         for i in range(first, last):
             if use_dist:
+                tb = time.perf_counter()
                 if args.overlap:
                     pending.wait()  # `stream` waits for frame i (the host does not)
                     pending = bcast(i + 1, True) if i + 1 < last else None
                 else:
                     bcast(i, False)
+                if timed:
+                    host_t["broadcast"] += time.perf_counter() - tb
             if counting:
                 c = C.c_uint64(0)
                 launch(i, C.byref(c), timed)
@@ -688,6 +719,17 @@ def main():
                         "reference, a side note -- the PACKED layout moves fewer bytes than that record holds",
             },
         }
+        n_h = max(1, host_t["steps"])
+        out["host_us_per_step"] = {
+            "integrate_calls": host_t["launch"] / n_h * 1e6, "event_records": host_t["events"] / n_h * 1e6,
+            "broadcast_calls": host_t["broadcast"] / n_h * 1e6 if use_dist else None,
+            "total": (host_t["launch"] + host_t["events"] + host_t["broadcast"]) / n_h * 1e6,
+            "frac_of_kernel": (host_t["launch"] + host_t["events"] + host_t["broadcast"]) / n_h * 1e3 / kern_ms if kern_ms else None,
+            "note": "rank 0's host time spent ENQUEUEING one timed step (two ctypes calls with pre-bound arguments: cull planes + "
+                    "integrate; two event records; the frame broadcast's wait() + next issue at N > 1) -- the GPU runs behind it" +
+                    ("; backend gloo stages device tensors through the host inside broadcast(): its share is not RCCL's" if use_dist and backend != "nccl" else "")}
+        if args.dry_run_ranks:
+            out["dry_run"] = f"{world} ranks on ONE GPU over gloo: control flow only, no number here is a scaling number"
         if use_dist:
             out["multi_gpu"] = {"host": "one process per GPU, torch.distributed", "world_size": dist.get_world_size(),
                                 "per_rank_kernel_ms": per_rank_kernel_ms, "frame_broadcast_ms_isolated": bcast_ms,

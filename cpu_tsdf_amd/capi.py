@@ -152,6 +152,7 @@ SIGNATURES = {
     "tsdf_hip_reference_cull_planes": (C.c_int, [C.POINTER(TsdfParams), _f64p, _f32p]),
     "tsdf_hip_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),
+    "tsdf_hip_multi_link_stats": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_multi_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsdf_hip_multi_kernel_ms": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.POINTER(C.c_int32)]),
 }

@@ -280,6 +280,7 @@ struct TsdfTuning {
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
   int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (5: 128 voxels x 8 rows per block pass; Scene B at 2048^3: 0.37 ms against 0.60 at 6)
+  int zfast;           // integrate launches hand out blocks planes-fastest: -1 when the frame outgrows an XCD's L2 (default), 0 never, 1 always
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
 };
 const TsdfTuning &tsdf_tuning();

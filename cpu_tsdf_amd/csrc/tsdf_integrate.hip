@@ -57,6 +57,7 @@ struct IntegrateArgs {
   float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
   int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
+  int zfast;             // the hardware grid is (planes, row groups, x chunks) instead of (x chunks, row groups, planes): see tsdf_block_coords
   int64_t pitch;
 };
 
@@ -248,6 +249,24 @@ static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn
 
 // (buffer-descriptor access helpers: tsdf_buffer.h)
 
+// Logical block coordinates (x chunk, row group, plane) and logical grid extents of an integrate launch.  The hardware hands
+// out workgroups in the order x, y, z of the grid and deals consecutive ones to the eight XCDs in turn.  Default: x chunks
+// fastest -- the ~1800 blocks in flight stream three or four whole planes, whose voxels project to the WHOLE image.  zfast:
+// planes fastest -- the blocks in flight are one (x chunk, few row groups) column through all planes, which projects to a
+// narrow bundle of rays: the frame pixels they gather stay within an XCD's 4 MB L2 even when the frame does not
+// (1280x960 + colour = 9.8 MB, BASELINE configs[4]).
+struct BlockCoords {
+  unsigned bx, by, bz, gdx, gdy;
+};
+static __device__ __forceinline__ BlockCoords tsdf_block_coords(int zfast) {
+  BlockCoords c;
+  c.by = blockIdx.y, c.gdy = gridDim.y;
+  c.bx = zfast ? blockIdx.z : blockIdx.x;
+  c.bz = zfast ? blockIdx.x : blockIdx.z;
+  c.gdx = zfast ? gridDim.z : gridDim.x;
+  return c;
+}
+
 // Grid: x = chunks of TX quads along the row, y = groups of rpb*TY rows, z = planes.  No persistent
 // blocks: the hardware dispatcher balances the tail, and no index needs an integer division.
 // A thread owns one quad column (4 x-consecutive voxels) and walks rpb rows of it.  Everything that depends
@@ -332,9 +351,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             const uint32_t *__restrict__ row_iv) {
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
   static_assert(!(ALLIN && LIVE), "the ALLIN instance knows no row intervals");
+  const BlockCoords bc = tsdf_block_coords(a.zfast);
   bool strad = false;  // LIVE: this block's rows need their intervals (block-uniform)
   if (LIVE) {
-    const unsigned flag = live[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)];
+    const unsigned flag = live[bc.bx + bc.gdx * (bc.by + bc.gdy * bc.bz)];
     if (flag == 0u) return;
     strad = flag == 2u;
   }
@@ -349,19 +369,19 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   if (!TSDF_NO_BAND) reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
   if (PACKED) s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
   {
-    const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
+    const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
-    if (LIVE && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)blockIdx.z * a.ny + yy] : 0u;  // [launch plane][launch row]
+    if (LIVE && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)bc.bz * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
   __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
-  const int xq = (int)blockIdx.x * a.TX + tx;
-  const int zl = (int)blockIdx.z;
+  const int xq = (int)bc.bx * a.TX + tx;
+  const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0, chg = 0;
   // wave-uniform bases
-  const int row0 = (int)blockIdx.y * a.rpb * a.TY;
+  const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
   const unsigned span = (unsigned)rows * (unsigned)a.pitch;  // elements of this block's row group
@@ -690,7 +710,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     __syncthreads();
     const int fxb = max(1, a.TX >> 4);
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
-    const int xc0 = (a.x_abs0 + (int)blockIdx.x * a.TX * 4) >> 6;
+    const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
     const int n_fl = (yg1 - yg0 + 1) * fxb;
     for (int i = (int)tid; i < n_fl; i += 256) {
       const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
@@ -705,7 +725,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     if (chg) atomicAdd(&s_chg, chg);
     __syncthreads();
     if (tid == 0 && s_cnt) {
-      const unsigned b = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
+      const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
       atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
     }
@@ -737,23 +757,24 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
              const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,
              unsigned long long *__restrict__ n_obs, uint8_t *__restrict__ band) {
   const unsigned tid = threadIdx.x;
+  const BlockCoords bc = tsdf_block_coords(a.zfast);
   __shared__ float s_rcp[256];
   __shared__ float s_cy[256];
   __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
   reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
   s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
   {
-    const int yy = (int)blockIdx.y * a.rpb * a.TY + (int)tid;
+    const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
   }
   __syncthreads();
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
-  const int xq = (int)blockIdx.x * a.TX + tx;
-  const int zl = (int)blockIdx.z;
+  const int xq = (int)bc.bx * a.TX + tx;
+  const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0;
-  const int row0 = (int)blockIdx.y * a.rpb * a.TY;
+  const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
   const unsigned span = (unsigned)rows * (unsigned)a.pitch;
@@ -964,7 +985,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     __syncthreads();
     const int fxb = max(1, a.TX >> 4);
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
-    const int xc0 = (a.x_abs0 + (int)blockIdx.x * a.TX * 4) >> 6;
+    const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
     const int n_fl = (yg1 - yg0 + 1) * fxb;
     for (int i = (int)tid; i < n_fl; i += 256) {
       const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
@@ -981,7 +1002,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     if (cntB) atomicAdd(&s_cntB, cntB);
     __syncthreads();
     if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes (tsdf_integrate_collect2)
-      const unsigned b = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 511u;
+      const unsigned b = (bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u;
       if (s_cntA) atomicAdd(n_obs + b, (unsigned long long)s_cntA);
       if (s_cntB) atomicAdd(n_obs + 512u + b, (unsigned long long)s_cntB);
       atomicAdd(n_obs + 1024u + b, (unsigned long long)s_cnt);
@@ -1282,6 +1303,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.band_fx = h->band_fx;
   a.band_fy = h->band_fy;
   a.x_abs0 = a.y_abs0 = 0;
+  a.zfast = 0;
   return hh;
 }
 
@@ -1872,7 +1894,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   // LIVE launch: the frame cannot see the whole slab (or the reference's cull bites): row intervals + block flags
   const bool want_live = (tsdf_tuning().cull && !all_inside && row_intervals_usable(h, false)) || rc_rows;
   if (want_live) {
-    // narrow blocks: 64 quads of 4 rows, so that the flags and a wave's row skip follow the frustum's outline (a block
+    // narrow blocks: 32 quads (128 voxels) by 8 rows per pass, so that the flags and a wave's row skip follow the frustum's outline (a block
     // of a whole 1024-voxel row group is mostly outside it when the camera sits inside the volume)
     // (a slab that is wholly in view -- only the reference's cull decides anything -- keeps the streaming shape)
     const int ltx = std::max(4, std::min(8, tsdf_tuning().live_log2tx));  // 32 quads by default (a knob for A/B runs: 16 .. 256)
@@ -1976,7 +1998,10 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 && (a.y_abs0 & 3) == 0 ? h->band : nullptr;
   if (!band_arg) h->band_exact = false;
   if (pose_ok && !nothing_observable) {
-    const dim3 grid(gx, gy, gz), block(256);
+    // planes fastest when the frame outgrows an XCD's L2 (knob zfast: -1 auto, 0 / 1 force)
+    const size_t frame_bytes = npx * (color ? 8 : 4);
+    a.zfast = tsdf_tuning().zfast < 0 ? (frame_bytes > (3u << 20) && gx <= 65535u) : (tsdf_tuning().zfast != 0 && gx <= 65535u);
+    const dim3 grid(a.zfast ? gz : gx, gy, a.zfast ? gx : gz), block(256);
     h->last_launch[0] = fastproj && allin && !live;
     h->last_launch[1] = fastproj;
     h->last_launch[2] = live ? (rc_rows ? 2 : 1) : 0;
@@ -2127,7 +2152,8 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   if (!band_arg) h->band_exact = false;
   h->last_launch[0] = 2, h->last_launch[1] = 1, h->last_launch[2] = 0;
   h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
-  const dim3 grid(gx, gy, gz), block(256);
+  a.zfast = tsdf_tuning().zfast < 0 ? (npx * (color ? 8 : 4) > (3u << 20) && gx <= 65535u) : (tsdf_tuning().zfast != 0 && gx <= 65535u);
+  const dim3 grid(a.zfast ? gz : gx, gy, a.zfast ? gx : gz), block(256);
 #define LAUNCH2(ORDER, COLOR, COUNT)                                                                                    \
   hipLaunchKernelGGL((k_integrate2<ORDER, COLOR, COUNT>), grid, block, 0, h->stream, a, fb, h->d, h->rgb, h->k8, dA, dB, \
                      h->cam64, h->ctr[0], h->ctr[1], h->ctr[2], h->counter, band_arg)

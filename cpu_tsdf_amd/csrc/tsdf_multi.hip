@@ -53,6 +53,18 @@ struct tsdf_hip_multi {
   bool timing = false;
   std::vector<std::vector<hipEvent_t>> t_ev;  // per slab: start, stop, start, stop, ...
   std::vector<size_t> t_used;
+  // Copies between two slabs' devices: hipMemcpyPeerAsync where the driver grants peer access (xGMI), else -- access
+  // refused, or TSDF_HIP_NO_PEER=1, which routes EVERY cross-slab copy this way so that a one-GPU box can test it --
+  // through a pinned relay buffer on the host: device -> host on a relay stream of the source device, host -> device on
+  // the receiving slab's stream, chunk by chunk, every step ordered by events (tsdf_multi_copy).
+  bool relay_all = false;
+  std::vector<std::pair<int, int>> no_peer;  // device pairs whose peer access was refused
+  char *relay = nullptr;                     // pinned
+  size_t relay_cap = 0;
+  std::vector<std::pair<int, hipStream_t>> relay_stream;  // per source device
+  hipEvent_t relay_ev[3] = {nullptr, nullptr, nullptr};   // receiver's marker, relay filled, relay drained
+  bool relay_used = false;
+  uint64_t relay_bytes = 0;                  // bytes that took the relay (tsdf_hip_multi_render_stats-style report)
   // merged mesh of the last tsdf_hip_march (host)
   std::vector<float> verts;
   std::vector<uint8_t> rgb;
@@ -97,6 +109,13 @@ void tsdf_multi_free(tsdf_hip_volume *v) {
     if (m->ray_image) (void)hipFree(m->ray_image);
   }
   if (m->ray_table) (void)hipHostFree(m->ray_table);
+  if (m->relay) (void)hipHostFree(m->relay);
+  for (auto &rs : m->relay_stream) {
+    TsdfDeviceScope scope(rs.first);
+    (void)hipStreamDestroy(rs.second);
+  }
+  for (hipEvent_t e : m->relay_ev)
+    if (e) (void)hipEventDestroy(e);
   for (int s = 0; s < 2; ++s)
     if (m->pinned[s]) (void)hipHostFree(m->pinned[s]);
   for (size_t k = 0; k < m->slab.size(); ++k) {
@@ -152,6 +171,13 @@ extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *device
     }
     tsdf_build_centers(p->res[a], tsdf_node_size(*p, a), v->h_ctr[a], &v->levels[a]);
   }
+  if (n_devices > TSDF_MAX_SLABS) {  // (before any slab is allocated: ADVICE r03)
+    tsdf_set_error("too many slabs");
+    delete v->multi;
+    v->multi = nullptr;
+    delete v;
+    return TSDF_HIP_E_INVALID;
+  }
   // halo: what renderView's ray hand-off needs (the refinement walk and the normal's samples look back / ahead);
   // marching cubes and sampling use the first plane of it
   m->halo = n_devices > 1 ? std::max(1, tsdf_hip_render_halo(p)) : 0;
@@ -180,24 +206,32 @@ extern "C" int tsdf_hip_create_multi(const tsdf_params *p, const int32_t *device
     }
     s->stream = m->stream[k];
   }
-  if (n_devices > TSDF_MAX_SLABS) {
-    tsdf_set_error("too many slabs");
-    return fail(TSDF_HIP_E_INVALID);
-  }
   v->packed = m->slab[0]->packed;
   v->kmax = m->slab[0]->kmax;
   v->p.layout = m->slab[0]->p.layout;
-  // peer access between every pair of distinct devices (xGMI); a failure only means copies get staged by the runtime
+  // peer access between every pair of distinct devices (xGMI).  A pair the driver refuses is remembered and its copies
+  // take the host relay (tsdf_multi_copy): slower, never a hang, and said once on stderr.
+  {
+    const char *e = getenv("TSDF_HIP_NO_PEER");
+    m->relay_all = e && *e && atoi(e) != 0;
+  }
   for (int a = 0; a < n_devices; ++a)
     for (int b = 0; b < n_devices; ++b)
       if (devices[a] != devices[b]) {
         int can = 0;
+        bool ok = false;
         if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
           TsdfDeviceScope scope(devices[a]);
           const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-          if (e != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled included
+          ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+          if (e != hipSuccess) (void)hipGetLastError();
         } else {
           (void)hipGetLastError();
+        }
+        if (!ok && std::find(m->no_peer.begin(), m->no_peer.end(), std::make_pair(devices[a], devices[b])) == m->no_peer.end()) {
+          m->no_peer.push_back(std::make_pair((int)devices[a], (int)devices[b]));
+          fprintf(stderr, "libtsdf_hip: no peer access from GPU %d to GPU %d: frames, halo planes and ray records between their "
+                          "slabs go through pinned host memory\n", devices[a], devices[b]);
         }
       }
   m->ev.resize(n_devices, nullptr);
@@ -403,6 +437,76 @@ int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra,
   return asynchronous ? TSDF_HIP_OK : tsdf_multi_synchronize(h);
 }
 
+// One copy between (possibly) two devices, queued on `stream`, a stream of the RECEIVING device that has already been
+// made to wait for the source data (every caller orders source -> receiver by an event first).
+static int tsdf_multi_copy(tsdf_hip_multi *m, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream,
+                           bool cross_slab = true) {
+  if (!bytes) return TSDF_HIP_OK;
+  if (!cross_slab) {  // within one slab: never a link
+    TSDF_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    return TSDF_HIP_OK;
+  }
+  const bool refused = std::find(m->no_peer.begin(), m->no_peer.end(), std::make_pair(dst_dev, src_dev)) != m->no_peer.end() ||
+                       std::find(m->no_peer.begin(), m->no_peer.end(), std::make_pair(src_dev, dst_dev)) != m->no_peer.end();
+  if (!m->relay_all && !refused) {
+    if (dst_dev == src_dev) {
+      TSDF_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    } else {
+      TSDF_HIP_TRY(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream));
+    }
+    return TSDF_HIP_OK;
+  }
+  // ---- host relay ----
+  const size_t chunk_max = (size_t)32 << 20;
+  const size_t need = std::min(bytes, chunk_max);
+  if (need > m->relay_cap) {
+    if (m->relay) {
+      if (m->relay_used) TSDF_HIP_TRY(hipEventSynchronize(m->relay_ev[2]));  // the last drain of the old buffer
+      TSDF_HIP_TRY(hipHostFree(m->relay));
+      m->relay = nullptr, m->relay_cap = 0;
+    }
+    TSDF_HIP_TRY(hipHostMalloc((void **)&m->relay, need, hipHostMallocPortable));
+    m->relay_cap = need;
+  }
+  for (hipEvent_t &e : m->relay_ev)
+    if (!e) TSDF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipStream_t rs = nullptr;
+  for (auto &p : m->relay_stream)
+    if (p.first == src_dev) rs = p.second;
+  if (!rs) {
+    TsdfDeviceScope scope(src_dev);
+    TSDF_HIP_TRY(scope.err);
+    TSDF_HIP_TRY(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking));
+    m->relay_stream.push_back(std::make_pair(src_dev, rs));
+  }
+  for (size_t off = 0; off < bytes; off += chunk_max) {
+    const size_t n = std::min(chunk_max, bytes - off);
+    {
+      TsdfDeviceScope scope(dst_dev);
+      TSDF_HIP_TRY(scope.err);
+      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[0], stream));  // the receiver is ready (and the source data complete: see above)
+    }
+    {
+      TsdfDeviceScope scope(src_dev);
+      TSDF_HIP_TRY(scope.err);
+      TSDF_HIP_TRY(hipStreamWaitEvent(rs, m->relay_ev[0], 0));
+      if (m->relay_used) TSDF_HIP_TRY(hipStreamWaitEvent(rs, m->relay_ev[2], 0));  // the relay's last content has left it
+      TSDF_HIP_TRY(hipMemcpyAsync(m->relay, (const char *)src + off, n, hipMemcpyDeviceToHost, rs));
+      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[1], rs));
+    }
+    {
+      TsdfDeviceScope scope(dst_dev);
+      TSDF_HIP_TRY(scope.err);
+      TSDF_HIP_TRY(hipStreamWaitEvent(stream, m->relay_ev[1], 0));
+      TSDF_HIP_TRY(hipMemcpyAsync((char *)dst + off, m->relay, n, hipMemcpyHostToDevice, stream));
+      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[2], stream));
+    }
+    m->relay_used = true;
+    m->relay_bytes += n;
+  }
+  return TSDF_HIP_OK;
+}
+
 // Device frame (anywhere on the node) -> every slab's staging buffer by peer copy, ordered on the receiving slab's
 // stream.  A frame in slab `src`'s own staging buffer (tsdf_hip_organize) is ordered both ways by events: the copies
 // wait for that slab's stream, and that slab's later work waits for the copies.  A CALLER's buffer (src_slab < 0) must
@@ -437,14 +541,13 @@ static int fan_out_device(tsdf_handle h, const float *d_depth, const uint32_t *d
     if ((int)k == src_slab) continue;
     TSDF_ON_DEVICE(s->device);
     if (src_slab >= 0) TSDF_HIP_TRY(hipStreamWaitEvent(s->stream, m->ev[src_slab], 0));
-    if (s->device == src_dev) {
-      if (d_depth != s->frame_depth)
-        TSDF_HIP_TRY(hipMemcpyAsync(s->frame_depth, d_depth, npx * 4, hipMemcpyDeviceToDevice, s->stream));
-      if (color && d_bgra != s->frame_bgra)
-        TSDF_HIP_TRY(hipMemcpyAsync(s->frame_bgra, d_bgra, npx * 4, hipMemcpyDeviceToDevice, s->stream));
-    } else {
-      TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_depth, s->device, d_depth, src_dev, npx * 4, s->stream));
-      if (color) TSDF_HIP_TRY(hipMemcpyPeerAsync(s->frame_bgra, s->device, d_bgra, src_dev, npx * 4, s->stream));
+    if (d_depth != s->frame_depth) {
+      const int rc = tsdf_multi_copy(m, s->frame_depth, s->device, d_depth, src_dev, npx * 4, s->stream);
+      if (rc) return rc;
+    }
+    if (color && d_bgra != s->frame_bgra) {
+      const int rc = tsdf_multi_copy(m, s->frame_bgra, s->device, d_bgra, src_dev, npx * 4, s->stream);
+      if (rc) return rc;
     }
     // ... and the source after the receivers: whatever the source slab queues next (the next tsdf_hip_organize, the
     // next upload into its staging buffer) must not overwrite the frame while another GPU is still copying it
@@ -506,18 +609,17 @@ static int copy_planes(tsdf_hip_multi *m, int src, int dst, int z0, int nz) {
   }
   TSDF_ON_DEVICE(b->device);
   TSDF_HIP_TRY(hipStreamWaitEvent(b->stream, m->ev[src], 0));
-  auto cp = [&](void *dst_p, const void *src_p, size_t bytes) -> hipError_t {
-    if (a->device == b->device) return hipMemcpyAsync(dst_p, src_p, bytes, hipMemcpyDeviceToDevice, b->stream);
-    return hipMemcpyPeerAsync(dst_p, b->device, src_p, a->device, bytes, b->stream);
+  auto cp = [&](void *dst_p, const void *src_p, size_t bytes) -> int {
+    return tsdf_multi_copy(m, dst_p, b->device, src_p, a->device, bytes, b->stream);
   };
   const size_t n = (size_t)(plane * nz);
-  TSDF_HIP_TRY(cp(b->d + ob, a->d + oa, n * 4));
-  if (a->w) TSDF_HIP_TRY(cp(b->w + ob, a->w + oa, n * 4));
-  if (a->rgb) TSDF_HIP_TRY(cp(b->rgb + ob, a->rgb + oa, n * 4));
-  if (a->k8) TSDF_HIP_TRY(cp(b->k8 + ob, a->k8 + oa, n));
-  for (int c = 0; c < 4; ++c)
-    if (a->cn[c]) TSDF_HIP_TRY(cp(b->cn[c] + ob, a->cn[c] + oa, n * 4));
-  return TSDF_HIP_OK;
+  int rc = cp(b->d + ob, a->d + oa, n * 4);
+  if (!rc && a->w) rc = cp(b->w + ob, a->w + oa, n * 4);
+  if (!rc && a->rgb) rc = cp(b->rgb + ob, a->rgb + oa, n * 4);
+  if (!rc && a->k8) rc = cp(b->k8 + ob, a->k8 + oa, n);
+  for (int c = 0; c < 4 && !rc; ++c)
+    if (a->cn[c]) rc = cp(b->cn[c] + ob, a->cn[c] + oa, n * 4);
+  return rc;
 }
 
 // Every slab's stream waits for what every other slab has queued so far.
@@ -656,11 +758,6 @@ int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rg
 // the point-to-point copies: suspended records to the owner of their next plane (96 B each), finished rays to the
 // first slab (36 B each), where k_ray_deliver writes them into the image and applies :422.  No image-sized buffer
 // crosses a link and no stream is synchronised inside a round.
-static hipError_t copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream) {
-  if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
-  return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
-}
-
 int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv, float *out) {
   tsdf_hip_multi *m = h->multi;
   const int n_slab = (int)m->slab.size();
@@ -740,8 +837,9 @@ int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3],
         for (int e = 0; e < d; ++e) first += table(k, e);
         if (k != d) TSDF_HIP_TRY(hipStreamWaitEvent(sd->stream, m->ev[k], 0));
         const size_t rec = TSDF_HIP_RAY_RECORD_INTS * sizeof(int);
-        TSDF_HIP_TRY(copy_between(m->ray_list[d] + (size_t)at * TSDF_HIP_RAY_RECORD_INTS, sd->device,
-                                  m->ray_outbox[k] + (size_t)first * TSDF_HIP_RAY_RECORD_INTS, m->slab[k]->device, c * rec, sd->stream));
+        if ((rc = tsdf_multi_copy(m, m->ray_list[d] + (size_t)at * TSDF_HIP_RAY_RECORD_INTS, sd->device,
+                                  m->ray_outbox[k] + (size_t)first * TSDF_HIP_RAY_RECORD_INTS, m->slab[k]->device, c * rec, sd->stream, k != d)))
+          return rc;
         if (k != d) handed += c, bytes_between += (uint64_t)c * rec;
         at += c;
       }
@@ -758,8 +856,9 @@ int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3],
         if (!c) continue;
         if (k != 0) TSDF_HIP_TRY(hipStreamWaitEvent(s0->stream, m->ev[k], 0));
         const size_t rec = TSDF_RAY_FIN_INTS * sizeof(int);
-        TSDF_HIP_TRY(copy_between(m->ray_fin_in + (size_t)at * TSDF_RAY_FIN_INTS, s0->device, m->ray_finbox[k], m->slab[k]->device,
-                                  c * rec, s0->stream));
+        if ((rc = tsdf_multi_copy(m, m->ray_fin_in + (size_t)at * TSDF_RAY_FIN_INTS, s0->device, m->ray_finbox[k], m->slab[k]->device,
+                                  c * rec, s0->stream, k != 0)))
+          return rc;
         if (k != 0) bytes_between += (uint64_t)c * rec;
         at += c;
       }
@@ -783,6 +882,17 @@ int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3],
 extern "C" int tsdf_hip_multi_render_stats(tsdf_handle h, uint64_t out[4]) {
   if (!h || !h->multi || !out) return TSDF_HIP_E_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = h->multi->rv_stats[i];
+  return TSDF_HIP_OK;
+}
+
+// Report-only: how the slabs of this set reach each other -- out[0] = device pairs whose peer access the driver refused,
+// out[1] = 1 if every cross-slab copy takes the host relay (TSDF_HIP_NO_PEER=1), out[2] = bytes that went through the
+// relay since create.
+extern "C" int tsdf_hip_multi_link_stats(tsdf_handle h, uint64_t out[3]) {
+  if (!h || !h->multi || !out) return TSDF_HIP_E_INVALID;
+  out[0] = h->multi->no_peer.size();
+  out[1] = h->multi->relay_all ? 1 : 0;
+  out[2] = h->multi->relay_bytes;
   return TSDF_HIP_OK;
 }
 

@@ -141,6 +141,13 @@ int tsdf_hip_slab_count(tsdf_handle h);
  * slab to another, out[2] bytes that moved between slabs (hand-offs + finished rays to the first slab), out[3] host
  * waits (one per slab and round: the slabs of a round run concurrently). */
 int tsdf_hip_multi_render_stats(tsdf_handle h, uint64_t out[4]);
+/* Report-only, multi-GPU handles: how the slabs reach each other.  Copies between two slabs' GPUs (the frame fan-out of
+ * the device entry points, halo planes, ray records) are hipMemcpyPeerAsync where the driver grants peer access; a pair
+ * it refuses -- said once on stderr at create -- goes through a pinned relay buffer on the host instead (device -> host
+ * on the source GPU, host -> device on the receiver's stream, every step ordered by events: slower, never a hang).
+ * TSDF_HIP_NO_PEER=1 in the environment at create routes EVERY cross-slab copy that way (how a one-GPU box tests it).
+ * out[0] = refused device pairs, out[1] = 1 if everything is relayed, out[2] = bytes relayed since create. */
+int tsdf_hip_multi_link_stats(tsdf_handle h, uint64_t out[3]);
 /* Report-only, multi-GPU handles: per-slab k_integrate time.  While enabled, every slab's integrate launch is bracketed
  * by HIP events on that slab's stream; tsdf_hip_multi_kernel_ms synchronises slab k and returns the summed milliseconds
  * and the number of launches since timing was enabled (or last read). */

@@ -168,6 +168,22 @@ def test_config3_2048_cubed_colour_through_weight_saturation_then_mesh(gpu):
     # colours of six sub-boxes (sphere pole, a column along each axis, two shell corners) against the oracle
     n_checked = assert_mesh_boxes_equal_oracle(v, mesh, boxes_2048(), 2.0, 1, min_triangles=100000)
     print(f"2048^3 mesh: {len(vert) // 3} triangles, {n_checked} of them compared bit for bit with the oracle")
+    # ... and the WHOLE mesh against itself without the band-flag skip: k_mc_classify skips what no
+    # "band seen" flag is near -- a flag k_integrate failed to set would drop triangles anywhere in the grid, which six boxes
+    # cannot see.  Knob mc_skip = 0 makes classify read every voxel: same triangle count, same cell keys, same vertex bits.
+    keys = mesh["cells"].copy()
+    vert_h = np.ascontiguousarray(vert).reshape(-1).view(np.uint32)
+    digest = (int(vert_h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(vert_h)))
+    del mesh, vert, vert_h
+    try:
+        capi.set_tuning("mc_skip", 0)
+        full = mc.reconstruct(want_cells=True)
+    finally:
+        capi.set_tuning("mc_skip", 1)
+    assert len(full["cells"]) == len(keys) and np.array_equal(full["cells"], keys), (len(full["cells"]), len(keys))
+    fv = np.ascontiguousarray(full["vertices"]).reshape(-1).view(np.uint32)
+    assert (int(fv.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(fv))) == digest
+    vert = full["vertices"]
     r = np.linalg.norm(vert[::97].astype(np.float64), axis=1)
     box = np.abs(np.abs(vert[::97]).max(1) - sc.h)
     resid = np.minimum(np.abs(r - sc.r), box)

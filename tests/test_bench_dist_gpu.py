@@ -101,3 +101,24 @@ def test_bench_single_gpu_line_carries_the_host_path_rate(gpu):
     j = run([sys.executable, "bench.py"] + COMMON, {})
     hp = j["host_path"]
     assert hp["frames_per_s_sync_calls"] > 0 and hp["frames_per_s_async_ring"] > 0 and "error" not in hp
+
+
+def test_bench_dry_run_ranks_reports_the_host_cost_of_a_step(gpu):
+    """`python bench.py --dry-run-ranks 4` (VERDICT r03 next #6a): the full four-rank control flow on one GPU over gloo,
+    launched by bench.py itself; the line says it is a dry run and carries rank 0's host-side microseconds per step."""
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TSDF_BENCH_ONE_DEVICE", "TSDF_BENCH_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "bench.py", "--dry-run-ranks", "4"] + COMMON, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    check_contract(j, 4)
+    assert "dry_run" in j and j["multi_gpu"]["backend"] == "gloo" and j["multi_gpu"]["planes_per_gpu"] == 64
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+    hu = j["host_us_per_step"]
+    assert hu["integrate_calls"] > 0 and hu["event_records"] > 0 and hu["broadcast_calls"] > 0 and hu["total"] < 1e5
+    assert single["host_us_per_step"]["broadcast_calls"] is None and 0 < single["host_us_per_step"]["total"] < 2000

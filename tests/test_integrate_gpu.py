@@ -695,8 +695,8 @@ def test_calibration_sweeps_leave_every_bit_alone(gpu, color, layout):
 
 
 def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
-    """k_integrate is compiled in 96 instances (transform order x colour x certified
-    projection x counting x layout x {general, ALLIN, row intervals, ALLIN + row intervals}) and k_integrate2 in 8; this
+    """k_integrate is compiled in 80 instances (transform order x colour x certified
+    projection x counting x layout x {general, ALLIN (certified projection only), row intervals}) and k_integrate2 in 8; this
     test drives the public entry points into EVERY one of them -- knobs and poses choose, tsdf_hip_last_launch_info
     confirms which one ran -- on noisy frames with NaN holes, twice per volume so that the second update works on real
     state, and compares every voxel with the culled oracle (the reference's integrateCloud incl. its frustum cull)."""
@@ -708,13 +708,13 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
             for color in (False, True):
                 for layout in (capi.LAYOUT_PACKED, capi.LAYOUT_F32W):
                     for fp in (1, 0):
-                        for kind in ("general", "allin", "rows", "allin+rows"):
-                            if "allin" in kind and not fp:
+                        for kind in ("general", "allin", "rows", "cull"):
+                            if kind == "allin" and not fp:
                                 continue  # the ALLIN instances exist only with the certified projection
                             capi.set_tuning("fast_projection", fp)
                             capi.set_tuning("allin", 0 if kind == "general" else 1)
                             vol, sc = make_volume(res, W, H, color=color, order=order, max_weight=100.0)
-                            if kind == "allin+rows":  # whole grid in view, principal point 60 % off centre: the cull cuts the grid
+                            if kind == "cull":  # whole grid in view, principal point 60 % off centre: the reference's cull cuts the grid
                                 sc.cx += 0.6 * W / 2
                                 vol.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
                             vol.setLayout(layout)
@@ -723,7 +723,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                             for i in range(4):
                                 if kind == "rows":  # camera inside the grid
                                     tr = synth.look_at_pose((0.02 * i, 0.01, -0.03), target=(0.05, 0.0, 1.0))
-                                elif kind == "allin+rows":
+                                elif kind == "cull":
                                     psi = float(np.arctan(0.6 * (W / 2) / sc.fx))
                                     yaw = np.eye(4)
                                     yaw[0, 0], yaw[0, 2], yaw[2, 0], yaw[2, 2] = np.cos(psi), np.sin(psi), -np.sin(psi), np.cos(psi)
@@ -738,7 +738,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                                 got = vol.integrateCloud(dep, col, tr, count=count)
                                 assert got is True or got == want, (order, color, layout, fp, kind, i, got, want)
                                 info = launch_info(vol)
-                                expect = {"general": (0, 0), "allin": (1, 0), "rows": (0, None), "allin+rows": (1, 2)}[kind]
+                                expect = {"general": (0, 0), "allin": (1, 0), "rows": (0, None), "cull": (0, 2)}[kind]
                                 ok = info[0] == expect[0] and (expect[1] is None or info[2] == expect[1]) and info[1] == fp
                                 assert ok and (kind != "rows" or info[2] in (1, 2)), (order, color, layout, fp, kind, info)
                                 hit.add((order, color, layout, fp, count, kind))
@@ -775,4 +775,58 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
     finally:
         capi.set_tuning("fast_projection", -1)
         capi.set_tuning("allin", 1)
-    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 2) + 8, len(hit)  # 96 k_integrate + 8 k_integrate2 instances
+    # 8 x {certified: general, ALLIN, row intervals (camera inside), row intervals (cull); exact projection: the same without
+    # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 8 of k_integrate2
+    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 3) + 8, len(hit)
+
+
+def test_planes_fastest_block_order_changes_nothing(gpu):
+    """Knob zfast (tsdf_block_coords): the hardware grid handed out planes-first -- what a launch uses by itself when the
+    frame outgrows an XCD's L2 (1280x960 + colour) -- against the default order and the oracle: the whole grid in view
+    (ALLIN), a camera inside (row intervals, block flags indexed by logical coordinates), a Z-slab handle on a grid several
+    x chunks wide, counting or not; and a frame big enough to switch it on by itself."""
+    outs = {}
+    try:
+        for zfast in (0, 1):
+            capi.set_tuning("zfast", zfast)
+            res = []
+            for name, kw, slab, poses in (
+                    ("allin", dict(res=64, color=True), None, [synth.turntable_pose(i, 8, 0.25) for i in range(3)]),
+                    ("inside", dict(res=64, color=False), None, [synth.look_at_pose((0.01 * i, 0.0, -0.02), target=(0.0, 0.01, 1.0)) for i in range(3)]),
+                    ("wide slab", dict(res=64, color=True, res3=(2304, 40, 48), size3=(9.0, 0.15625, 0.1875), zmax=20.0), (7, 31),
+                     [synth.look_at_pose((0.5 * i - 0.5, 0.02, -11.0), target=(0.0, 0.0, 0.0)) for i in range(3)])):
+                vol, sc = make_volume(kw.pop("res"), 160, 120, **kw)
+                if slab:
+                    vol.setZSlab(*slab)
+                vol.reset()
+                ov = OracleVolume(vol._p)
+                color = bool(vol._p.integrate_color)
+                rng = np.random.RandomState(11)
+                for i, tr in enumerate(poses):
+                    dep = sc.depth(tr, noise_seed=9 + i) if name != "wide slab" else rng.uniform(10.8, 11.2, (120, 160)).astype(np.float32)
+                    col = sc.bgra(i) if color else None
+                    zb, ze = slab if slab else (0, 0)
+                    want = ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr), zb, ze)
+                    got = vol.integrateCloud(dep, col, tr, count=(i != 1))
+                    assert got is True or got == want, (zfast, name, i, got, want)
+                d, w, rgb = vol.download()
+                zs = slice(*slab) if slab else slice(None)
+                assert_same_f32(d, ov.d[zs], f"{name}: d")
+                assert np.array_equal(w, ov.w[zs]) and (rgb is None or np.array_equal(rgb, ov.rgb[zs]))
+                assert (w > 0).mean() > 0.05, name
+                res.append((d, w))
+                vol.close()
+            outs[zfast] = res
+    finally:
+        capi.set_tuning("zfast", -1)
+    for (d0, w0), (d1, w1) in zip(outs[0], outs[1]):
+        assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(w0, w1)
+    # a 1024x768 colour frame (6.3 MB) switches the order on by itself
+    vol, sc = make_volume(32, 1024, 768, color=True)
+    vol.reset()
+    ov = OracleVolume(vol._p)
+    tr = synth.turntable_pose(1, 8, sc.size)
+    dep, col = sc.depth(tr), sc.bgra(1)
+    assert vol.integrateCloud(dep, col, tr, count=True) == ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
+    compare(vol, ov)
+    vol.close()
