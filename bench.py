@@ -702,7 +702,7 @@ def main():
                 "algorithmic_bytes": {"read_per_observed_voxel": read_bpv, "observed_voxels": n_obs_rank,
                                       "changed_word_bytes": chg_rank, "changed_bytes_per_observed_voxel": chg_per_obs,
                                       "frame_bytes": bpp * W * H},
-                "traffic_from_profile": ({"tag": prof.get("tag"), "commit": prof.get("commit"), "read_bytes": prof.get("read_bytes"),
+                "traffic_from_profile": ({"tag": prof.get("tag"), "commit": prof.get("git_head_when_summarised"), "read_bytes": prof.get("read_bytes"),
                                      "written_bytes": prof.get("written_bytes"),
                                      "frac_of_peak_by_traffic": prof["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "kernel_ms_in_profile": prof.get("kernel_ms_in_profile")} if prof else why),

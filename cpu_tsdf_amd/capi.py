@@ -149,6 +149,7 @@ SIGNATURES = {
     "tsdf_hip_set_reference_cull": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_integrate_device2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_void_p, _f32p, _f32p,
                                              _u64p, C.POINTER(C.c_int32)]),
+    "tsdf_hip_set_frame_pairing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsdf_hip_reference_cull_planes": (C.c_int, [C.POINTER(TsdfParams), _f64p, _f32p]),
     "tsdf_hip_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tsdf_hip_multi_render_stats": (C.c_int, [C.c_void_p, _u64p]),
@@ -189,13 +190,19 @@ def _torch_first():
     2.10+rocm7.0, tests/test_multi_gpu.py run on its own).  The other order works and is what bench.py and zslab.py
     always did.  So, where torch is installed and not yet imported, import it before the library
     (TSDF_HIP_NO_TORCH_PRELOAD=1 skips this; a process without torch is not affected)."""
-    import importlib.util
     import sys
     if "torch" in sys.modules or os.environ.get("TSDF_HIP_NO_TORCH_PRELOAD") == "1":
         return
+    try:  # only a ROCm build of torch carries a HIP runtime of its own: read its version from the metadata, without importing it
+        from importlib import metadata
+        if "rocm" not in metadata.version("torch"):
+            return
+    except Exception:  # no torch, or no metadata: nothing to order
+        return
     try:
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
+        import torch  # noqa: F401
+        if os.environ.get("TSDF_HIP_VERBOSE"):
+            print("cpu_tsdf_amd.capi: imported torch before libtsdf_hip.so (its bundled ROCm runtime must load first)", file=sys.stderr)
     except Exception:  # a broken torch installation must not keep the library from loading
         pass
 

@@ -82,6 +82,7 @@ struct tsdf_hip_volume {
   bool ref_cull = false;   // tsdf_hip_set_reference_cull: replicate getFrustumCulledVoxels with these planes
   float cull_planes[24] = {0};
   int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
+  bool pair_pending = false;  // frame pairing: a committed frame sits uploaded in its ring slot, its launch waiting for a partner
   bool pair_fused = false;  // the last tsdf_integrate_launch2 went through k_integrate2 (else two launches)
   unsigned long long pair_first_observed = 0, pair_first_changed = 0;  // ... of its first launch when it did not
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
@@ -190,6 +191,15 @@ struct TsdfDeviceScope {
 #define TSDF_ON_DEVICE(dev)          \
   TsdfDeviceScope _device_scope(dev); \
   TSDF_HIP_TRY(_device_scope.err)
+// Entry points that read or write the volume: on the handle's device, and after a frame that frame pairing is still
+// holding back (tsdf_hip_set_frame_pairing: its kernel launch waits for a partner frame) has been launched on its own.
+int tsdf_pipeline_flush(tsdf_hip_volume *v);
+#define TSDF_ENTER(h)                                  \
+  TSDF_ON_DEVICE((h)->device);                         \
+  if ((h)->pair_pending) {                             \
+    const int _rc_flush = tsdf_pipeline_flush(h);      \
+    if (_rc_flush) return _rc_flush;                   \
+  }
 
 // Per-axis voxel-centre table (tsdf_core.hip): the octree's node-centre recurrence, or the closed form.
 void tsdf_build_centers(int res, float size, std::vector<float> &out, int *levels);
@@ -280,7 +290,7 @@ struct TsdfTuning {
   int allin;           // integrate: use the ALLIN kernel instance when the whole slab is provably in range and in the image (1)
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
   int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (5: 128 voxels x 8 rows per block pass; Scene B at 2048^3: 0.37 ms against 0.60 at 6)
-  int zfast;           // integrate launches hand out blocks planes-fastest: -1 when the frame outgrows an XCD's L2 (default), 0 never, 1 always
+  int zfast;           // integrate launches hand out blocks planes-fastest: 1 always (default: 16.26 against 16.60 ms at 2048^3 + colour, 15.5 against 16.9 ms on a 4096 x 4096 x 512 slab with 1280x960 frames), 0 never, -1 only when the frame outgrows an XCD's L2
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
 };
 const TsdfTuning &tsdf_tuning();

@@ -57,7 +57,7 @@ static TsdfTuning &tuning_storage() {
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
-                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", -1), env_int("TSDF_HIP_FUSE2", 1)};
+                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1)};
   return t;
 }
 
@@ -724,7 +724,7 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
 extern "C" int tsdf_hip_reset(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_reset(h);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t n = h->pitch * h->ny * h->nz_alloc;
   const float minus_one = -1.f;
   uint32_t bits;
@@ -759,6 +759,9 @@ extern "C" int tsdf_hip_destroy(tsdf_handle h) {
 extern "C" int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_set_stream (a stream belongs to one device)");
+  {
+    TSDF_ENTER(h);  // a frame that frame pairing holds back is launched on the stream it was committed for
+  }
   h->stream = (hipStream_t)hip_stream;
   return TSDF_HIP_OK;
 }
@@ -766,7 +769,7 @@ extern "C" int tsdf_hip_set_stream(tsdf_handle h, void *hip_stream) {
 extern "C" int tsdf_hip_synchronize(tsdf_handle h) {
   if (!h) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_synchronize(h);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }
@@ -907,7 +910,7 @@ static int block_transfer(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
     tsdf_set_error("RGB_NORMALIZED / LAB colour state cannot be set from r,g,b bytes");
     return TSDF_HIP_E_UNSUPPORTED;
   }
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t plane = (int64_t)nx * ny;
   int64_t max_planes = (int64_t)(64 << 20) / plane;  // <= 64 Mi voxels (256 MiB of floats) per chunk
   if (max_planes < 1) max_planes = 1;
@@ -1005,7 +1008,7 @@ static int variance_block(tsdf_handle h, int x0, int y0, int z0, int nx, int ny,
     tsdf_set_error("this volume keeps no M_ / nsample_ state (only volumes loaded with weight_by_variance do)");
     return TSDF_HIP_E_INVALID;
   }
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t plane = (int64_t)nx * ny;
   const int64_t max_planes = std::max<int64_t>(1, (int64_t)(64 << 20) / plane);
   rc = tsdf_ensure_scratch(h, (size_t)std::min<int64_t>(max_planes, nz) * plane * sizeof(float));
@@ -1055,7 +1058,7 @@ extern "C" int tsdf_hip_download_color_state(tsdf_handle h, int plane_index, int
   }
   int rc = check_block(h, 0, 0, z0, h->nx, h->ny, nz);
   if (rc) return rc;
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t plane = (int64_t)h->nx * h->ny;
   const int64_t max_planes = std::max<int64_t>(1, (int64_t)(64 << 20) / plane);
   rc = tsdf_ensure_scratch(h, (size_t)std::min<int64_t>(max_planes, nz) * plane * sizeof(float));
@@ -1155,7 +1158,7 @@ static int planes_device(tsdf_handle h, int z0, int nz, void *d, void *w, void *
     tsdf_set_error("volume has no colour plane");
     return TSDF_HIP_E_INVALID;
   }
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t n = (int64_t)h->nx * h->ny * nz;
   const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
   const int zl0 = z0 - h->z_first;

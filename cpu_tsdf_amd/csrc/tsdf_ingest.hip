@@ -98,7 +98,7 @@ extern "C" int tsdf_hip_organize(tsdf_handle h, const float *xyz, size_t xyz_str
   if (h->multi)
     return tsdf_multi_organize(h, xyz, xyz_stride, bgra, bgra_stride, n, cloud_units, zero_nans, world_to_cam, depth_out, bgra_out,
                                n_valid);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const tsdf_params &p = h->p;
   const size_t npx = (size_t)p.image_width * p.image_height;
   // scratch: zbuf[npx] u64 | points | colours

@@ -2225,7 +2225,7 @@ extern "C" int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a,
     if (!rc) rc = tsdf_multi_integrate_device(h, d_depth_b, d_bgra_b, cam_from_vol_b, n_observed ? n_observed + 1 : nullptr);
     return rc;
   }
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   bool f = false;
   const int rc = tsdf_integrate_launch2(h, d_depth_a, d_bgra_a, cam_from_vol_a, planes_a, d_depth_b, d_bgra_b, cam_from_vol_b, planes_b,
                                         n_observed != nullptr, &f);
@@ -2271,6 +2271,50 @@ static int host_expf_fuses_r() {
   return expf(probe) == 0x1.f45326p-92f ? 1 : 0;  // the unfused form (and the correctly rounded value) is 0x1.f45324p-92
 }
 
+// tsdf_expf_glibc on n host floats (the current device).
+static __global__ void k_expf(const float *__restrict__ in, float *__restrict__ out, size_t n, int fused_r) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = tsdf_expf_glibc(in[i], fused_r != 0);
+}
+static int device_expf(const float *in, size_t n, float *out, int fused_r) {
+  float *di = nullptr, *dout = nullptr;
+  TSDF_HIP_TRY(hipMalloc(&di, n * 4));
+  TSDF_HIP_TRY(hipMalloc(&dout, n * 4));
+  TSDF_HIP_TRY(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, n, fused_r);
+  TSDF_HIP_TRY(hipGetLastError());
+  TSDF_HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(di);
+  (void)hipFree(dout);
+  return TSDF_HIP_OK;
+}
+
+// The device's expf is a restatement of ONE libm (glibc >= 2.27's table algorithm, in the flavour the probe above selects).
+// On another libm -- musl, an older glibc, a vectorised build -- the reference's std::exp(float) is a different function and
+// weight_by_variance_ would silently drift from the host's results.  So the first volume that switches the weighting on
+// checks: 4096 floats spread over the whole argument range, the device against THIS host's expf, bit for bit.
+static int expf_matches_this_host(int fused_r) {
+  static int verdict = -1;  // -1 unknown, 0 differs, 1 equal
+  if (verdict >= 0) return verdict;
+  const size_t n = 4096;
+  std::vector<float> in(n), dev(n);
+  uint32_t s = 0x9e3779b9u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    const float u = (float)(s >> 8) * (1.0f / 16777216.0f);                  // [0, 1)
+    const float mag = ldexpf(1.0f + u, (int)(i % 34) - 26);                    // 2^-26 .. 2^7.99: the weighting's exponents are <= 0,
+    in[i] = (i & 1) ? mag : -mag;                                              // the positive half guards the shared code path
+  }
+  if (device_expf(in.data(), n, dev.data(), fused_r) != TSDF_HIP_OK) return -1;
+  verdict = 1;
+  for (size_t i = 0; i < n; ++i) {
+    const volatile float x = in[i];
+    const float want = expf(x);
+    if (memcmp(&want, &dev[i], 4) != 0 && !(std::isnan(want) && std::isnan(dev[i]))) verdict = 0;
+  }
+  return verdict;
+}
+
 extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int weight_by_variance) {
   if (!h) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_set_weighting(h, weight_by_depth, weight_by_variance);
@@ -2283,38 +2327,32 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
     return TSDF_HIP_E_UNSUPPORTED;
   }
   if (weight_by_variance && !h->vm) {  // OctreeNode::M_ / nsample_ per voxel, zero like a fresh octree's
-    TSDF_ON_DEVICE(h->device);
+    TSDF_ENTER(h);
     const size_t n = (size_t)(h->pitch * h->ny * h->nz_alloc);
     TSDF_HIP_TRY(hipMalloc(&h->vm, n * sizeof(float)));
     TSDF_HIP_TRY(hipMalloc(&h->vn, n * sizeof(int32_t)));
     TSDF_HIP_TRY(hipMemsetAsync(h->vm, 0, n * sizeof(float), h->stream));
     TSDF_HIP_TRY(hipMemsetAsync(h->vn, 0, n * sizeof(int32_t), h->stream));
   }
+  h->expf_fused_r = host_expf_fuses_r();
+  if (weight_by_variance) {
+    TSDF_ON_DEVICE(h->device);
+    if (expf_matches_this_host(h->expf_fused_r) == 0) {
+      tsdf_set_error("weight_by_variance_: this host's expf is not the glibc algorithm the device restates (4096-float spot check "
+                     "differs): integrating would not reproduce the reference's std::exp(float) on this machine");
+      return TSDF_HIP_E_UNSUPPORTED;
+    }
+  }
   h->weight_by_depth = weight_by_depth != 0;
   h->weight_by_variance = weight_by_variance != 0;
-  h->expf_fused_r = host_expf_fuses_r();
   return TSDF_HIP_OK;
 }
 
 #ifdef TSDF_HIP_TEST_HOOKS
 // Test hook: the device's std::exp(float) of the variance weighting (tsdf_expf_glibc in this host's flavour) on n floats.
-static __global__ void k_selftest_expf(const float *__restrict__ in, float *__restrict__ out, size_t n, int fused_r) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = tsdf_expf_glibc(in[i], fused_r != 0);
-}
 extern "C" int tsdf_hip_selftest_expf(const float *in, size_t n, float *out) {
   if (!in || !out || !n) return TSDF_HIP_E_INVALID;
-  const int fused_r = host_expf_fuses_r();
-  float *di = nullptr, *dout = nullptr;
-  TSDF_HIP_TRY(hipMalloc(&di, n * 4));
-  TSDF_HIP_TRY(hipMalloc(&dout, n * 4));
-  TSDF_HIP_TRY(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_selftest_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, n, fused_r);
-  TSDF_HIP_TRY(hipGetLastError());
-  TSDF_HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(di);
-  (void)hipFree(dout);
-  return TSDF_HIP_OK;
+  return device_expf(in, n, out, host_expf_fuses_r());
 }
 #endif  // TSDF_HIP_TEST_HOOKS
 
@@ -2322,7 +2360,7 @@ extern "C" int tsdf_hip_integrate_device(tsdf_handle h, const float *d_depth, co
                                          const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !d_depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_integrate_device(h, d_depth, d_bgra, cam_from_vol, n_observed);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   return launch_integrate(h, d_depth, d_bgra, cam_from_vol, n_observed);
 }
 
@@ -2330,7 +2368,7 @@ extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8
                                   const float cam_from_vol[12], uint64_t *n_observed) {
   if (!h || !depth || !cam_from_vol) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_integrate(h, depth, bgra, cam_from_vol, n_observed, false);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   const bool color = h->p.integrate_color != 0;
   if (color && !bgra) {
@@ -2354,17 +2392,24 @@ extern "C" int tsdf_hip_integrate(tsdf_handle h, const float *depth, const uint8
 // every other entry point is ordered after it on the handle's stream; errors of the asynchronous part surface
 // at the next synchronising call (tsdf_hip_synchronize, download, march, ...).
 struct tsdf_hip_pipeline {
+  static const int SLOTS = 4;  // two frames may wait for their shared sweep while the next two are being staged
   hipStream_t copy_stream = nullptr;
-  float *pinned[2] = {nullptr, nullptr};   // host, [depth | bgra]
-  float *device[2] = {nullptr, nullptr};   // device, [depth | bgra]
-  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  float *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // host, [depth | bgra]
+  float *device[SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // device, [depth | bgra]
+  hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr, nullptr}, consumed[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long frames = 0;
+  // frame pairing (tsdf_hip_set_frame_pairing): a committed frame whose kernel launch waits for a partner
+  bool pairing = false;
+  int pend_slot = 0;
+  float pend_T[12];
+  bool pend_has_planes = false;
+  float pend_planes[24];
 };
 
 void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
   tsdf_hip_pipeline *p = v->pipe;
   if (!p) return;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < tsdf_hip_pipeline::SLOTS; ++i) {
     if (p->consumed[i]) (void)hipEventSynchronize(p->consumed[i]);
     if (p->pinned[i]) (void)hipHostFree(p->pinned[i]);
     if (p->device[i]) (void)hipFree(p->device[i]);
@@ -2374,6 +2419,7 @@ void tsdf_pipeline_destroy(tsdf_hip_volume *v) {
   if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   delete p;
   v->pipe = nullptr;
+  v->pair_pending = false;
 }
 
 // The ring itself: tsdf_hip_frame_begin hands out the next pinned slot (waiting until the kernel that last read it
@@ -2388,8 +2434,8 @@ static int pipeline_ready(tsdf_handle h) {
   // slot pointers to the next tsdf_hip_frame_begin
   auto build = [&]() -> int {
     TSDF_HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocDefault));
+    for (int i = 0; i < tsdf_hip_pipeline::SLOTS; ++i) {
+      TSDF_HIP_TRY(hipHostMalloc((void **)&p->pinned[i], npx * 8, hipHostMallocPortable));
       TSDF_HIP_TRY(hipMalloc((void **)&p->device[i], npx * 8));
       TSDF_HIP_TRY(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
       TSDF_HIP_TRY(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
@@ -2405,6 +2451,41 @@ static int pipeline_ready(tsdf_handle h) {
 int tsdf_multi_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra);
 int tsdf_multi_frame_commit(tsdf_handle h, const float T[12]);
 
+// Frame pairing launches the frame it has been holding back on its own: with that frame's pose and cull planes, the
+// handle's current planes put back afterwards.  Called by every entry point that reads or writes the volume (TSDF_ENTER).
+int tsdf_pipeline_flush(tsdf_hip_volume *h) {
+  tsdf_hip_pipeline *p = h->pipe;
+  if (!h->pair_pending || !p) {
+    h->pair_pending = false;
+    return TSDF_HIP_OK;
+  }
+  h->pair_pending = false;
+  const bool color = h->p.integrate_color != 0;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  const bool cur_has = h->ref_cull;
+  float cur[24];
+  for (int i = 0; i < 24; ++i) cur[i] = h->cull_planes[i];
+  h->ref_cull = p->pend_has_planes;
+  for (int i = 0; i < 24; ++i) h->cull_planes[i] = p->pend_has_planes ? p->pend_planes[i] : 0.f;
+  const int s = p->pend_slot;
+  const int rc = tsdf_integrate_launch(h, p->device[s], color ? reinterpret_cast<const uint32_t *>(p->device[s] + npx) : nullptr, p->pend_T, false);
+  h->ref_cull = cur_has;
+  for (int i = 0; i < 24; ++i) h->cull_planes[i] = cur[i];
+  if (rc) return rc;
+  TSDF_HIP_TRY(hipEventRecord(p->consumed[s], h->stream));
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_set_frame_pairing(tsdf_handle h, int on) {
+  if (!h) return TSDF_HIP_E_INVALID;
+  if (h->multi) return on ? TSDF_HIP_E_UNSUPPORTED : TSDF_HIP_OK;  // (a multi-GPU set integrates frame by frame)
+  TSDF_ENTER(h);  // (switching it off launches what was waiting)
+  const int rc = pipeline_ready(h);
+  if (rc) return rc;
+  h->pipe->pairing = on != 0;
+  return TSDF_HIP_OK;
+}
+
 extern "C" int tsdf_hip_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra) {
   if (!h || !depth) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_frame_begin(h, depth, bgra);
@@ -2413,9 +2494,9 @@ extern "C" int tsdf_hip_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra
   if (rc) return rc;
   tsdf_hip_pipeline *p = h->pipe;
   const size_t npx = (size_t)h->p.image_width * h->p.image_height;
-  const int slot = (int)(p->frames & 1ull);
-  // the slot was last used two frames ago: its kernel must be done before the staging buffers are reused
-  if (p->frames >= 2) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot]));
+  const int slot = (int)(p->frames % tsdf_hip_pipeline::SLOTS);
+  // the slot was last used SLOTS frames ago: its kernel must be done before the staging buffers are reused
+  if (p->frames >= (unsigned)tsdf_hip_pipeline::SLOTS) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot]));
   *depth = p->pinned[slot];
   if (bgra) *bgra = h->p.integrate_color ? reinterpret_cast<uint8_t *>(p->pinned[slot] + npx) : nullptr;
   return TSDF_HIP_OK;
@@ -2432,14 +2513,30 @@ extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]
   tsdf_hip_pipeline *p = h->pipe;
   const bool color = h->p.integrate_color != 0;
   const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
-  const int slot = (int)(p->frames & 1ull);
+  const int slot = (int)(p->frames % tsdf_hip_pipeline::SLOTS);
   TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], p->pinned[slot], bytes, hipMemcpyHostToDevice, p->copy_stream));
   TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
   TSDF_HIP_TRY(hipStreamWaitEvent(h->stream, p->copied[slot], 0));
-  const int rc = launch_integrate(h, p->device[slot], color ? reinterpret_cast<const uint32_t *>(p->device[slot] + npx) : nullptr,
-                                  cam_from_vol, nullptr);
-  if (rc) return rc;
-  TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
+  auto bgra_of = [&](int s) { return color ? reinterpret_cast<const uint32_t *>(p->device[s] + npx) : nullptr; };
+  if (h->pair_pending) {  // the partner has arrived: one sweep for both where the poses allow it, two launches otherwise
+    h->pair_pending = false;
+    const int sa = p->pend_slot;
+    const int rc = tsdf_integrate_launch2(h, p->device[sa], bgra_of(sa), p->pend_T, p->pend_has_planes ? p->pend_planes : nullptr,
+                                          p->device[slot], bgra_of(slot), cam_from_vol, h->ref_cull ? h->cull_planes : nullptr, false, nullptr);
+    if (rc) return rc;
+    TSDF_HIP_TRY(hipEventRecord(p->consumed[sa], h->stream));
+    TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
+  } else if (p->pairing) {  // uploaded, but its kernel waits for the next frame (or for any other call on the volume)
+    p->pend_slot = slot;
+    for (int i = 0; i < 12; ++i) p->pend_T[i] = cam_from_vol[i];
+    p->pend_has_planes = h->ref_cull;
+    for (int i = 0; i < 24; ++i) p->pend_planes[i] = h->cull_planes[i];
+    h->pair_pending = true;
+  } else {
+    const int rc = launch_integrate(h, p->device[slot], bgra_of(slot), cam_from_vol, nullptr);
+    if (rc) return rc;
+    TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
+  }
   p->frames++;
   return TSDF_HIP_OK;
 }
@@ -2549,7 +2646,7 @@ k_calib_read(const uint32_t *__restrict__ D, int64_t n, uint32_t *__restrict__ s
 extern "C" int tsdf_hip_selftest_read_sweep(tsdf_handle h, int stride_bytes, uint64_t *span_bytes, uint64_t *dwords_read) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_selftest_read_sweep");
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t plane = h->pitch * h->ny;
   const uint32_t *base = reinterpret_cast<const uint32_t *>(h->d) + (int64_t)(h->z_begin - h->z_first) * plane;
   const int64_t span = (int64_t)(h->z_end - h->z_begin) * plane * 4;
@@ -2653,7 +2750,7 @@ extern "C" int tsdf_hip_selftest_row_intervals(const tsdf_params *p, const float
 extern "C" int tsdf_hip_selftest_sweep(tsdf_handle h, uint64_t *bytes_read, uint64_t *bytes_written) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_selftest_sweep");
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const int64_t plane = h->pitch * h->ny;
   const int64_t first4 = (int64_t)(h->z_begin - h->z_first) * plane / 4;
   const int64_t n4 = (int64_t)(h->z_end - h->z_begin) * plane / 4;
@@ -2820,7 +2917,7 @@ extern "C" int tsdf_hip_selftest_project(tsdf_handle h, const float *g, size_t n
                                          int32_t *pix_exact, uint8_t *ambiguous) {
   if (!h || !g || !n || !pix_fast || !pix_exact || !ambiguous) return TSDF_HIP_E_INVALID;
   if (h->multi) h = tsdf_multi_first(h);  // the projection only reads the intrinsics, which every slab holds
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const IntegrateHost a = make_args(h, ident);
   if (!fast_projection_ok(a, true, true)) {

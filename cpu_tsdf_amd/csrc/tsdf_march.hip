@@ -598,7 +598,7 @@ static int ensure_buf(T **buf, size_t *cap_elems, size_t need, hipStream_t s) {
 extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
   if (!h || color_mode < 0 || color_mode > 2) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_march(h, w_min, color_mode, n_tri);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const tsdf_params &p = h->p;
   if (p.res[0] >= (1 << 20) || p.res[1] >= (1 << 20) || p.res[2] >= (1 << 20)) return TSDF_HIP_E_UNSUPPORTED;
   McArgs a;
@@ -853,7 +853,7 @@ extern "C" int tsdf_hip_march_stats(tsdf_handle h, uint64_t out[4]) {
 extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *cell) {
   if (!h) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_march_fetch(h, verts, rgb, cell);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
   if (rgb && !h->mc_has_rgb) {
@@ -873,7 +873,7 @@ extern "C" int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, u
 extern "C" int tsdf_hip_march_fetch_device(tsdf_handle h, float *d_verts, uint8_t *d_rgb, uint64_t *d_cell) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_march_fetch_device (the merged mesh of a multi-GPU set lives on the host)");
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   const size_t n = (size_t)h->mc_ntri;
   if (!n) return TSDF_HIP_OK;
   if (d_verts)

@@ -451,7 +451,7 @@ static int raycast_impl(tsdf_handle h, const float rot[9], const float origin[3]
                         float *out) {
   if (!h || !rot || !origin || !out || downsample < 1) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_raycast(h, rot, origin, downsample, inv, out);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   if (inv) {
@@ -497,7 +497,7 @@ extern "C" int tsdf_hip_raycast_begin(tsdf_handle h, const float rot[9], const f
                                       int32_t *d_state) {
   if (!h || !rot || !origin || !d_state || downsample < 1) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_begin");
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   const int64_t n = (int64_t)a.nw * a.nh;
@@ -511,7 +511,7 @@ extern "C" int tsdf_hip_raycast_advance(tsdf_handle h, const float rot[9], const
   if (!h || !rot || !origin || !d_state || !d_delta || downsample < 1 || world < 1 || rank < 0 || rank >= world)
     return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_advance");
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   const int64_t n = (int64_t)a.nw * a.nh;
@@ -546,7 +546,7 @@ extern "C" int tsdf_hip_raycast_advance_list(tsdf_handle h, const float rot[9], 
     return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_raycast_advance_list");
   if (!count) return TSDF_HIP_OK;
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   RayArgs a;
   if (make_ray_args(h, rot, origin, downsample, a)) return TSDF_HIP_E_INVALID;
   int rc = tsdf_ensure_scratch(h, 16);
@@ -805,7 +805,7 @@ k_lookup_index(const GridView g, const int own_lo, const int own_hi, const float
 extern "C" int tsdf_hip_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
   if (!h || !xyz || !n || !rgb || !found) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_lookup_rgb(h, xyz, n, rgb, found);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   if (h->lab_img) {  // LABNode::getRGB: exact bytes through the host's pow
     int rc = tsdf_ensure_scratch(h, n * 12);
     if (rc) return rc;
@@ -867,7 +867,7 @@ k_selftest_containing(const GridView g, const float *__restrict__ xyz, size_t n,
 extern "C" int tsdf_hip_selftest_containing(tsdf_handle h, const float *xyz, size_t n, int32_t *idx) {
   if (!h || !xyz || !n || !idx) return TSDF_HIP_E_INVALID;
   if (h->multi) h = tsdf_multi_first(h);  // the descent only reads the centre tables, which every slab holds
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   int rc = tsdf_ensure_scratch(h, n * 24);
   if (rc) return rc;
   float *d_xyz = (float *)h->scratch;
@@ -959,7 +959,7 @@ extern "C" int tsdf_hip_sample(tsdf_handle h, const float *xyz, size_t n, float 
                                uint8_t *ok) {
   if (!h || !xyz || !n) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_sample(h, xyz, n, val, grad, hess, ok);
-  TSDF_ON_DEVICE(h->device);
+  TSDF_ENTER(h);
   // scratch layout: xyz[3n] val[n] grad[3n] hess[9n] floats, ok[n] bytes
   const size_t fl = 16 * n;
   int rc = tsdf_ensure_scratch(h, fl * sizeof(float) + n + 16);

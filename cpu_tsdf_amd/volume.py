@@ -164,6 +164,8 @@ class TSDFVolumeOctree:
             capi.check(lib.tsdf_hip_set_weighting(h, *weighting), "set_weighting")
         if self._stream is not None and not getattr(self, "_devices", None):  # (a stream belongs to one device)
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
+        if getattr(self, "_frame_pairing", False) and not devs:
+            capi.check(lib.tsdf_hip_set_frame_pairing(self._h, 1), "set_frame_pairing")
         self._is_empty = True
 
     def close(self):
@@ -246,6 +248,14 @@ class TSDFVolumeOctree:
                                                   capi.as_f32p(T), C.byref(n) if count else None), "integrate_device")
         self._is_empty = False
         return int(n.value) if count else True
+
+    def setFramePairing(self, flag):
+        """Not in the reference: pipelined integrateCloud calls (pipelined=True) are integrated two per kernel sweep where
+        both poses see the whole volume (tsdf_hip_set_frame_pairing); a frame waits for its partner until the next
+        integrateCloud or any other call on the volume.  Same voxels, bit for bit."""
+        self._frame_pairing = bool(flag)
+        if self._h:
+            capi.check(capi.load().tsdf_hip_set_frame_pairing(self._h, int(self._frame_pairing)), "set_frame_pairing")
 
     def integrateCloudDevice2(self, frame_a, frame_b, count=False):
         """Two frames in one call (tsdf_hip_integrate_device2): each frame = (depth_ptr, bgra_ptr, trans), device pointers

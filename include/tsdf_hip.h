@@ -338,6 +338,16 @@ int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a, const uint
                                const float *planes_a, const float *d_depth_b, const uint32_t *d_bgra_b,
                                const float cam_from_vol_b[12], const float *planes_b, uint64_t *n_observed, int32_t *fused);
 
+/* Frame pairing for the pipelined host entry points (tsdf_hip_frame_begin / _commit, tsdf_hip_integrate_async); not in the
+ * reference.  While on, a committed frame is uploaded at once but its kernel launch waits: when the NEXT frame is
+ * committed the two are integrated by one tsdf_hip_integrate_device2-style call (one sweep of the volume for both where
+ * the handle and both poses allow it, else two launches, frame order kept either way); any other entry point that reads
+ * or writes the volume (synchronize, integrate, download, march, raycast, sample, save, reset, ...) first launches a
+ * waiting frame on its own.  Results are identical to pairing off; what changes is when the kernels run (a stream of
+ * frames: ~14 instead of ~16 ms per frame at 2048^3 + colour).  Each frame keeps the cull planes that
+ * were in force (tsdf_hip_set_reference_cull) when IT was committed.  Single-GPU handles only; off by default. */
+int tsdf_hip_set_frame_pairing(tsdf_handle h, int on);
+
 /* Host only: those six planes from the forward pose `trans` (row-major 4x4 doubles, camera -> volume, what
  * integrateCloud is called with) and the camera of `p` [PCL-recall: filters/impl/frustum_culling.hpp]. */
 int tsdf_hip_reference_cull_planes(const tsdf_params *p, const double trans[16], float planes[24]);

@@ -271,6 +271,8 @@ int ct_download(void *h, float *d, float *w, uint8_t *rgb) {
 void ct_set_devices(void *h, const int *devices, int n) { V(h)->setDevices(std::vector<int>(devices, devices + n)); }
 // Drop-in build only: replicate the reference's frustum cull where it is not a no-op (the reference always culls).
 void ct_set_reference_cull(void *h, int flag) { V(h)->setReferenceCull(flag != 0); }
+// Drop-in build only: integrateCloud calls two per kernel sweep where the poses allow it (same voxels).
+void ct_set_frame_pairing(void *h, int flag) { V(h)->setFramePairing(flag != 0); }
 #endif
 
 }  // extern "C"

@@ -101,6 +101,7 @@ def load(path=LIB):
         L.ct_download.argtypes = [C.c_void_p, _f, _f, _u8]
         L.ct_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.ct_set_reference_cull.argtypes = [C.c_void_p, C.c_int]
+        L.ct_set_frame_pairing.argtypes = [C.c_void_p, C.c_int]
     _libs[path] = L
     return L
 
@@ -118,7 +119,8 @@ class RefVolume:
     Octree::init pre-splits to full resolution (src/lib/octree.cpp:593-599), the mode used for parity."""
 
     def __init__(self, res, size, width, height, fx, fy, cx, cy, zmin, zmax, trunc=(0.03, 0.03), max_weight=100.0,
-                 color=False, dense=True, max_cell=0.5, lib_path=LIB, color_mode=None, devices=None, reference_cull=None):
+                 color=False, dense=True, max_cell=0.5, lib_path=LIB, color_mode=None, devices=None, reference_cull=None,
+                 frame_pairing=False):
         self.L = load(lib_path)
         self.h = C.c_void_p(self.L.ct_create())
         self.res, self.size, self.W, self.H, self.color = res, float(size), width, height, bool(color)
@@ -138,6 +140,8 @@ class RefVolume:
         L.ct_set_num_random_splits(h, 1)
         if reference_cull is not None:  # drop-in build only: TSDFVolumeOctree::setReferenceCull (None = the class's default)
             L.ct_set_reference_cull(h, int(bool(reference_cull)))
+        if frame_pairing:  # drop-in build only: TSDFVolumeOctree::setFramePairing
+            L.ct_set_frame_pairing(h, 1)
         if devices:  # drop-in build only: TSDFVolumeOctree::setDevices
             L.ct_set_devices(h, (C.c_int * len(devices))(*devices), len(devices))
         L.ct_reset(h)

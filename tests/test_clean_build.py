@@ -1,0 +1,53 @@
+"""A from-scratch build: the libraries the driver's GPU box runs normally travel with the tree,
+prebuilt; here a COPY of the sources alone (no object, no library) is compiled with the recipes of cpu_tsdf_amd/build.py --
+product library, test library, C++ shell -- and checked: CPU tier = it builds and exports the boundary; GPU tier = smoke()
+(integrateCloud vs the oracle) runs on what was just built."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fresh_tree(dst):
+    ignore = shutil.ignore_patterns("lib", "bin", "__pycache__", "*.so", "*.o", "_ref", "variants")
+    for d in ("cpu_tsdf_amd", "include", "compat", "oracle"):
+        shutil.copytree(os.path.join(ROOT, d), os.path.join(dst, d), ignore=ignore)
+    shutil.copy(os.path.join(ROOT, "__graft_entry__.py"), dst)
+    os.makedirs(os.path.join(dst, "tests"))
+    for f in ("__init__.py", "common.py"):
+        p = os.path.join(ROOT, "tests", f)
+        if os.path.exists(p):
+            shutil.copy(p, os.path.join(dst, "tests", f))
+    assert not any(f.endswith((".so", ".o")) for _, _, fs in os.walk(dst) for f in fs)
+
+
+BUILD = ("import sys; sys.path.insert(0, '.'); from cpu_tsdf_amd import build as b; b.clean(); "
+         "b.build_hip(force=True); b.build_hip(force=True, test_hooks=True); b.build_shell(force=True); print('BUILT')")
+
+
+def run(code, cwd, timeout):
+    env = {k: v for k, v in os.environ.items() if k not in ("TSDF_HIP_LIB_PATH", "PYTHONPATH")}
+    return subprocess.run([sys.executable, "-c", code], cwd=cwd, env=env, text=True, capture_output=True, timeout=timeout)
+
+
+def test_sources_alone_build_both_libraries_and_the_shell(tmp_path):
+    fresh_tree(str(tmp_path))
+    out = run(BUILD, str(tmp_path), 1500)
+    assert out.returncode == 0 and "BUILT" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    lib = tmp_path / "cpu_tsdf_amd" / "lib"
+    names = {n: subprocess.check_output(["nm", "-D", "--defined-only", str(lib / n)], text=True) for n in
+             ("libtsdf_hip.so", "libtsdf_hip_test.so", "libcpu_tsdf_hip.so")}
+    assert "tsdf_hip_integrate_device2" in names["libtsdf_hip.so"] and "selftest" not in names["libtsdf_hip.so"]
+    assert "tsdf_hip_selftest_row_intervals" in names["libtsdf_hip_test.so"]
+    assert "TSDFVolumeOctree" in names["libcpu_tsdf_hip.so"]
+
+
+@pytest.mark.gpu
+def test_smoke_runs_on_a_from_scratch_build(gpu, tmp_path):
+    fresh_tree(str(tmp_path))
+    out = run(BUILD + "; import __graft_entry__ as g; g.smoke()", str(tmp_path), 1800)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

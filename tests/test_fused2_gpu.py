@@ -160,3 +160,43 @@ def test_fused_sweep_on_a_z_slab_and_a_wide_grid(gpu):
     assert np.array_equal(w, ov.w[5:29]) and np.array_equal(rgb, ov.rgb[5:29])
     assert (w > 0).mean() > 0.5
     vol.close()
+
+
+def test_frame_pairing_of_the_pipelined_host_path_changes_no_voxel(gpu):
+    """tsdf_hip_set_frame_pairing (TSDFVolumeOctree.setFramePairing): pipelined integrateCloud calls are held back one
+    frame and integrated two per sweep; any other call on the volume launches a waiting frame first.  An odd number of
+    frames, a renderView and a counted integrateCloud in between, cameras that do and do not qualify for the fused sweep:
+    every intermediate result equals the unpaired volume's and the oracle."""
+    vols = []
+    for pairing in (True, False):
+        vol, sc = make_volume(64, color=True)
+        vol.setFramePairing(pairing)
+        vol.reset()
+        vols.append(vol)
+    ov = OracleVolume(vols[0]._p)
+    poses = [synth.turntable_pose(i, 8, sc.size) for i in range(4)] + [synth.look_at_pose((0.01, 0.0, -0.02), target=(0.0, 0.0, 1.0))] + \
+            [synth.turntable_pose(i, 8, sc.size) for i in (5, 6)]
+    infos = []
+    for i, tr in enumerate(poses):
+        dep, col = sc.depth(tr, noise_seed=21 + i), sc.bgra(i)
+        ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
+        for v in vols:
+            v.integrateCloud(dep, col, tr, pipelined=True)
+        infos.append(launch_info(vols[0])[0])
+        if i == 2:  # a query while frame 2 waits for its partner: it is launched on its own first
+            a, b = (v.renderView(poses[1], 2, camera_frame=False) for v in vols)
+            assert_same_f32(a, b, "renderView with a frame waiting")
+            assert_same_f32(a[..., :6], ov.raycast(poses[1], 2)[..., :6], "renderView vs oracle")
+    # frames 0+1 went through one sweep; frame 2 alone (the renderView); 3+4 as two launches (4 sits inside the grid); 5+6 fused
+    assert infos[1] == 2 and infos[6] == 2 and infos[4] != 2, infos
+    for v in vols:
+        compare(v, ov)
+    # one more frame: it waits ... until the download inside compare() launches it
+    tr = synth.turntable_pose(7, 8, sc.size)
+    dep, col = sc.depth(tr, noise_seed=99), sc.bgra(7)
+    ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
+    for v in vols:
+        v.integrateCloud(dep, col, tr, pipelined=True)
+    for v in vols:
+        compare(v, ov)
+        v.close()
