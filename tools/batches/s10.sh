@@ -1,0 +1,11 @@
+set -u
+ROOT=$PWD
+mkdir -p gpurun_out/prof_r04_refcull gpurun_out/prof_r04_sceneb
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_r04_refcull/trace -o bench --output-format csv -- python $ROOT/bench.py --steps 12 --warmup 2 --cpu-baseline 0 --host-path 0 --extras 0 --principal-offset 0.6 > $ROOT/gpurun_out/prof_r04_refcull/bench_under_rocprof.json 2> $ROOT/gpurun_out/prof_r04_refcull/bench.err; echo rc=$?
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_r04_sceneb/trace -o sceneb --output-format csv -- python -c "import sys; sys.path.insert(0, '$ROOT'); import bench, json; print(json.dumps(bench.scene_b_leg(2048, 1, 0.0)))" > $ROOT/gpurun_out/prof_r04_sceneb/scene_b.json 2> $ROOT/gpurun_out/prof_r04_sceneb/err.log; echo rc=$?
+cd $ROOT
+for t in refcull sceneb; do find gpurun_out/prof_r04_$t -name "*_kernel_stats.csv" -exec cp {} gpurun_out/prof_r04_$t/kernel_stats.csv \; ; find gpurun_out/prof_r04_$t -name "*.csv" -size +2M -delete; done
+tail -2 gpurun_out/prof_r04_sceneb/scene_b.json | cut -c1-300
+head -6 gpurun_out/prof_r04_sceneb/kernel_stats.csv | cut -c1-60,220-330
+head -8 gpurun_out/prof_r04_refcull/kernel_stats.csv | cut -c1-60,220-330
