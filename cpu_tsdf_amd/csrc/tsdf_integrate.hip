@@ -746,8 +746,13 @@ struct Frame2 {
   float m[12];        // frame B's cam_from_vol
   unsigned bgra_off;  // ... and the byte offset of its colour image from its depth image
 };
+#ifndef TSDF_K2_PIPE
+#define TSDF_K2_PIPE 0  // 1 = two-row software pipeline (ISSUE(r + 1) before RETIRE(r)): built and measured in round 4 -- 32 more
+                        // registers of row state: at 4 waves 32 VGPRs spill (27.9 ms per frame), at 3 waves none (16.9 ms), against
+                        // 13.3 ms for issue + retire back to back at 5 waves (profiles/r04_ab_k_integrate2.txt): occupancy wins again
+#endif
 #ifndef TSDF_WPE_K2
-#define TSDF_WPE_K2 5
+#define TSDF_WPE_K2 (TSDF_K2_PIPE ? 4 : 5)
 #endif
 
 template <int ORDER, bool COLOR, bool COUNT>
@@ -790,15 +795,20 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
     const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;
     const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
-    for (int r = 0; r < a.rpb; ++r) {
-      const int y = row0 + ty + r * a.TY;
-      if (y >= a.ny) break;
+    // A row's work in two stages: ISSUE(r) = project both frames and request everything the row needs at once -- the two
+    // frames' depth / colour gathers and the quad's voxel words (read whether or not a voxel turns out to be observed: in
+    // this regime -- the whole slab in view -- three quarters are) -- so that a row costs ONE memory round trip per PAIR of
+    // frames (issuing frame B's gathers only after frame A's had returned: 16.1 instead of 13.3 ms per frame); RETIRE(r) =
+    // finish updateVoxel for both frames on the loaded values and write back what changed.
+    struct RowLoads {
+      float zsA[4], zsB[4], gzA[4], gzB[4];
+      uint32_t csA[4], csB[4];
+      u4 d4, c4;
+      uint32_t k4;
+    };
+    auto issue = [&](int r, RowLoads &L) {
       const unsigned soff = (unsigned)r * row_step;
       const float cy = s_cy[ty + r * a.TY];
-      // ---- one memory round trip per row for BOTH frames: project A, project B, then issue every load the row needs --
-      // the two frames' depth / colour gathers and the quad's voxel words (read whether or not a voxel turns out to be
-      // observed: in this regime -- the whole slab in view -- three quarters are) -- before anything waits
-      // pcl::transformPoint (hpp:145) + reprojectPoint (.cpp:611-617) of the four voxels for one frame
       auto project = [&](const float (&m)[12], int (&pix)[4], float (&gzs)[4]) {
         float yt[3], zt[3];
         uint32_t margin[4];
@@ -846,26 +856,26 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         }
       };
       int pixA[4], pixB[4];
-      float gzA[4], gzB[4];
-      project(a.m, pixA, gzA);
-      project(fb.m, pixB, gzB);
-      float zsA[4], zsB[4];
-      uint32_t csA[4], csB[4];
+      project(a.m, pixA, L.gzA);
+      project(fb.m, pixB, L.gzB);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        zsA[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, 0, TSDF_GATHER_AUX));
-        csA[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, (int)a.bgra_off, TSDF_GATHER_AUX) : 0u;
+        L.zsA[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, 0, TSDF_GATHER_AUX));
+        L.csA[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, (int)a.bgra_off, TSDF_GATHER_AUX) : 0u;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        zsB[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, 0, TSDF_GATHER_AUX));
-        csB[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, (int)fb.bgra_off, TSDF_GATHER_AUX) : 0u;
+        L.zsB[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, 0, TSDF_GATHER_AUX));
+        L.csB[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, (int)fb.bgra_off, TSDF_GATHER_AUX) : 0u;
       }
-      const u4 d4 = bload128(rsD, voff, soff);
-      u4 c4 = {0u, 0u, 0u, 0u};
-      uint32_t k4 = 0u;
-      if (COLOR) c4 = bload128(rsC, voff, soff);
-      if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+      L.d4 = bload128(rsD, voff, soff);
+      L.c4 = (u4){0u, 0u, 0u, 0u};
+      L.k4 = 0u;
+      if (COLOR) L.c4 = bload128(rsC, voff, soff);
+      if (!COLOR) L.k4 = bload32(rsK, voff >> 2, soff >> 2);
+    };
+    auto retire = [&](int r, const RowLoads &L) {
+      const unsigned soff = (unsigned)r * row_step;
       // ---- hpp:152-198 for one frame: NaN test, projective distance, hinge, normalisation ---------------------------
       // returns bit j = voxel j reaches addObservation; bit 4 = one of them lies inside the truncation band
       auto finish = [&](const float (&zs)[4], const float (&gzs)[4], float (&dn)[4]) -> unsigned {
@@ -892,9 +902,11 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         return obs;
       };
       float dnA[4], dnB[4];
-      const unsigned obsA = finish(zsA, gzA, dnA);
-      const unsigned obsB = finish(zsB, gzB, dnB);
-      if (!((obsA | obsB) & 15u)) continue;
+      const unsigned obsA = finish(L.zsA, L.gzA, dnA);
+      const unsigned obsB = finish(L.zsB, L.gzB, dnB);
+      if (!((obsA | obsB) & 15u)) return;
+      const u4 d4 = L.d4, c4 = L.c4;
+      const uint32_t k4 = L.k4;
       const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       uint32_t du[4], kw[4];  // the state both updates work on: distance bits; colour | count << 24 (or only the count there)
@@ -961,8 +973,8 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
           kw[j] = act ? (COLOR ? cv[j] : k1[j]) : kw[j];
         }
       };
-      apply(obsA, dnA, csA);
-      apply(obsB, dnB, csB);
+      apply(obsA, dnA, L.csA);
+      apply(obsB, dnB, L.csB);
       // ---- write back what changed ----------------------------------------------------------------------------
       uint32_t diff_d = 0u, diff_c = 0u, k4n = 0u;
 #pragma unroll
@@ -979,7 +991,28 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       if (diff_d) bstore128(rsD, voff, soff, (u4){du[0], du[1], du[2], du[3]});
       if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){kw[0], kw[1], kw[2], kw[3]});
       if (!COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
+    };
+    // rows this thread walks: r = 0 .. nrows - 1 (row0 + ty + r * TY < ny)
+    const int left = a.ny - row0 - ty;
+    const int nrows = left <= 0 ? 0 : min(a.rpb, (left + a.TY - 1) / a.TY);
+#if TSDF_K2_PIPE
+    RowLoads L0, L1;
+    if (nrows > 0) issue(0, L0);
+    for (int r = 0; r < nrows; r += 2) {
+      if (r + 1 < nrows) issue(r + 1, L1);
+      retire(r, L0);
+      if (r + 1 < nrows) {
+        if (r + 2 < nrows) issue(r + 2, L0);
+        retire(r + 1, L1);
+      }
     }
+#else
+    for (int r = 0; r < nrows; ++r) {
+      RowLoads L;
+      issue(r, L);
+      retire(r, L);
+    }
+#endif
   }
   if (band) {
     __syncthreads();
