@@ -336,7 +336,9 @@ def host_path_leg(vol, sc, poses, color, first, last):
     try:
         idx = list(range(first, last))
         frames = [(np.ascontiguousarray(sc.depth(poses[i])), np.ascontiguousarray(sc.bgra(i)) if color else None) for i in idx]
-        for name, pipelined in (("frames_per_s_sync_calls", False), ("frames_per_s_async_ring", True)):
+        for name, pipelined, pairing in (("frames_per_s_sync_calls", False, False), ("frames_per_s_async_ring", True, False),
+                                         ("frames_per_s_async_ring_frame_pairing", True, True)):
+            vol.setFramePairing(pairing)  # (tsdf_hip_set_frame_pairing: two queued frames share one sweep of the volume)
             vol.integrateCloud(frames[0][0], frames[0][1], poses[idx[0]], pipelined=pipelined)
             vol.synchronize()
             t0 = time.perf_counter()
@@ -344,6 +346,7 @@ def host_path_leg(vol, sc, poses, color, first, last):
                 vol.integrateCloud(d, c, poses[i], pipelined=pipelined)
             vol.synchronize()
             out[name] = len(idx) / (time.perf_counter() - t0)
+        vol.setFramePairing(False)
         out["calls"] = len(idx)
         out["note"] = ("host-pointer entry points, the timed region's own frames, one 2.4 MB-class frame per call over PCIe; "
                        "report-only, the headline `value` is timed with frames resident in HBM.  This leg runs AFTER the timed "
