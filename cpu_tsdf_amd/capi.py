@@ -160,6 +160,7 @@ SIGNATURES = {
 
 # include/tsdf_hip_test.h: only libtsdf_hip_test.so (and the A/B variants of tools/build_variant.py) export these
 TEST_SIGNATURES = {
+    "tsdf_hip_selftest_checksum": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_selftest_occupancy_mc": (C.c_int, [C.POINTER(C.c_int)]),
     "tsdf_hip_selftest_div_count": (C.c_int, [_f32p, C.POINTER(C.c_uint32), _f32p, _u8p, C.c_size_t]),
     "tsdf_hip_selftest_cvt_pk_u8": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_uint32)]),

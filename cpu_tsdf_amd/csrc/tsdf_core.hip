@@ -1198,3 +1198,41 @@ extern "C" int tsdf_hip_set_planes_device(tsdf_handle h, int z0, int nz, const f
   if (h && z0 < h->z_end && z0 + nz > h->z_begin) h->band_exact = false;
   return planes_device<false>(h, z0, nz, const_cast<float *>(d), const_cast<float *>(w), const_cast<uint32_t *>(rgb));
 }
+
+#ifdef TSDF_HIP_TEST_HOOKS
+// Test hook: position-dependent checksums of the owned planes, computed on the device: for each plane array the sum over
+// all owned words of word * odd(index) mod 2^64 (a swap of two unequal words or a change of any word changes it).  How
+// the tests compare WHOLE 2048^3 volumes integrated through different kernel instances / launch orders without moving
+// 69 GB to the host.  out[0] = d, out[1] = w (0 in the PACKED layout), out[2] = rgb | count words (0 without colour),
+// out[3] = the count bytes of a colourless PACKED volume (0 otherwise).
+static __global__ void __launch_bounds__(256)
+k_checksum(const uint32_t *__restrict__ p, int64_t n, unsigned long long *__restrict__ out) {
+  unsigned long long acc = 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc += (unsigned long long)p[i] * (((unsigned long long)i * 2ull + 1ull) * 0x9E3779B97F4A7C15ull | 1ull);
+  for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63u) == 0u) atomicAdd(out, acc);
+}
+
+extern "C" int tsdf_hip_selftest_checksum(tsdf_handle h, uint64_t out[4]) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  TSDF_NOT_ON_MULTI(h, "tsdf_hip_selftest_checksum");
+  TSDF_ENTER(h);
+  const int64_t plane = h->pitch * h->ny, first = (int64_t)(h->z_begin - h->z_first) * plane,
+                n = (int64_t)(h->z_end - h->z_begin) * plane;
+  TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 4 * sizeof(unsigned long long), h->stream));
+  const unsigned grid = 256u * (unsigned)tsdf_tuning().blocks_per_cu;
+  const void *arr[4] = {h->d, h->w, h->rgb, nullptr};
+  for (int k = 0; k < 3; ++k)
+    if (arr[k])
+      hipLaunchKernelGGL(k_checksum, dim3(grid), dim3(256), 0, h->stream, reinterpret_cast<const uint32_t *>(arr[k]) + first, n, h->counter + k);
+  if (h->k8)  // bytes, four to a word (pitch is a multiple of 4)
+    hipLaunchKernelGGL(k_checksum, dim3(grid), dim3(256), 0, h->stream, reinterpret_cast<const uint32_t *>(h->k8 + first), n / 4, h->counter + 3);
+  TSDF_HIP_TRY(hipGetLastError());
+  unsigned long long c[4];
+  TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 4; ++k) out[k] = c[k];
+  return TSDF_HIP_OK;
+}
+#endif  // TSDF_HIP_TEST_HOOKS

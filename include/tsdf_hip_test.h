@@ -81,6 +81,11 @@ int tsdf_hip_selftest_occupancy_mc(int out[2]);
  * TSDF_HIP_* environment variables, which the product library reads once) at run time.  No knob changes results. */
 int tsdf_hip_set_tuning(const char *name, int value);
 
+/* Test hook: position-dependent 64-bit checksums of the handle's OWNED planes, computed on the device (sum over the words
+ * of word * odd(index)): out[0] d, out[1] w (F32W), out[2] rgb | count words (colour), out[3] count bytes (colourless
+ * PACKED); 0 for a plane the layout does not have.  Lets whole 2048^3 volumes be compared without a 69 GB download. */
+int tsdf_hip_selftest_checksum(tsdf_handle h, uint64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ def test_the_product_library_exports_the_boundary_and_nothing_else():
     knob; libtsdf_hip_test.so exports that plus exactly the hooks of include/tsdf_hip_test.h; the ctypes tables mirror both."""
     product, hooks = declared_functions(), declared_functions("tsdf_hip_test.h")
     assert not [n for n in product if "selftest" in n or n == "tsdf_hip_set_tuning"]
-    assert all("selftest" in n or n == "tsdf_hip_set_tuning" for n in hooks) and len(hooks) == 17
+    assert all("selftest" in n or n == "tsdf_hip_set_tuning" for n in hooks) and len(hooks) == 18
     assert exported(capi.PRODUCT_LIB_PATH) == product
     assert exported(capi.TEST_LIB_PATH) == sorted(product + hooks)
     assert sorted(capi.SIGNATURES) == product and sorted(capi.TEST_SIGNATURES) == hooks

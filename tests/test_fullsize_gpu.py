@@ -213,3 +213,102 @@ def test_config4_eight_slabs_end_to_end_equal_one_handle(gpu):
     multi.close()
     one.close()
 
+
+
+@pytest.mark.parametrize("color", [True, False])
+def test_2048_cubed_whole_volume_is_the_same_through_every_kernel_path(gpu, color):
+    """at the headline size the planes are compared with the oracle on a few plane groups only.  This
+    closes the gap by transitivity: the SAME six noisy frames (NaN holes, past no weight limit) are integrated into a 2048^3
+    volume through (a) the ALLIN instance, (b) the general instance (knob allin = 0), (c) x-chunks-fastest block order
+    (zfast = 0), (d) two frames per sweep (k_integrate2), (e) the row-interval instance with the reference's cull carried
+    per voxel row -- forced by handing over planes that cut nothing but fail the host's whole-slab proof -- and the WHOLE
+    volume's position-dependent checksums (tsdf_hip_selftest_checksum: every word of every plane) must be equal; path (a)
+    is then compared with the oracle on plane groups as usual.  A wrong voxel anywhere in 8.6 G shows."""
+    import ctypes as C
+    if free_gb() < 80:
+        pytest.skip("needs ~70 GB of free HBM")
+    res, W, H = 2048, 640, 480
+    lib = capi.load()
+
+    def make():
+        vol = TSDFVolumeOctree()
+        sc = configure(vol, (res,) * 3, (res * 2.0 ** -8,) * 3, W, H, color)
+        vol.reset()
+        return vol, sc
+
+    def checksum(vol):
+        out = (C.c_uint64 * 4)()
+        capi.check(lib.tsdf_hip_selftest_checksum(vol._need(), out), "checksum")
+        return tuple(int(v) for v in out)
+
+    def info(vol):
+        out = (C.c_int32 * 4)()
+        capi.check(lib.tsdf_hip_last_launch_info(vol._need(), out), "info")
+        return list(out)
+
+    vol, sc = make()
+    frames_ = []
+    for i in range(6):
+        tr = synth.turntable_pose(i, 44, sc.size)
+        dep = sc.depth(tr, noise_seed=500 + i)
+        dep[(i * 11) % 40::41, ::5] = np.nan
+        t = torch.empty((2, H, W), dtype=torch.float32, device="cuda")
+        t[0].copy_(torch.from_numpy(dep))
+        col = sc.bgra(i) if color else None
+        if color:
+            t[1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(col))
+        frames_.append((tr, dep, col, t))
+    torch.cuda.synchronize()
+    vol.close()
+
+    def run(name, knob=None, pairs=False, loose_planes=False):
+        if knob:
+            capi.set_tuning(*knob)
+        try:
+            vol, _ = make()
+            seen = set()
+            if pairs:
+                for k in range(3):
+                    a, b = frames_[2 * k], frames_[2 * k + 1]
+                    fused, _ = vol.integrateCloudDevice2((a[3][0].data_ptr(), a[3][1].data_ptr() if color else 0, a[0]),
+                                                         (b[3][0].data_ptr(), b[3][1].data_ptr() if color else 0, b[0]))
+                    assert fused
+                    seen.add(info(vol)[0])
+            else:
+                for tr, dep, col, t in frames_:
+                    if loose_planes:  # planes far outside the grid (every voxel kept) but not provably so for the host's corner test
+                        vol.setReferenceCull(False)
+                        pl = np.zeros(24, np.float32)
+                        x_last = sc.size / 2 - sc.size / res / 2          # centre of the last voxel along x
+                        pl[0::4], pl[3::4] = 1.0, np.float32(-(x_last + 1e-6))  # x <= x_last + 1e-6: keeps every voxel, by a margin the host cannot prove
+                        capi.check(lib.tsdf_hip_set_reference_cull(vol._need(), capi.as_f32p(pl)), "planes")
+                        capi.check(lib.tsdf_hip_integrate_device(vol._need(), C.c_void_p(t[0].data_ptr()), C.c_void_p(t[1].data_ptr()) if color else None,
+                                                                 capi.as_f32p(synth.cam_from_vol_f32(tr)), None), "integrate")
+                    else:
+                        vol.integrateCloudDevice(t[0].data_ptr(), t[1].data_ptr() if color else 0, tr)
+                    seen.add((info(vol)[0], info(vol)[2]))
+            c = checksum(vol)
+            return vol, c, seen
+        finally:
+            if knob:
+                capi.set_tuning(knob[0], {"allin": 1, "zfast": 1}[knob[0]])
+
+    base, c_allin, seen = run("allin")
+    assert seen == {(1, 0)}, seen
+    # path (a) against the oracle on plane groups
+    groups = [(0, 2), (1023, 1025), (1600, 1602)]
+    for a, b in groups:
+        o = SlabOracle(base._p, a, b)
+        for tr, dep, col, _ in frames_:
+            o.integrate(dep, col, synth.cam_from_vol_f32(tr))
+        d, w, rgb = base.download(z0=a, nz=b - a)
+        assert_same_f32(d, o.d, f"d planes {a}:{b}")
+        assert np.array_equal(w, o.w) and (not color or np.array_equal(rgb, o.rgb))
+    base.close()
+    for name, kw, want in (("general", dict(knob=("allin", 0)), {(0, 0)}), ("x-fastest", dict(knob=("zfast", 0)), {(1, 0)}),
+                           ("two frames per sweep", dict(pairs=True), {2}), ("row intervals", dict(loose_planes=True), {(0, 2)})):
+        vol, c, seen = run(name, **kw)
+        vol.close()
+        assert seen == want, (name, seen)
+        assert c == c_allin, (name, c, c_allin)
+    assert c_allin[0] != 0 and (c_allin[2] != 0 if color else c_allin[3] != 0)
