@@ -247,7 +247,8 @@ bool TSDFVolumeOctree::commitFrame(const Eigen::Affine3d &trans) {
   float T[12];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) T[4 * r + c] = trans_inv.matrix()(r, c);
-  const int rc = tsdf_hip_frame_commit(h_, T);
+  int rc = tsdf_hip_frame_commit(h_, T);
+  if (!rc && synchronous_) rc = tsdf_hip_synchronize(h_);  // (also launches a frame that pairing was holding back)
   if (rc) {
     report("integrateCloud", rc);
     return false;
