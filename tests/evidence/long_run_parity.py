@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--pipelined", type=int, default=0, help="hand frames over with tsdf_hip_integrate_async")
+    ap.add_argument("--pairing", type=int, default=0, help="frame pairing of the pipelined path (tsdf_hip_set_frame_pairing): two frames per sweep")
     ap.add_argument("--raycast-every", type=int, default=0, help="renderView from the current pose every K frames (configs[2])")
     a = ap.parse_args()
     res = a.res
@@ -47,12 +48,20 @@ def main():
         slab0 = (res - a.planes) // 2
         slab1 = slab0 + a.planes
         v.setZSlab(slab0, slab1)
+    if a.pairing:
+        a.pipelined = 1
+        v.setFramePairing(True)
     v.reset()
     groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 300, res - 298)]
     if a.planes:
         groups = [(slab0, slab0 + 2), ((slab0 + slab1) // 2, (slab0 + slab1) // 2 + 2), (slab1 - 2, slab1)]
     oracles = [SlabOracle(v._p, zb, ze) for zb, ze in groups]
     t_gpu = t_cpu = t_synth = t_ray = 0.0
+    fused_launches = 0
+    info4 = None
+    if a.pairing:
+        import ctypes as C0
+        info4 = (C0.c_int32 * 4)()
     mismatches = n_views = 0
     ray_err = []
     per_call = []
@@ -65,6 +74,9 @@ def main():
         t2 = time.perf_counter()
         t_gpu += t2 - t1
         per_call.append((t2 - t1) * 1e3)
+        if info4 is not None and i % 2 == 1:
+            capi.check(capi.load().tsdf_hip_last_launch_info(v._need(), info4), "info")
+            fused_launches += int(info4[0] == 2)
         if a.raycast_every and (i + 1) % a.raycast_every == 0:
             tq = time.perf_counter()
             view = v.renderView(tr, 1)  # camera frame: z is directly comparable with the noise-free depth image
@@ -112,6 +124,7 @@ def main():
                     f", integrateColor={bool(a.color)}, {a.frames} distinct noisy {a.width}x{a.height} frames through the host entry "
                     "point (" + ("pinned two-slot ring, upload overlapped with the previous kernel" if a.pipelined else "PCIe upload + sync per frame") + ")" + ("" if a.planes else ", then marching cubes"),
         "frames": a.frames,
+        **({"frame_pairing": True, "pairs_integrated_in_one_sweep": fused_launches} if a.pairing else {}),
         # synchronous calls: the host waits for upload + kernel, so host time per call IS the frame rate incl. upload;
         # asynchronous calls return once the frame is staged: host time per call says nothing about the GPU's rate
         # (the old name frames_per_s_incl_upload invited quoting 3267 frames/s) and is named for what it is
