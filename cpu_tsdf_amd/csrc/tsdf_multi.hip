@@ -61,8 +61,15 @@ struct tsdf_hip_multi {
   std::vector<std::pair<int, int>> no_peer;  // device pairs whose peer access was refused
   char *relay = nullptr;                     // pinned
   size_t relay_cap = 0;
-  std::vector<std::pair<int, hipStream_t>> relay_stream;  // per source device
-  hipEvent_t relay_ev[3] = {nullptr, nullptr, nullptr};   // receiver's marker, relay filled, relay drained
+  // per device (an event may only be recorded on a stream of the device it was created on; waiting across devices is fine):
+  // a relay stream for the device-to-host half, and three events -- receiver's marker, relay filled, relay drained
+  struct RelayDev {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  };
+  std::vector<RelayDev> relay_dev;
+  hipEvent_t relay_last_drain = nullptr;  // the `drained` event of the copy that used the relay last (any device)
   bool relay_used = false;
   uint64_t relay_bytes = 0;                  // bytes that took the relay (tsdf_hip_multi_render_stats-style report)
   // merged mesh of the last tsdf_hip_march (host)
@@ -110,12 +117,12 @@ void tsdf_multi_free(tsdf_hip_volume *v) {
   }
   if (m->ray_table) (void)hipHostFree(m->ray_table);
   if (m->relay) (void)hipHostFree(m->relay);
-  for (auto &rs : m->relay_stream) {
-    TsdfDeviceScope scope(rs.first);
-    (void)hipStreamDestroy(rs.second);
+  for (auto &rd : m->relay_dev) {
+    TsdfDeviceScope scope(rd.dev);
+    if (rd.stream) (void)hipStreamDestroy(rd.stream);
+    for (hipEvent_t e : rd.ev)
+      if (e) (void)hipEventDestroy(e);
   }
-  for (hipEvent_t e : m->relay_ev)
-    if (e) (void)hipEventDestroy(e);
   for (int s = 0; s < 2; ++s)
     if (m->pinned[s]) (void)hipHostFree(m->pinned[s]);
   for (size_t k = 0; k < m->slab.size(); ++k) {
@@ -461,45 +468,56 @@ static int tsdf_multi_copy(tsdf_hip_multi *m, void *dst, int dst_dev, const void
   const size_t need = std::min(bytes, chunk_max);
   if (need > m->relay_cap) {
     if (m->relay) {
-      if (m->relay_used) TSDF_HIP_TRY(hipEventSynchronize(m->relay_ev[2]));  // the last drain of the old buffer
+      if (m->relay_last_drain) TSDF_HIP_TRY(hipEventSynchronize(m->relay_last_drain));  // the last drain of the old buffer
       TSDF_HIP_TRY(hipHostFree(m->relay));
       m->relay = nullptr, m->relay_cap = 0;
     }
     TSDF_HIP_TRY(hipHostMalloc((void **)&m->relay, need, hipHostMallocPortable));
     m->relay_cap = need;
   }
-  for (hipEvent_t &e : m->relay_ev)
-    if (!e) TSDF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  hipStream_t rs = nullptr;
-  for (auto &p : m->relay_stream)
-    if (p.first == src_dev) rs = p.second;
-  if (!rs) {
-    TsdfDeviceScope scope(src_dev);
+  auto relay_of = [&](int dev, tsdf_hip_multi::RelayDev **out) -> int {  // the device's relay stream and events, made on first use
+    for (auto &rd : m->relay_dev)
+      if (rd.dev == dev) {
+        *out = &rd;
+        return TSDF_HIP_OK;
+      }
+    TsdfDeviceScope scope(dev);
     TSDF_HIP_TRY(scope.err);
-    TSDF_HIP_TRY(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking));
-    m->relay_stream.push_back(std::make_pair(src_dev, rs));
-  }
+    tsdf_hip_multi::RelayDev rd;
+    rd.dev = dev;
+    TSDF_HIP_TRY(hipStreamCreateWithFlags(&rd.stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : rd.ev) TSDF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->relay_dev.reserve(TSDF_MAX_SLABS + 8);  // (pointers into the vector stay valid)
+    m->relay_dev.push_back(rd);
+    *out = &m->relay_dev.back();
+    return TSDF_HIP_OK;
+  };
+  tsdf_hip_multi::RelayDev *S = nullptr, *R = nullptr;
+  int rc = relay_of(src_dev, &S);
+  if (!rc) rc = relay_of(dst_dev, &R);
+  if (rc) return rc;
   for (size_t off = 0; off < bytes; off += chunk_max) {
     const size_t n = std::min(chunk_max, bytes - off);
     {
       TsdfDeviceScope scope(dst_dev);
       TSDF_HIP_TRY(scope.err);
-      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[0], stream));  // the receiver is ready (and the source data complete: see above)
+      TSDF_HIP_TRY(hipEventRecord(R->ev[0], stream));  // the receiver is ready (and the source data complete: see above)
     }
     {
       TsdfDeviceScope scope(src_dev);
       TSDF_HIP_TRY(scope.err);
-      TSDF_HIP_TRY(hipStreamWaitEvent(rs, m->relay_ev[0], 0));
-      if (m->relay_used) TSDF_HIP_TRY(hipStreamWaitEvent(rs, m->relay_ev[2], 0));  // the relay's last content has left it
-      TSDF_HIP_TRY(hipMemcpyAsync(m->relay, (const char *)src + off, n, hipMemcpyDeviceToHost, rs));
-      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[1], rs));
+      TSDF_HIP_TRY(hipStreamWaitEvent(S->stream, R->ev[0], 0));
+      if (m->relay_last_drain) TSDF_HIP_TRY(hipStreamWaitEvent(S->stream, m->relay_last_drain, 0));  // the relay's last content has left it
+      TSDF_HIP_TRY(hipMemcpyAsync(m->relay, (const char *)src + off, n, hipMemcpyDeviceToHost, S->stream));
+      TSDF_HIP_TRY(hipEventRecord(S->ev[1], S->stream));
     }
     {
       TsdfDeviceScope scope(dst_dev);
       TSDF_HIP_TRY(scope.err);
-      TSDF_HIP_TRY(hipStreamWaitEvent(stream, m->relay_ev[1], 0));
+      TSDF_HIP_TRY(hipStreamWaitEvent(stream, S->ev[1], 0));
       TSDF_HIP_TRY(hipMemcpyAsync((char *)dst + off, m->relay, n, hipMemcpyHostToDevice, stream));
-      TSDF_HIP_TRY(hipEventRecord(m->relay_ev[2], stream));
+      TSDF_HIP_TRY(hipEventRecord(R->ev[2], stream));
+      m->relay_last_drain = R->ev[2];
     }
     m->relay_used = true;
     m->relay_bytes += n;
