@@ -295,7 +295,7 @@ int tsdf_hip_render_halo(const tsdf_params *p);
 /* Placement of the voxel planes (not in the reference).  On MI355X the physical pages behind an allocation decide how
  * fast a streaming read-modify-write of it runs (a 2048^3 volume integrates in 17.9 ms or in 18.4-19.0 ms depending on
  * the allocation), so tsdf_hip_create allocates the planes of a volume of 4 GiB or more up to
- * `alloc_tries` times (tsdf_hip_set_tuning / TSDF_HIP_ALLOC_TRIES, default 3, 1 = off; a second candidate is only
+ * `alloc_tries` times (TSDF_HIP_ALLOC_TRIES in the environment, default 3, 1 = off; a second candidate is only
  * tried while it fits next to the first), sweeps each candidate once and keeps the fastest.  The search ends early
  * at a candidate that streams at >= 5.55 TB/s (the fastest class) and goes on for up to alloc_tries more (8 at most)
  * while none has reached 5.15 TB/s.  This reports what happened: ms[i] = probe sweep of candidate i (negative = not
@@ -468,8 +468,7 @@ int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
  * range and projects inside the image with a pixel to spare -- the camera-outside-the-volume case -- so the per-voxel range /
  * image-bounds tests are compiled out), 2 k_integrate2 (two frames in one sweep); out[1] = 1 with the certified fp32
  * projection; out[2] = 0 no row intervals, 1 row intervals + block flags (the frame sees part of the slab), 2 the same with
- * the reference's frustum cull carried in the intervals (with out[0] = 1: an ALLIN pass over the blocks the cull leaves
- * whole + an interval pass over the rest); out[3] = blocks launched (0: nothing could be observed). */
+ * the reference's frustum cull carried in the intervals; out[3] = blocks launched (0: nothing could be observed). */
 int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]);
 
 const char *tsdf_hip_error_string(int code);
