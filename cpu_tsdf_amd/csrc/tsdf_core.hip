@@ -531,8 +531,8 @@ extern "C" int tsdf_hip_reference_cull_planes(const tsdf_params *p, const double
   const float dist[2] = {p->max_sensor_dist, p->min_sensor_dist};  // far, near (:643-644)
   V3 centre[2], corner[2][4];  // corner: tl, tr, bl, br
   for (int f = 0; f < 2; ++f) {
-    // (`tan` of a float divided by an int, evaluated in double: the C reading of PCL's expression, which the oracle and
-    // the stand-in the reference is compiled against share)
+    // (`tan` of a float divided by an int, evaluated in double: `tan (vfov_rad / 2)` with the double overload, as a C
+    // compiler reads PCL's expression and as the stand-in the reference is compiled against here evaluates it)
     const float hgt = (float)(2 * tan((double)(vrad / 2)) * dist[f]), wid = (float)(2 * tan((double)(hrad / 2)) * dist[f]);
     for (int i = 0; i < 3; ++i) {
       const float c = T.v[i] + view.v[i] * dist[f], u = up.v[i] * hgt / 2, r = right.v[i] * wid / 2;
