@@ -799,6 +799,9 @@ extern "C" int tsdf_hip_device_planes(tsdf_handle h, float **d, float **w, uint3
                                       int32_t *z_first, int32_t *nz_alloc) {
   if (!h) return TSDF_HIP_E_INVALID;
   TSDF_NOT_ON_MULTI(h, "tsdf_hip_device_planes");
+  {
+    TSDF_ENTER(h);  // a frame that frame pairing holds back is launched before the caller looks at the planes
+  }
   h->band_exact = false;  // the caller may write through these pointers
   if (d) *d = h->d;
   if (w) *w = h->w;
