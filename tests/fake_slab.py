@@ -87,8 +87,9 @@ class OracleSlab:
         return torch.empty((H, W), dtype=torch.float32), (torch.empty((H, W, 4), dtype=torch.uint8) if self.color else None)
 
     def integrate_tensor(self, depth, bgra, trans):
-        self.ov.integrate(depth.numpy(), bgra.numpy() if bgra is not None else None, synth.cam_from_vol_f32(trans),
-                          self.z_begin, self.z_end)
+        # as the HIP slab does by default: the reference's integrateCloud incl. its frustum cull (hpp:93-94), this rank's planes
+        self.ov.integrate_culled(depth.numpy(), bgra.numpy() if bgra is not None else None, np.asarray(trans, dtype=np.float64),
+                                 synth.cam_from_vol_f32(trans), self.z_begin, self.z_end)
 
     def _pack_rgb(self, rgb):
         c = rgb.astype(np.int32)
