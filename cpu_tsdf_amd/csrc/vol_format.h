@@ -445,6 +445,10 @@ inline bool read_open_chunk_parallel(S &f, ReadCtx &c, int depth) {
     if (nchild == 0) {
       pieces.push_back({a1, used, depth + 1});  // a leaf child: one record
     } else if (nchild == 8) {
+      if (depth + 1 > 24) {  // the one check read_node makes on an inner record that is not itself handed to it here
+        c.err = "malformed octree node";
+        return false;
+      }
       for (int k2 = 0; k2 < 8; ++k2) {
         const size_t a2 = used;
         if (!scan_subtree(f, c, rec, used, budget)) return false;
