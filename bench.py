@@ -23,7 +23,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 
 roofline.achieved uses the ALGORITHMIC bytes of the shipped HBM layout, measured per frame by the kernel's counting
 instance: bytes of the voxel words an observed voxel must read (PACKED colour: d + colour|count word = 8 B) + bytes
-of the words whose value changed (tsdf_hip_last_count_detail) + the frame.  SURVEY 8d's figure for the reference's
+of the words whose value changed (tsdf_hip_last_count_detail) + the frame: a per-voxel figure of the LAYOUT, the same
+since round 2.  The kernel moves less than that where it can tell a voxel's distance from its observation count and does
+not read it: `roofline.bytes_moved` prices exactly what it has to move (4 B less per such voxel,
+tsdf_hip_last_read_detail) and is the figure that agrees with the PMC traffic.  SURVEY 8d's figure for the reference's
 own (d, w, rgb) record, 24 B per observed voxel, stays as a labelled side note (`reference_record_*`): the PACKED
 layout moves fewer bytes than that record holds, so a fraction computed from it can exceed 1 and means nothing.
 roofline.traffic is the PMC measurement (rocprofv3 FETCH_SIZE / WRITE_SIZE over THIS command's timed launches,
@@ -250,16 +253,19 @@ def scene_b_leg(res, color, cpu_seconds):
         ms = e0.elapsed_time(e1) / nf
         info = (C.c_int32 * 4)()
         capi.check(lib.tsdf_hip_last_launch_info(h, info), "last_launch_info")
-        detail = (C.c_uint64 * 2)()
+        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
         run(nf // 2, C.byref(c))
         capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+        capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
         packed = v.getLayout() == capi.LAYOUT_PACKED
         read_bpv = ((8 if color else 5) if packed else (12 if color else 8))
         alg = read_bpv * int(detail[0]) + int(detail[1]) + (8 if color else 4) * sc.width * sc.height
         out.update({"grid": [res] * 3, "size_m": 10.0, "sensor_range_m": [0.0, 3.0], "observed_voxels_per_frame": int(c.value),
                     "gpu_ms_per_frame": ms, "gpu_frames_per_s": 1e3 / ms,
                     "launch": {"row_intervals": int(info[2]), "reference_cull_in_intervals": bool(info[2] == 2), "blocks": int(info[3])},
-                    "algorithmic_bytes_per_frame": alg, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_frame": alg, "distance_words_not_read": int(rdet[0]),
+                    "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_of_hbm_peak_by_bytes_moved": (alg - 4 * int(rdet[0])) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "ms per frame = rows + flags + k_integrate (HIP events around 12 frames); algorithmic bytes as in roofline"})
         v.close()
         if cpu_seconds > 0:
@@ -307,19 +313,23 @@ def fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, packed
     e1.record(stream)
     torch.cuda.synchronize()
     ms_launch = e0.elapsed_time(e1) / n_pairs
-    detail, n2 = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
-    obs = chg = per_frame = 0
+    detail, n2, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+    obs = chg = per_frame = imp = 0
     for k in range(n_pairs):
         pair(k, n2)
         capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+        capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
         obs, chg, per_frame = obs + int(detail[0]), chg + int(detail[1]), per_frame + int(n2[0]) + int(n2[1])
-    obs, chg = obs / n_pairs, chg / n_pairs
+        imp += int(rdet[0])
+    obs, chg, imp = obs / n_pairs, chg / n_pairs, imp / n_pairs
     read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))
     alg = read_bpv * obs + chg + 2 * (8 if args.color else 4) * W * H
     return {"one_sweep_per_pair": bool(was.value), "pairs_timed": n_pairs, "ms_per_launch": ms_launch, "ms_per_frame": ms_launch / 2,
             "frames_per_s": 2e3 / ms_launch, "kernel": "k_integrate2" if was.value else "k_integrate x 2",
             "algorithmic_bytes_per_launch": alg, "voxels_observed_by_either_frame": obs,
             "voxels_observed_per_frame": per_frame / (2 * n_pairs), "changed_word_bytes_per_launch": chg,
+            "distance_words_not_read_per_launch": imp,
+            "frac_of_hbm_peak_by_bytes_moved": (alg - 4 * imp) / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "achieved_GBps": alg / (ms_launch * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "report-only: tsdf_hip_integrate_device2 reads and writes each voxel word once per PAIR of frames; the planes "
                     "are bit-identical to frame-by-frame integration (tests/test_fused2_gpu.py); the headline `value` is the "
@@ -560,13 +570,13 @@ def main():
         if rc:
             capi.check(rc, "integrate_device")
 
-    counted = []  # (observed voxels, changed-word bytes) of every counted launch
+    counted = []  # (observed voxels, changed-word bytes, observed voxels whose distance word was not read) of every counted launch
 
     def run(first, last, counting=False, timed=False):
         """Frames [first, last): broadcast + integrate, the next frame's broadcast in flight under each kernel.
         counting: through the counting instance of the kernel (synchronous), results appended to `counted`."""
         pending = bcast(first, True) if (use_dist and args.overlap and first < last) else None
-        detail = (C.c_uint64 * 2)()
+        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
         for i in range(first, last):
             if use_dist:
                 tb = time.perf_counter()
@@ -581,7 +591,8 @@ def main():
                 c = C.c_uint64(0)
                 launch(i, C.byref(c), timed)
                 capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
-                counted.append((int(detail[0]), int(detail[1])))
+                capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
+                counted.append((int(detail[0]), int(detail[1]), int(rdet[0])))
             else:
                 launch(i, None, timed)
 
@@ -617,6 +628,7 @@ def main():
     run(args.warmup, n_total, counting=True)
     n_obs_rank = sum(c[0] for c in counted) / args.steps
     chg_rank = sum(c[1] for c in counted) / args.steps
+    imp_rank = sum(c[2] for c in counted) / args.steps
     chg_per_obs = chg_rank / n_obs_rank if n_obs_rank else 0.0
 
     # Two frames per sweep (tsdf_hip_integrate_device2 -> k_integrate2), report-only side field: the same timed frames
@@ -660,7 +672,8 @@ def main():
         bpp = 8 if args.color else 4                              # frame bytes per pixel (depth + bgra)
         ref_bpv = 24 if args.color else 16                        # the reference's (d, w, rgb) record, read + write
         read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))  # voxel words an observed voxel must read
-        alg_bytes = read_bpv * n_obs_rank + chg_rank + bpp * W * H  # rank 0's launch
+        alg_bytes = read_bpv * n_obs_rank + chg_rank + bpp * W * H  # rank 0's launch: the layout's per-voxel figure x observed voxels
+        moved_bytes = alg_bytes - 4 * imp_rank                      # ... what the kernel has to move: distances it rebuilds from counts are not read
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         sha = kernel_sha16()
         key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
@@ -703,8 +716,17 @@ def main():
                 "kernel": "k_integrate", "kernel_ms": kern_ms, "kernel_sha16": sha,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes": {"read_per_observed_voxel": read_bpv, "observed_voxels": n_obs_rank,
+                                      "distance_words_not_read": imp_rank, "distance_bytes_not_read": 4 * imp_rank,
                                       "changed_word_bytes": chg_rank, "changed_bytes_per_observed_voxel": chg_per_obs,
                                       "frame_bytes": bpp * W * H},
+                "bytes_moved": {"per_launch": moved_bytes, "GBps": moved_bytes / (kern_ms * 1e-3) / 1e9,
+                                "frac": moved_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "what this kernel has to move: algorithmic_bytes_per_launch minus 4 B for every observed voxel whose "
+                                        "distance word it did not read (a cell never observed inside the truncation band holds only the hinge "
+                                        "value and the reset value, and the count says which: DESIGN.md 3.1c).  THIS is the figure the PMC "
+                                        "traffic agrees with and the kernel's real share of the HBM peak; `frac` keeps the layout's per-voxel "
+                                        "figure of rounds 2-4 (comparable across rounds: time per unit of work), so with implied distances on "
+                                        "`traffic` is BELOW `algorithmic_bytes_per_launch`"},
                 "traffic_from_profile": ({"tag": prof.get("tag"), "commit": prof.get("git_head_when_summarised"), "read_bytes": prof.get("read_bytes"),
                                      "written_bytes": prof.get("written_bytes"),
                                      "frac_of_peak_by_traffic": prof["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -716,8 +738,9 @@ def main():
                                   "written: 24 B with colour, 16 B without) + the frame; it exceeds what the kernel moves because the "
                                   "shipped PACKED layout holds the weight as a count in the colour word's free byte (8 B per voxel) and "
                                   "unchanged words are not written back -- a value above 1 is that ratio, not a bandwidth",
-                "note": "achieved/frac: algorithmic bytes of the shipped HBM layout (words an observed voxel must read + words whose "
-                        "value changed, counted by the kernel's counting instance + the frame) / kernel_ms; traffic: PMC FETCH_SIZE x2 + "
+                "note": "achieved/frac: algorithmic bytes of the shipped HBM layout (the words of an observed voxel + words whose "
+                        "value changed, counted by the kernel's counting instance + the frame) / kernel_ms; bytes_moved: the same minus the "
+                        "distance words the kernel can tell from the counts and does not read; traffic: PMC FETCH_SIZE x2 + "
                         "WRITE_SIZE over this command's timed launches; reference_record_*: SURVEY 8d's 24 B (16 B) record of the "
                         "reference, a side note -- the PACKED layout moves fewer bytes than that record holds",
             },

@@ -110,6 +110,7 @@ SIGNATURES = {
     "tsdf_hip_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(_f32p), C.POINTER(_u8p)]),
     "tsdf_hip_frame_commit": (C.c_int, [C.c_void_p, _f32p]),
     "tsdf_hip_last_count_detail": (C.c_int, [C.c_void_p, _u64p]),
+    "tsdf_hip_last_read_detail": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_march_timing": (C.c_int, [C.c_void_p, _f32p, _u64p]),
     "tsdf_hip_march_stats": (C.c_int, [C.c_void_p, _u64p]),
     "tsdf_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, _f32p]),

@@ -72,6 +72,13 @@ struct tsdf_hip_volume {
   uint8_t *band = nullptr;
   int band_fx = 0, band_fy = 0;
   bool band_exact = false;
+  // Implied distances (k_integrate's s_bin): in a cell whose flag is 0 every observed voxel sits at the hinge value p of ALL
+  // launches since the reset, and every other voxel at the reset value.  rest_state: 0 no flag-keeping launch yet, 1 all of
+  // them so far were PACKED launches with hinge_fixed, kmax >= 1 and p == rest_bits, 2 one was not (until the next reset).
+  int rest_state = 0;
+  uint32_t rest_bits = 0;
+  unsigned long long last_implied = 0;  // tsdf_hip_last_read_detail
+  bool last_implied_on = false;
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
   uint32_t *row_iv = nullptr;      // row intervals of a LIVE launch (k_rows, tsdf_integrate.hip), one word per voxel row
@@ -84,7 +91,7 @@ struct tsdf_hip_volume {
   int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
   bool pair_pending = false;  // frame pairing: a committed frame sits uploaded in its ring slot, its launch waiting for a partner
   bool pair_fused = false;  // the last tsdf_integrate_launch2 went through k_integrate2 (else two launches)
-  unsigned long long pair_first_observed = 0, pair_first_changed = 0;  // ... of its first launch when it did not
+  unsigned long long pair_first_observed = 0, pair_first_changed = 0, pair_first_implied = 0;  // ... of its first launch when it did not
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
   bool count_ran = false;  // that launch really ran (finite pose, something observable)
   hipStream_t stream = nullptr;
@@ -124,6 +131,7 @@ int tsdf_multi_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, cons
                         uint64_t *n_valid);
 int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_observed);
 int tsdf_multi_last_count_detail(tsdf_handle h, uint64_t out[2]);
+int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[2]);
 int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, uint8_t *rgb);
 int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok);
 int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found);
@@ -292,6 +300,7 @@ struct TsdfTuning {
   int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (5: 128 voxels x 8 rows per block pass; Scene B at 2048^3: 0.37 ms against 0.60 at 6)
   int zfast;           // integrate launches hand out blocks planes-fastest: 1 always (default: 16.26 against 16.60 ms at 2048^3 + colour, 15.5 against 16.9 ms on a 4096 x 4096 x 512 slab with 1280x960 frames), 0 never, -1 only when the frame outgrows an XCD's L2
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
+  int implied_d;       // PACKED integrate launches do not read distance words the "band seen" flags and the counts determine (1)
 };
 const TsdfTuning &tsdf_tuning();
 // Edge of the voxel blocks save / load stream through host memory: TSDF_HIP_VOL_CHUNK, read at EVERY call (an I/O path: a

@@ -57,7 +57,7 @@ static TsdfTuning &tuning_storage() {
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
-                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1)};
+                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1), env_int("TSDF_HIP_IMPLIED_D", 1)};
   return t;
 }
 
@@ -99,6 +99,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.refcull_plain = value;
   else if (n == "fuse2")
     t.fuse2 = value;
+  else if (n == "implied_d")
+    t.implied_d = value;
   else if (n == "live_log2tx")
     t.live_log2tx = value;
   else if (n == "zfast")
@@ -710,8 +712,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   v->band_fx = (v->nx + 63) / 64;
   v->band_fy = (v->ny + 3) / 4;
   TRY_OR_BAIL(hipMalloc(&v->band, (size_t)v->band_fx * v->band_fy * v->nz_alloc));
-  TRY_OR_BAIL(hipMalloc(&v->counter, 2048 * sizeof(unsigned long long)));
-  TRY_OR_BAIL(hipMemset(v->counter, 0, 2048 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMalloc(&v->counter, 3072 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMemset(v->counter, 0, 3072 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL
   rc = tsdf_hip_reset(v);
   if (rc != TSDF_HIP_OK) return bail(rc);
@@ -744,6 +746,7 @@ extern "C" int tsdf_hip_reset(tsdf_handle h) {
   if (rc) return rc;
   TSDF_HIP_TRY(hipMemsetAsync(h->band, 0, (size_t)h->band_fx * h->band_fy * h->nz_alloc, h->stream));
   h->band_exact = true;  // every distance is -1: no voxel inside the band
+  h->rest_state = 0;
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   return TSDF_HIP_OK;
 }

@@ -56,6 +56,7 @@ struct IntegrateArgs {
   int ref_cull;          // replicate the reference's frustum cull (getFrustumCulledVoxels): six plane tests per voxel centre
   float cull[24];        // its planes l, r, t, b, far, near (tsdf_hip_set_reference_cull), 4 floats each
   int band_fx, band_fy;  // "band seen" flags: cells of 64 x 4 x 1 voxels, [allocated plane][fy][fx] (tsdf_common.h)
+  int implied_d;         // PACKED: in a cell whose flag is still 0 a voxel's distance follows from its count (see k_integrate)
   int x_abs0, y_abs0;    // grid x / y of the launch's first voxel / row (the launch may be a sub-box of the slab)
   int zfast;             // the hardware grid is (planes, row groups, x chunks) instead of (x chunks, row groups, planes): see tsdf_block_coords
   int64_t pitch;
@@ -279,6 +280,37 @@ static __device__ __forceinline__ BlockCoords tsdf_block_coords(int zfast) {
 // K8 (no colour); w = min(k, max_weight), k' = min(k + 1, kmax); a thread then moves 8 (5) bytes per voxel
 // each way instead of 12 (8), and 1/(k+1) comes from a 256-entry LDS table of refined reciprocals.
 // COUNT = accumulate the observed-voxel counter.
+// Implied distances (see k_integrate's s_bin): the "band seen" flags of a block's cells as they stood BEFORE the launch, in
+// the order of the block's own s_band (row group major, TX / 16 cells per row group); cells without voxels read 0.
+static __device__ __forceinline__ void tsdf_flags_before(const IntegrateArgs &a, const BlockCoords &bc, const uint8_t *band,
+                                                         uint8_t *s_bin, unsigned tid) {
+  const int row0 = (int)bc.by * a.rpb * a.TY;
+  const int rows = min(a.rpb * a.TY, a.ny - row0);
+  const int fxb = max(1, a.TX >> 4);
+  const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
+  const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
+  const int n_fl = (yg1 - yg0 + 1) * fxb;
+  for (int i = (int)tid; i < 1024; i += 256) {
+    const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+    s_bin[i] = i < n_fl && yg < a.band_fy && xc < a.band_fx ? band[((int64_t)(a.zl0 + (int)bc.bz) * a.band_fy + yg) * a.band_fx + xc] : (uint8_t)0;
+  }
+}
+// ... and from them, per wave: bit r = none of the cells the wave's 64 quads lie in during pass r (rows ty + r * TY) had its
+// flag set.  A wave covers max(1, 64 / TX) rows by min(TX, 64) quads per pass; lane r works out pass r.  (Passes beyond 63
+// -- only with the rows_per_block knob turned up on a one-row tile -- read their distances.)
+static __device__ __forceinline__ uint64_t tsdf_quiet_passes(const IntegrateArgs &a, const uint8_t *s_bin, unsigned tid) {
+  const int lane = (int)(tid & 63u), w0 = (int)(tid & ~63u);  // the wave's first thread
+  const int fxb = max(1, a.TX >> 4);
+  const int rows_w = max(1, 64 >> a.log2TX), ncell = max(1, min(a.TX, 64) >> 4);
+  const int ty0 = w0 >> a.log2TX, c0 = (w0 & (a.TX - 1)) >> 4;
+  bool q = lane < a.rpb;
+  if (q) {
+    for (int rr = 0; rr < rows_w; ++rr)
+      for (int c = 0; c < ncell; ++c) q &= s_bin[((ty0 + rr + lane * a.TY) >> 2) * fxb + c0 + c] == 0;
+  }
+  return __builtin_amdgcn_ballot_w64(q);
+}
+
 #ifndef TSDF_GUARD_ON_RESULT
 #define TSDF_GUARD_ON_RESULT 1  // PACKED update: guard the divider on its result (v_cmp_class) instead of on its numerator
 #endif
@@ -373,13 +405,32 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
     if (LIVE && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)bc.bz * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
+  // IMPLIED DISTANCES (PACKED, a.implied_d).  The flags as they stood BEFORE this launch, same cells and same order as
+  // s_band.  While the flags describe the planes (tsdf_hip_volume::band_exact) and every launch since the reset used the
+  // same hinge value p = pos / neg with (p*w + p)/(w + 1) == p (a.hinge_fixed; the host keeps that record,
+  // tsdf_hip_volume::rest_state), a cell whose flag is 0 has only ever been observed in FREE SPACE -- every update of a
+  // voxel in it was addObservation(p, ...) -- so the distance of each of its voxels follows from its count: k == 0 is the
+  // reset value -1 (never observed; kmax >= 1), k > 0 is p.  Such a quad does not READ its distance words: they are
+  // rebuilt from the counts, the update runs on them unchanged, and whatever it changes (a first observation: -1 -> p; a
+  // first observation inside the band, which also sets the flag) is stored as ever.  A cell belongs to ONE block of a
+  // launch and a voxel to one thread, so the pre-launch flag is the right one for every row of the cell whatever the other
+  // waves of the block do meanwhile.  In the headline's regime this is most of the volume (free space between the camera
+  // and the surface): 71 % of the observed voxels' distance words stay unread at 2048^3, 17.5 of the launch's 77 GB -- for
+  // 3 % of its time (16.3-16.6 -> 15.8-16.1 ms; 12.3 -> 11.8 ms without colour; profiles/r04_ab_implied_distances.txt):
+  // what binds the kernel is the row's dependent chain and the VALU, not the bytes.  The decision is per WAVE and per pass
+  // (a scalar branch): a per-lane one (exec-masked load, finer: 85 % unread) needs the lane's cell index in a register the
+  // kernel does not have -- it was spilled and its reload waited for every store in flight: 18.1 ms, measured.
+  __shared__ uint8_t s_bin[PACKED ? 1024 : 1];
+  if (PACKED && a.implied_d) tsdf_flags_before(a, bc, band, s_bin, tid);
   __syncthreads();
+  // bit r: in its pass r over the block's rows this WAVE touches no flagged cell (wave-uniform: one scalar branch per row)
+  const uint64_t quiet = PACKED && a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
   const int xq = (int)bc.bx * a.TX + tx;
   const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0, chg = 0;
+  unsigned cnt = 0, chg = 0, imp = 0;
   // wave-uniform bases
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
@@ -561,14 +612,20 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {(unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24};
       uint32_t k4 = 0u;
 #elif !TSDF_EARLY_VOXEL_LOADS
-      const u4 d4 = bload128(rsD, voff, soff);
+      // (PACKED) the distance words are only read where the cell's flag says they cannot be told from the counts
+      const bool d_read = !PACKED || !(r < 64 && (quiet >> r & 1ull));
+      u4 d4 = {0u, 0u, 0u, 0u};
+      if (d_read) d4 = bload128(rsD, voff, soff);
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
       if (!PACKED) w4 = bload128(rsW, voff, soff);
       if (COLOR) c4 = bload128(rsC, voff, soff);
       if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
 #endif
-      const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
+#if TSDF_EXP_NO_VLOAD || TSDF_EARLY_VOXEL_LOADS
+      const bool d_read = true;
+#endif
+      uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       const uint32_t w0u[4] = {w4.x, w4.y, w4.z, w4.w};
       float d0[4], w0[4];
@@ -583,6 +640,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           // tsdf_decode_w (neither is NaN here).  (With an integer max_weight the min is the identity, but leaving it
           // out lets LLVM turn the colour sums into integer multiplies and byte shuffles: +70 instructions, measured.)
           w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
+          if (!d_read) {  // never observed: the reset value; else the hinge value (see s_bin)
+            d0u[j] = kw[j] >> 24 ? __float_as_uint(a.pos_over_neg) : 0xbf800000u;
+            d0[j] = __uint_as_float(d0u[j]);
+          }
         }
       }
       float dv[4], wv[4];
@@ -693,6 +754,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         diff_w |= wn_u[j] ^ w0u[j];
         diff_c |= cv[j] ^ c0[j];
         cnt += act[j] ? 1u : 0u;
+        if (COUNT && PACKED) imp += act[j] && !d_read ? 1u : 0u;  // observed voxels whose distance word was not read
         if (COUNT)  // bytes of voxel words whose VALUE changed: what any layout-preserving kernel has to write
           chg += (!PACKED && wn_u[j] != w0u[j] ? 4u : 0u) + (COLOR && cv[j] != c_before[j] ? 4u : 0u);
       }
@@ -717,17 +779,20 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
-  if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes
-    __shared__ unsigned s_cnt, s_chg;
-    if (tid == 0) s_cnt = s_chg = 0;
+  if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes,
+                // slots 2048.. = observed voxels whose distance word was not read
+    __shared__ unsigned s_cnt, s_chg, s_imp;
+    if (tid == 0) s_cnt = s_chg = s_imp = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     if (chg) atomicAdd(&s_chg, chg);
+    if (imp) atomicAdd(&s_imp, imp);
     __syncthreads();
     if (tid == 0 && s_cnt) {
       const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
       atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
+      if (s_imp) atomicAdd(n_obs + 2048u + (b & 1023u), (unsigned long long)s_imp);
     }
   }
 }
@@ -772,13 +837,16 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
     s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
   }
+  __shared__ uint8_t s_bin[1024];  // the flags before this launch: where 0, distances follow from the counts (k_integrate's s_bin)
+  if (a.implied_d) tsdf_flags_before(a, bc, band, s_bin, tid);
   __syncthreads();
+  const uint64_t quiet = a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
   const int xq = (int)bc.bx * a.TX + tx;
   const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0;
+  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0, imp = 0;
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
@@ -805,6 +873,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       uint32_t csA[4], csB[4];
       u4 d4, c4;
       uint32_t k4;
+      bool d_read;
     };
     auto issue = [&](int r, RowLoads &L) {
       const unsigned soff = (unsigned)r * row_step;
@@ -868,7 +937,9 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         L.zsB[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, 0, TSDF_GATHER_AUX));
         L.csB[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, (int)fb.bgra_off, TSDF_GATHER_AUX) : 0u;
       }
-      L.d4 = bload128(rsD, voff, soff);
+      L.d_read = !(r < 64 && (quiet >> r & 1ull));
+      L.d4 = (u4){0u, 0u, 0u, 0u};
+      if (L.d_read) L.d4 = bload128(rsD, voff, soff);
       L.c4 = (u4){0u, 0u, 0u, 0u};
       L.k4 = 0u;
       if (COLOR) L.c4 = bload128(rsC, voff, soff);
@@ -907,13 +978,14 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       if (!((obsA | obsB) & 15u)) return;
       const u4 d4 = L.d4, c4 = L.c4;
       const uint32_t k4 = L.k4;
-      const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
+      uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       uint32_t du[4], kw[4];  // the state both updates work on: distance bits; colour | count << 24 (or only the count there)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        du[j] = d0u[j];
         kw[j] = COLOR ? c0[j] : ((k4 << (24 - 8 * j)) & 0xff000000u);
+        if (!L.d_read) d0u[j] = kw[j] >> 24 ? hinge_bits : 0xbf800000u;  // never observed: the reset value; else the hinge value
+        du[j] = d0u[j];
       }
       // ---- OctreeNode / RGBNode::addObservation (octree.cpp:152-163, 328-337) of one frame on that state ----
       auto apply = [&](unsigned obs, const float (&dn)[4], const uint32_t (&cs)[4]) {
@@ -984,6 +1056,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         if (!COLOR) k4n |= (kw[j] & 0xff000000u) >> (24 - 8 * j);
         cnt += ((obsA | obsB) >> j & 1u);
         if (COUNT) cntA += (obsA >> j & 1u), cntB += (obsB >> j & 1u);
+        if (COUNT) imp += L.d_read ? 0u : ((obsA | obsB) >> j & 1u);
         if (COUNT) chg += (du[j] != d0u[j] ? 4u : 0u) + (COLOR && kw[j] != c0[j] ? 4u : 0u);
       }
       if (COUNT && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
@@ -1026,20 +1099,23 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     }
   }
   if (COUNT) {
-    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB;
-    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = 0;
+    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB, s_imp;
+    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = s_imp = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     if (chg) atomicAdd(&s_chg, chg);
     if (cntA) atomicAdd(&s_cntA, cntA);
     if (cntB) atomicAdd(&s_cntB, cntB);
+    if (imp) atomicAdd(&s_imp, imp);
     __syncthreads();
-    if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes (tsdf_integrate_collect2)
+    if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes, voxels (of either) whose
+                              // distance word was not read (tsdf_integrate_collect2)
       const unsigned b = (bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u;
       if (s_cntA) atomicAdd(n_obs + b, (unsigned long long)s_cntA);
       if (s_cntB) atomicAdd(n_obs + 512u + b, (unsigned long long)s_cntB);
       atomicAdd(n_obs + 1024u + b, (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1536u + b, (unsigned long long)s_chg);
+      if (s_imp) atomicAdd(n_obs + 2048u + b, (unsigned long long)s_imp);
     }
   }
 }
@@ -1631,6 +1707,23 @@ static bool fast_projection_ok(const IntegrateHost &a, bool color, bool force = 
          a.a.H < (1 << 23);
 }
 
+// Implied distances (k_integrate's s_bin): the record of what every flag-keeping launch since the reset did to voxels in
+// cells whose flag stayed 0, and whether THIS launch may rebuild distances from counts there.  `flags_kept`: the launch
+// maintains the "band seen" flags (else band_exact is already false and no later launch asks).
+static int implied_distances(tsdf_handle h, const IntegrateArgs &a, bool flags_kept) {
+  if (!flags_kept) return 0;
+  uint32_t bits;
+  memcpy(&bits, &a.pos_over_neg, 4);
+  if (!(h->packed && a.hinge_fixed && h->kmax >= 1u))
+    h->rest_state = 2;  // free space may now rest anywhere (or a count of 0 no longer means "never observed")
+  else if (h->rest_state == 0)
+    h->rest_state = 1, h->rest_bits = bits;
+  else if (h->rest_state == 1 && h->rest_bits != bits)
+    h->rest_state = 2;  // the truncation limits changed: two hinge values in the planes
+  return h->rest_state == 1 && tsdf_tuning().implied_d ? 1 : 0;
+}
+
+
 // Index box of the voxels a frame can possibly observe.  updateVoxel only touches a voxel whose centre maps to
 // 0 < g.z <= max_sensor_dist with a pixel (int)(g.x*fx/g.z + cx) inside the image (hpp:146, .cpp:611-617), i.e.
 // a point of the pyramid spanned by the camera centre and the far corners of the (slightly widened) image --
@@ -2019,7 +2112,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       live = h->live;
     }
   }
-  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 3072 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
   // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
   // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
@@ -2032,6 +2125,8 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
   // otherwise this launch keeps no flags and marching cubes reads everything until the next reset
   uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 && (a.y_abs0 & 3) == 0 ? h->band : nullptr;
   if (!band_arg) h->band_exact = false;
+  a.implied_d = implied_distances(h, a, band_arg != nullptr);
+  h->last_implied_on = a.implied_d != 0;
   if (pose_ok && !nothing_observable) {
     // planes fastest when the frame outgrows an XCD's L2 (knob zfast: -1 auto, 0 / 1 force)
     const size_t frame_bytes = npx * (color ? 8 : 4);
@@ -2092,7 +2187,8 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
   }
-  h->count_slots = count ? 2048 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed
+  h->count_slots = count ? 3072 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed, 2048.. the observed
+                                      // voxels whose distance word was not read
   h->count_ran = pose_ok && !nothing_observable;
   return TSDF_HIP_OK;
 }
@@ -2105,15 +2201,17 @@ int tsdf_integrate_collect(tsdf_handle h, uint64_t *n_observed) {
     tsdf_set_error("tsdf_integrate_collect without a counting launch");
     return TSDF_HIP_E_INVALID;
   }
-  unsigned long long c[2048];
+  unsigned long long c[3072];
   const int slots = h->count_slots;
   TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, (size_t)slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  unsigned long long sum = 0, changed = 0;
+  unsigned long long sum = 0, changed = 0, implied = 0;
   for (int i = 0; i < 1024; ++i) sum += c[i];
-  for (int i = 1024; i < slots; ++i) changed += c[i];
+  for (int i = 1024; i < slots && i < 2048; ++i) changed += c[i];
+  for (int i = 2048; i < slots; ++i) implied += c[i];
   h->last_observed = h->count_ran ? sum : 0;
   h->last_changed_bytes = h->count_ran ? changed : 0;
+  h->last_implied = h->count_ran ? implied : 0;
   h->count_slots = 0;
   if (n_observed) *n_observed = h->last_observed;
   return TSDF_HIP_OK;
@@ -2171,7 +2269,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
     if (!rc && count) {
       uint64_t n = 0;
       rc = tsdf_integrate_collect(h, &n);
-      h->pair_first_observed = n, h->pair_first_changed = h->last_changed_bytes;
+      h->pair_first_observed = n, h->pair_first_changed = h->last_changed_bytes, h->pair_first_implied = h->last_implied;
     }
     if (!rc) rc = tsdf_hip_set_reference_cull(h, planesB);
     if (!rc) rc = tsdf_integrate_launch(h, dB, cB, TB, count);
@@ -2182,9 +2280,11 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   for (int i = 0; i < 24; ++i) h->cull_planes[i] = planesB ? planesB[i] : 0.f;
   h->count_slots = 0;
   h->count_ran = false;
-  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2048 * sizeof(unsigned long long), h->stream));
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2560 * sizeof(unsigned long long), h->stream));
   uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 ? h->band : nullptr;
   if (!band_arg) h->band_exact = false;
+  a.implied_d = implied_distances(h, a, band_arg != nullptr);
+  h->last_implied_on = a.implied_d != 0;
   h->last_launch[0] = 2, h->last_launch[1] = 1, h->last_launch[2] = 0;
   h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
   a.zfast = tsdf_tuning().zfast < 0 ? (npx * (color ? 8 : 4) > (3u << 20) && gx <= 65535u) : (tsdf_tuning().zfast != 0 && gx <= 65535u);
@@ -2213,7 +2313,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
 #undef L2B
 #undef LAUNCH2
   TSDF_HIP_TRY(hipGetLastError());
-  h->count_slots = count ? 2048 : 0;
+  h->count_slots = count ? 2560 : 0;
   h->count_ran = true;
   h->pair_fused = true;
   return TSDF_HIP_OK;
@@ -2230,20 +2330,22 @@ int tsdf_integrate_collect2(tsdf_handle h, uint64_t n_observed[2]) {
     n_observed[0] = h->pair_first_observed, n_observed[1] = nb;
     h->last_observed = h->pair_first_observed + nb;  // (an upper bound of the union; the words were read twice anyway)
     h->last_changed_bytes += h->pair_first_changed;
+    h->last_implied += h->pair_first_implied;
     return TSDF_HIP_OK;
   }
   if (!h->count_slots) {
     tsdf_set_error("tsdf_integrate_collect2 without a counting launch");
     return TSDF_HIP_E_INVALID;
   }
-  unsigned long long c[2048];
+  unsigned long long c[2560];
   TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  unsigned long long sum[4] = {0, 0, 0, 0};  // A, B, union, changed bytes: 512 striped slots each
-  for (int i = 0; i < 2048; ++i) sum[i >> 9] += c[i];
+  unsigned long long sum[5] = {0, 0, 0, 0, 0};  // A, B, union, changed bytes, distance words not read: 512 striped slots each
+  for (int i = 0; i < 2560; ++i) sum[i >> 9] += c[i];
   n_observed[0] = sum[0], n_observed[1] = sum[1];
   h->last_observed = sum[2];
   h->last_changed_bytes = sum[3];
+  h->last_implied = sum[4];
   h->count_slots = 0;
   return TSDF_HIP_OK;
 }
@@ -2277,6 +2379,14 @@ extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
   if (h->multi) return tsdf_multi_last_count_detail(h, out);
   out[0] = h->last_observed;
   out[1] = h->last_changed_bytes;
+  return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[2]) {
+  if (!h || !out) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_last_read_detail(h, out);
+  out[0] = h->last_implied;
+  out[1] = h->last_implied_on ? 1 : 0;
   return TSDF_HIP_OK;
 }
 

@@ -346,7 +346,8 @@ static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed)
     if (t1) TSDF_HIP_TRY(hipEventRecord(t1, s->stream));
   }
   if (n_observed) {
-    unsigned long long total = 0, changed = 0;
+    unsigned long long total = 0, changed = 0, implied = 0;
+    bool implied_on = true;
     for (tsdf_handle s : m->slab) {
       TSDF_ON_DEVICE(s->device);
       uint64_t n = 0;
@@ -354,10 +355,14 @@ static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed)
       if (rc) return rc;
       total += n;
       changed += s->last_changed_bytes;
+      implied += s->last_implied;
+      implied_on = implied_on && s->last_implied_on;
     }
     *n_observed = total;
     h->last_observed = total;
     h->last_changed_bytes = changed;
+    h->last_implied = implied;
+    h->last_implied_on = implied_on;
   }
   return TSDF_HIP_OK;
 }
@@ -606,6 +611,12 @@ int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_ob
   int rc = fan_out_device(h, s0->frame_depth, s0->p.integrate_color ? s0->frame_bgra : nullptr, 0);
   if (rc) return rc;
   return integrate_all(h, T, n_observed);
+}
+
+int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[2]) {
+  out[0] = h->last_implied;
+  out[1] = h->last_implied_on ? 1 : 0;
+  return TSDF_HIP_OK;
 }
 
 int tsdf_multi_last_count_detail(tsdf_handle h, uint64_t out[2]) {

@@ -217,6 +217,11 @@ int tsdf_hip_integrate_staged(tsdf_handle h, const float cam_from_vol[12], uint6
  * of voxel words whose VALUE changed (4 per distance / weight / colour word, 1 per count byte) -- with the bytes read
  * per observed voxel this is the algorithmic traffic of the chosen HBM layout (bench.py's roofline). */
 int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]);
+/* Of the same call: out[0] = observed voxels whose DISTANCE word was not read, because the kernel could tell it from the
+ * voxel's observation count (PACKED layout: in a cell of 64 x 4 x 1 voxels that no frame since the reset has observed
+ * inside the truncation band, an observed voxel sits at max_dist_pos / max_dist_neg and an unobserved one at the reset
+ * value) -- 4 bytes each that the launch did not move; out[1] = 1 if the launch was allowed to do so. */
+int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[2]);
 
 /* The two observation weightings of updateVoxel -- include/cpu_tsdf/impl/tsdf_volume_octree.hpp:200-204.  The
  * reference has no setter for them: weight_by_depth_ / weight_by_variance_ only become true through load()
@@ -476,7 +481,7 @@ const char *tsdf_hip_last_error(void);
 int tsdf_hip_device_count(void);
 /* ABI version of this header. */
 int tsdf_hip_abi_version(void);
-#define TSDF_HIP_ABI_VERSION 13
+#define TSDF_HIP_ABI_VERSION 14
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/tsdf_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in cpu_tsdf_amd/capi.py"
-    assert lib.tsdf_hip_abi_version() == 13
+    assert lib.tsdf_hip_abi_version() == 14
 
 
 def test_the_product_library_exports_the_boundary_and_nothing_else():
@@ -50,7 +50,7 @@ def test_the_product_library_exports_the_boundary_and_nothing_else():
     code = ("from cpu_tsdf_amd import capi; lib = capi.load(); assert capi.LIB_PATH == capi.PRODUCT_LIB_PATH; "
             "assert not capi.has_test_hooks() and not hasattr(lib, 'tsdf_hip_set_tuning'); print(lib.tsdf_hip_abi_version())")
     env = {k: v for k, v in os.environ.items() if k != "TSDF_HIP_LIB_PATH"}
-    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, PYTHONPATH=ROOT), text=True).strip() == "13"
+    assert subprocess.check_output([sys.executable, "-c", code], env=dict(env, PYTHONPATH=ROOT), text=True).strip() == "14"
 
 
 def test_torch_enters_the_process_before_the_library():

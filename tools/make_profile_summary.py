@@ -86,6 +86,8 @@ def main():
                         "WRITE_SIZE_KiB": write["k_calib_rmw"]["WRITE_SIZE"], "ratio_write": cal_w,
                         "narrow_reads": narrow},
         "algorithmic_bytes_per_launch": bf["roofline"]["algorithmic_bytes_per_launch"],
+        # what the kernel has to move (distance words it rebuilds from the counts are not read): the figure the traffic follows
+        "bytes_moved_per_launch": (bf["roofline"].get("bytes_moved") or {}).get("per_launch"),
         "kernel_ms_in_profile": {"kernel_trace_avg_timed_instance": trace[timed_instance(trace)]["duration_ns"] / 1e6,
                                  "bench_line_same_run": bt["roofline"]["kernel_ms"],
                                  "bench_line_fetch_pass": bf["roofline"]["kernel_ms"]},
