@@ -253,7 +253,7 @@ def scene_b_leg(res, color, cpu_seconds):
         ms = e0.elapsed_time(e1) / nf
         info = (C.c_int32 * 4)()
         capi.check(lib.tsdf_hip_last_launch_info(h, info), "last_launch_info")
-        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 3)()
         run(nf // 2, C.byref(c))
         capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
         capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
@@ -265,7 +265,8 @@ def scene_b_leg(res, color, cpu_seconds):
                     "launch": {"row_intervals": int(info[2]), "reference_cull_in_intervals": bool(info[2] == 2), "blocks": int(info[3])},
                     "algorithmic_bytes_per_frame": alg, "distance_words_not_read": int(rdet[0]),
                     "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "frac_of_hbm_peak_by_bytes_moved": (alg - 4 * int(rdet[0])) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "plane_bytes_requested": int(rdet[2]),
+                    "frac_of_hbm_peak_by_bytes_moved": (int(rdet[2]) + int(detail[1]) + (8 if color else 4) * sc.width * sc.height) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "ms per frame = rows + flags + k_integrate (HIP events around 12 frames); algorithmic bytes as in roofline"})
         v.close()
         if cpu_seconds > 0:
@@ -313,15 +314,16 @@ def fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, packed
     e1.record(stream)
     torch.cuda.synchronize()
     ms_launch = e0.elapsed_time(e1) / n_pairs
-    detail, n2, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
-    obs = chg = per_frame = imp = 0
+    detail, n2, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_uint64 * 3)()
+    obs = chg = per_frame = imp = req = 0
     for k in range(n_pairs):
         pair(k, n2)
         capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
         capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
         obs, chg, per_frame = obs + int(detail[0]), chg + int(detail[1]), per_frame + int(n2[0]) + int(n2[1])
         imp += int(rdet[0])
-    obs, chg, imp = obs / n_pairs, chg / n_pairs, imp / n_pairs
+        req += int(rdet[2])
+    obs, chg, imp, req = obs / n_pairs, chg / n_pairs, imp / n_pairs, req / n_pairs
     read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))
     alg = read_bpv * obs + chg + 2 * (8 if args.color else 4) * W * H
     return {"one_sweep_per_pair": bool(was.value), "pairs_timed": n_pairs, "ms_per_launch": ms_launch, "ms_per_frame": ms_launch / 2,
@@ -329,7 +331,8 @@ def fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, packed
             "algorithmic_bytes_per_launch": alg, "voxels_observed_by_either_frame": obs,
             "voxels_observed_per_frame": per_frame / (2 * n_pairs), "changed_word_bytes_per_launch": chg,
             "distance_words_not_read_per_launch": imp,
-            "frac_of_hbm_peak_by_bytes_moved": (alg - 4 * imp) / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "plane_bytes_requested_per_launch": req,
+            "frac_of_hbm_peak_by_bytes_moved": (req + chg + 2 * (8 if args.color else 4) * W * H) / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "achieved_GBps": alg / (ms_launch * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "report-only: tsdf_hip_integrate_device2 reads and writes each voxel word once per PAIR of frames; the planes "
                     "are bit-identical to frame-by-frame integration (tests/test_fused2_gpu.py); the headline `value` is the "
@@ -576,7 +579,7 @@ def main():
         """Frames [first, last): broadcast + integrate, the next frame's broadcast in flight under each kernel.
         counting: through the counting instance of the kernel (synchronous), results appended to `counted`."""
         pending = bcast(first, True) if (use_dist and args.overlap and first < last) else None
-        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 3)()
         for i in range(first, last):
             if use_dist:
                 tb = time.perf_counter()
@@ -592,7 +595,7 @@ def main():
                 launch(i, C.byref(c), timed)
                 capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
                 capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
-                counted.append((int(detail[0]), int(detail[1]), int(rdet[0])))
+                counted.append((int(detail[0]), int(detail[1]), int(rdet[0]), int(rdet[2])))
             else:
                 launch(i, None, timed)
 
@@ -629,6 +632,7 @@ def main():
     n_obs_rank = sum(c[0] for c in counted) / args.steps
     chg_rank = sum(c[1] for c in counted) / args.steps
     imp_rank = sum(c[2] for c in counted) / args.steps
+    req_rank = sum(c[3] for c in counted) / args.steps
     chg_per_obs = chg_rank / n_obs_rank if n_obs_rank else 0.0
 
     # Two frames per sweep (tsdf_hip_integrate_device2 -> k_integrate2), report-only side field: the same timed frames
@@ -673,7 +677,10 @@ def main():
         ref_bpv = 24 if args.color else 16                        # the reference's (d, w, rgb) record, read + write
         read_bpv = ((8 if args.color else 5) if packed else (12 if args.color else 8))  # voxel words an observed voxel must read
         alg_bytes = read_bpv * n_obs_rank + chg_rank + bpp * W * H  # rank 0's launch: the layout's per-voxel figure x observed voxels
-        moved_bytes = alg_bytes - 4 * imp_rank                      # ... what the kernel has to move: distances it rebuilds from counts are not read
+        # ... and what the kernel moves: the plane bytes it requests (distances it rebuilds from the counts are not read; the
+        # words of a quad none of whose voxels turns out to be observed are, since the request goes out with the frame gather)
+        # + the changed words + the frame.  The plain kernels do not count requests: then the layout's figure stands in
+        moved_bytes = (req_rank if req_rank else read_bpv * n_obs_rank - 4 * imp_rank) + chg_rank + bpp * W * H
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         sha = kernel_sha16()
         key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
@@ -717,16 +724,17 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes": {"read_per_observed_voxel": read_bpv, "observed_voxels": n_obs_rank,
                                       "distance_words_not_read": imp_rank, "distance_bytes_not_read": 4 * imp_rank,
+                                      "plane_bytes_requested": req_rank,
                                       "changed_word_bytes": chg_rank, "changed_bytes_per_observed_voxel": chg_per_obs,
                                       "frame_bytes": bpp * W * H},
                 "bytes_moved": {"per_launch": moved_bytes, "GBps": moved_bytes / (kern_ms * 1e-3) / 1e9,
                                 "frac": moved_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "what this kernel has to move: algorithmic_bytes_per_launch minus 4 B for every observed voxel whose "
-                                        "distance word it did not read (a cell never observed inside the truncation band holds only the hinge "
-                                        "value and the reset value, and the count says which: DESIGN.md 3.1c).  THIS is the figure the PMC "
-                                        "traffic agrees with and the kernel's real share of the HBM peak; `frac` keeps the layout's per-voxel "
-                                        "figure of rounds 2-4 (comparable across rounds: time per unit of work), so with implied distances on "
-                                        "`traffic` is BELOW `algorithmic_bytes_per_launch`"},
+                                "note": "what this kernel moves: the plane bytes it requests (counted by its counting instance: no distance word "
+                                        "where a cell never observed inside the truncation band lets the count tell it, DESIGN.md 3.1c; the words "
+                                        "of every quad it visits, observed or not, because the request goes out together with the frame gather) "
+                                        "+ the changed words + the frame.  THIS is the figure the PMC traffic agrees with and the kernel's real "
+                                        "share of the HBM peak; `frac` keeps the layout's per-voxel figure of rounds 2-4 (comparable across "
+                                        "rounds: time per unit of work), so `traffic` is BELOW `algorithmic_bytes_per_launch`"},
                 "traffic_from_profile": ({"tag": prof.get("tag"), "commit": prof.get("git_head_when_summarised"), "read_bytes": prof.get("read_bytes"),
                                      "written_bytes": prof.get("written_bytes"),
                                      "frac_of_peak_by_traffic": prof["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

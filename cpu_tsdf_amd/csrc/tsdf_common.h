@@ -77,7 +77,7 @@ struct tsdf_hip_volume {
   // them so far were PACKED launches with hinge_fixed, kmax >= 1 and p == rest_bits, 2 one was not (until the next reset).
   int rest_state = 0;
   uint32_t rest_bits = 0;
-  unsigned long long last_implied = 0;  // tsdf_hip_last_read_detail
+  unsigned long long last_implied = 0, last_read_bytes = 0;  // tsdf_hip_last_read_detail
   bool last_implied_on = false;
   uint8_t *live = nullptr;         // brick-cull flags, one per k_integrate block
   size_t live_cap = 0;
@@ -91,7 +91,7 @@ struct tsdf_hip_volume {
   int last_launch[4] = {0, 0, 0, 0};  // tsdf_hip_last_launch_info: ALLIN instance, fast projection, brick flags, blocks
   bool pair_pending = false;  // frame pairing: a committed frame sits uploaded in its ring slot, its launch waiting for a partner
   bool pair_fused = false;  // the last tsdf_integrate_launch2 went through k_integrate2 (else two launches)
-  unsigned long long pair_first_observed = 0, pair_first_changed = 0, pair_first_implied = 0;  // ... of its first launch when it did not
+  unsigned long long pair_first_observed = 0, pair_first_changed = 0, pair_first_implied = 0, pair_first_read = 0;  // ... of its first launch when it did not
   int count_slots = 0;     // counter slots the last counting launch filled (0 = none pending), tsdf_integrate_collect
   bool count_ran = false;  // that launch really ran (finite pose, something observable)
   hipStream_t stream = nullptr;
@@ -131,7 +131,7 @@ int tsdf_multi_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, cons
                         uint64_t *n_valid);
 int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_observed);
 int tsdf_multi_last_count_detail(tsdf_handle h, uint64_t out[2]);
-int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[2]);
+int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[3]);
 int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, uint8_t *rgb);
 int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok);
 int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found);

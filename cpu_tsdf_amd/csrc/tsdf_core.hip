@@ -712,8 +712,8 @@ extern "C" int tsdf_hip_create(const tsdf_params *p, tsdf_handle *out) {
   v->band_fx = (v->nx + 63) / 64;
   v->band_fy = (v->ny + 3) / 4;
   TRY_OR_BAIL(hipMalloc(&v->band, (size_t)v->band_fx * v->band_fy * v->nz_alloc));
-  TRY_OR_BAIL(hipMalloc(&v->counter, 3072 * sizeof(unsigned long long)));
-  TRY_OR_BAIL(hipMemset(v->counter, 0, 3072 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMalloc(&v->counter, 4096 * sizeof(unsigned long long)));
+  TRY_OR_BAIL(hipMemset(v->counter, 0, 4096 * sizeof(unsigned long long)));
 #undef TRY_OR_BAIL
   rc = tsdf_hip_reset(v);
   if (rc != TSDF_HIP_OK) return bail(rc);

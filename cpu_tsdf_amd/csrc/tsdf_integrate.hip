@@ -315,8 +315,9 @@ static __device__ __forceinline__ uint64_t tsdf_quiet_passes(const IntegrateArgs
 #define TSDF_GUARD_ON_RESULT 1  // PACKED update: guard the divider on its result (v_cmp_class) instead of on its numerator
 #endif
 #ifndef TSDF_EARLY_VOXEL_LOADS
-#define TSDF_EARLY_VOXEL_LOADS 0
+#define TSDF_EARLY_VOXEL_LOADS 0  // A/B: the quad's voxel words are requested together with the frame gather (see there): measured, off
 #endif
+
 #ifndef TSDF_COLOR_PK
 #define TSDF_COLOR_PK 0  // 1 / 2: colour bytes through v_cvt_pk_u8_f32, assuming it truncates / rounds to nearest even
 #endif
@@ -415,8 +416,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   // first observation inside the band, which also sets the flag) is stored as ever.  A cell belongs to ONE block of a
   // launch and a voxel to one thread, so the pre-launch flag is the right one for every row of the cell whatever the other
   // waves of the block do meanwhile.  In the headline's regime this is most of the volume (free space between the camera
-  // and the surface): 71 % of the observed voxels' distance words stay unread at 2048^3, 17.5 of the launch's 77 GB -- for
-  // 3 % of its time (16.3-16.6 -> 15.8-16.1 ms; 12.3 -> 11.8 ms without colour; profiles/r04_ab_implied_distances.txt):
+  // and the surface): 71 % of the observed voxels' distance words stay unread at 2048^3, 19 of the launch's 77 GB -- for
+  // 3-5 % of its time (16.2-16.6 -> 15.5-15.8 ms; 12.0-12.3 -> 11.6 ms without colour; profiles/r04_ab_implied_distances.txt):
   // what binds the kernel is the row's dependent chain and the VALU, not the bytes.  The decision is per WAVE and per pass
   // (a scalar branch): a per-lane one (exec-masked load, finer: 85 % unread) needs the lane's cell index in a register the
   // kernel does not have -- it was spilled and its reload waited for every store in flight: 18.1 ms, measured.
@@ -430,7 +431,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   const int xq = (int)bc.bx * a.TX + tx;
   const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0, chg = 0, imp = 0;
+  unsigned cnt = 0, chg = 0, imp = 0, rdb = 0;
   // wave-uniform bases
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
@@ -545,15 +546,27 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (j == 3) pix[3] = p;
       }
 #if TSDF_EARLY_VOXEL_LOADS
-      // the voxel words of the quad are requested TOGETHER with the frame gather instead of after its result: one
-      // memory latency per row instead of two in a row, at the price of reading the planes for quads none of whose
-      // voxels turns out to be observed (behind the surface, no return)
-      const u4 d4 = bload128(rsD, voff, soff);
+      constexpr bool EARLY = PACKED;  // (F32W reads three planes per voxel and is the one key that feels the extra bytes: 22.3 -> 24.6 ms)
+      // the voxel words of the quad are requested TOGETHER with the frame gather instead of after its result: one memory
+      // latency per row instead of two in a row, at the price of reading the planes for quads none of whose voxels turns out
+      // to be observed (behind the surface, no return).  Measured on top of the implied distances (s_bin), same box,
+      // alternating (profiles/r04_ab_implied_distances.txt): 2048^3 + colour 15.48-15.97 -> 15.32-15.41 ms for 58.2 -> 71.1 GB
+      // per launch, without colour 11.60 -> 11.29, the configs[4] slab 14.61 -> 14.58: one to three per cent for a fifth more
+      // traffic, and a frame that sees little of the slab (a wall in front of the camera) would wait a voxel-plane round trip
+      // for every row it has nothing to do in.  OFF.
+      // (The compiler issues them IN FRONT of the gather, whose wait therefore covers them: vector memory returns in issue
+      // order.  Behind it -- the gather's results first, the voxel words still in flight -- LLVM sinks them below the
+      // `if (!any) continue` that follows, sched_barrier or not; the branch round the distance load is what keeps them here.)
+      const bool d_read = !PACKED || !(r < 64 && (quiet >> r & 1ull));
+      u4 d4 = {0u, 0u, 0u, 0u};
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
-      if (!PACKED) w4 = bload128(rsW, voff, soff);
-      if (COLOR) c4 = bload128(rsC, voff, soff);
-      if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+      if (EARLY) {
+        if (d_read) d4 = bload128(rsD, voff, soff);
+        if (COLOR) c4 = bload128(rsC, voff, soff);
+        if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+        if (COUNT) rdb += (d_read ? 16u : 0u) + (COLOR ? 16u : 4u);  // plane bytes requested
+      }
 #endif
       // ---- gather the frame (L2-resident); pixel -1 is out of the descriptor's range and reads 0 ----------
       float zs[4];
@@ -611,19 +624,23 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const u4 d4 = {hb_, hb_, hb_, hb_};
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {(unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24, (unsigned)r << 24};
       uint32_t k4 = 0u;
-#elif !TSDF_EARLY_VOXEL_LOADS
+      const bool d_read = true;
+#else
+#if !TSDF_EARLY_VOXEL_LOADS
       // (PACKED) the distance words are only read where the cell's flag says they cannot be told from the counts
+      constexpr bool EARLY = false;
       const bool d_read = !PACKED || !(r < 64 && (quiet >> r & 1ull));
       u4 d4 = {0u, 0u, 0u, 0u};
-      if (d_read) d4 = bload128(rsD, voff, soff);
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
-      if (!PACKED) w4 = bload128(rsW, voff, soff);
-      if (COLOR) c4 = bload128(rsC, voff, soff);
-      if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
 #endif
-#if TSDF_EXP_NO_VLOAD || TSDF_EARLY_VOXEL_LOADS
-      const bool d_read = true;
+      if (!EARLY) {
+        if (d_read) d4 = bload128(rsD, voff, soff);
+        if (!PACKED) w4 = bload128(rsW, voff, soff);
+        if (COLOR) c4 = bload128(rsC, voff, soff);
+        if (PACKED && !COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+        if (COUNT) rdb += (d_read ? 16u : 0u) + (!PACKED ? 16u : 0u) + (COLOR ? 16u : 0u) + (PACKED && !COLOR ? 4u : 0u);
+      }
 #endif
       uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -640,10 +657,6 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           // tsdf_decode_w (neither is NaN here).  (With an integer max_weight the min is the identity, but leaving it
           // out lets LLVM turn the colour sums into integer multiplies and byte shuffles: +70 instructions, measured.)
           w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
-          if (!d_read) {  // never observed: the reset value; else the hinge value (see s_bin)
-            d0u[j] = kw[j] >> 24 ? __float_as_uint(a.pos_over_neg) : 0xbf800000u;
-            d0[j] = __uint_as_float(d0u[j]);
-          }
         }
       }
       float dv[4], wv[4];
@@ -679,11 +692,25 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         bool off_hinge = any_div;
         // (ALLIN: without the `observed` mask -- a quad with an unobserved voxel off the hinge just takes the general
         // path, which is always right)
+        if (d_read) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) off_hinge |= (ALLIN || act[j]) && d0u[j] != __float_as_uint(a.pos_over_neg);
+          for (int j = 0; j < 4; ++j) off_hinge |= (ALLIN || act[j]) && d0u[j] != __float_as_uint(a.pos_over_neg);
+        } else {  // distances not read (see s_bin): off the hinge value <=> never observed <=> count 0
+#pragma unroll
+          for (int j = 0; j < 4; ++j) off_hinge |= (ALLIN || act[j]) && kw[j] < 0x01000000u;
+        }
         d_moves = __builtin_amdgcn_ballot_w64(off_hinge) != 0ull;  // wave-uniform: one scalar branch
       }
 #endif
+      if (PACKED && !d_read && d_moves) {
+        // ... and only a wave in which a distance can move needs them at all: never observed = the reset value, else the
+        // hinge value
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d0u[j] = kw[j] < 0x01000000u ? 0xbf800000u : __float_as_uint(a.pos_over_neg);
+          d0[j] = __uint_as_float(d0u[j]);
+        }
+      }
       bool d_touched = false;  // this lane's distances went through an update (else dv == d0 and nothing is compared or stored)
       if (safe) {
         Rcp32 rs[4];
@@ -781,18 +808,20 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   }
   if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes,
                 // slots 2048.. = observed voxels whose distance word was not read
-    __shared__ unsigned s_cnt, s_chg, s_imp;
-    if (tid == 0) s_cnt = s_chg = s_imp = 0;
+    __shared__ unsigned s_cnt, s_chg, s_imp, s_rdb;
+    if (tid == 0) s_cnt = s_chg = s_imp = s_rdb = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     if (chg) atomicAdd(&s_chg, chg);
     if (imp) atomicAdd(&s_imp, imp);
+    if (rdb) atomicAdd(&s_rdb, rdb);
     __syncthreads();
-    if (tid == 0 && s_cnt) {
+    if (tid == 0 && (s_cnt || s_rdb)) {  // (slots 3072..: bytes of the voxel planes the launch requested, observed voxel or not)
       const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
-      atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
+      if (s_cnt) atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
       if (s_imp) atomicAdd(n_obs + 2048u + (b & 1023u), (unsigned long long)s_imp);
+      if (s_rdb) atomicAdd(n_obs + 3072u + (b & 1023u), (unsigned long long)s_rdb);
     }
   }
 }
@@ -846,7 +875,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
   const int xq = (int)bc.bx * a.TX + tx;
   const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0, imp = 0;
+  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0, imp = 0, rdb = 0;
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
@@ -944,6 +973,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       L.k4 = 0u;
       if (COLOR) L.c4 = bload128(rsC, voff, soff);
       if (!COLOR) L.k4 = bload32(rsK, voff >> 2, soff >> 2);
+      if (COUNT) rdb += (L.d_read ? 16u : 0u) + (COLOR ? 16u : 4u);  // plane bytes requested
     };
     auto retire = [&](int r, const RowLoads &L) {
       const unsigned soff = (unsigned)r * row_step;
@@ -1099,15 +1129,17 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     }
   }
   if (COUNT) {
-    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB, s_imp;
-    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = s_imp = 0;
+    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB, s_imp, s_rdb;
+    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = s_imp = s_rdb = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     if (chg) atomicAdd(&s_chg, chg);
     if (cntA) atomicAdd(&s_cntA, cntA);
     if (cntB) atomicAdd(&s_cntB, cntB);
     if (imp) atomicAdd(&s_imp, imp);
+    if (rdb) atomicAdd(&s_rdb, rdb);
     __syncthreads();
+    if (tid == 0 && s_rdb) atomicAdd(n_obs + 2560u + ((bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u), (unsigned long long)s_rdb);
     if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes, voxels (of either) whose
                               // distance word was not read (tsdf_integrate_collect2)
       const unsigned b = (bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u;
@@ -2112,7 +2144,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       live = h->live;
     }
   }
-  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 3072 * sizeof(unsigned long long), h->stream));
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 4096 * sizeof(unsigned long long), h->stream));
   // A pose with a non-finite (or absurdly large) entry makes g.x/g.y/g.z non-finite or out of sensor
   // range for every voxel, and the reference then observes nothing (u/v become INT_MIN or g.z fails
   // hpp:146 / .cpp:616).  Same here, without launching: the kernel may assume finite arithmetic.
@@ -2187,8 +2219,8 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
   }
-  h->count_slots = count ? 3072 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed, 2048.. the observed
-                                      // voxels whose distance word was not read
+  h->count_slots = count ? 4096 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed, 2048.. the observed
+                                      // voxels whose distance word was not read, 3072.. the plane bytes requested
   h->count_ran = pose_ok && !nothing_observable;
   return TSDF_HIP_OK;
 }
@@ -2201,17 +2233,19 @@ int tsdf_integrate_collect(tsdf_handle h, uint64_t *n_observed) {
     tsdf_set_error("tsdf_integrate_collect without a counting launch");
     return TSDF_HIP_E_INVALID;
   }
-  unsigned long long c[3072];
+  unsigned long long c[4096];
   const int slots = h->count_slots;
   TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, (size_t)slots * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  unsigned long long sum = 0, changed = 0, implied = 0;
+  unsigned long long sum = 0, changed = 0, implied = 0, read_bytes = 0;
   for (int i = 0; i < 1024; ++i) sum += c[i];
   for (int i = 1024; i < slots && i < 2048; ++i) changed += c[i];
-  for (int i = 2048; i < slots; ++i) implied += c[i];
+  for (int i = 2048; i < slots && i < 3072; ++i) implied += c[i];
+  for (int i = 3072; i < slots; ++i) read_bytes += c[i];
   h->last_observed = h->count_ran ? sum : 0;
   h->last_changed_bytes = h->count_ran ? changed : 0;
   h->last_implied = h->count_ran ? implied : 0;
+  h->last_read_bytes = h->count_ran ? read_bytes : 0;
   h->count_slots = 0;
   if (n_observed) *n_observed = h->last_observed;
   return TSDF_HIP_OK;
@@ -2270,6 +2304,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
       uint64_t n = 0;
       rc = tsdf_integrate_collect(h, &n);
       h->pair_first_observed = n, h->pair_first_changed = h->last_changed_bytes, h->pair_first_implied = h->last_implied;
+      h->pair_first_read = h->last_read_bytes;
     }
     if (!rc) rc = tsdf_hip_set_reference_cull(h, planesB);
     if (!rc) rc = tsdf_integrate_launch(h, dB, cB, TB, count);
@@ -2280,7 +2315,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   for (int i = 0; i < 24; ++i) h->cull_planes[i] = planesB ? planesB[i] : 0.f;
   h->count_slots = 0;
   h->count_ran = false;
-  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 2560 * sizeof(unsigned long long), h->stream));
+  if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 3072 * sizeof(unsigned long long), h->stream));
   uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 ? h->band : nullptr;
   if (!band_arg) h->band_exact = false;
   a.implied_d = implied_distances(h, a, band_arg != nullptr);
@@ -2313,7 +2348,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
 #undef L2B
 #undef LAUNCH2
   TSDF_HIP_TRY(hipGetLastError());
-  h->count_slots = count ? 2560 : 0;
+  h->count_slots = count ? 3072 : 0;
   h->count_ran = true;
   h->pair_fused = true;
   return TSDF_HIP_OK;
@@ -2331,21 +2366,23 @@ int tsdf_integrate_collect2(tsdf_handle h, uint64_t n_observed[2]) {
     h->last_observed = h->pair_first_observed + nb;  // (an upper bound of the union; the words were read twice anyway)
     h->last_changed_bytes += h->pair_first_changed;
     h->last_implied += h->pair_first_implied;
+    h->last_read_bytes += h->pair_first_read;
     return TSDF_HIP_OK;
   }
   if (!h->count_slots) {
     tsdf_set_error("tsdf_integrate_collect2 without a counting launch");
     return TSDF_HIP_E_INVALID;
   }
-  unsigned long long c[2560];
+  unsigned long long c[3072];
   TSDF_HIP_TRY(hipMemcpyAsync(c, h->counter, sizeof c, hipMemcpyDeviceToHost, h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
-  unsigned long long sum[5] = {0, 0, 0, 0, 0};  // A, B, union, changed bytes, distance words not read: 512 striped slots each
-  for (int i = 0; i < 2560; ++i) sum[i >> 9] += c[i];
+  unsigned long long sum[6] = {0, 0, 0, 0, 0, 0};  // A, B, union, changed bytes, distance words not read, plane bytes requested: 512 striped slots each
+  for (int i = 0; i < 3072; ++i) sum[i >> 9] += c[i];
   n_observed[0] = sum[0], n_observed[1] = sum[1];
   h->last_observed = sum[2];
   h->last_changed_bytes = sum[3];
   h->last_implied = sum[4];
+  h->last_read_bytes = sum[5];
   h->count_slots = 0;
   return TSDF_HIP_OK;
 }
@@ -2382,11 +2419,12 @@ extern "C" int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]) {
   return TSDF_HIP_OK;
 }
 
-extern "C" int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[2]) {
+extern "C" int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[3]) {
   if (!h || !out) return TSDF_HIP_E_INVALID;
   if (h->multi) return tsdf_multi_last_read_detail(h, out);
   out[0] = h->last_implied;
   out[1] = h->last_implied_on ? 1 : 0;
+  out[2] = h->last_read_bytes;
   return TSDF_HIP_OK;
 }
 

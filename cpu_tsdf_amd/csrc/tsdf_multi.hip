@@ -346,7 +346,7 @@ static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed)
     if (t1) TSDF_HIP_TRY(hipEventRecord(t1, s->stream));
   }
   if (n_observed) {
-    unsigned long long total = 0, changed = 0, implied = 0;
+    unsigned long long total = 0, changed = 0, implied = 0, read_bytes = 0;
     bool implied_on = true;
     for (tsdf_handle s : m->slab) {
       TSDF_ON_DEVICE(s->device);
@@ -356,12 +356,14 @@ static int integrate_all(tsdf_handle h, const float T[12], uint64_t *n_observed)
       total += n;
       changed += s->last_changed_bytes;
       implied += s->last_implied;
+      read_bytes += s->last_read_bytes;
       implied_on = implied_on && s->last_implied_on;
     }
     *n_observed = total;
     h->last_observed = total;
     h->last_changed_bytes = changed;
     h->last_implied = implied;
+    h->last_read_bytes = read_bytes;
     h->last_implied_on = implied_on;
   }
   return TSDF_HIP_OK;
@@ -613,9 +615,10 @@ int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_ob
   return integrate_all(h, T, n_observed);
 }
 
-int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[2]) {
+int tsdf_multi_last_read_detail(tsdf_handle h, uint64_t out[3]) {
   out[0] = h->last_implied;
   out[1] = h->last_implied_on ? 1 : 0;
+  out[2] = h->last_read_bytes;
   return TSDF_HIP_OK;
 }
 

@@ -220,8 +220,10 @@ int tsdf_hip_last_count_detail(tsdf_handle h, uint64_t out[2]);
 /* Of the same call: out[0] = observed voxels whose DISTANCE word was not read, because the kernel could tell it from the
  * voxel's observation count (PACKED layout: in a cell of 64 x 4 x 1 voxels that no frame since the reset has observed
  * inside the truncation band, an observed voxel sits at max_dist_pos / max_dist_neg and an unobserved one at the reset
- * value) -- 4 bytes each that the launch did not move; out[1] = 1 if the launch was allowed to do so. */
-int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[2]);
+ * value) -- 4 bytes each that the launch did not move; out[1] = 1 if the launch was allowed to do so;
+ * out[2] = bytes of the voxel planes the launch REQUESTED (it asks for a quad's words together with the frame pixels, so
+ * also for quads none of whose voxels turns out to be observed; 0 for the plain kernels, which do not count). */
+int tsdf_hip_last_read_detail(tsdf_handle h, uint64_t out[3]);
 
 /* The two observation weightings of updateVoxel -- include/cpu_tsdf/impl/tsdf_volume_octree.hpp:200-204.  The
  * reference has no setter for them: weight_by_depth_ / weight_by_variance_ only become true through load()

@@ -21,8 +21,9 @@ pytestmark = pytest.mark.gpu
 
 
 def read_detail(vol):
-    out = (C.c_uint64 * 2)()
+    out = (C.c_uint64 * 3)()
     capi.check(capi.load().tsdf_hip_last_read_detail(vol._need(), out), "last_read_detail")
+    assert int(out[2]) >= 4 * (int(out[0]) > 0)  # the launch requested plane bytes
     return int(out[0]), int(out[1])
 
 
