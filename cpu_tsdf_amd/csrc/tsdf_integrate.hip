@@ -286,12 +286,13 @@ static __device__ __forceinline__ void tsdf_flags_before(const IntegrateArgs &a,
                                                          uint8_t *s_bin, unsigned tid) {
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
-  const int fxb = max(1, a.TX >> 4);
+  const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;  // cells per row group of the block: TX / 16, a power of two
   const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
   const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
-  const int n_fl = (yg1 - yg0 + 1) * fxb;
-  for (int i = (int)tid; i < 1024; i += 256) {
-    const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+  const int n_fl = (yg1 - yg0 + 1) << lf;
+  const int n_all = ((a.rpb * a.TY + 3) >> 2) << lf;  // every cell tsdf_quiet_passes may look at (<= 1024)
+  for (int i = (int)tid; i < n_all; i += 256) {
+    const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
     s_bin[i] = i < n_fl && yg < a.band_fy && xc < a.band_fx ? band[((int64_t)(a.zl0 + (int)bc.bz) * a.band_fy + yg) * a.band_fx + xc] : (uint8_t)0;
   }
 }
@@ -797,12 +798,12 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   }
   if (!TSDF_NO_BAND && band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
     __syncthreads();
-    const int fxb = max(1, a.TX >> 4);
+    const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
     const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
-    const int n_fl = (yg1 - yg0 + 1) * fxb;
+    const int n_fl = (yg1 - yg0 + 1) << lf;
     for (int i = (int)tid; i < n_fl; i += 256) {
-      const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+      const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
       if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
@@ -1119,12 +1120,12 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
   }
   if (band) {
     __syncthreads();
-    const int fxb = max(1, a.TX >> 4);
+    const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
     const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
-    const int n_fl = (yg1 - yg0 + 1) * fxb;
+    const int n_fl = (yg1 - yg0 + 1) << lf;
     for (int i = (int)tid; i < n_fl; i += 256) {
-      const int yg = yg0 + i / fxb, xc = xc0 + i % fxb;
+      const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
       if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
