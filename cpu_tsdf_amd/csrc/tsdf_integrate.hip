@@ -28,6 +28,9 @@
 #include "tsdf_hip_test.h"
 #endif
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 struct IntegrateArgs {
   float m[12];        // cam_from_vol, row-major 3x4
   float fxf, fyf, cxf, cyf;  // the same, rounded to float (fast projection path); cxf/cyf carry the +band shift
@@ -108,6 +111,56 @@ static __device__ __forceinline__ int project_fast(const IntegrateArgs &a, float
   ambiguous = !cert;
   const bool in = (unsigned)u < (unsigned)a.W && (unsigned)v < (unsigned)a.H;
   return in ? (int)__umul24((unsigned)v, (unsigned)a.W) + u : -1;  // W, H < 2^24 (checked on the host)
+}
+
+// ALLIN: pcl::transformPoint (hpp:145) + the certified fp32 reprojectPoint (project_fast<true>) for the four voxels of a
+// quad, on float PAIRS -- voxels (0, 1) and (2, 3): every product, sum and fma below is the scalar code's own operation on
+// the same operands (v_pk_mul / v_pk_add / v_pk_fma_f32 round each half like the scalar instruction), so g, R~ and the
+// certificate are bit for bit those of the scalar form; written on pairs so that the compiler keeps ONE pairing from the
+// centres to the pixel index (the scalar form cost eight register shuffles per row).  cxv = the quad's x centres, ytv = the
+// row's part of the transform (k_integrate's s_yt), zt = the plane's part (used by the left-to-right order only).
+template <int ORDER>
+static __device__ __forceinline__ void project_quad_allin(const IntegrateArgs &a, const float (&m)[12], const double *__restrict__ cam,
+                                                          const f4 cxv, const f4 ytv, const float (&zt)[3], int (&pix)[4],
+                                                          float (&gzs)[4]) {
+  const f2 cxa = {cxv.x, cxv.y}, cxb = {cxv.z, cxv.w};
+  const float yt[3] = {ytv.x, ytv.y, ytv.z};
+  f2 ga[3], gb[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (ORDER == TSDF_XFORM_PCL_SSE) {
+      ga[q] = cxa * m[4 * q] + yt[q];
+      gb[q] = cxb * m[4 * q] + yt[q];
+    } else {
+      ga[q] = ((cxa * m[4 * q] + yt[q]) + zt[q]) + m[4 * q + 3];
+      gb[q] = ((cxb * m[4 * q] + yt[q]) + zt[q]) + m[4 * q + 3];
+    }
+  }
+  const f2 ya = {__builtin_amdgcn_rcpf(ga[2].x), __builtin_amdgcn_rcpf(ga[2].y)};
+  const f2 yb = {__builtin_amdgcn_rcpf(gb[2].x), __builtin_amdgcn_rcpf(gb[2].y)};
+  const f2 cxf2 = {a.cxf, a.cxf}, cyf2 = {a.cyf, a.cyf};
+  const f2 rua = __builtin_elementwise_fma(ga[0] * a.fxf, ya, cxf2), rub = __builtin_elementwise_fma(gb[0] * a.fxf, yb, cxf2);
+  const f2 rva = __builtin_elementwise_fma(ga[1] * a.fyf, ya, cyf2), rvb = __builtin_elementwise_fma(gb[1] * a.fyf, yb, cyf2);
+  const float ru[4] = {rua.x, rua.y, rub.x, rub.y}, rv[4] = {rva.x, rva.y, rvb.x, rvb.y};
+  gzs[0] = ga[2].x, gzs[1] = ga[2].y, gzs[2] = gb[2].x, gzs[3] = gb[2].y;
+  // the certificate: the fractions lie in [0, 1), so their bit patterns order like the values; ONE compare of the least of
+  // the eight against max(hb_u, hb_v) certifies the quad
+  uint32_t fu[4], fv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fu[j] = __float_as_uint(__builtin_amdgcn_fractf(ru[j]));
+    fv[j] = __float_as_uint(__builtin_amdgcn_fractf(rv[j]));
+    pix[j] = (int)__umul24((unsigned)(int)rv[j], (unsigned)a.W) + (int)ru[j];  // v_cvt_i32_f32 truncates; W, H < 2^24
+  }
+  const uint32_t hb = __float_as_uint(a.hb_max);
+  const uint32_t least = min(min(min(fu[0], fv[0]), min(min(fu[1], fv[1]), fu[2])), min(min(fv[2], fu[3]), fv[3]));
+  if (!(least > hb)) {  // rare (a fraction ~4 * band of the voxels): the exact fp64 projection, a copy per voxel of the quad,
+                        // each under its own exec mask (an empty one is a skipped branch)
+    const float gx[4] = {ga[0].x, ga[0].y, gb[0].x, gb[0].y}, gy[4] = {ga[1].x, ga[1].y, gb[1].x, gb[1].y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (!(min(fu[j], fv[j]) > hb)) pix[j] = project_exact(a, cam, gx[j], gy[j], gzs[j]);
+  }
 }
 
 // std::exp(float) as the reference's host evaluates it (hpp:204): glibc's expf (sysdeps/ieee754/flt-32/e_expf.c, the 2017
@@ -221,17 +274,19 @@ static __device__ __forceinline__ void add_observation_ieee(float &d, float &w, 
 //    lies within 1/2 - 1/(2D) of floor(N/D).
 template <bool COLOR, bool DIST = true>
 static __device__ __forceinline__ void add_observation_fast(float &d, float &w, uint32_t &rgb, float dn,
-                                                            uint32_t bgra, float wmax, const Rcp32 &rs, uint32_t base = 0u) {
+                                                            uint32_t bgra, float wmax, const Rcp32 &rs, uint32_t base = 0u,
+                                                            const float *hy_tab = nullptr) {
   const float wsum = w + 1.f;  // rs = rcp32_prepare(wsum) (nb and y are all that is used)
   if (COLOR) {
 #if TSDF_COLOR_PK
-    const float hy = TSDF_COLOR_PK == 2 ? __builtin_fmaf(0.5f, rs.y, -0.5f) : 0.5f * rs.y;
+    // hy_tab: the offset comes with the count's table entry (KEntry) instead of being derived from y per voxel
+    const float hy = hy_tab ? *hy_tab : TSDF_COLOR_PK == 2 ? __builtin_fmaf(0.5f, rs.y, -0.5f) : 0.5f * rs.y;
     const float t0 = __builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
     const float t1 = __builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 8) & 255u), (float)((bgra >> 8) & 255u)), rs.y, hy);
     const float t2 = __builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 16) & 255u), (float)(bgra & 255u)), rs.y, hy);
     rgb = __builtin_amdgcn_cvt_pk_u8_f32(t0, 0u, __builtin_amdgcn_cvt_pk_u8_f32(t1, 1u, __builtin_amdgcn_cvt_pk_u8_f32(t2, 2u, base)));
 #else
-    const float hy = 0.5f * rs.y;
+    const float hy = hy_tab ? *hy_tab : 0.5f * rs.y;
     const uint32_t q0 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)(rgb & 255u), (float)((bgra >> 16) & 255u)), rs.y, hy);
     const uint32_t q1 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 8) & 255u), (float)((bgra >> 8) & 255u)), rs.y, hy);
     const uint32_t q2 = (uint32_t)__builtin_fmaf(__builtin_fmaf(w, (float)((rgb >> 16) & 255u), (float)(bgra & 255u)), rs.y, hy);
@@ -322,6 +377,35 @@ static __device__ __forceinline__ uint64_t tsdf_quiet_passes(const IntegrateArgs
 #ifndef TSDF_COLOR_PK
 #define TSDF_COLOR_PK 0  // 1 / 2: colour bytes through v_cvt_pk_u8_f32, assuming it truncates / rounds to nearest even
 #endif
+// Round 5 instruction diet of the PACKED instances (profiles/r05_isa_phase_mix.txt has the per-phase counts):
+#ifndef TSDF_KTAB
+#define TSDF_KTAB 1  // everything addObservation derives from the count k alone -- the decoded weight, the refined reciprocal of
+                     // k + 1, the colour rounding offset, the count after the observation -- comes from ONE 16-byte LDS entry per
+                     // voxel (ds_read_b128) instead of a 4-byte reciprocal + seven VALU operations per voxel
+#endif
+#ifndef TSDF_AMB_UNROLL
+#define TSDF_AMB_UNROLL 1  // the exact fp64 re-projection of uncertified voxels: four straight copies, one per voxel of the quad,
+                           // each under its own exec mask (an empty one is a skipped branch), instead of ONE copy in a loop that
+                           // selects its operands by voxel index through ~90 exec-mask instructions per trip
+#endif
+#ifndef TSDF_PROJ_F2
+#define TSDF_PROJ_F2 1  // ALLIN: transform + projection written on explicit float pairs (v_pk_mul / v_pk_add / v_pk_fma_f32 with
+                        // the pairs (0,1), (2,3) throughout: no register shuffles), the x centres re-read from LDS per row
+#endif
+struct __attribute__((aligned(16))) KEntry {
+  float w;      // tsdf_decode_w(k) = min(k, max_weight)
+  float y;      // Rcp32(k + 1).y: the refined reciprocal of the divisor k + 1
+  float hy;     // the colour average's rounding offset: y / 2 before a truncating conversion, y / 2 - 1 / 2 before v_cvt_pk_u8_f32
+  uint32_t k1;  // min(k + 1, kmax) << 24: the count after this observation, in byte 3 of a word
+};
+static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a, unsigned k) {
+  KEntry e;
+  e.w = __builtin_fminf((float)k, a.wmax);
+  e.y = rcp32_prepare((float)(k + 1u)).y;
+  e.hy = TSDF_COLOR_PK == 2 ? __builtin_fmaf(0.5f, e.y, -0.5f) : 0.5f * e.y;
+  e.k1 = min(k << 24, a.kcap) + a.kinc;  // saturate BEFORE adding (kmax == 255 would wrap byte 3); both 0 when kmax == 0
+  return e;
+}
 #ifndef TSDF_SKIP_FIXED_HINGE
 #define TSDF_SKIP_FIXED_HINGE 1  // PACKED: waves whose observed voxels all stay at the hinge value skip the d ladder
 #endif
@@ -393,18 +477,42 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     strad = flag == 2u;
   }
   const unsigned tid = threadIdx.x;
+#if TSDF_KTAB
+  __shared__ KEntry s_tab[PACKED ? 256 : 1];  // per count k: decoded weight, Rcp32(k + 1).y, colour rounding offset, next count
+#else
   __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
-  __shared__ float s_cy[256];   // y centres of this block's rows (rpb * TY <= 256)
+#endif
+  // per row of this block (rpb * TY <= 256): the row's part of pcl::transformPoint -- yt[q] = cy * m[q][1] + (cz * m[q][2] + m[q][3])
+  // in PCL's SSE order, m[q][1] * cy in the other -- worked out once per block by the thread of that number instead of by every
+  // thread in every row (the very same operations: bit-identical), and the z part with it: no per-thread zt registers
+  __shared__ f4 s_yt[256];
+  constexpr bool F2 = TSDF_PROJ_F2 && ALLIN && FASTPROJ;  // transform + projection on float pairs (see the row loop)
+  __shared__ f4 s_cx[F2 ? 256 : 1];  // F2: every thread's own four x centres, re-read each row (16 B of LDS instead of four registers)
   __shared__ uint32_t s_iv[LIVE ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
   // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
   // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
   __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
   if (!TSDF_NO_BAND) reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+#if TSDF_KTAB
+  if (PACKED) s_tab[tid] = tsdf_ktab_entry(a, tid);
+#else
   if (PACKED) s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
+#endif
   {
     const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
-    s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
+    {
+      const float cy_ = ctry[yy < a.ny ? yy : a.ny - 1], cz_ = ctrz[a.z_global0 + (int)bc.bz];
+      f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        t[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy_ * a.m[4 * q + 1] + (cz_ * a.m[4 * q + 2] + a.m[4 * q + 3]) : a.m[4 * q + 1] * cy_;
+      s_yt[tid] = t;
+    }
+    if (F2) {  // each thread parks the x centres of ITS quad (ALLIN: nx is a multiple of 4, every quad is whole)
+      const int xq_ = (int)bc.bx * a.TX + (int)(tid & (unsigned)(a.TX - 1));
+      if (xq_ < a.qpr) s_cx[tid] = *reinterpret_cast<const f4 *>(ctrx + xq_ * 4);
+    }
     if (LIVE && strad) s_iv[tid] = yy < a.ny ? row_iv[(int64_t)bc.bz * a.ny + yy] : 0u;  // [launch plane][launch row]
   }
   // IMPLIED DISTANCES (PACKED, a.implied_d).  The flags as they stood BEFORE this launch, same cells and same order as
@@ -472,16 +580,13 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (!((unsigned)(x4 + 3) - iv_lo < iv_len + 3u)) continue;
       }
       const unsigned soff = (unsigned)r * row_step;
-      const float cy = s_cy[ty + r * a.TY];
-      float yt[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * a.m[4 * q + 1] + zt[q] : a.m[4 * q + 1] * cy;
+      const f4 ytv = s_yt[ty + r * a.TY];
+      const float yt[3] = {ytv.x, ytv.y, ytv.z};
 #if TSDF_RECOMPUTE_PX
       // the x products are redone per row (12 multiplies, six packed) instead of living in 12 registers across the
       // loop: the kernel waits for memory, not for the VALU, and registers are what limits the waves in flight
       float px[4][3];
-      {
+      if constexpr (!F2) {
         float cxr[4] = {cxs[0], cxs[1], cxs[2], cxs[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cxr[j]));  // (keeps LLVM from hoisting the products back out)
@@ -500,9 +605,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // ---- range test (hpp:146, .cpp:616) + reprojectPoint (.cpp:611-617), voxel by voxel ----------------
       int pix[4];
       float gzs[4];
+      bool any = false, lowz = false;
+      if constexpr (F2) {
+        asm volatile("" ::: "memory");  // (a compiler barrier, no instruction: the read below is redone each row, so neither
+                                        // the centres nor their products live in registers across the loop)
+        project_quad_allin<ORDER>(a, a.m, cam, s_cx[tid], ytv, zt, pix, gzs);
+      } else {
       unsigned amb_mask = 0;
       uint32_t margin[4] = {0u, 0u, 0u, 0u};  // ALLIN: bits of min(fract(ru), fract(rv)) per voxel
-      bool any = false, lowz = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
@@ -531,8 +641,15 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
             if (!(margin[j] > hb)) amb_mask |= 1u << j;
         }
       }
-      // Voxels whose fp32 projection could not be certified: redo them exactly, one at a time through a
-      // single copy of the fp64 code (rare: a fraction ~4*band of the voxels).
+      // Voxels whose fp32 projection could not be certified: redo them exactly (rare: a fraction ~4*band of the voxels).
+#if TSDF_AMB_UNROLL
+      if (FASTPROJ && amb_mask) {  // a copy of the fp64 code per voxel of the quad, each under its own exec mask
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (amb_mask >> j & 1u) pix[j] = project_exact(a, cam, transform(j, 0), transform(j, 1), transform(j, 2));
+      }
+#else
+      // ... one at a time through a single copy of the fp64 code
       while (FASTPROJ && amb_mask) {
         const int j = __builtin_ctz(amb_mask);
         amb_mask &= amb_mask - 1;
@@ -545,6 +662,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (j == 1) pix[1] = p;
         if (j == 2) pix[2] = p;
         if (j == 3) pix[3] = p;
+      }
+#endif
       }
 #if TSDF_EARLY_VOXEL_LOADS
       constexpr bool EARLY = PACKED;  // (F32W reads three planes per voxel and is the one key that feels the extra bytes: 22.3 -> 24.6 ms)
@@ -605,6 +724,13 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         any |= act[j];
         any_div |= act[j] && !(raw[j] > a.pos);
       }
+      // The colour gathers are retired HERE, with the depth gathers they were issued behind (they return in order, a few
+      // cycles later), not wherever their first use falls: a quad none of whose voxels is observed leaves the row without
+      // ever using them, and a gather still in flight across the back edge makes the compiler guard the next row's first
+      // write to its register with an s_waitcnt vmcnt -- an in-order counter, so that wait also covers the previous row's
+      // voxel STORES, in every row, whether the path was taken or not (the third memory round trip of a row, found in
+      // round 5: profiles/r05_isa_phase_mix.txt)
+      if (COLOR) asm volatile("" ::"v"(cs[0]), "v"(cs[1]), "v"(cs[2]), "v"(cs[3]));
       if (!any) continue;
       if (any_div) {  // free space (every observed voxel of the wave beyond the hinge) skips all four ladders
 #pragma unroll
@@ -648,25 +774,33 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const uint32_t w0u[4] = {w4.x, w4.y, w4.z, w4.w};
       float d0[4], w0[4];
       uint32_t kw[4];  // PACKED: the count in byte 3 of a word (colour word, or the k8 byte moved there)
+      float dv[4], wv[4];
+      uint32_t cv[4], k1[4];
+#if TSDF_KTAB
+      float ky[4], khy[4];  // PACKED: Rcp32(k + 1).y and the colour rounding offset of each voxel's count
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         d0[j] = __uint_as_float(d0u[j]);
         w0[j] = __uint_as_float(w0u[j]);
         kw[j] = 0u;
+        k1[j] = 0u;
         if (PACKED) {
           kw[j] = COLOR ? c0[j] : (k4 << (24 - 8 * j));
+#if TSDF_KTAB
+          const KEntry e = s_tab[kw[j] >> 24];  // one ds_read_b128
+          w0[j] = e.w, ky[j] = e.y, khy[j] = e.hy, k1[j] = e.k1;
+#else
           // tsdf_decode_w (neither is NaN here).  (With an integer max_weight the min is the identity, but leaving it
           // out lets LLVM turn the colour sums into integer multiplies and byte shuffles: +70 instructions, measured.)
           w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
+          // the count after this observation, k' = min(k + 1, kmax), as byte 3 of a word (saturate BEFORE adding: with
+          // kmax == 255 an in-place add would wrap byte 3 to zero; kcap = (kmax - 1) << 24 and kinc = 1 << 24, both 0
+          // when kmax == 0)
+          k1[j] = min(kw[j] & 0xff000000u, a.kcap) + a.kinc;  // == min(k + 1, kmax) << 24
+#endif
         }
       }
-      float dv[4], wv[4];
-      uint32_t cv[4], k1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)  // PACKED: the count after this observation, k' = min(k + 1, kmax), as byte 3 of a word
-        // (saturate BEFORE adding: with kmax == 255 an in-place add would wrap byte 3 to zero; kcap = (kmax - 1) << 24
-        // and kinc = 1 << 24, both 0 when kmax == 0)
-        k1[j] = !PACKED ? 0u : min(kw[j] & 0xff000000u, a.kcap) + a.kinc;  // == min(k + 1, kmax) << 24
       // F32W: the fast update is exact if update_is_safe().  PACKED: the divisor k + 1 is an integer in
       // [1, 256] (unless the weight sits at a non-integer max_weight), for which the scale-free ladder is
       // exact whenever its RESULT is a normal number (residuals of a normal numerator against an integer
@@ -722,11 +856,19 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           cv[j] = c0[j];
           if (PACKED) {
             rs[j].nb = -(w0[j] + 1.f);
+#if TSDF_KTAB
+            rs[j].y = ky[j];  // w0 + 1 == k + 1 here (w0 is an integer)
+#else
             rs[j].y = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
+#endif
           } else {
             rs[j] = rcp32_prepare(w0[j] + 1.f);
           }
+#if TSDF_KTAB
+          add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u, PACKED ? &khy[j] : nullptr);
+#else
           add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
+#endif
         }
         if (d_moves) {  // distance
           d_touched = true;
@@ -858,25 +1000,35 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
              unsigned long long *__restrict__ n_obs, uint8_t *__restrict__ band) {
   const unsigned tid = threadIdx.x;
   const BlockCoords bc = tsdf_block_coords(a.zfast);
-  __shared__ float s_rcp[256];
-  __shared__ float s_cy[256];
+  __shared__ KEntry s_tab[256];        // per count k: decoded weight, Rcp32(k + 1).y, colour rounding offset, next count (k_integrate)
+  __shared__ f4 s_ytA[256], s_ytB[256];  // per row of the block: the row's part of each frame's transform (k_integrate's s_yt)
+  __shared__ f4 s_cx[256];             // every thread's own four x centres, re-read each row
   __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
   reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
-  s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
+  s_tab[tid] = tsdf_ktab_entry(a, tid);
   {
     const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
-    s_cy[tid] = ctry[yy < a.ny ? yy : a.ny - 1];
+    const float cy_ = ctry[yy < a.ny ? yy : a.ny - 1], cz_ = ctrz[a.z_global0 + (int)bc.bz];
+    f4 tA = {0.f, 0.f, 0.f, 0.f}, tB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      tA[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy_ * a.m[4 * q + 1] + (cz_ * a.m[4 * q + 2] + a.m[4 * q + 3]) : a.m[4 * q + 1] * cy_;
+      tB[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy_ * fb.m[4 * q + 1] + (cz_ * fb.m[4 * q + 2] + fb.m[4 * q + 3]) : fb.m[4 * q + 1] * cy_;
+    }
+    s_ytA[tid] = tA, s_ytB[tid] = tB;
+    const int xq_ = (int)bc.bx * a.TX + (int)(tid & (unsigned)(a.TX - 1));
+    if (xq_ < a.qpr) s_cx[tid] = *reinterpret_cast<const f4 *>(ctrx + xq_ * 4);  // (nx is a multiple of 4: every quad is whole)
   }
-  __shared__ uint8_t s_bin[1024];  // the flags before this launch: where 0, distances follow from the counts (k_integrate's s_bin)
-  if (a.implied_d) tsdf_flags_before(a, bc, band, s_bin, tid);
+  // (No implied distances here -- k_integrate's s_bin: built into this kernel in round 4, they cost it 0.5 ms per frame of
+  // scalar work and nineteen spilled scalar registers for bytes an issue-bound kernel gains nothing from, DESIGN 3.1b;
+  // compiled out in round 5.  The host still keeps the record, and this kernel keeps the flags, for the launches that use them.)
   __syncthreads();
-  const uint64_t quiet = a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
   const int xq = (int)bc.bx * a.TX + tx;
   const int zl = (int)bc.bz;
   const Rcp32 rneg = rcp32_prepare(a.neg);
-  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0, imp = 0, rdb = 0;
+  unsigned cnt = 0, chg = 0, cntA = 0, cntB = 0, rdb = 0;
   const int row0 = (int)bc.by * a.rpb * a.TY;
   const int rows = min(a.rpb * a.TY, a.ny - row0);
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
@@ -889,8 +1041,9 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
   if (xq < a.qpr) {
     const int x4 = xq * 4;
     const float cz = ctrz[a.z_global0 + zl];
-    const float4 cx4 = *reinterpret_cast<const float4 *>(ctrx + x4);
-    const float cxs[4] = {cx4.x, cx4.y, cx4.z, cx4.w};
+    float ztA[3], ztB[3];  // the plane's part of the transform: only the left-to-right order still needs it per thread
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ztA[q] = a.m[4 * q + 2] * cz, ztB[q] = fb.m[4 * q + 2] * cz;
     const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;
     const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
     // A row's work in two stages: ISSUE(r) = project both frames and request everything the row needs at once -- the two
@@ -903,60 +1056,13 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       uint32_t csA[4], csB[4];
       u4 d4, c4;
       uint32_t k4;
-      bool d_read;
     };
     auto issue = [&](int r, RowLoads &L) {
       const unsigned soff = (unsigned)r * row_step;
-      const float cy = s_cy[ty + r * a.TY];
-      auto project = [&](const float (&m)[12], int (&pix)[4], float (&gzs)[4]) {
-        float yt[3], zt[3];
-        uint32_t margin[4];
-        float cxr[4] = {cxs[0], cxs[1], cxs[2], cxs[3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cxr[j]));  // (keeps the x products out of loop-carried registers)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          zt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cz * m[4 * q + 2] + m[4 * q + 3] : m[4 * q + 2] * cz;
-          yt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy * m[4 * q + 1] + zt[q] : m[4 * q + 1] * cy;
-        }
-        auto transform = [&](int j, int q) -> float {
-          const float px = cxr[j] * m[4 * q];
-          if (ORDER == TSDF_XFORM_PCL_SSE) return px + yt[q];
-          return ((px + yt[q]) + zt[q]) + m[4 * q + 3];
-        };
-        unsigned amb_mask = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float gx = transform(j, 0), gy = transform(j, 1), gz = transform(j, 2);
-          gzs[j] = gz;
-          bool amb;
-          pix[j] = project_fast<true>(a, gx, gy, gz, amb, &margin[j]);
-        }
-        {
-          const uint32_t hb = __float_as_uint(a.hb_max);
-          if (!(min(min(margin[0], margin[1]), min(margin[2], margin[3])) > hb)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (!(margin[j] > hb)) amb_mask |= 1u << j;
-          }
-        }
-        while (amb_mask) {  // rare: the exact fp64 projection, one voxel at a time through one copy of the code
-          const int j = __builtin_ctz(amb_mask);
-          amb_mask &= amb_mask - 1;
-          float g[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            g[q] = j == 0 ? transform(0, q) : j == 1 ? transform(1, q) : j == 2 ? transform(2, q) : transform(3, q);
-          const int pe = project_exact(a, cam, g[0], g[1], g[2]);
-          if (j == 0) pix[0] = pe;
-          if (j == 1) pix[1] = pe;
-          if (j == 2) pix[2] = pe;
-          if (j == 3) pix[3] = pe;
-        }
-      };
       int pixA[4], pixB[4];
-      project(a.m, pixA, L.gzA);
-      project(fb.m, pixB, L.gzB);
+      asm volatile("" ::: "memory");  // (compiler barrier: the LDS reads below are redone each row, see k_integrate)
+      project_quad_allin<ORDER>(a, a.m, cam, s_cx[tid], s_ytA[ty + r * a.TY], ztA, pixA, L.gzA);
+      project_quad_allin<ORDER>(a, fb.m, cam, s_cx[tid], s_ytB[ty + r * a.TY], ztB, pixB, L.gzB);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         L.zsA[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFA, pixA[j], 0, 0, TSDF_GATHER_AUX));
@@ -967,17 +1073,23 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         L.zsB[j] = __uint_as_float(tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, 0, TSDF_GATHER_AUX));
         L.csB[j] = COLOR ? tsdf_struct_buffer_load_u32(rsFB, pixB[j], 0, (int)fb.bgra_off, TSDF_GATHER_AUX) : 0u;
       }
-      L.d_read = !(r < 64 && (quiet >> r & 1ull));
-      L.d4 = (u4){0u, 0u, 0u, 0u};
-      if (L.d_read) L.d4 = bload128(rsD, voff, soff);
+      L.d4 = bload128(rsD, voff, soff);
       L.c4 = (u4){0u, 0u, 0u, 0u};
       L.k4 = 0u;
       if (COLOR) L.c4 = bload128(rsC, voff, soff);
       if (!COLOR) L.k4 = bload32(rsK, voff >> 2, soff >> 2);
-      if (COUNT) rdb += (L.d_read ? 16u : 0u) + (COLOR ? 16u : 4u);  // plane bytes requested
+      if (COUNT) rdb += 16u + (COLOR ? 16u : 4u);  // plane bytes requested
     };
     auto retire = [&](int r, const RowLoads &L) {
       const unsigned soff = (unsigned)r * row_step;
+      // everything the row requested is retired HERE, together (one wait: the voxel words were issued last): a quad none of
+      // whose voxels is observed leaves without touching most of it, and a load still in flight across the back edge makes
+      // the next row wait, in order, for the previous row's voxel STORES as well (see k_integrate)
+      if (COLOR)
+        asm volatile("" ::"v"(L.csA[0]), "v"(L.csA[1]), "v"(L.csA[2]), "v"(L.csA[3]), "v"(L.csB[0]), "v"(L.csB[1]), "v"(L.csB[2]),
+                     "v"(L.csB[3]), "v"(L.d4), "v"(L.c4));
+      else
+        asm volatile("" ::"v"(L.d4), "v"(L.k4));
       // ---- hpp:152-198 for one frame: NaN test, projective distance, hinge, normalisation ---------------------------
       // returns bit j = voxel j reaches addObservation; bit 4 = one of them lies inside the truncation band
       auto finish = [&](const float (&zs)[4], const float (&gzs)[4], float (&dn)[4]) -> unsigned {
@@ -1009,26 +1121,25 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
       if (!((obsA | obsB) & 15u)) return;
       const u4 d4 = L.d4, c4 = L.c4;
       const uint32_t k4 = L.k4;
-      uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
+      const uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       uint32_t du[4], kw[4];  // the state both updates work on: distance bits; colour | count << 24 (or only the count there)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         kw[j] = COLOR ? c0[j] : ((k4 << (24 - 8 * j)) & 0xff000000u);
-        if (!L.d_read) d0u[j] = kw[j] >> 24 ? hinge_bits : 0xbf800000u;  // never observed: the reset value; else the hinge value
         du[j] = d0u[j];
       }
       // ---- OctreeNode / RGBNode::addObservation (octree.cpp:152-163, 328-337) of one frame on that state ----
       auto apply = [&](unsigned obs, const float (&dn)[4], const uint32_t (&cs)[4]) {
         if (!(obs & 15u)) return;
         const bool any_div = (obs & 16u) != 0u;
-        float d0[4], w0[4], dv[4], wv[4];
+        float d0[4], w0[4], dv[4], wv[4], ky[4], khy[4];
         uint32_t cv[4], k1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           d0[j] = __uint_as_float(du[j]);
-          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);  // tsdf_decode_w
-          k1[j] = min(kw[j] & 0xff000000u, a.kcap) + a.kinc;      // min(k + 1, kmax) << 24
+          const KEntry e = s_tab[kw[j] >> 24];  // tsdf_decode_w, Rcp32(k + 1).y, colour offset, min(k + 1, kmax) << 24
+          w0[j] = e.w, ky[j] = e.y, khy[j] = e.hy, k1[j] = e.k1;
         }
         bool d_moves = true;
         if (a.hinge_fixed) {  // free space resting at the hinge value stays there (host-checked identity): skip the d ladder
@@ -1046,8 +1157,8 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
             wv[j] = w0[j];
             cv[j] = kw[j];
             rs[j].nb = -(w0[j] + 1.f);
-            rs[j].y = s_rcp[kw[j] >> 24];
-            add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
+            rs[j].y = ky[j];
+            add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u, &khy[j]);
           }
           if (d_moves) {
             d_touched = true;
@@ -1087,7 +1198,6 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
         if (!COLOR) k4n |= (kw[j] & 0xff000000u) >> (24 - 8 * j);
         cnt += ((obsA | obsB) >> j & 1u);
         if (COUNT) cntA += (obsA >> j & 1u), cntB += (obsB >> j & 1u);
-        if (COUNT) imp += L.d_read ? 0u : ((obsA | obsB) >> j & 1u);
         if (COUNT) chg += (du[j] != d0u[j] ? 4u : 0u) + (COLOR && kw[j] != c0[j] ? 4u : 0u);
       }
       if (COUNT && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
@@ -1130,25 +1240,23 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
     }
   }
   if (COUNT) {
-    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB, s_imp, s_rdb;
-    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = s_imp = s_rdb = 0;
+    __shared__ unsigned s_cnt, s_chg, s_cntA, s_cntB, s_rdb;
+    if (tid == 0) s_cnt = s_chg = s_cntA = s_cntB = s_rdb = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     if (chg) atomicAdd(&s_chg, chg);
     if (cntA) atomicAdd(&s_cntA, cntA);
     if (cntB) atomicAdd(&s_cntB, cntB);
-    if (imp) atomicAdd(&s_imp, imp);
     if (rdb) atomicAdd(&s_rdb, rdb);
     __syncthreads();
     if (tid == 0 && s_rdb) atomicAdd(n_obs + 2560u + ((bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u), (unsigned long long)s_rdb);
-    if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes, voxels (of either) whose
-                              // distance word was not read (tsdf_integrate_collect2)
+    if (tid == 0 && s_cnt) {  // 512 striped slots each: frame A, frame B, either, changed bytes, (slots 2048.. stay 0: voxels
+                              // whose distance word was not read -- none in this kernel), plane bytes requested (tsdf_integrate_collect2)
       const unsigned b = (bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy) & 511u;
       if (s_cntA) atomicAdd(n_obs + b, (unsigned long long)s_cntA);
       if (s_cntB) atomicAdd(n_obs + 512u + b, (unsigned long long)s_cntB);
       atomicAdd(n_obs + 1024u + b, (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1536u + b, (unsigned long long)s_chg);
-      if (s_imp) atomicAdd(n_obs + 2048u + b, (unsigned long long)s_imp);
     }
   }
 }
@@ -2270,8 +2378,14 @@ static bool fusable_pose(tsdf_handle h, const IntegrateHost &hh, const float T[1
   return slab_all_inside(h, T) && zlo_margin_ok(T, h) && fast_projection_ok(hh, h->p.integrate_color != 0);
 }
 
-int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, const float TA[12], const float *planesA,
-                           const float *dB, const uint32_t *cB, const float TB[12], const float *planesB, bool count, bool *fused) {
+int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, const float TA[12], const float *planesA_,
+                           const float *dB, const uint32_t *cB, const float TB[12], const float *planesB_, bool count, bool *fused) {
+  // The callers' plane arrays may BE the handle's own (frame pairing hands frame B's planes over as h->cull_planes), and
+  // the two-launch path below rewrites that array for frame A before frame B is launched: work on copies.
+  float planes_copy[2][24];
+  const float *planesA = nullptr, *planesB = nullptr;
+  if (planesA_) memcpy(planes_copy[0], planesA_, sizeof planes_copy[0]), planesA = planes_copy[0];
+  if (planesB_) memcpy(planes_copy[1], planesB_, sizeof planes_copy[1]), planesB = planes_copy[1];
   const tsdf_params &p = h->p;
   const bool color = p.integrate_color != 0;
   if (color && (!cA || !cB)) {
@@ -2319,8 +2433,9 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   if (count) TSDF_HIP_TRY(hipMemsetAsync(h->counter, 0, 3072 * sizeof(unsigned long long), h->stream));
   uint8_t *band_arg = h->band_exact && ((a.rpb * a.TY) & 3) == 0 ? h->band : nullptr;
   if (!band_arg) h->band_exact = false;
-  a.implied_d = implied_distances(h, a, band_arg != nullptr);
-  h->last_implied_on = a.implied_d != 0;
+  (void)implied_distances(h, a, band_arg != nullptr);  // the record every flag-keeping launch keeps (rest_state); k_integrate2
+  a.implied_d = 0;                                      // itself reads every distance word (see the kernel)
+  h->last_implied_on = false;
   h->last_launch[0] = 2, h->last_launch[1] = 1, h->last_launch[2] = 0;
   h->last_launch[3] = (int)std::min<uint64_t>((uint64_t)gx * gy * gz, 0x7fffffffu);
   a.zfast = tsdf_tuning().zfast < 0 ? (npx * (color ? 8 : 4) > (3u << 20) && gx <= 65535u) : (tsdf_tuning().zfast != 0 && gx <= 65535u);

@@ -1,0 +1,160 @@
+"""GPU tier: the one-process-per-GPU host (cpu_tsdf_amd/zslab.py) with REAL HIP slabs at world size 2 and 3 (VERDICT r04
+next #5).  gpurun exposes one GPU, so the ranks share device 0 and talk over gloo (RCCL refuses two ranks
+per device); everything else is what an N-GPU node runs: `ZSlabVolume` with the default slab factory (HipSlab), frame
+ingest on the LAST rank and broadcast to the others, per-rank k_integrate on its own Z-slab, one-plane halo exchange
+(src/lib/marching_cubes_tsdf_octree.cpp:145-177: a cell reads planes z and z + 1) and per-rank meshing merged by the
+reference's Morton order, renderView by ray hand-off in both exchange forms (tsdf_volume_octree.cpp:360, 401-406),
+getFxn / gradient routing, and the distributed .vol checkpoint written and read back.
+
+Compared, on rank 0 / in the parent: every voxel (d, w, rgb gathered from the ranks) with ONE TSDFVolumeOctree on the
+GPU holding the whole grid, bit for bit, and with the CPU oracle; the merged mesh, every rendered view, the sampled
+values, and the planes after save -> load."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpu_tsdf_amd import synth
+from cpu_tsdf_amd.zslab import ZSlabVolume, slab_range
+from tests.common import assert_same_f32
+
+pytestmark = pytest.mark.gpu
+
+RES, W, H, NF = 64, 80, 60, 6
+
+
+def configure(v):
+    sc = synth.scene_a(RES, W, H)
+    v.setResolution(RES, RES, RES)
+    v.setGridSize(sc.size, sc.size, sc.size)
+    v.setImageSize(W, H)
+    v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+    v.setSensorDistanceBounds(0.0, 3 * sc.size)
+    v.setIntegrateColor(True)
+
+
+def views(size):
+    return [synth.turntable_pose(1, 8, size), synth.turntable_pose(3, 16, size, tilt=0.5),
+            synth.look_at_pose((0.05, 0.02, -0.3)), synth.look_at_pose((0.02, -0.2, 0.01), target=(0.0, 0.0, 0.0))]
+
+
+def frames(sc):
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        yield i, tr, sc.depth(tr), sc.bgra(i)
+
+
+def sample_points():
+    return np.random.RandomState(5).uniform(-0.06, 0.06, (400, 3)).astype(np.float32)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)  # every rank on the one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol = ZSlabVolume(configure, RES)  # default factory: a HIP slab per rank; no CPU path exists
+    from cpu_tsdf_amd.zslab import HipSlab
+    assert isinstance(vol.slab, HipSlab) and (vol.z_begin, vol.z_end) == slab_range(RES, world, rank)
+    sc = synth.scene_a(RES, W, H)
+    src = world - 1  # ingest on the LAST rank: the others only ever see the frame through the broadcast
+    for i, tr, dep, col in frames(sc):
+        if rank == src:
+            vol.integrateCloud(dep, col, tr, src=src)
+        else:
+            vol.integrateCloud(None, None, tr, src=src)
+    mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    renders, rounds = [], []
+    for k, tr in enumerate(views(sc.size)):
+        a = vol.renderView(tr, 1 + (k == 1), exchange="allreduce")
+        rounds.append(vol.last_render_rounds)
+        b = vol.renderView(tr, 1 + (k == 1), exchange="p2p")
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"p2p hand-off differs from the all-reduce form, view {k}"
+        renders.append(a)
+    samp = vol.sample(sample_points())
+    zb, ze = vol.z_begin, vol.z_end
+    d, w, rgb = vol.download_local()
+    # checkpoint: one .vol of the whole grid written on the last rank, read back on rank 0 into new slabs
+    vol_path = out_path + ".vol"
+    vol.global_transform = synth.turntable_pose(1, 8, sc.size)
+    vol.save(vol_path, dst=world - 1)
+    dist.barrier()
+    back = ZSlabVolume.load(vol_path, src=0)
+    assert (back.z_begin, back.z_end) == (zb, ze) and isinstance(back.slab, HipSlab)
+    d2, w2, rgb2 = back.download_local()
+    same_after_load = bool(np.array_equal(d2.view(np.uint32), d.view(np.uint32)) and np.array_equal(w2, w) and np.array_equal(rgb2, rgb))
+    back_view = back.renderView(views(sc.size)[0], 1)
+    assert np.array_equal(back_view.view(np.uint32), renders[0].view(np.uint32)), "renderView after save -> load"
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((zb, ze, d, w, rgb, same_after_load), gathered, dst=0)
+    if rank == 0:
+        # download_local returns the slab's own planes (without halo)
+        assert all(g[2].shape[0] == g[1] - g[0] for g in gathered)
+        np.savez(out_path, verts=mesh["vertices"], rgb=mesh["rgb"], cells=mesh["cells"], ok=samp[0], val=samp[1], grad=samp[2],
+                 d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
+                 c=np.concatenate([g[4] for g in gathered]), bounds=np.array([[g[0], g[1]] for g in gathered]),
+                 same_after_load=np.array([g[5] for g in gathered]), rounds=np.array(rounds),
+                 **{f"view{k}": r for k, r in enumerate(renders)})
+    back.close()
+    vol.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_slabs_in_separate_processes_equal_one_volume(gpu, world, tmp_path):
+    out = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got["bounds"].tolist() == [list(slab_range(RES, world, r)) for r in range(world)]
+    # the truth twice over: ONE HIP volume holding the whole grid, and the CPU oracle
+    from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, TSDFVolumeOctree
+    from oracle.oracle import OracleVolume
+    sc = synth.scene_a(RES, W, H)
+    one = TSDFVolumeOctree()
+    configure(one)
+    one.reset()
+    ov = OracleVolume(one._p)
+    for i, tr, dep, col in frames(sc):
+        one.integrateCloud(dep, col, tr)
+        ov.integrate(dep, col, synth.cam_from_vol_f32(tr))
+    d1, w1, c1 = one.download()
+    assert_same_f32(got["d"], d1, f"d, world {world} vs one handle")
+    assert np.array_equal(got["w"], w1) and np.array_equal(got["c"], c1)
+    assert_same_f32(got["d"], ov.d, "d vs oracle")
+    assert np.array_equal(got["w"], ov.w) and np.array_equal(got["c"], ov.rgb)
+    assert got["same_after_load"].all(), "planes after save -> load differ on some rank"
+    # mesh: the ranks' triangles merged by the Morton key == one handle's mesh == the oracle's
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(one)
+    mc.setMinWeight(1.0)
+    mc.setColorByRGB(True)
+    m1 = mc.reconstruct()
+    verts, rgb, cells = ov.march(1.0, 1)
+    assert len(cells) > 1000 and np.array_equal(got["cells"], cells), "merged triangle order"
+    assert_same_f32(got["verts"], verts, "mesh vertices vs oracle")
+    assert np.array_equal(got["rgb"], rgb)
+    assert_same_f32(got["verts"], np.asarray(m1["vertices"], np.float32).reshape(got["verts"].shape), "mesh vertices vs one handle")
+    # renderView by ray hand-off == one handle's ray loop, bit for bit
+    hits = 0
+    for k, tr in enumerate(views(sc.size)):
+        want = one.renderView(tr, 1 + (k == 1))
+        assert_same_f32(got[f"view{k}"], want, f"view {k}")
+        hits += int(np.isfinite(want[..., 0]).sum())
+    assert hits > 2000 and 2 <= got["rounds"].max() <= world + 2
+    # getFxn / gradient: every point answered by the rank that holds its eight neighbours
+    ok, val, grad, _ = ov.sample(sample_points())
+    assert np.array_equal(got["ok"], ok) and ok.sum() > 100
+    assert_same_f32(got["val"][ok], val[ok], "sampled values")
+    assert_same_f32(got["grad"][ok], grad[ok], "sampled gradients")
+    one.close()
