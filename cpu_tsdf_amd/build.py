@@ -27,7 +27,9 @@ BINDIR = os.path.join(_HERE, "bin")
 
 # -ffp-contract=off: the reference CPU build has no FMA (no -march in its CMakeLists.txt), and
 # per-voxel parity needs the same separate mul/add roundings on the GPU.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result"]
+# -Werror=undef: a compile-time switch tested by #if before its default is defined silently reads as 0 in the default build
+# and as its value in a -D build (round 5: the colour update compiled one way, its table the other; every -D variant passed)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result", "-Werror=undef"]
 HOST_FLAGS = ["-std=c++14", "-O2", "-fPIC", "-fopenmp", "-ffp-contract=off", "-Wall", "-Wno-unknown-pragmas"]
 
 

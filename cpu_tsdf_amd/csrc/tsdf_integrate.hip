@@ -28,6 +28,15 @@
 #include "tsdf_hip_test.h"
 #endif
 
+// (compile-time switch used by add_observation_fast below: its default has to come first)
+#ifndef TSDF_COLOR_PK
+#define TSDF_COLOR_PK 2  // 2: colour bytes through v_cvt_pk_u8_f32 (one convert-and-pack per channel, rounds to nearest even:
+                         // tests/test_div_gpu.py pins that).  Round 2 measured it 2 % SLOWER in a kernel that waited for memory;
+                         // in round 5's issue-bound kernels it is the faster form (k_integrate2 11.76 -> 11.53 ms per frame, the
+                         // configs[4] slab 13.37 -> 13.10, k_integrate 13.6 either way: profiles/r05_ab_diet_call2.txt).  0 = three
+                         // truncating conversions + shifts and ors; 1 assumed truncation of the packed form and is WRONG.
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -371,17 +380,27 @@ static __device__ __forceinline__ uint64_t tsdf_quiet_passes(const IntegrateArgs
 #define TSDF_GUARD_ON_RESULT 1  // PACKED update: guard the divider on its result (v_cmp_class) instead of on its numerator
 #endif
 #ifndef TSDF_EARLY_VOXEL_LOADS
-#define TSDF_EARLY_VOXEL_LOADS 0  // A/B: the quad's voxel words are requested together with the frame gather (see there): measured, off
+#define TSDF_EARLY_VOXEL_LOADS 2  // 1: a quad's voxel words are requested together with the frame gather (one memory round trip per
+                                  // row instead of two, a fifth more traffic: measured in round 4, left off); 2 (round 5, ON): only
+                                  // by the quads PREDICTED to be observed (their own outcome one row earlier) -- 13.8 -> 13.45 ms at
+                                  // 2048^3 + colour, 9.96 -> 9.27 without, the configs[4] slab 12.87 -> 12.60, for 0.8 % more traffic
+                                  // (58.19 -> 58.63 GB; plain early loads: 71.1 GB for 13.6 ms); profiles/r05_ab_diet_call3.txt
 #endif
 
-#ifndef TSDF_COLOR_PK
-#define TSDF_COLOR_PK 0  // 1 / 2: colour bytes through v_cvt_pk_u8_f32, assuming it truncates / rounds to nearest even
-#endif
 // Round 5 instruction diet of the PACKED instances (profiles/r05_isa_phase_mix.txt has the per-phase counts):
 #ifndef TSDF_KTAB
-#define TSDF_KTAB 1  // everything addObservation derives from the count k alone -- the decoded weight, the refined reciprocal of
+#define TSDF_KTAB 0  // 1: everything addObservation derives from the count k alone -- the decoded weight, the refined reciprocal of
                      // k + 1, the colour rounding offset, the count after the observation -- comes from ONE 16-byte LDS entry per
-                     // voxel (ds_read_b128) instead of a 4-byte reciprocal + seven VALU operations per voxel
+                     // voxel (ds_read_b128) instead of an 8-byte entry + five VALU operations per voxel.  Measured in k_integrate
+                     // (profiles/r05_ab_diet_call1.txt): 14.15 against 13.87 ms without it -- sixteen registers of table values
+                     // in flight cost more than the operations they save (and with the v_cvt_pk_u8 colour path on top they spill:
+                     // 16.3 ms).  OFF there; k_integrate2, which runs at 5 waves and has the registers, keeps its table.
+#endif
+#ifndef TSDF_LEAN_K
+#define TSDF_LEAN_K 1  // (without TSDF_KTAB) the count's decode without its v_min, the next count without its mask: see the decode step
+#endif
+#ifndef TSDF_LEAN_BAND
+#define TSDF_LEAN_BAND 1  // the in-band test of a quad behind one compare of the least raw distance (see there)
 #endif
 #ifndef TSDF_AMB_UNROLL
 #define TSDF_AMB_UNROLL 1  // the exact fp64 re-projection of uncertified voxels: four straight copies, one per voxel of the quad,
@@ -480,13 +499,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #if TSDF_KTAB
   __shared__ KEntry s_tab[PACKED ? 256 : 1];  // per count k: decoded weight, Rcp32(k + 1).y, colour rounding offset, next count
 #else
-  __shared__ float s_rcp[256];  // s_rcp[k] = Rcp32(k + 1).y
+  __shared__ f2 s_rcp[256];  // s_rcp[k] = {Rcp32(k + 1).y, the colour average's rounding offset for that divisor (KEntry::hy)}
 #endif
   // per row of this block (rpb * TY <= 256): the row's part of pcl::transformPoint -- yt[q] = cy * m[q][1] + (cz * m[q][2] + m[q][3])
   // in PCL's SSE order, m[q][1] * cy in the other -- worked out once per block by the thread of that number instead of by every
   // thread in every row (the very same operations: bit-identical), and the z part with it: no per-thread zt registers
   __shared__ f4 s_yt[256];
   constexpr bool F2 = TSDF_PROJ_F2 && ALLIN && FASTPROJ;  // transform + projection on float pairs (see the row loop)
+  constexpr bool LEAN_K1 = TSDF_LEAN_K && !TSDF_KTAB && TSDF_COLOR_PK == 2 && PACKED && COLOR;  // (see the decode step)
   __shared__ f4 s_cx[F2 ? 256 : 1];  // F2: every thread's own four x centres, re-read each row (16 B of LDS instead of four registers)
   __shared__ uint32_t s_iv[LIVE ? 256 : 1];  // LIVE: the row intervals of this block's rows, lo | len << 16 (launch-relative x)
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
@@ -497,7 +517,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #if TSDF_KTAB
   if (PACKED) s_tab[tid] = tsdf_ktab_entry(a, tid);
 #else
-  if (PACKED) s_rcp[tid] = rcp32_prepare((float)(tid + 1u)).y;
+  if (PACKED) {
+    const KEntry e = tsdf_ktab_entry(a, tid);
+    s_rcp[tid] = (f2){e.y, e.hy};
+  }
 #endif
   {
     const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
@@ -570,6 +593,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     }
     const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;  // byte offset inside the row group
     const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
+#if TSDF_EARLY_VOXEL_LOADS
+    bool pred_obs = true;  // TSDF_EARLY_VOXEL_LOADS == 2: this quad was observed in the previous row (the first row asks early)
+#endif
     for (int r = 0; r < a.rpb; ++r) {
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
@@ -681,7 +707,12 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       u4 d4 = {0u, 0u, 0u, 0u};
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
-      if (EARLY) {
+      // TSDF_EARLY_VOXEL_LOADS == 2 (round 5): only the quads PREDICTED to be observed ask early -- the predictor is the quad's
+      // own outcome in the previous row of the block (surfaces are coherent from row to row: the prediction fails where a
+      // surface begins or ends along y), a mispredicted observed quad asks late as before, a mispredicted unobserved one has
+      // read its words for nothing: the one-round-trip row without the fifth more traffic.
+      const bool ask_early = EARLY && (TSDF_EARLY_VOXEL_LOADS != 2 || pred_obs);
+      if (ask_early) {
         if (d_read) d4 = bload128(rsD, voff, soff);
         if (COLOR) c4 = bload128(rsC, voff, soff);
         if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
@@ -722,7 +753,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         act[j] = (ALLIN || pix[j] >= 0) && raw[j] >= -a.neg;
         dn[j] = a.pos_over_neg;                                         // hpp:189-192: raw > pos clamps
         any |= act[j];
-        any_div |= act[j] && !(raw[j] > a.pos);
+        if (!TSDF_LEAN_BAND) any_div |= act[j] && !(raw[j] > a.pos);
+      }
+      if (TSDF_LEAN_BAND) {
+        // "some observed voxel lies inside the truncation band" (any_div) decides nothing but which path a wave takes, so the
+        // hot path asks a cheaper question first -- is the least of the four raw values (NaN ignored by v_min) at most pos? --
+        // true for every quad any_div is true for, and otherwise only for a quad with a voxel BEHIND the surface next to
+        // free-space ones (a surface row, where the wave takes that path anyway); the exact test runs only then
+        if (__builtin_fminf(__builtin_fminf(raw[0], raw[1]), __builtin_fminf(raw[2], raw[3])) <= a.pos) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) any_div |= act[j] && !(raw[j] > a.pos);
+        }
       }
       // The colour gathers are retired HERE, with the depth gathers they were issued behind (they return in order, a few
       // cycles later), not wherever their first use falls: a quad none of whose voxels is observed leaves the row without
@@ -731,7 +772,25 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // voxel STORES, in every row, whether the path was taken or not (the third memory round trip of a row, found in
       // round 5: profiles/r05_isa_phase_mix.txt)
       if (COLOR) asm volatile("" ::"v"(cs[0]), "v"(cs[1]), "v"(cs[2]), "v"(cs[3]));
+#if TSDF_EARLY_VOXEL_LOADS
+      if (EARLY) {  // ... and so are the early voxel words (a quad that turns out unobserved never looks at them)
+        if (COLOR)
+          asm volatile("" ::"v"(d4), "v"(c4));
+        else
+          asm volatile("" ::"v"(d4), "v"(k4));
+      }
+      const bool asked_early = ask_early;
+      pred_obs = any;
+#endif
       if (!any) continue;
+#if TSDF_EARLY_VOXEL_LOADS == 2
+      if (EARLY && !asked_early) {  // an observed quad the predictor missed: its words are requested now
+        if (d_read) d4 = bload128(rsD, voff, soff);
+        if (COLOR) c4 = bload128(rsC, voff, soff);
+        if (!COLOR) k4 = bload32(rsK, voff >> 2, soff >> 2);
+        if (COUNT) rdb += (d_read ? 16u : 0u) + (COLOR ? 16u : 4u);
+      }
+#endif
       if (any_div) {  // free space (every observed voxel of the wave beyond the hinge) skips all four ladders
 #pragma unroll
         for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
@@ -777,8 +836,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       float dv[4], wv[4];
       uint32_t cv[4], k1[4];
 #if TSDF_KTAB
-      float ky[4], khy[4];  // PACKED: Rcp32(k + 1).y and the colour rounding offset of each voxel's count
+      float ky[4];
 #endif
+      float khy[4] = {0.f, 0.f, 0.f, 0.f};  // PACKED: the colour rounding offset of each voxel's divisor (with Rcp32(k + 1).y from LDS)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         d0[j] = __uint_as_float(d0u[j]);
@@ -791,13 +851,21 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           const KEntry e = s_tab[kw[j] >> 24];  // one ds_read_b128
           w0[j] = e.w, ky[j] = e.y, khy[j] = e.hy, k1[j] = e.k1;
 #else
-          // tsdf_decode_w (neither is NaN here).  (With an integer max_weight the min is the identity, but leaving it
-          // out lets LLVM turn the colour sums into integer multiplies and byte shuffles: +70 instructions, measured.)
-          w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
+          // tsdf_decode_w (neither is NaN here).  With an integer max_weight the min is the identity -- and the ALLIN
+          // instance is only launched with one, and with kmax == max_weight (launch_integrate) -- but leaving it out lets
+          // LLVM turn the colour sums into integer multiplies and byte shuffles (+70 instructions, measured): TSDF_LEAN_K
+          // hides the value behind an empty asm instead of paying a v_min per voxel for that.
+          if (TSDF_LEAN_K && ALLIN) {
+            w0[j] = (float)(kw[j] >> 24);
+            asm volatile("" : "+v"(w0[j]));
+          } else {
+            w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
+          }
           // the count after this observation, k' = min(k + 1, kmax), as byte 3 of a word (saturate BEFORE adding: with
           // kmax == 255 an in-place add would wrap byte 3 to zero; kcap = (kmax - 1) << 24 and kinc = 1 << 24, both 0
-          // when kmax == 0)
-          k1[j] = min(kw[j] & 0xff000000u, a.kcap) + a.kinc;  // == min(k + 1, kmax) << 24
+          // when kmax == 0).  LEAN_K1: v_cvt_pk_u8_f32 rewrites bytes 0-2 of the word it is handed, so there the old
+          // colour bytes may ride along under the clamp (kcap | 0xffffff) and the mask goes away
+          k1[j] = LEAN_K1 ? min(kw[j], a.kcap | 0xffffffu) + a.kinc : min(kw[j] & 0xff000000u, a.kcap) + a.kinc;  // == min(k + 1, kmax) << 24 (| old rgb)
 #endif
         }
       }
@@ -859,16 +927,13 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #if TSDF_KTAB
             rs[j].y = ky[j];  // w0 + 1 == k + 1 here (w0 is an integer)
 #else
-            rs[j].y = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
+            const f2 yh = s_rcp[kw[j] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
+            rs[j].y = yh.x, khy[j] = yh.y;
 #endif
           } else {
             rs[j] = rcp32_prepare(w0[j] + 1.f);
           }
-#if TSDF_KTAB
           add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u, PACKED ? &khy[j] : nullptr);
-#else
-          add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u);
-#endif
         }
         if (d_moves) {  // distance
           d_touched = true;
@@ -900,7 +965,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           wv[j] = w0[j];
           cv[j] = c0[j] & 0xffffffu;
           add_observation_ieee<COLOR>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax);
-          if (COLOR) cv[j] |= k1[j];  // both flavours return the colour with the new count in byte 3
+          if (COLOR) cv[j] |= k1[j] & 0xff000000u;  // both flavours return the colour with the new count in byte 3
         }
       }
       uint32_t diff_w = 0u, diff_c = 0u, k4n = 0u;
@@ -2625,8 +2690,8 @@ extern "C" int tsdf_hip_set_weighting(tsdf_handle h, int weight_by_depth, int we
     tsdf_set_error("weight_by_variance needs float weights and TSDF_COLOR_RGB: create / load the volume with TSDF_LAYOUT_F32W");
     return TSDF_HIP_E_UNSUPPORTED;
   }
+  TSDF_ENTER(h);  // a frame that pairing holds back was committed under the OLD weighting: it is launched first
   if (weight_by_variance && !h->vm) {  // OctreeNode::M_ / nsample_ per voxel, zero like a fresh octree's
-    TSDF_ENTER(h);
     const size_t n = (size_t)(h->pitch * h->ny * h->nz_alloc);
     TSDF_HIP_TRY(hipMalloc(&h->vm, n * sizeof(float)));
     TSDF_HIP_TRY(hipMalloc(&h->vn, n * sizeof(int32_t)));
@@ -2822,9 +2887,17 @@ extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]
     const int sa = p->pend_slot;
     const int rc = tsdf_integrate_launch2(h, p->device[sa], bgra_of(sa), p->pend_T, p->pend_has_planes ? p->pend_planes : nullptr,
                                           p->device[slot], bgra_of(slot), cam_from_vol, h->ref_cull ? h->cull_planes : nullptr, false, nullptr);
-    if (rc) return rc;
-    TSDF_HIP_TRY(hipEventRecord(p->consumed[sa], h->stream));
-    TSDF_HIP_TRY(hipEventRecord(p->consumed[slot], h->stream));
+    // Whatever the launch did, both ring slots are handed back in order (their `consumed` events recorded, the frame
+    // counter advanced): a failure must not leave a slot whose upload or launch state the next frame_begin cannot know
+    // (ADVICE r04).  A failed launch integrated NEITHER frame or only the first: the error text says a frame was lost.
+    (void)hipEventRecord(p->consumed[sa], h->stream);
+    (void)hipEventRecord(p->consumed[slot], h->stream);
+    if (rc) {
+      p->frames++;
+      const std::string why = tsdf_hip_last_error();
+      tsdf_set_error("paired commit failed -- the frame held back for pairing and this one are LOST (not integrated): " + why);
+      return rc;
+    }
   } else if (p->pairing) {  // uploaded, but its kernel waits for the next frame (or for any other call on the volume)
     p->pend_slot = slot;
     for (int i = 0; i < 12; ++i) p->pend_T[i] = cam_from_vol[i];

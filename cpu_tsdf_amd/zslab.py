@@ -229,6 +229,50 @@ def out_sum(out, group):
     return out
 
 
+def _host_staged(group):
+    """gloo's POINT-TO-POINT operations hand the tensor's raw pointer to the transport (ProcessGroupGloo::send / recv build
+    an unbound buffer on `data_ptr()`): there is no device support behind them and no stream ordering -- on this platform the
+    host CAN dereference a device pointer, so a device tensor "works", racing with the kernels that write or read it (round
+    5: three HIP ranks over gloo faulted one run in two in the ray hand-off, tests/test_zslab_hip_ranks_gpu.py).  With gloo,
+    device tensors therefore travel through a host copy; RCCL ("nccl"), the backend of a real node, takes them as they are.
+    (gloo's collectives -- broadcast, all_reduce, all_gather -- do stage device tensors themselves.)"""
+    return dist.get_backend(group) == "gloo"
+
+
+def p2p_batch(ops, group):
+    """ops = [("send" | "recv", tensor, peer), ...]: one batch_isend_irecv, waited for."""
+    if not ops:
+        return
+    stage = _host_staged(group)
+    batch, landed = [], []
+    for kind, t, peer in ops:
+        buf = t
+        if stage and t.is_cuda:
+            if kind == "send":
+                buf = t.detach().cpu()  # a synchronous copy, ordered behind the kernels that produced t
+            else:
+                buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+                landed.append((t, buf))
+        batch.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group))
+    for req in dist.batch_isend_irecv(batch):
+        req.wait()
+    for t, buf in landed:
+        t.copy_(buf)
+
+
+def send_tensor(t, dst, group):
+    dist.send(t.detach().cpu() if _host_staged(group) and t.is_cuda else t, dst, group=group)
+
+
+def recv_tensor(t, src, group):
+    if _host_staged(group) and t.is_cuda:
+        buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+        dist.recv(buf, src, group=group)
+        t.copy_(buf)
+    else:
+        dist.recv(t, src, group=group)
+
+
 def _default_factory(configure, z_begin, z_end, nz, rank, halo=1):
     if capi.load().tsdf_hip_device_count() <= 0:
         raise RuntimeError("ZSlabVolume needs a HIP device per rank (there is no CPU fallback)")
@@ -311,18 +355,16 @@ class ZSlabVolume:
                 if s0 < s1:
                     send = self.slab.get_planes(s0, s1 - s0)
                     keep.append(send)
-                    ops += [dist.P2POp(dist.isend, t, r, self.group) for t in send if t is not None]
+                    ops += [("send", t, r) for t in send if t is not None]
             # what I want of rank r's planes
             for a, b in want:
                 r0, r1 = max(a, zb), min(b, ze)
                 if r0 < r1:
                     buf = self.slab.plane_buffers(r1 - r0)
                     recvs.append((r0, buf))
-                    ops += [dist.P2POp(dist.irecv, t, r, self.group) for t in buf if t is not None]
+                    ops += [("recv", t, r) for t in buf if t is not None]
         self.slab.synchronize()
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        p2p_batch(ops, self.group)
         for z0, buf in recvs:
             self.slab.set_planes(z0, *buf)
 
@@ -384,18 +426,16 @@ class ZSlabVolume:
                     if has_rgb:
                         all_c[sl] = rgb
                 else:
-                    ops.append(dist.P2POp(dist.irecv, all_v[sl], r, self.group))
-                    ops.append(dist.P2POp(dist.irecv, all_k[sl], r, self.group))
+                    ops.append(("recv", all_v[sl], r))
+                    ops.append(("recv", all_k[sl], r))
                     if has_rgb:
-                        ops.append(dist.P2POp(dist.irecv, all_c[sl], r, self.group))
+                        ops.append(("recv", all_c[sl], r))
         elif counts[self.rank]:
-            ops.append(dist.P2POp(dist.isend, verts, dst, self.group))
-            ops.append(dist.P2POp(dist.isend, cells, dst, self.group))
+            ops.append(("send", verts, dst))
+            ops.append(("send", cells, dst))
             if has_rgb:
-                ops.append(dist.P2POp(dist.isend, rgb, dst, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+                ops.append(("send", rgb, dst))
+        p2p_batch(ops, self.group)
         if self.rank != dst:
             return None
         order = torch.argsort(morton_x_major_torch(all_k), stable=True)
@@ -460,21 +500,19 @@ class ZSlabVolume:
                 if has_rgb:
                     out_c[sl] = rgb[src]
             else:
-                ops.append(dist.P2POp(dist.irecv, out_v[sl], r, self.group))
-                ops.append(dist.P2POp(dist.irecv, out_k[sl], r, self.group))
+                ops.append(("recv", out_v[sl], r))
+                ops.append(("recv", out_k[sl], r))
                 if has_rgb:
-                    ops.append(dist.P2POp(dist.irecv, out_c[sl], r, self.group))
+                    ops.append(("recv", out_c[sl], r))
         for q in range(self.world):
             src = slice(bounds[q], bounds[q + 1])
             if q == self.rank or bounds[q + 1] == bounds[q]:
                 continue
-            ops.append(dist.P2POp(dist.isend, verts[src].contiguous(), q, self.group))
-            ops.append(dist.P2POp(dist.isend, cells[src].contiguous(), q, self.group))
+            ops.append(("send", verts[src].contiguous(), q))
+            ops.append(("send", cells[src].contiguous(), q))
             if has_rgb:
-                ops.append(dist.P2POp(dist.isend, rgb[src].contiguous(), q, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+                ops.append(("send", rgb[src].contiguous(), q))
+        p2p_batch(ops, self.group)
         order = torch.argsort(morton_x_major_torch(out_k), stable=True)
         first = int(table[:, :self.rank].sum())
         return out_v[order], (out_c[order] if has_rgb else None), out_k[order], first
@@ -615,14 +653,12 @@ class ZSlabVolume:
                     continue
                 if table[self.rank][r]:
                     sends.append(sus[dest == r].contiguous())
-                    ops.append(dist.P2POp(dist.isend, sends[-1], r, self.group))
+                    ops.append(("send", sends[-1], r))
                     self.last_p2p_records += int(table[self.rank][r])
                 if table[r][self.rank]:
                     parts.append(torch.empty((int(table[r][self.rank]), state.shape[1]), dtype=torch.int32, device=dev))
-                    ops.append(dist.P2POp(dist.irecv, parts[-1], r, self.group))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                    ops.append(("recv", parts[-1], r))
+            p2p_batch(ops, self.group)
             mine = torch.cat(parts).contiguous()
         raise RuntimeError("ray hand-off did not converge")
 
@@ -664,11 +700,12 @@ class ZSlabVolume:
                 if r == root:
                     got = part
                 else:
-                    dist.send(torch.from_numpy(self._pack_block(*part)).to(dev), root, group=self.group)
+                    blob = torch.from_numpy(self._pack_block(*part))
+                    send_tensor(blob if _host_staged(self.group) else blob.to(dev), root, self.group)
                     continue
             elif self.rank == root:
-                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device=dev)
-                dist.recv(buf, r, group=self.group)
+                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device="cpu" if _host_staged(self.group) else dev)
+                recv_tensor(buf, r, self.group)
                 got = self._unpack_block(buf.cpu().numpy(), c, n)
             else:
                 continue
@@ -687,10 +724,11 @@ class ZSlabVolume:
                 if r == root:
                     self._store(x0, y0, lo, *part)
                 else:
-                    dist.send(torch.from_numpy(self._pack_block(*part)).to(dev), r, group=self.group)
+                    blob = torch.from_numpy(self._pack_block(*part))
+                    send_tensor(blob if _host_staged(self.group) else blob.to(dev), r, self.group)
             elif self.rank == r:
-                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device=dev)
-                dist.recv(buf, root, group=self.group)
+                buf = torch.empty(self._block_bytes(c, n), dtype=torch.uint8, device="cpu" if _host_staged(self.group) else dev)
+                recv_tensor(buf, root, self.group)
                 self._store(x0, y0, lo, *self._unpack_block(buf.cpu().numpy(), c, n))
 
     def _store(self, x0, y0, z0, d, w, rgb):

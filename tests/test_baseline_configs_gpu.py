@@ -9,6 +9,7 @@ configs[2]  1024^3, 300 frames with a renderView every 25: sampled plane groups 
 configs[3]  2048^3 with colour, 104 frames through saturation, sampled planes against the C oracle, then the mesh.
 Reference lines: include/cpu_tsdf/impl/tsdf_volume_octree.hpp:113-218, src/lib/octree.cpp:152-163 (saturation),
 src/lib/tsdf_volume_octree.cpp:278-424 (renderView)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -188,4 +189,50 @@ def test_config3_2048_cubed_colour_through_weight_saturation_then_mesh(gpu):
     box = np.abs(np.abs(vert[::97]).max(1) - sc.h)
     resid = np.minimum(np.abs(r - sc.r), box)
     assert np.median(resid) < 0.03 and np.quantile(resid, 0.99) < 0.25, (np.median(resid), np.quantile(resid, 0.99))
+    v.close()
+
+
+def test_config3_all_1000_frames_paired_then_unpaired_then_mesh(gpu):
+    """configs[3] IN FULL, driver-run (VERDICT r04 next #6a; rounds 1-4 ran it by hand: profiles/r0*_long_run_2048_1000frames*.json):
+    2048^3, integrateColor, 1000 DISTINCT noisy 640x480 frames through the pipelined host entry point -- frame pairing (two
+    frames per sweep, k_integrate2) on for the first 500, off for the rest -- three plane groups against the C oracle at frames
+    250 / 500 / 750 / 1000 (the weight saturates at 100: nine tenths of the run are the EMA regime of octree.cpp:157-159), then
+    MarchingCubesTSDFOctree::reconstruct with six sub-boxes of the mesh compared with the oracle bit for bit."""
+    if torch.cuda.mem_get_info()[0] / 2 ** 30 < 80:
+        pytest.skip("needs ~70 GB of free HBM")
+    res, n_frames = 2048, 1000
+    groups = [(res // 2 - 1, res // 2 + 1), (res // 3, res // 3 + 2), (res - 300, res - 298)]
+    v, sc = product(res, True)
+    v.setFramePairing(True)
+    oracles = [SlabOracle(v._p, a, b) for a, b in groups]
+    info = (C.c_int32 * 4)()
+    fused = 0
+    for i in range(n_frames):
+        if i == n_frames // 2:
+            v.setFramePairing(False)   # (launches a frame still waiting for its partner)
+        tr = synth.turntable_pose(i, n_frames, sc.size, tilt=0.15 * np.sin(i * 0.05))
+        dep, col = sc.depth(tr, noise_seed=12345 + i), sc.bgra(i)
+        v.integrateCloud(dep, col, tr, pipelined=True)
+        if i < n_frames // 2 and i % 2 == 1:
+            capi.check(capi.load().tsdf_hip_last_launch_info(v._need(), info), "last_launch_info")
+            fused += int(info[0] == 2)
+        T = synth.cam_from_vol_f32(tr)
+        for o in oracles:
+            o.integrate(dep, col, T)
+        if i + 1 in (250, 500, 750, 1000):
+            for (a, b), o in zip(groups, oracles):
+                d, w, rgb = v.download(z0=a, nz=b - a)
+                assert_same_f32(d, o.d, f"d planes {a}:{b} after frame {i + 1}")
+                assert np.array_equal(w, o.w) and np.array_equal(rgb, o.rgb), f"w / rgb planes {a}:{b} after frame {i + 1}"
+    assert fused == n_frames // 4, fused   # every pair of the first half went through ONE sweep
+    assert max(float(o.w.max()) for o in oracles) == 100.0
+    assert np.mean([float((o.w == 100.0).mean()) for o in oracles[:2]]) > 0.5
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(v)
+    mc.setMinWeight(2.0)
+    mc.setColorByRGB(True)
+    mesh = mc.reconstruct(want_cells=True)
+    assert len(mesh["vertices"]) > 3 * 10 ** 7
+    n_checked = assert_mesh_boxes_equal_oracle(v, mesh, boxes_2048(), 2.0, 1, min_triangles=100000)
+    print(f"2048^3 after 1000 frames: {len(mesh['vertices']) // 3} triangles, {n_checked} compared bit for bit with the oracle")
     v.close()

@@ -51,3 +51,13 @@ def test_smoke_runs_on_a_from_scratch_build(gpu, tmp_path):
     fresh_tree(str(tmp_path))
     out = run(BUILD + "; import __graft_entry__ as g; g.smoke()", str(tmp_path), 1800)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_timed_kernel_instances_stay_within_their_register_budget():
+    """tools/isa_guard.py --check: the instances the bench times keep their VGPR count, scratch size and
+    occupancy, and no register spill is reloaded on the row path (a scratch reload there waits for every voxel store in flight:
+    measured at +15 % in round 5).  The same check runs inside __graft_entry__.build()."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_guard.py"), "--check"], cwd=ROOT, text=True,
+                         capture_output=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok ") == 4 and "BAD" not in out.stdout, out.stdout

@@ -200,3 +200,40 @@ def test_frame_pairing_of_the_pipelined_host_path_changes_no_voxel(gpu):
     for v in vols:
         compare(v, ov)
         v.close()
+
+
+def test_frame_pairing_when_the_reference_cull_decides_voxels(gpu):
+    """with pairing on, frame B's cull planes reach tsdf_integrate_launch2 as the handle's OWN array, which the
+    two-launch path used to overwrite with frame A's before launching B.  A principal point 60 % off centre makes the
+    reference's frustum cull (1.1 x FOV about the optical axis) cut voxels, so such pairs cannot fuse and take that path, each
+    frame with planes of its own (distinct poses); the paired volume must equal the unpaired one and the culled oracle."""
+    vols = []
+    for pairing in (True, False):
+        vol, sc = make_volume(64, color=True)
+        sc.cx += 0.6 * sc.width / 2
+        vol.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        vol.setFramePairing(pairing)
+        vol.reset()
+        vols.append(vol)
+    ov = OracleVolume(vols[0]._p)
+    plain = OracleVolume(vols[0]._p)   # the same frames WITHOUT the cull: shows that the cull decided voxels
+    # yawed about the camera's y axis so that the grid's centre still projects to the image centre: the grid then sits OFF the
+    # optical axis and one side of it leaves the cull's pyramid (bench.py --principal-offset does the same)
+    psi = float(np.arctan(0.6 * (sc.width / 2) / sc.fx))
+    yaw = np.eye(4)
+    yaw[0, 0], yaw[0, 2], yaw[2, 0], yaw[2, 2] = np.cos(psi), np.sin(psi), -np.sin(psi), np.cos(psi)
+    poses = [synth.turntable_pose(i, 7, sc.size, tilt=0.1 * i) @ yaw for i in range(6)]
+    cut, infos = [], []
+    for i, tr in enumerate(poses):
+        dep, col = sc.depth(tr, noise_seed=31 + i), sc.bgra(i)
+        n_cull = ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
+        cut.append(plain.integrate(dep, col, synth.cam_from_vol_f32(tr)) - n_cull)
+        for v in vols:
+            v.integrateCloud(dep, col, tr, pipelined=True)
+        infos.append(launch_info(vols[0])[0])
+    assert min(cut[:5]) > 0, cut                   # the frames lost voxels to the cull (the last one none: its pair is mixed) ...
+    assert all(i != 2 for i in infos), infos       # ... so no pair went through the fused sweep: two launches each
+    for v in vols:
+        compare(v, ov)
+        v.close()
+    assert not np.array_equal(ov.w, plain.w)

@@ -63,6 +63,12 @@ def _worker(rank, world, port, out_path):
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)  # every rank on the one GPU
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def trace(what):  # TSDF_TEST_TRACE=1: which phase a rank is in (a GPU fault kills the process without a Python traceback)
+        if os.environ.get("TSDF_TEST_TRACE"):
+            if os.environ["TSDF_TEST_TRACE"] == "1":
+                torch.cuda.synchronize()
+            print(f"[rank {rank}/{world}] {what}", flush=True)
     vol = ZSlabVolume(configure, RES)  # default factory: a HIP slab per rank; no CPU path exists
     from cpu_tsdf_amd.zslab import HipSlab
     assert isinstance(vol.slab, HipSlab) and (vol.z_begin, vol.z_end) == slab_range(RES, world, rank)
@@ -73,23 +79,30 @@ def _worker(rank, world, port, out_path):
             vol.integrateCloud(dep, col, tr, src=src)
         else:
             vol.integrateCloud(None, None, tr, src=src)
+    trace("integrated")
     mesh = vol.reconstruct(w_min=1.0, color_by_rgb=True)
+    trace("meshed")
     renders, rounds = [], []
     for k, tr in enumerate(views(sc.size)):
         a = vol.renderView(tr, 1 + (k == 1), exchange="allreduce")
         rounds.append(vol.last_render_rounds)
+        trace(f"view {k} allreduce")
         b = vol.renderView(tr, 1 + (k == 1), exchange="p2p")
+        trace(f"view {k} p2p")
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"p2p hand-off differs from the all-reduce form, view {k}"
         renders.append(a)
     samp = vol.sample(sample_points())
+    trace("sampled")
     zb, ze = vol.z_begin, vol.z_end
     d, w, rgb = vol.download_local()
     # checkpoint: one .vol of the whole grid written on the last rank, read back on rank 0 into new slabs
     vol_path = out_path + ".vol"
     vol.global_transform = synth.turntable_pose(1, 8, sc.size)
     vol.save(vol_path, dst=world - 1)
+    trace("saved")
     dist.barrier()
     back = ZSlabVolume.load(vol_path, src=0)
+    trace("loaded")
     assert (back.z_begin, back.z_end) == (zb, ze) and isinstance(back.slab, HipSlab)
     d2, w2, rgb2 = back.download_local()
     same_after_load = bool(np.array_equal(d2.view(np.uint32), d.view(np.uint32)) and np.array_equal(w2, w) and np.array_equal(rgb2, rgb))
