@@ -81,6 +81,7 @@ struct IntegrateArgs {
 // cannot occur (the host rejects non-finite / absurd poses before launching).
 static __device__ __forceinline__ int project_exact(const IntegrateArgs &a, const double *__restrict__ cam,
                                                     float gx, float gy, float gz) {
+  // [phase: exact fp64 re-projection (rare: uncertified voxels)]
   const Rcp64 rz = rcp64_prepare((double)gz);
   const int u = (int)(div64((double)gx * cam[0], rz) + cam[2]);  // cam = fx, fy, cx, cy
   const int v = (int)(div64((double)gy * cam[1], rz) + cam[3]);
@@ -132,6 +133,7 @@ template <int ORDER>
 static __device__ __forceinline__ void project_quad_allin(const IntegrateArgs &a, const float (&m)[12], const double *__restrict__ cam,
                                                           const f4 cxv, const f4 ytv, const float (&zt)[3], int (&pix)[4],
                                                           float (&gzs)[4]) {
+  // [phase: transform (hpp:143-145)]
   const f2 cxa = {cxv.x, cxv.y}, cxb = {cxv.z, cxv.w};
   const float yt[3] = {ytv.x, ytv.y, ytv.z};
   f2 ga[3], gb[3];
@@ -145,6 +147,7 @@ static __device__ __forceinline__ void project_quad_allin(const IntegrateArgs &a
       gb[q] = ((cxb * m[4 * q] + yt[q]) + zt[q]) + m[4 * q + 3];
     }
   }
+  // [phase: project (.cpp:611-617, certified fp32)]
   const f2 ya = {__builtin_amdgcn_rcpf(ga[2].x), __builtin_amdgcn_rcpf(ga[2].y)};
   const f2 yb = {__builtin_amdgcn_rcpf(gb[2].x), __builtin_amdgcn_rcpf(gb[2].y)};
   const f2 cxf2 = {a.cxf, a.cxf}, cyf2 = {a.cyf, a.cyf};
@@ -154,6 +157,7 @@ static __device__ __forceinline__ void project_quad_allin(const IntegrateArgs &a
   gzs[0] = ga[2].x, gzs[1] = ga[2].y, gzs[2] = gb[2].x, gzs[3] = gb[2].y;
   // the certificate: the fractions lie in [0, 1), so their bit patterns order like the values; ONE compare of the least of
   // the eight against max(hb_u, hb_v) certifies the quad
+  // [phase: certificate + pixel index]
   uint32_t fu[4], fv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -163,6 +167,7 @@ static __device__ __forceinline__ void project_quad_allin(const IntegrateArgs &a
   }
   const uint32_t hb = __float_as_uint(a.hb_max);
   const uint32_t least = min(min(min(fu[0], fv[0]), min(min(fu[1], fv[1]), fu[2])), min(min(fv[2], fu[3]), fv[3]));
+  // [phase: exact fp64 re-projection (rare: uncertified voxels)]
   if (!(least > hb)) {  // rare (a fraction ~4 * band of the voxels): the exact fp64 projection, a copy per voxel of the quad,
                         // each under its own exec mask (an empty one is a skipped branch)
     const float gx[4] = {ga[0].x, ga[0].y, gb[0].x, gb[0].y}, gy[4] = {ga[1].x, ga[1].y, gb[1].x, gb[1].y};
@@ -251,6 +256,7 @@ static __device__ __forceinline__ bool numerator_ok(float v) {  // +0, or 2^-100
 template <bool COLOR>
 static __device__ __forceinline__ void add_observation_ieee(float &d, float &w, uint32_t &rgb, float dn,
                                                             uint32_t bgra, float wmax) {
+  // [phase: IEEE fallback (rare)]
   const float wn = 1.f;
   const float wsum = w + wn;
   if (COLOR) {
@@ -285,6 +291,7 @@ template <bool COLOR, bool DIST = true>
 static __device__ __forceinline__ void add_observation_fast(float &d, float &w, uint32_t &rgb, float dn,
                                                             uint32_t bgra, float wmax, const Rcp32 &rs, uint32_t base = 0u,
                                                             const float *hy_tab = nullptr) {
+  // [phase: colour update (octree.cpp:328-337)]
   const float wsum = w + 1.f;  // rs = rcp32_prepare(wsum) (nb and y are all that is used)
   if (COLOR) {
 #if TSDF_COLOR_PK
@@ -302,6 +309,7 @@ static __device__ __forceinline__ void add_observation_fast(float &d, float &w, 
     rgb = q0 | (q1 << 8) | (q2 << 16) | base;
 #endif
   }
+  // [phase: d update (octree.cpp:152-163)]
   if (DIST) d = div32_fast(d * w + dn, rs);
   w = wsum;
   if (w > wmax) w = wmax;
@@ -398,6 +406,9 @@ static __device__ __forceinline__ uint64_t tsdf_quiet_passes(const IntegrateArgs
 #endif
 #ifndef TSDF_LEAN_K
 #define TSDF_LEAN_K 1  // (without TSDF_KTAB) the count's decode without its v_min, the next count without its mask: see the decode step
+#endif
+#ifndef TSDF_SWAR_K
+#define TSDF_SWAR_K 1  // PACKED without colour: the quad's four count bytes are updated in one word (see k4n in k_integrate)
 #endif
 #ifndef TSDF_LEAN_BAND
 #define TSDF_LEAN_BAND 1  // the in-band test of a quad behind one compare of the least raw distance (see there)
@@ -596,6 +607,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #if TSDF_EARLY_VOXEL_LOADS
     bool pred_obs = true;  // TSDF_EARLY_VOXEL_LOADS == 2: this quad was observed in the previous row (the first row asks early)
 #endif
+    // [phase: row setup (loop control, row's transform part from LDS)]
     for (int r = 0; r < a.rpb; ++r) {
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
@@ -628,6 +640,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (ORDER == TSDF_XFORM_PCL_SSE) return px[j][q] + yt[q];
         return ((px[j][q] + yt[q]) + zt[q]) + a.m[4 * q + 3];
       };
+      // [phase: transform + project, general instance (not in ALLIN)]
       // ---- range test (hpp:146, .cpp:616) + reprojectPoint (.cpp:611-617), voxel by voxel ----------------
       int pix[4];
       float gzs[4];
@@ -711,6 +724,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // own outcome in the previous row of the block (surfaces are coherent from row to row: the prediction fails where a
       // surface begins or ends along y), a mispredicted observed quad asks late as before, a mispredicted unobserved one has
       // read its words for nothing: the one-round-trip row without the fifth more traffic.
+      // [phase: voxel loads]
       const bool ask_early = EARLY && (TSDF_EARLY_VOXEL_LOADS != 2 || pred_obs);
       if (ask_early) {
         if (d_read) d4 = bload128(rsD, voff, soff);
@@ -719,6 +733,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (COUNT) rdb += (d_read ? 16u : 0u) + (COLOR ? 16u : 4u);  // plane bytes requested
       }
 #endif
+      // [phase: frame gather]
       // ---- gather the frame (L2-resident); pixel -1 is out of the descriptor's range and reads 0 ----------
       float zs[4];
       uint32_t cs[4] = {0u, 0u, 0u, 0u};
@@ -737,6 +752,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
         }
       }
+      // [phase: hinge / normalise (hpp:159-198)]
       // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
       // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
       // at least 2^-39 in magnitude (difference of two floats one of which is >= 2^-14), and at most
@@ -765,6 +781,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           for (int j = 0; j < 4; ++j) any_div |= act[j] && !(raw[j] > a.pos);
         }
       }
+      // [phase: leave the row if nothing is observed; late voxel loads]
       // The colour gathers are retired HERE, with the depth gathers they were issued behind (they return in order, a few
       // cycles later), not wherever their first use falls: a quad none of whose voxels is observed leaves the row without
       // ever using them, and a gather still in flight across the back edge makes the compiler guard the next row's first
@@ -791,10 +808,12 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (COUNT) rdb += (d_read ? 16u : 0u) + (COLOR ? 16u : 4u);
       }
 #endif
+      // [phase: normalise: raw / neg ladder (rows with an in-band voxel)]
       if (any_div) {  // free space (every observed voxel of the wave beyond the hinge) skips all four ladders
 #pragma unroll
         for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
       }
+      // [phase: IEEE fallback (rare)]
       if (lowz || !a.neg_in_window) {  // operands outside the scale-free window: the compiler's IEEE division
         // An fdiv is ONE cheap-looking IR instruction, so LLVM would if-convert this rare block into the hot path
         // (and the backend then expands every division into ~10 VALU ops there); the empty volatile asm keeps
@@ -804,6 +823,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         for (int j = 0; j < 4; ++j)
           if (act[j] && !(raw[j] > a.pos)) dn[j] = raw[j] / a.neg;
       }
+      // [phase: voxel loads]
       // ---- read-modify-write -----------------------------------------------------------------------------
 #if TSDF_EXP_NO_VLOAD
       const uint32_t hb_ = __float_as_uint(a.pos_over_neg);
@@ -828,6 +848,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (COUNT) rdb += (d_read ? 16u : 0u) + (!PACKED ? 16u : 0u) + (COLOR ? 16u : 0u) + (PACKED && !COLOR ? 4u : 0u);
       }
 #endif
+      // [phase: decode count / weight (PACKED)]
       uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
       const uint32_t w0u[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -857,7 +878,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           // hides the value behind an empty asm instead of paying a v_min per voxel for that.
           if (TSDF_LEAN_K && ALLIN) {
             w0[j] = (float)(kw[j] >> 24);
-            asm volatile("" : "+v"(w0[j]));
+            if (COLOR) asm volatile("" : "+v"(w0[j]));  // (without colour only the rare distance ladder reads it)
           } else {
             w0[j] = __builtin_fminf((float)(kw[j] >> 24), a.wmax);
           }
@@ -874,6 +895,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // exact whenever its RESULT is a normal number (residuals of a normal numerator against an integer
       // divisor are multiples of 2^-149, so they are exact; only a subnormal quotient can double-round); a
       // result that is zero, subnormal or non-finite sends the quad to the IEEE path instead.
+      // [phase: band / implied-distance flags, hinge rest test]
       bool safe = true;
       if (!PACKED) {
 #pragma unroll
@@ -901,6 +923,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         } else {  // distances not read (see s_bin): off the hinge value <=> never observed <=> count 0
 #pragma unroll
           for (int j = 0; j < 4; ++j) off_hinge |= (ALLIN || act[j]) && kw[j] < 0x01000000u;
+          // (TSDF_SWAR_K, ALLIN without colour: the same question of the four count bytes at once -- is one of them zero?)
+          if (TSDF_SWAR_K && ALLIN && !COLOR) off_hinge = any_div || ((k4 - 0x01010101u) & ~k4 & 0x80808080u) != 0u;
         }
         d_moves = __builtin_amdgcn_ballot_w64(off_hinge) != 0ull;  // wave-uniform: one scalar branch
       }
@@ -915,13 +939,16 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         }
       }
       bool d_touched = false;  // this lane's distances went through an update (else dv == d0 and nothing is compared or stored)
+      // [phase: colour update (octree.cpp:328-337)]
       if (safe) {
         Rcp32 rs[4];
 #pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] = d0[j], wv[j] = w0[j], cv[j] = c0[j];
+        // PACKED without colour: the reciprocal of k + 1 is only wanted where a distance moves (wave-uniform: d_moves is a ballot);
+        // in resting free space the count bytes are all there is to update
+        if (COLOR || !PACKED || d_moves)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {  // colour and weight: every observed voxel
-          dv[j] = d0[j];
-          wv[j] = w0[j];
-          cv[j] = c0[j];
           if (PACKED) {
             rs[j].nb = -(w0[j] + 1.f);
 #if TSDF_KTAB
@@ -935,6 +962,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           }
           add_observation_fast<COLOR, false>(dv[j], wv[j], cv[j], dn[j], cs[j], a.wmax, rs[j], COLOR ? k1[j] : 0u, PACKED ? &khy[j] : nullptr);
         }
+        // [phase: d update (octree.cpp:152-163)]
         if (d_moves) {  // distance
           d_touched = true;
           // a voxel of this quad was observed inside the truncation band: its distance may turn negative, which is what
@@ -955,6 +983,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 #endif
         }
       }
+      // [phase: IEEE fallback (rare)]
       if (!safe) {
         d_touched = true;
         if (!TSDF_NO_BAND && any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
@@ -968,6 +997,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cv[j] |= k1[j] & 0xff000000u;  // both flavours return the colour with the new count in byte 3
         }
       }
+      // [phase: select / change detection / store]
       uint32_t diff_w = 0u, diff_c = 0u, k4n = 0u;
       uint32_t wn_u[4];
       const uint32_t c_before[4] = {c0[0], c0[1], c0[2], c0[3]};
@@ -983,7 +1013,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (PACKED && !COLOR) k4n |= (act[j] ? k1[j] : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
+        if (PACKED && !COLOR && !TSDF_SWAR_K) k4n |= (act[j] ? k1[j] : (kw[j] & 0xff000000u)) >> (24 - 8 * j);
         wn_u[j] = act[j] ? __float_as_uint(wv[j]) : w0u[j];
         cv[j] = act[j] ? cv[j] : c0[j];
         diff_w |= wn_u[j] ^ w0u[j];
@@ -992,6 +1022,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (COUNT && PACKED) imp += act[j] && !d_read ? 1u : 0u;  // observed voxels whose distance word was not read
         if (COUNT)  // bytes of voxel words whose VALUE changed: what any layout-preserving kernel has to write
           chg += (!PACKED && wn_u[j] != w0u[j] ? 4u : 0u) + (COLOR && cv[j] != c_before[j] ? 4u : 0u);
+      }
+      if (PACKED && !COLOR && TSDF_SWAR_K) {
+        // The four counts of the quad in one word (TSDF_SWAR_K): k' = k + (observed && k < kmax) per byte, == min(k + 1, kmax)
+        // for every count the layout can hold (k <= kmax).  "k < kmax" for all four at once: the even and the odd bytes sit
+        // in 16-bit fields with bit 8 set on top; after subtracting kmax from each field that bit survives exactly where
+        // k >= kmax (256 + k - kmax stays within the field: no borrow crosses it).  ~13 operations instead of 28 per quad.
+        const uint32_t km2 = a.kmax * 0x00010001u;
+        const uint32_t te = ((k4 & 0x00ff00ffu) | 0x01000100u) - km2, to = (((k4 >> 8) & 0x00ff00ffu) | 0x01000100u) - km2;
+        const uint32_t lt = ((~te >> 8) & 0x00010001u) | (((~to >> 8) & 0x00010001u) << 8);  // 0x01 in byte j: k_j < kmax
+        const uint32_t actb = (act[0] ? 0x00000001u : 0u) | (act[1] ? 0x00000100u : 0u) | (act[2] ? 0x00010000u : 0u) | (act[3] ? 0x01000000u : 0u);
+        k4n = k4 + (lt & actb);
       }
       if (COUNT && PACKED && !COLOR) chg += (unsigned)__popc(((k4n ^ k4) | ((k4n ^ k4) >> 1) | ((k4n ^ k4) >> 2) | ((k4n ^ k4) >> 3) |
                                                             ((k4n ^ k4) >> 4) | ((k4n ^ k4) >> 5) | ((k4n ^ k4) >> 6) | ((k4n ^ k4) >> 7)) & 0x01010101u);
