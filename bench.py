@@ -462,10 +462,14 @@ def main():
     size3 = tuple(r * voxel for r in res3)
     S = size3[0]
     W, H = args.width, args.height
-    slab_gb = (z_end - z_begin) * res * res * 8 / 2 ** 30
-    if slab_gb > 250:
-        raise SystemExit(f"a {z_end - z_begin}-plane slab of a {res}x{res} grid is {slab_gb:.0f} GiB: use more GPUs "
-                         f"(configs[4] needs >= 4)")
+    bytes_per_voxel = (12 if args.color else 8) if args.layout == "f32w" else (8 if args.color else 5)
+    slab_gb = (z_end - z_begin) * res * res * bytes_per_voxel / 2 ** 30
+    free_gb_before = torch.cuda.mem_get_info(dev)[0] / 2 ** 30
+    # preflight: the slab's planes (configs[4]: 512 planes of 4096^2 = 64 GiB PACKED, 103 GB with float weights) must fit THIS
+    # rank's GPU next to what is already on it -- said here, in plain words, instead of as a hipMalloc failure inside create
+    if slab_gb > 250 or slab_gb * 1.02 + 1.0 > free_gb_before:
+        raise SystemExit(f"rank {rank}: a {z_end - z_begin}-plane slab of a {res}x{res} grid needs {slab_gb:.0f} GiB of HBM, "
+                         f"{free_gb_before:.0f} GiB are free on cuda:{local_rank}: use more GPUs (configs[4] needs >= 4) or fewer --planes")
     sc = synth.Scene(S, W, H)  # sphere + far-face box scaled to the x/y extent
     if res3[2] != res3[0]:
         sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
@@ -657,6 +661,7 @@ def main():
 
     t = torch.tensor([wall, kern_ms, n_obs_rank, chg_rank], dtype=torch.float64, device=dev)
     per_rank_kernel_ms = [kern_ms]
+    per_rank_observed = [n_obs_rank]
     if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -665,6 +670,9 @@ def main():
         allk = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
         dist.all_gather(allk, t[1:2].clone())
         per_rank_kernel_ms = [float(x) for x in allk]
+        allo = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allo, t[2:3].clone())
+        per_rank_observed = [float(x) for x in allo]   # load balance of the Z-slabs: observed voxels per frame and slab
         wall = float(tmax[0])
         n_obs_all = float(tsum[2])
     else:
@@ -785,9 +793,21 @@ def main():
         if args.dry_run_ranks:
             out["dry_run"] = f"{world} ranks on ONE GPU over gloo: control flow only, no number here is a scaling number"
         if use_dist:
+            n_dev = torch.cuda.device_count()
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # (a build without the nccl bindings: say so instead of dying in a report field)
+                rccl = repr(e)
             out["multi_gpu"] = {"host": "one process per GPU, torch.distributed", "world_size": dist.get_world_size(),
                                 "per_rank_kernel_ms": per_rank_kernel_ms, "frame_broadcast_ms_isolated": bcast_ms,
-                                "overlap": bool(args.overlap), "backend": backend, "planes_per_gpu": z_end - z_begin}
+                                "overlap": bool(args.overlap), "backend": backend, "planes_per_gpu": z_end - z_begin,
+                                # what the first run on a real node should show at a glance
+                                "observed_voxels_per_rank": per_rank_observed,
+                                "kernel_ms_spread": (max(per_rank_kernel_ms) / min(per_rank_kernel_ms)) if min(per_rank_kernel_ms) > 0 else None,
+                                "rccl_version": rccl, "visible_devices": n_dev,
+                                "peer_access": [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n_dev)]
+                                                for i in range(n_dev)],
+                                "slab_hbm_gib_per_rank": slab_gb, "free_hbm_gib_before_create_rank0": free_gb_before}
         if calibration:
             out["calibration"] = calibration
         if world == 1 and args.extras:

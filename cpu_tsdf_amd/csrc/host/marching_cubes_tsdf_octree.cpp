@@ -47,6 +47,7 @@ static bool run_march(const TSDFVolumeOctree::ConstPtr &vol, float w_min, int mo
     PCL_ERROR("[cpu_tsdf::MarchingCubesTSDFOctree::reconstruct] no TSDF volume set (or reset() not called)\n");
     return false;
   }
+  if (!vol->cubicForQueries("MarchingCubesTSDFOctree::reconstruct")) return false;
   uint64_t n_tri = 0;
   int rc = tsdf_hip_march(vol->handle(), w_min, mode, &n_tri);
   if (rc == 0 && n_tri) {

@@ -147,6 +147,11 @@ class TSDFVolumeOctree : public TSDFInterface {
 
  private:
   bool ready(const char *who) const;
+ public:
+  // false (and a PCL_ERROR) if setGridSize was not a cube: renderView / getFxn... / MarchingCubesTSDFOctree refuse then
+  // (the reference mixes two geometries there; see the definition)
+  bool cubicForQueries(const char *who) const;
+ private:
   tsdf_params p_;
   tsdf_handle h_;
   float max_cell_size_[3];

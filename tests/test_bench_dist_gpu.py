@@ -61,6 +61,11 @@ def test_bench_two_ranks_one_gpu_over_gloo(gpu, overlap):
             {"TSDF_BENCH_ONE_DEVICE": "1", "TSDF_BENCH_BACKEND": "gloo"})
     check_contract(j, 2)
     assert j["multi_gpu"]["planes_per_gpu"] == 128 and len(j["multi_gpu"]["per_rank_kernel_ms"]) == 2
+    # the diagnostics of the first run on a real node: load balance, peer access, RCCL, HBM preflight
+    mg = j["multi_gpu"]
+    assert len(mg["observed_voxels_per_rank"]) == 2 and sum(mg["observed_voxels_per_rank"]) == j["config"]["observed_voxels_per_frame"]
+    assert mg["peer_access"][0][0] is True and mg["visible_devices"] >= 1 and mg["rccl_version"]
+    assert 0 < mg["slab_hbm_gib_per_rank"] < mg["free_hbm_gib_before_create_rank0"] and mg["kernel_ms_spread"] >= 1.0
     # every voxel is observed by exactly one slab: the two ranks' counts add up to the single-handle count
     assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
 
