@@ -315,7 +315,14 @@ pcl::PointCloud<pcl::PointNormal>::Ptr TSDFVolumeOctree::renderView(const Eigen:
   const int new_height = p_.image_height / downsampleBy;
   pcl::PointCloud<pcl::PointNormal>::Ptr cloud(new pcl::PointCloud<pcl::PointNormal>(new_width, new_height));
   cloud->is_dense = false;
-  if (!ready("renderView") || !cubicForQueries("renderView")) return cloud;  // (an all-NaN cloud, is_dense = false)
+  if (!ready("renderView") || !cubicForQueries("renderView")) {  // an all-NaN cloud (every ray a miss), is_dense = false
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    for (size_t i = 0; i < cloud->size(); ++i) {
+      pcl::PointNormal &pt = cloud->points[i];
+      pt.x = pt.y = pt.z = pt.normal_x = pt.normal_y = pt.normal_z = nan;
+    }
+    return cloud;
+  }
   const Eigen::Matrix3f rot = trans.rotation().cast<float>();     // :303
   const Eigen::Vector3f org = trans.translation().cast<float>();  // :304
   float r9[9], o3[3];

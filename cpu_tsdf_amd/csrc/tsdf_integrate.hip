@@ -717,7 +717,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // order.  Behind it -- the gather's results first, the voxel words still in flight -- LLVM sinks them below the
       // `if (!any) continue` that follows, sched_barrier or not; the branch round the distance load is what keeps them here.)
       const bool d_read = !PACKED || !(r < 64 && (quiet >> r & 1ull));
-      u4 d4 = {0u, 0u, 0u, 0u};
+      // (no initial value: where the distance words are not read they are either rebuilt from the counts -- a wave in which a
+      // distance can move -- or never looked at; four v_mov per row for a value nobody reads were 2 % of the row's operations)
+      u4 d4;
+      asm volatile("" : "=v"(d4));
       u4 w4 = {0u, 0u, 0u, 0u}, c4 = {0u, 0u, 0u, 0u};
       uint32_t k4 = 0u;
       // TSDF_EARLY_VOXEL_LOADS == 2 (round 5): only the quads PREDICTED to be observed ask early -- the predictor is the quad's
