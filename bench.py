@@ -333,6 +333,7 @@ def fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, packed
             "voxels_observed_per_frame": per_frame / (2 * n_pairs), "changed_word_bytes_per_launch": chg,
             "distance_words_not_read_per_launch": imp,
             "plane_bytes_requested_per_launch": req,
+            "bytes_moved_per_launch": req + chg + 2 * (8 if args.color else 4) * W * H,
             "frac_of_hbm_peak_by_bytes_moved": (req + chg + 2 * (8 if args.color else 4) * W * H) / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "achieved_GBps": alg / (ms_launch * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "report-only: tsdf_hip_integrate_device2 reads and writes each voxel word once per PAIR of frames; the planes "

@@ -93,6 +93,19 @@ def main():
                                  "bench_line_fetch_pass": bf["roofline"]["kernel_ms"]},
         "frac_of_8TBps_by_traffic": (rd + wr) / (trace[timed_instance(trace)]["duration_ns"] * 1e-9) / 8e12,
     }
+    # k_integrate2 (two frames per sweep: the bench line's extras.fused2 leg), when the profiled command ran it: its own
+    # counters instead of an algorithmic estimate
+    if "k_integrate2" in fetch and "k_integrate2" in write and "k_integrate2" in trace:
+        rd2 = fetch["k_integrate2"]["FETCH_SIZE"] * 1024 * round(cal_r)
+        wr2 = write["k_integrate2"]["WRITE_SIZE"] * 1024 * round(cal_w)
+        ms2 = trace["k_integrate2"]["duration_ns"] / 1e6
+        f2 = (bt.get("extras") or {}).get("fused2") or {}
+        out[key]["fused2"] = {"kernel": "k_integrate2", "launches_averaged": fetch["k_integrate2"]["dispatches"],
+                              "read_bytes_per_launch": rd2, "written_bytes_per_launch": wr2, "hbm_bytes_per_launch": rd2 + wr2,
+                              "hbm_bytes_per_frame": (rd2 + wr2) / 2, "kernel_ms_trace_avg": ms2, "ms_per_frame": ms2 / 2,
+                              "frac_of_8TBps_by_traffic": (rd2 + wr2) / (ms2 * 1e-3) / 8e12,
+                              "bench_line_ms_per_frame_same_run": f2.get("ms_per_frame"),
+                              "kernel_counted_bytes_per_launch": f2.get("bytes_moved_per_launch")}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out[key], indent=1))
 
