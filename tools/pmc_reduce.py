@@ -24,7 +24,7 @@ def names(name):
     for key in KEYS:
         if key in name:
             m = re.search(re.escape(key) + r"<([^>]*)>", name)
-            if m and key in ("k_integrate", "k_mc_classify", "k_raycast", "k_calib_read"):
+            if m and key in ("k_integrate", "k_integrate2", "k_mc_classify", "k_raycast", "k_calib_read"):
                 return [key, key + "<" + m.group(1).replace(" ", "") + ">"]
             return [key]
     return [name[:48]]
