@@ -467,6 +467,17 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
 #define TSDF_WPE_PACKED 7  // waves per SIMD the non-counting ALLIN instances ask for: 72 VGPRs, reachable since the x products are redone per
                            // row (TSDF_RECOMPUTE_PX)
 #endif
+#ifndef TSDF_WPE_PACKED_COLOR
+#define TSDF_WPE_PACKED_COLOR 8  // ... and the timed colour instance (ALLIN, PACKED, colour, certified projection): 64 VGPRs.  Round 4
+                                 // measured 8 waves at 21.4 ms (spills on the row path); after round 5's diet the row body fits
+                                 // (no spill reload on the row path, tools/isa_guard.py) and the eighth wave buys 1.5-2 %: 13.31 / 13.48
+                                 // against 13.63 / 13.65 ms, the configs[4] slab 13.11 against 13.25 (profiles/r05_ab_eight_waves_call19.txt).
+                                 // The colourless instance stays at TSDF_WPE_PACKED: it fits 8 waves as it is (49 VGPRs), and asking
+                                 // for them shrinks its scalar budget (9.51 against 9.07 ms)
+#endif
+// waves per SIMD an instance asks for
+#define TSDF_WPE_OF(ORDER, COLOR, FASTPROJ, COUNT, PACKED, ALLIN) \
+  ((ALLIN) && !(COUNT) && (PACKED) && (COLOR) && (FASTPROJ) ? TSDF_WPE_PACKED_COLOR : (ALLIN) && !(COUNT) && ((PACKED) || !(COLOR)) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL)
 #ifndef TSDF_WPE_GENERAL
 #define TSDF_WPE_GENERAL 7  // ... and every other instance (general, row intervals, counting): 72 VGPRs + two dozen SGPRs spilled into
                             // VGPR lanes + 30-60 B of scratch, 17.7 against 18.7 ms at 2048^3 + colour (round 4).  Round 3 kept these at 6
@@ -491,7 +502,7 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
 // alternative -- an ALLIN pass over the blocks flagged 1 plus an interval pass over those flagged 2 -- was built and
 // measured slower, profiles/r04_refcull_dual_launch_measured_and_removed.txt.)
 template <int ORDER, bool COLOR, bool FASTPROJ, bool COUNT, bool PACKED, bool ALLIN = false, bool LIVE = false>
-static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) < TSDF_WPE_MAX ? (ALLIN && !COUNT && (PACKED || !COLOR) ? TSDF_WPE_PACKED : TSDF_WPE_GENERAL) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_WPE_OF(ORDER, COLOR, FASTPROJ, COUNT, PACKED, ALLIN) < TSDF_WPE_MAX ? TSDF_WPE_OF(ORDER, COLOR, FASTPROJ, COUNT, PACKED, ALLIN) : TSDF_WPE_MAX, TSDF_WPE_MAX)))
 k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt, uint32_t *__restrict__ RGB,
             uint8_t *__restrict__ K8, const float *__restrict__ depth, const double *__restrict__ cam,
             const float *__restrict__ ctrx, const float *__restrict__ ctry, const float *__restrict__ ctrz,

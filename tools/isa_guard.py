@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 # mangled-name prefix -> (what, max VGPRs, max scratch bytes, least occupancy)
 BUDGET = {
-    "_ZL11k_integrateILi0ELb1ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED colour (headline)", 72, 16, 7),
+    "_ZL11k_integrateILi0ELb1ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED colour (headline)", 64, 16, 8),
     "_ZL11k_integrateILi0ELb0ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED no colour", 64, 16, 8),
     "_ZL12k_integrate2ILi0ELb1ELb0E": ("k_integrate2 colour", 96, 0, 5),
     "_ZL12k_integrate2ILi0ELb0ELb0E": ("k_integrate2 no colour", 96, 0, 5),

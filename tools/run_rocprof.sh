@@ -8,6 +8,7 @@
 # bench.py warms up through the COUNTING instance of k_integrate, so the non-counting instance in every table is
 # exactly the timed launches (first-after-reset launch excluded).  Outputs: gpurun_out/prof_<tag>/;
 # tools/pmc_reduce.py -> summary_*.json; tools/make_profile_summary.py <tag> copies the judged parts to profiles/.
+# (every rocprofv3 command runs under `timeout 400`: a counter pass that aborts inside the tool can otherwise sit until gpurun's limit)
 # usage: tools/run_rocprof.sh TAG [STEPS [PMC_STEPS [EXTRA_BENCH_ARGS [lite]]]]
 #   EXTRA_BENCH_ARGS  e.g. "--layout f32w", "--color 0", "--res 4096 --planes 512 --width 1280 --height 960": another
 #                     pmc_traffic.json key (bench.py quotes roofline.traffic per key);  lite = trace + FETCH + WRITE only
@@ -24,17 +25,17 @@ ROOT=$(pwd)
 cd /tmp
 BENCH="python $ROOT/bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 --host-path 0 $EXTRA"
 [ -n "$LITE" ] && BENCH="$BENCH --extras 0"
-rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
+timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
   $BENCH --steps $STEPS > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$C -o pmc --output-format csv -- \
+  timeout 400 rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$C -o pmc --output-format csv -- \
     $BENCH --steps $PMC_STEPS --calib 2 > $ROOT/$OUT/bench_pmc_$C.json 2> $ROOT/$OUT/bench_pmc_$C.err
 done
 if [ -z "$LITE" ]; then
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
   -d $ROOT/$OUT/pmc_SQ -o pmc --output-format csv -- \
   $BENCH --steps $PMC_STEPS > $ROOT/$OUT/bench_pmc_SQ.json 2> $ROOT/$OUT/bench_pmc_SQ.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD TCC_HIT_sum TCC_MISS_sum \
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD TCC_HIT_sum TCC_MISS_sum \
   -d $ROOT/$OUT/pmc_SQ2 -o pmc --output-format csv -- \
   $BENCH --steps $PMC_STEPS > $ROOT/$OUT/bench_pmc_SQ2.json 2> $ROOT/$OUT/bench_pmc_SQ2.err
 fi
