@@ -24,6 +24,7 @@ TEST_OBJDIR = os.path.join(_HERE, "lib", "obj_test")
 SHELL_LIB = os.path.join(LIBDIR, "libcpu_tsdf_hip.so")
 PROG = os.path.join(CSRC, "prog")
 BINDIR = os.path.join(_HERE, "bin")
+EXPORTS = os.path.join(CSRC, "exports.map")
 
 # -ffp-contract=off: the reference CPU build has no FMA (no -march in its CMakeLists.txt), and
 # per-voxel parity needs the same separate mul/add roundings on the GPU.
@@ -46,7 +47,7 @@ def _stale(target, deps):
 
 
 def needs_build(test_hooks=False):
-    return _stale(TEST_LIB if test_hooks else LIB, sources() + _headers())
+    return _stale(TEST_LIB if test_hooks else LIB, sources() + _headers() + [EXPORTS])
 
 
 def _hipcc():
@@ -82,7 +83,8 @@ def build_hip(force=False, verbose=False, test_hooks=False):
     objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in sources()]
     # -Bsymbolic: calls between the library's own entry points stay inside it, whatever else the process has loaded (the
     # product and the test build can sit in one process: the C++ drop-in links the former, the Python tests load the latter)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", lib]
+    # --version-script: the dynamic symbol table holds the tsdf_hip_* entry points and nothing else (csrc/exports.map)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-Wl,--version-script=" + EXPORTS] + objs + ["-o", lib]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

@@ -451,6 +451,12 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
 #ifndef TSDF_EXP_NO_VLOAD
 #define TSDF_EXP_NO_VLOAD 0
 #endif
+#if TSDF_EXP_NO_VLOAD && TSDF_EARLY_VOXEL_LOADS
+#error "TSDF_EXP_NO_VLOAD declares the voxel words itself: build it with -DTSDF_EARLY_VOXEL_LOADS=0 (tools/ab_bound.sh does)"
+#endif
+#if !TSDF_GUARD_ON_RESULT && TSDF_EARLY_VOXEL_LOADS
+#error "TSDF_GUARD_ON_RESULT=0 tests the numerator d0 * w0 + dn BEFORE unread distance words are rebuilt from the counts, and with TSDF_EARLY_VOXEL_LOADS those words have no initial value: build that A/B with -DTSDF_EARLY_VOXEL_LOADS=0"
+#endif
 #ifndef TSDF_GATHER_AUX
 #define TSDF_GATHER_AUX 0  // cache policy of the ALLIN instance's frame gather (A/B: the default keeps the frame in L2)
 #endif

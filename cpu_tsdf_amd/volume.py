@@ -16,6 +16,11 @@ from . import capi
 from .synth import cam_from_vol_f32, eigen_affine_inverse
 
 
+class NonCubicQueryWarning(UserWarning):
+    """renderView / getFxn / reconstruct on a non-cubic setGridSize: answered on the flat grid's geometry (see
+    TSDFVolumeOctree._cubic_for_queries)."""
+
+
 class TSDFVolumeOctree:
     """Drop-in for ``cpu_tsdf::TSDFVolumeOctree`` (flat SoA grid in HBM instead of an octree)."""
 
@@ -314,11 +319,31 @@ class TSDFVolumeOctree:
         self._is_empty = False
         return int(c.value) if count else True
 
+    def _cubic_for_queries(self, who):
+        """The C++ shell REFUSES the queries on a non-cubic setGridSize (TSDFVolumeOctree::cubicForQueries,
+        csrc/host/tsdf_volume_octree.cpp: the reference looks per-axis voxel indices, tsdf_volume_octree.cpp:553-574, up in an
+        octree that is a cube of edge size_x, octree.cpp:244-266 -- a mixture of two geometries a flat grid does not
+        reproduce).  This front end is also what the Z-slab hosts, the bench's slabs and the full-size tests drive, whose
+        grids are deliberately flat and non-cubic, so it answers on the flat-grid geometry -- and says so: a
+        NonCubicQueryWarning, once per call site (the two front ends used to disagree silently).
+        ``strict_noncubic = True`` on the object turns the warning into the C++ shell's refusal (ValueError)."""
+        sx, sy, sz = (float(v) for v in self._p.size)
+        if sx == sy and sx == sz:
+            return
+        msg = (f"TSDFVolumeOctree.{who}: grid size {sx:g} x {sy:g} x {sz:g} is not a cube: the reference mixes per-axis closed-form "
+               "indices with an octree that is a cube of edge size_x; this answer is for the flat grid's own geometry "
+               "(the C++ drop-in refuses this call)")
+        if getattr(self, "strict_noncubic", False):
+            raise ValueError(msg)
+        import warnings
+        warnings.warn(msg, NonCubicQueryWarning, stacklevel=3)
+
     def renderView(self, trans=None, downsampleBy=1, camera_frame=True, pinned=False):
         """tsdf_volume_octree.cpp:278-424.  Returns (H/ds, W/ds, 8) float32: xyz, normal, t*, iterations.
         With camera_frame (the reference's behaviour) xyz/normal are moved back by trans^-1 (:422).
         pinned: the result is a view of a pinned buffer owned by this volume, which the GPU writes by DMA (no host
         copy); it is overwritten by the next pinned renderView of the same size."""
+        self._cubic_for_queries("renderView")
         h = self._need()
         trans = np.eye(4) if trans is None else np.asarray(trans, dtype=np.float64)
         ds = int(downsampleBy)
@@ -414,6 +439,7 @@ class TSDFVolumeOctree:
 
     def sample(self, pts, want_grad=True, want_hess=True):
         """getFxn / getGradient / getHessian (tsdf_volume_octree.cpp:655-828), batched."""
+        self._cubic_for_queries("getFxn / getGradient / getHessian")
         h = self._need()
         pts = capi.f32c(pts).reshape(-1, 3)
         n = pts.shape[0]
@@ -577,6 +603,7 @@ class MarchingCubesTSDFOctree:
         """marching_cubes_tsdf_octree.cpp:108-143.  Returns dict(vertices (3n,3) float32 after the global
         transform, polygons (n,3) int32 = [3i,3i+1,3i+2], rgb (3n,3) uint8 or None, cells)."""
         vol = self._vol
+        vol._cubic_for_queries("MarchingCubesTSDFOctree.reconstruct")
         h = vol._need()
         lib = capi.load()
         mode = 2 if self._by_conf else (1 if self._by_rgb else 0)

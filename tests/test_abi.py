@@ -24,6 +24,13 @@ def exported(path):
     return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("tsdf_hip_"))
 
 
+def dynamic_symbols(path):
+    """EVERY defined name of the dynamic symbol table, whatever its type."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+
+
 def test_library_loads_and_exports_every_declared_symbol():
     lib = capi.load()
     names = declared_functions()
@@ -43,6 +50,10 @@ def test_the_product_library_exports_the_boundary_and_nothing_else():
     assert all("selftest" in n or n == "tsdf_hip_set_tuning" for n in hooks) and len(hooks) == 18
     assert exported(capi.PRODUCT_LIB_PATH) == product
     assert exported(capi.TEST_LIB_PATH) == sorted(product + hooks)
+    # ... and nothing else of ANY kind (C++ internals such as _Z11tsdf_tuningv used to be dynamic symbols;
+    # cpu_tsdf_amd/csrc/exports.map keeps everything that is not tsdf_hip_* local)
+    assert dynamic_symbols(capi.PRODUCT_LIB_PATH) == product
+    assert dynamic_symbols(capi.TEST_LIB_PATH) == sorted(product + hooks)
     assert sorted(capi.SIGNATURES) == product and sorted(capi.TEST_SIGNATURES) == hooks
     # the product binds without the hooks (a fresh interpreter: this process runs on the test build)
     import subprocess
@@ -175,3 +186,25 @@ def test_python_mirror_voxel_center_and_index_equal_the_reference():
             ok, mine = v.getVoxelIndex(x, y, z)
             assert ok == inside and mine == tuple(idx), (x, y, z, mine, tuple(idx))
         ref.close()
+
+
+def test_python_front_end_flags_queries_on_a_non_cubic_grid_size():
+    """the C++ shell refuses renderView / getFxn / reconstruct on a non-cubic setGridSize (cubicForQueries); the
+    Python classes answer on the flat grid's geometry (Z-slab hosts, the bench's slabs) -- with a NonCubicQueryWarning, or the
+    same refusal under strict_noncubic.  The check runs before any device call, so no GPU is needed."""
+    import warnings
+    from cpu_tsdf_amd.volume import MarchingCubesTSDFOctree, NonCubicQueryWarning, TSDFVolumeOctree
+    v = TSDFVolumeOctree()
+    v.setGridSize(4.0, 4.0, 4.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        v._cubic_for_queries("renderView")  # a cube: silent
+    v.setGridSize(4.0, 4.0, 0.5)
+    with pytest.warns(NonCubicQueryWarning, match="not a cube"):
+        v._cubic_for_queries("renderView")
+    v.strict_noncubic = True
+    mc = MarchingCubesTSDFOctree()
+    mc.setInputTSDF(v)
+    for call in (lambda: v.renderView(), lambda: v.getFxn(np.zeros((1, 3), np.float32)), lambda: mc.reconstruct()):
+        with pytest.raises(ValueError, match="not a cube"):
+            call()

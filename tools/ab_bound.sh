@@ -4,7 +4,7 @@
 # (gpurun -- tools/ab_bound.sh run): one bench line per variant into gpurun_out/ab_bound/.
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS="base: wpe5:-DTSDF_WPE_MAX=5 wpe4:-DTSDF_WPE_MAX=4 wpe3:-DTSDF_WPE_MAX=3 nostore:-DTSDF_EXP_NO_STORE=1 nogather:-DTSDF_EXP_NO_GATHER=1 novload:-DTSDF_EXP_NO_VLOAD=1 novload_nostore:-DTSDF_EXP_NO_VLOAD=1,-DTSDF_EXP_NO_STORE=1 ${EXTRA_VARIANTS}"
+VARIANTS="base: wpe5:-DTSDF_WPE_MAX=5 wpe4:-DTSDF_WPE_MAX=4 wpe3:-DTSDF_WPE_MAX=3 nostore:-DTSDF_EXP_NO_STORE=1 nogather:-DTSDF_EXP_NO_GATHER=1 novload:-DTSDF_EXP_NO_VLOAD=1,-DTSDF_EARLY_VOXEL_LOADS=0 novload_nostore:-DTSDF_EXP_NO_VLOAD=1,-DTSDF_EARLY_VOXEL_LOADS=0,-DTSDF_EXP_NO_STORE=1 ${EXTRA_VARIANTS}"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do n=${v%%:*}; f=${v#*:}; python tools/build_variant.py $n ${f//,/ } > /dev/null & done; wait
   ls cpu_tsdf_amd/lib/variants/*/libtsdf_hip.so

@@ -22,7 +22,7 @@ def main():
         procs.append(subprocess.Popen([b._hipcc()] + b.HIPCC_FLAGS + ["-DTSDF_HIP_TEST_HOOKS"] + flags + inc + ["-c", src, "-o", obj]))
     if any(p.wait() for p in procs):
         raise SystemExit("hipcc failed")
-    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", os.path.join(out, "libtsdf_hip.so")])
+    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-Wl,--version-script=" + b.EXPORTS] + objs + ["-o", os.path.join(out, "libtsdf_hip.so")])
     print(os.path.join(out, "libtsdf_hip.so"))
 
 

@@ -33,7 +33,14 @@ def assemble(flags):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "integrate.s")
         cmd = [b._hipcc()] + b.HIPCC_FLAGS + list(flags) + ["-I" + os.path.join(ROOT, "include"), "-I" + b.CSRC, "-S", "--cuda-device-only", src, "-o", out]
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        # hipcc warns about the unused --hip-link on every -S run: drop that line, show everything else (a real
+        # compile error used to vanish in DEVNULL)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "argument unused during compilation" not in ln)
+        if err.strip():
+            print(err, file=sys.stderr)
+        if r.returncode:
+            raise SystemExit(f"isa_guard: hipcc -S failed with exit code {r.returncode}")
         return open(out).read().splitlines()
 
 
@@ -41,7 +48,11 @@ def inspect(lines, prefix):
     start = next((i for i, ln in enumerate(lines) if ln.startswith(prefix) and ln.rstrip().endswith(prefix) is False and ":" in ln), None)
     if start is None:
         return None
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    # the kernel's text ends at its .Lfunc_end label (a kernel may hold more than one s_endpgm: early exits); the resource
+    # comments (NumVgprs, ScratchSize, Occupancy ...) follow it
+    end = next((i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")), None)
+    if end is None:
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end + 1]
     meta = "\n".join(lines[end:end + 120])
 
