@@ -84,6 +84,12 @@ def parse():
                     "rocprof run turns it off so that k_integrate's average is the headline workload's alone")
     ap.add_argument("--host", choices=["process", "inprocess"], default="process",
                     help="N>1: one process per GPU over RCCL (default) or ONE process driving all GPUs through tsdf_hip_create_multi")
+    ap.add_argument("--keys", type=int, default=1, help="N=1 with --extras: also time the secondary integrate keys in this run -- the "
+                    "headline grid in the SATURATED regime (w == max_weight), the colourless 2048^3 grid, one configs[4] slab "
+                    "(4096x4096x512, 1280x960) -- each with kernel_ms, bytes moved, frac and its PMC quote (extras.keys)")
+    ap.add_argument("--presaturate", type=int, default=0, help="launches BEFORE the warm-up (cycling through the timed frames): the "
+                    "timed region then runs in the saturated regime w == max_weight (>= 100 for the default max_weight): how "
+                    "tools/run_rocprof.sh profiles that key")
     ap.add_argument("--host-path", type=int, default=1, help="N=1: also time the host-pointer entry point (report-only side field)")
     ap.add_argument("--principal-offset", type=float, default=0.0, help="evidence runs: move the principal point by this fraction "
                     "of the half-width and yaw every turntable camera so that the grid's centre still projects to the image "
@@ -285,6 +291,111 @@ def scene_b_leg(res, color, cpu_seconds):
                 out.update({"cpu_reference_frames_per_s": n / spent, "cpu_cores": cores, "cpu_frames_timed": n})
     except Exception as e:
         out["error"] = repr(e)
+    return out
+
+
+def key_leg(res3, W, H, color, steps=10, warm=2, presaturate=0, slab_of=None):
+    """One SECONDARY bench key in the driver-run line: its own volume (freed before returning),
+    `warm + steps` Scene-A turntable frames resident in HBM, the warm-up through the counting instance, HIP events on the
+    kernel's stream around each of `steps` timed launches, then the same frames once more through the counting instance for
+    the bytes the kernel moves (plane bytes requested + changed words + frame) -- the headline's own definition of
+    roofline.achieved / frac -- and the PMC quote of profiles/pmc_traffic.json for the key while the kernel-source hash
+    matches.  presaturate: launches before the warm-up (the saturated regime: w == max_weight, octree.cpp:157-159)."""
+    import torch
+    from cpu_tsdf_amd import capi, synth
+    from cpu_tsdf_amd.volume import TSDFVolumeOctree, reference_cull_planes
+    out = {}
+    v = None
+    try:
+        voxel = 2.0 ** -8
+        size3 = tuple(r * voxel for r in res3)
+        S = size3[0]
+        sc = synth.Scene(S, W, H)
+        if res3[2] != res3[0]:
+            sc.h = np.array([0.47 * size3[0], 0.47 * size3[1], 0.47 * size3[2]])
+        v = TSDFVolumeOctree()
+        v.setResolution(*res3)
+        v.setGridSize(*size3)
+        v.setImageSize(W, H)
+        v.setCameraIntrinsics(sc.fx, sc.fy, sc.cx, sc.cy)
+        v.setSensorDistanceBounds(0.0, 3.0 * max(size3))
+        v.setDepthTruncationLimits(0.03, 0.03)
+        v.setIntegrateColor(bool(color))
+        stream = torch.cuda.current_stream()
+        v.setStream(stream.cuda_stream)
+        v.reset()
+        lib, h = capi.load(), v._need()
+        n = warm + steps
+        radius = 2.2 * max(size3) / S
+        poses = [synth.turntable_pose(i, n, S, radius_factor=radius) for i in range(n)]
+        T = [synth.cam_from_vol_f32(p) for p in poses]
+        planes = [reference_cull_planes(v._p, p) for p in poses]
+        fr = torch.empty((n, 2 if color else 1, H, W), dtype=torch.float32, device="cuda")
+        for i, p in enumerate(poses):
+            fr[i, 0].copy_(torch.from_numpy(sc.depth(p)))
+            if color:
+                fr[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
+
+        def run(i, count=None):
+            capi.check(lib.tsdf_hip_set_reference_cull(h, capi.as_f32p(planes[i])), "set_reference_cull")
+            capi.check(lib.tsdf_hip_integrate_device(h, C.c_void_p(fr[i, 0].data_ptr()), C.c_void_p(fr[i, 1].data_ptr()) if color else None,
+                                                     capi.as_f32p(T[i]), count), "key_leg")
+        for k in range(presaturate):
+            run(warm + k % steps)
+        c = C.c_uint64(0)
+        for i in range(warm):
+            run(i, C.byref(c))
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for k in range(steps):
+            ev[k][0].record(stream)
+            run(warm + k)
+            ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        info = (C.c_int32 * 4)()
+        capi.check(lib.tsdf_hip_last_launch_info(h, info), "last_launch_info")
+        detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 3)()
+        n_obs = chg = req = imp = 0
+        for k in range(steps):
+            run(warm + k, C.byref(c))
+            capi.check(lib.tsdf_hip_last_count_detail(h, detail), "last_count_detail")
+            capi.check(lib.tsdf_hip_last_read_detail(h, rdet), "last_read_detail")
+            n_obs += int(detail[0]); chg += int(detail[1]); imp += int(rdet[0]); req += int(rdet[2])
+        n_obs, chg, imp, req = n_obs / steps, chg / steps, imp / steps, req / steps
+        packed = v.getLayout() == capi.LAYOUT_PACKED
+        bpp = 8 if color else 4
+        read_bpv = ((8 if color else 5) if packed else (12 if color else 8))
+        moved = (req if req else read_bpv * n_obs - 4 * imp) + chg + bpp * W * H
+        sha = kernel_sha16()
+        key = f"{res3[0]}x{res3[1]}x{res3[2]}_c{int(bool(color))}_{'packed' if packed else 'f32w'}" + ("_saturated" if presaturate else "")
+        prof, why = pmc_traffic(key, sha)
+        out = {"key": key, "grid": list(res3), "image": [W, H], "color": bool(color), "layout": "packed" if packed else "f32w",
+               "presaturate_launches": presaturate, "steps": steps,
+               "instance": {0: "general", 1: "ALLIN", 2: "k_integrate2"}.get(int(info[0]) & 0xff, "?") + (" + row intervals" if info[2] else "") +
+                           (", software-pipelined row loop (k_integrate_p)" if int(info[0]) & 0x100 else ""),
+               "kernel_ms": ms, "frames_per_s": 1e3 / ms, "Mvoxels_per_s": float(res3[0]) * res3[1] * res3[2] / (ms * 1e-3) / 1e6,
+               "observed_voxels_per_frame": n_obs, "distance_words_not_read": imp, "plane_bytes_requested": req,
+               "changed_word_bytes": chg, "bytes_moved_per_launch": moved, "GBps": moved / (ms * 1e-3) / 1e9,
+               "frac": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+               "frac_check": ({"pmc_bytes_per_launch": prof["hbm_bytes_per_launch"], "kernel_counted_bytes_per_launch": moved,
+                               "relative_difference": abs(prof["hbm_bytes_per_launch"] - moved) / prof["hbm_bytes_per_launch"],
+                               "agree_within_5_percent": abs(prof["hbm_bytes_per_launch"] - moved) / prof["hbm_bytes_per_launch"] < 0.05,
+                               "profile_tag": prof.get("tag"), "kernel_ms_in_profile": prof.get("kernel_ms_in_profile")} if prof else {"note": why})}
+        if slab_of:
+            out["note"] = slab_of
+    except Exception as e:  # a report-only leg never breaks the bench line
+        out["error"] = repr(e)
+    finally:
+        if v is not None:
+            v.close()
+        try:
+            import torch as _t
+            _t.cuda.synchronize()
+            _t.cuda.empty_cache()
+        except Exception:
+            pass
     return out
 
 
@@ -613,6 +724,8 @@ def main():
     # Warm-up launches go through the COUNTING template instance of k_integrate (they integrate exactly the same
     # way), so that in a `rocprofv3 --kernel-trace --stats` / --pmc table of this command the non-counting instance
     # holds the K timed launches and nothing else: its averages there are directly comparable with roofline.*.
+    for k in range(args.presaturate):  # the saturated regime: every observed voxel at w == max_weight before anything is timed
+        launch(args.warmup + k % args.steps)
     run(0, args.warmup, counting=True)
     barrier()
     t0 = time.perf_counter()
@@ -625,7 +738,8 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in pairs) / args.steps
     info4 = (C.c_int32 * 4)()
     capi.check(lib.tsdf_hip_last_launch_info(h, info4), "last_launch_info")
-    last_info = {"instance": {0: "general", 1: "ALLIN", 2: "k_integrate2"}.get(int(info4[0]), "?") + (" + row intervals" if info4[2] else ""),
+    last_info = {"instance": {0: "general", 1: "ALLIN", 2: "k_integrate2"}.get(int(info4[0]) & 0xff, "?") + (" + row intervals" if info4[2] else "") +
+                             (", software-pipelined row loop (k_integrate_p)" if int(info4[0]) & 0x100 else ""),
                  "certified_fp32_projection": bool(info4[1]), "reference_cull_decides_voxels": bool(info4[2] == 2), "blocks": int(info4[3])}
 
     # Algorithmic bytes of the timed frames, counted outside the timed region by running the same frames once more
@@ -649,6 +763,49 @@ def main():
             fused2 = fused2_leg(lib, h, frames_dev, T_all, planes_all, args, stream, W, H, vol.getLayout() == capi.LAYOUT_PACKED)
         except Exception as e:  # never let a report-only leg break the bench line
             fused2 = {"error": repr(e)}
+
+    # The SATURATED regime on the headline volume (report-only, extras.keys): after >= 100 more frames every observed voxel
+    # sits at w == max_weight (octree.cpp:157-159) -- where configs[3] spends nine tenths of its 1000 frames -- so the count
+    # byte stops ticking and the colour word is only rewritten where the running average moves a channel.
+    saturated = None
+    if world == 1 and not use_dist and args.extras == 1 and args.keys and not args.presaturate:
+        try:
+            n_pre = 110
+            for k in range(n_pre):
+                launch(args.warmup + k % args.steps)
+            torch.cuda.synchronize(dev)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for k in range(args.steps):
+                pl, dp, cp, tp = bound_args(args.warmup + k)
+                evs[k][0].record(stream)
+                capi.check(set_cull(h, pl) or integ(h, dp, cp, tp, None), "integrate_device")
+                evs[k][1].record(stream)
+            torch.cuda.synchronize(dev)
+            sat_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+            del counted[:]
+            run(args.warmup, n_total, counting=True)
+            s_obs, s_chg = sum(c[0] for c in counted) / args.steps, sum(c[1] for c in counted) / args.steps
+            s_imp, s_req = sum(c[2] for c in counted) / args.steps, sum(c[3] for c in counted) / args.steps
+            pk = vol.getLayout() == capi.LAYOUT_PACKED
+            s_bpv = ((8 if args.color else 5) if pk else (12 if args.color else 8))
+            s_moved = (s_req if s_req else s_bpv * s_obs - 4 * s_imp) + s_chg + (8 if args.color else 4) * W * H
+            s_key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if pk else 'f32w'}_saturated"
+            s_prof, s_why = pmc_traffic(s_key, kernel_sha16())
+            saturated = {"key": s_key, "grid": list(res3), "image": [W, H], "color": bool(args.color), "presaturate_launches": n_pre,
+                         "weights": "every observed voxel at w == max_weight (the headline's timed region runs at w <= %d)" % (args.warmup + args.steps),
+                         "steps": args.steps, "kernel_ms": sat_ms, "frames_per_s": 1e3 / sat_ms,
+                         "Mvoxels_per_s": float(res3[0]) * res3[1] * res3[2] / (sat_ms * 1e-3) / 1e6,
+                         "observed_voxels_per_frame": s_obs, "plane_bytes_requested": s_req, "changed_word_bytes": s_chg,
+                         "bytes_moved_per_launch": s_moved, "GBps": s_moved / (sat_ms * 1e-3) / 1e9,
+                         "frac": s_moved / (sat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": s_prof["hbm_bytes_per_launch"] if s_prof else None,
+                         "frac_check": ({"pmc_bytes_per_launch": s_prof["hbm_bytes_per_launch"], "kernel_counted_bytes_per_launch": s_moved,
+                                         "relative_difference": abs(s_prof["hbm_bytes_per_launch"] - s_moved) / s_prof["hbm_bytes_per_launch"],
+                                         "agree_within_5_percent": abs(s_prof["hbm_bytes_per_launch"] - s_moved) / s_prof["hbm_bytes_per_launch"] < 0.05,
+                                         "profile_tag": s_prof.get("tag"), "kernel_ms_in_profile": s_prof.get("kernel_ms_in_profile")}
+                                        if s_prof else {"note": s_why})}
+        except Exception as e:
+            saturated = {"error": repr(e)}
 
     # isolated cost of one frame broadcast (report only)
     bcast_ms = None
@@ -694,7 +851,7 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         moved_gbps = moved_bytes / (kern_ms * 1e-3) / 1e9
         sha = kernel_sha16()
-        key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}"
+        key = f"{res3[0]}x{res3[1]}x{z_end - z_begin}_c{args.color}_{'packed' if packed else 'f32w'}" + ("_saturated" if args.presaturate else "")
         prof, why = pmc_traffic(key, sha)
         # the parsed fraction is the one profiles/ reproduces: when a PMC profile of THIS kernel source exists, the kernel's own
         # byte count must agree with the counters within 5 %; a disagreement is carried in frac_check.agree_within_5_percent
@@ -819,6 +976,18 @@ def main():
                 out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and not use_dist and args.host_path:
             out["host_path"] = host_path_leg(vol, sc, poses, bool(args.color), args.warmup, n_total)
+        if world == 1 and not use_dist and args.extras == 1 and args.keys:
+            # every integrate key in the driver-run line; the headline volume is freed first
+            keys = {}
+            if saturated is not None:
+                keys["saturated"] = saturated
+            vol.close()
+            torch.cuda.empty_cache()
+            if not (res3 == (2048, 2048, 2048) and not args.color and packed):
+                keys["colourless"] = key_leg((2048, 2048, 2048), 640, 480, False)
+            keys["config4_slab"] = key_leg((4096, 4096, 512), 1280, 960, True,
+                                           slab_of="one Z-slab of BASELINE configs[4] (4096^3 over 8 GPUs = 512 planes per GPU), 1280x960 frames")
+            out["extras"]["keys"] = keys
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sc, res3, size3, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -57,7 +57,8 @@ static TsdfTuning &tuning_storage() {
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
-                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1), env_int("TSDF_HIP_IMPLIED_D", 1)};
+                         env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1), env_int("TSDF_HIP_IMPLIED_D", 1),
+                         env_int("TSDF_HIP_PIPE", 1)};
   return t;
 }
 
@@ -101,6 +102,8 @@ extern "C" int tsdf_hip_set_tuning(const char *name, int value) {
     t.fuse2 = value;
   else if (n == "implied_d")
     t.implied_d = value;
+  else if (n == "pipe")
+    t.pipe = value;
   else if (n == "live_log2tx")
     t.live_log2tx = value;
   else if (n == "zfast")

@@ -494,6 +494,67 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
                             // tests/test_integrate_gpu.py::test_every_reachable_k_integrate_instance_equals_the_oracle now gates every
                             // instance of the shipped build
 #endif
+// TSDF_PHASE_TIMER (diagnostic build only, never shipped: tools/build_variant.py phase -DTSDF_PHASE_TIMER=1): a thread trace in
+// software.  This image has no decoder library for rocprofv3 --att (profiles/r06_att_attempt.txt), so the row loop times
+// ITSELF: every wave reads the shader clock (s_memtime) at the phase boundaries of a row and adds the differences to a dozen
+// lane-private accumulators (VGPRs: opaque to the compiler, so they do not raise the scalar register pressure), one atomic add
+// per accumulator and wave at the end into 1024 striped slots of g_phase; the host sums them after each launch and appends a
+// line to $TSDF_HIP_PHASE_FILE.  A mark names the values its phase produced as asm inputs, so the compiler's s_waitcnt for
+// them falls in front of it: the interval that ends there INCLUDES the wait.  Reading the clock costs a scalar-memory round
+// trip per mark (the kernel runs ~1.6x slower): the SHARES of the phases are what this build is for, not its time.
+#ifndef TSDF_PHASE_TIMER
+#define TSDF_PHASE_TIMER 0
+#endif
+#if TSDF_PHASE_TIMER
+#define TSDF_NPHASE 16
+__device__ unsigned long long g_phase[1024 * TSDF_NPHASE];
+static __device__ __forceinline__ uint32_t tsdf_clock_lo() {
+  uint64_t t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (uint32_t)t;
+}
+#define TSDF_NACC 9  // lane-private accumulators that live across the row loop: phases 0-7 + the count of observed rows (8)
+#define PT_DECL                                                   \
+  uint32_t pt_acc[TSDF_NACC];                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < TSDF_NACC; ++i_) asm volatile("v_mov_b32 %0, 0" : "=v"(pt_acc[i_])); \
+  const unsigned pt_blk = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) & 1023u; \
+  uint32_t pt_prev = tsdf_clock_lo();                             \
+  const uint32_t pt_t0 = pt_prev
+#define PT_MARK(k)                           \
+  do {                                       \
+    const uint32_t pt_now = tsdf_clock_lo(); \
+    pt_acc[k] += pt_now - pt_prev;           \
+    pt_prev = pt_now;                        \
+  } while (0)
+/* outside the row loop: straight to the global slot, nothing kept in a register */                    \
+
+#define PT_MARK_OUT(k)                                                                                 \
+  do {                                                                                                 \
+    const uint32_t pt_now = tsdf_clock_lo();                                                           \
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase[pt_blk * TSDF_NPHASE + (k)], (unsigned long long)(pt_now - pt_prev)); \
+    pt_prev = pt_now;                                                                                  \
+  } while (0)
+#define PT_COUNT(k) pt_acc[k] += 1u
+#define PT_DEP4(a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_) : "memory")
+#define PT_DEP1(a_) asm volatile("" ::"v"(a_) : "memory")
+#define PT_FLUSH()                                                                                       \
+  do {                                                                                                   \
+    const uint32_t pt_now = tsdf_clock_lo();                                                             \
+    if ((threadIdx.x & 63u) == 0u) {                                                                     \
+      atomicAdd(&g_phase[pt_blk * TSDF_NPHASE + 15], (unsigned long long)(pt_now - pt_t0));              \
+      _Pragma("unroll") for (int i_ = 0; i_ < TSDF_NACC; ++i_)                                           \
+          atomicAdd(&g_phase[pt_blk * TSDF_NPHASE + i_], (unsigned long long)pt_acc[i_]);                \
+    }                                                                                                    \
+  } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#define PT_MARK_OUT(k)
+#define PT_COUNT(k)
+#define PT_DEP4(a_, b_, c_, d_)
+#define PT_DEP1(a_)
+#define PT_FLUSH()
+#endif
 // ALLIN (only with FASTPROJ): the host has proved (launch_integrate, `all_inside`: the slab's eight corner voxels, a
 // convex frustum) that EVERY voxel of the launch passes the sensor-range test of hpp:146 and projects inside the image
 // with a pixel to spare, and nx is a multiple of 4: the per-voxel range compares, the image-bounds compares and the
@@ -517,6 +578,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   // brick-level frustum cull (k_cull below): a block none of whose voxels can be observed leaves at once
   static_assert(!(ALLIN && LIVE), "the ALLIN instance knows no row intervals");
   const BlockCoords bc = tsdf_block_coords(a.zfast);
+  PT_DECL;
   bool strad = false;  // LIVE: this block's rows need their intervals (block-uniform)
   if (LIVE) {
     const unsigned flag = live[bc.bx + bc.gdx * (bc.by + bc.gdy * bc.bz)];
@@ -586,6 +648,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   __syncthreads();
   // bit r: in its pass r over the block's rows this WAVE touches no flagged cell (wave-uniform: one scalar branch per row)
   const uint64_t quiet = PACKED && a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
+  PT_MARK_OUT(9);  // block prologue: tables, row transforms, flags, barrier
   const int tx = (int)(tid & (unsigned)(a.TX - 1));
   const int ty = (int)(tid >> a.log2TX);
   const int xq = (int)bc.bx * a.TX + tx;
@@ -666,6 +729,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         asm volatile("" ::: "memory");  // (a compiler barrier, no instruction: the read below is redone each row, so neither
                                         // the centres nor their products live in registers across the loop)
         project_quad_allin<ORDER>(a, a.m, cam, s_cx[tid], ytv, zt, pix, gzs);
+        PT_DEP4(pix[0], pix[1], pix[2], pix[3]);
+        PT_MARK(0);  // loop control + LDS reads + transform + projection + certificate (+ exact fallback)
       } else {
       unsigned amb_mask = 0;
       uint32_t margin[4] = {0u, 0u, 0u, 0u};  // ALLIN: bits of min(fract(ru), fract(rv)) per voxel
@@ -772,6 +837,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
         }
       }
+      PT_MARK(1);  // early voxel loads + frame gather ISSUED
+      PT_DEP4(zs[0], zs[1], zs[2], zs[3]);
+      PT_MARK(2);  // ... and the gathered depths HAVE ARRIVED (the wait also covers the early voxel words: in-order return)
       // [phase: hinge / normalise (hpp:159-198)]
       // ---- hpp:152-198: NaN test, projective SDF, hinge, normalisation ----------------------------------
       // raw / neg through the scale-free ladder: a surviving raw is 0 or, because g.z >= 2^-14 (else `lowz`),
@@ -819,7 +887,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       const bool asked_early = ask_early;
       pred_obs = any;
 #endif
+      PT_MARK(3);  // raw distances, observed / in-band tests
       if (!any) continue;
+      PT_COUNT(8);
 #if TSDF_EARLY_VOXEL_LOADS == 2
       if (EARLY && !asked_early) {  // an observed quad the predictor missed: its words are requested now
         if (d_read) d4 = bload128(rsD, voff, soff);
@@ -868,6 +938,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         if (COUNT) rdb += (d_read ? 16u : 0u) + (!PACKED ? 16u : 0u) + (COLOR ? 16u : 0u) + (PACKED && !COLOR ? 4u : 0u);
       }
 #endif
+      PT_MARK(4);  // normalise ladder (in-band rows), late loads issued
+      if (COLOR) PT_DEP4(c4.x, c4.y, c4.z, c4.w); else PT_DEP1(k4);
+      PT_MARK(5);  // the voxel words HAVE ARRIVED (late askers wait here; early askers' words came with the gather)
       // [phase: decode count / weight (PACKED)]
       uint32_t d0u[4] = {d4.x, d4.y, d4.z, d4.w};
       const uint32_t c0[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -1017,6 +1090,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cv[j] |= k1[j] & 0xff000000u;  // both flavours return the colour with the new count in byte 3
         }
       }
+      PT_DEP4(dv[0], dv[1], cv[0], cv[1]);
+      PT_MARK(6);  // decode, flags, hinge rest test, colour + distance update
       // [phase: select / change detection / store]
       uint32_t diff_w = 0u, diff_c = 0u, k4n = 0u;
       uint32_t wn_u[4];
@@ -1062,8 +1137,10 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       } else
       if (COLOR && diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
       if (PACKED && !COLOR && k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
+      PT_MARK(7);  // select, change detection, stores issued
     }
   }
+  PT_MARK_OUT(10);  // what is left of the loop (rows that left early are in 0-3), exit
   if (!TSDF_NO_BAND && band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
     __syncthreads();
     const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
@@ -1075,6 +1152,8 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
+  PT_MARK_OUT(12);  // epilogue: barrier + flag write-out
+  PT_FLUSH();
   if (COUNT) {  // block reduction, then one of 1024 striped counters (summed by the host); slots 1024.. = changed bytes,
                 // slots 2048.. = observed voxels whose distance word was not read
     __shared__ unsigned s_cnt, s_chg, s_imp, s_rdb;
@@ -1086,6 +1165,265 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     if (rdb) atomicAdd(&s_rdb, rdb);
     __syncthreads();
     if (tid == 0 && (s_cnt || s_rdb)) {  // (slots 3072..: bytes of the voxel planes the launch requested, observed voxel or not)
+      const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
+      if (s_cnt) atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
+      if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
+      if (s_imp) atomicAdd(n_obs + 2048u + (b & 1023u), (unsigned long long)s_imp);
+      if (s_rdb) atomicAdd(n_obs + 3072u + (b & 1023u), (unsigned long long)s_rdb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_integrate_p (round 6): the ALLIN PACKED instance WITHOUT colour -- BASELINE configs[1] / [2], the reference's default
+// (integrate_color_(false), src/lib/tsdf_volume_octree.cpp:78) -- as a two-stage SOFTWARE PIPELINE over the block's rows.
+//
+// What bound k_integrate's colourless instance (profiles/r06_phase_c0.txt, r06_c0_summary_pmc_*.json):
+// a wave's row is ONE dependent chain -- LDS reads -> transform / projection / certificate -> frame gather (an L2 round
+// trip) -> observed / hinge tests -> count update -> store -- run back to back; eight waves per SIMD take turns on the
+// VALU, and whenever most of them sit in the gather's s_waitcnt at once the SIMD idles: ~85 % VALU-active, with
+// neither fewer operations nor fewer bytes moving the time (round 5's four A/Bs).  Here a wave keeps TWO rows in flight:
+//
+//   stage A(r)  "issue":   LDS reads, pcl::transformPoint + certified projection of row r (hpp:143-149), then the row's
+//                          loads all at once: [distance words] + count bytes + four depth gathers
+//   stage B(r)  "consume": hpp:152-198 on the gathered depths, addObservation (octree.cpp:152-163), stores
+//
+//   A(0);  loop:  A(r+1)  B(r)  A(r+2)  B(r+1)  ...          (two row-register sets taken in turn: no register copies)
+//
+// B(r)'s wait for its loads is `s_waitcnt vmcnt(N)` with N = the loads A(r+1) has just issued BEHIND them (the counter
+// is in order), so a row's gather has a whole A + B of other work to come back in and the wave hardly ever stalls on it.
+// For the compiler to count N the steady-state loop issues a STATIC number of loads per stage: no predicted / late voxel
+// loads here -- the count bytes are requested for every quad (1 B per voxel: unobserved quads cost 2 % more traffic) and
+// the distance words per WAVE and pass (the implied-distance decision of k_integrate, a scalar branch whose two paths
+// differ by one load: the wait is conservative by that one load at most).
+// Same arithmetic as k_integrate<ORDER, false, true, COUNT, true, true, false>, operation for operation; the host
+// launches it instead of that instance when, additionally, every block's rows exist (ny a multiple of the block's rows),
+// the hinge value rests (hinge_fixed) and max_dist_neg lies in the scale-free divider's window -- else the old instance.
+#ifndef TSDF_WPE_PIPE
+#define TSDF_WPE_PIPE 7  // the SCALAR budget of seven waves (LLVM grants 8 waves 80 SGPRs, 7 waves 96+: at 8 the row loop carried 118
+                         // v_readlane / v_writelane scalar spills, at 7 it carries 5) ...
+#endif
+struct PipeRow {      // what stage A hands to stage B
+  float gz[4];        // g.z of the quad's four voxels
+  uint32_t z[4];      // gathered depths (bits; in flight)
+  uint32_t k4;        // the quad's four count bytes (in flight)
+  u4 d4;              // its distance words, where the pass reads them (in flight)
+};
+
+template <int ORDER, bool COUNT>
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_WPE_PIPE < TSDF_WPE_MAX ? TSDF_WPE_PIPE : TSDF_WPE_MAX, TSDF_WPE_MAX)))
+k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict__ K8, const float *__restrict__ depth,
+              const double *__restrict__ cam, const float *__restrict__ ctrx, const float *__restrict__ ctry,
+              const float *__restrict__ ctrz, unsigned long long *__restrict__ n_obs, uint8_t *__restrict__ band) {
+  const BlockCoords bc = tsdf_block_coords(a.zfast);
+  const unsigned tid = threadIdx.x;
+  __shared__ f2 s_rcp[256];  // s_rcp[k] = {Rcp32(k + 1).y, unused here}
+  __shared__ f4 s_yt[256];   // the rows' part of pcl::transformPoint (see k_integrate)
+  __shared__ f4 s_cx[256];   // every thread's own four x centres
+  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
+  __shared__ uint8_t s_bin[1024];
+  reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+  {
+    const KEntry e = tsdf_ktab_entry(a, tid);
+    s_rcp[tid] = (f2){e.y, e.hy};
+    const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
+    const float cy_ = ctry[yy < a.ny ? yy : a.ny - 1], cz_ = ctrz[a.z_global0 + (int)bc.bz];
+    f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      t[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy_ * a.m[4 * q + 1] + (cz_ * a.m[4 * q + 2] + a.m[4 * q + 3]) : a.m[4 * q + 1] * cy_;
+    s_yt[tid] = t;
+    const int xq_ = (int)bc.bx * a.TX + (int)(tid & (unsigned)(a.TX - 1));
+    if (xq_ < a.qpr) s_cx[tid] = *reinterpret_cast<const f4 *>(ctrx + xq_ * 4);
+  }
+  if (a.implied_d) tsdf_flags_before(a, bc, band, s_bin, tid);
+  __syncthreads();
+  const uint64_t quiet = a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
+  const int tx = (int)(tid & (unsigned)(a.TX - 1));
+  const int ty = (int)(tid >> a.log2TX);
+  const int xq = (int)bc.bx * a.TX + tx;
+  const int zl = (int)bc.bz;
+  const Rcp32 rneg = rcp32_prepare(a.neg);
+  unsigned cnt = 0, chg = 0, imp = 0, rdb = 0;
+  const int row0 = (int)bc.by * a.rpb * a.TY;
+  const int rows = min(a.rpb * a.TY, a.ny - row0);  // == rpb * TY (the host checked)
+  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
+  const unsigned span = (unsigned)rows * (unsigned)a.pitch;
+  const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
+  const rsrc_t rsK = make_rsrc(K8 + e0, span);
+  const i4_rsrc rsFi = make_rsrc_2d(depth, 4u, 0xffffffffu);
+  const uint32_t pbits = __float_as_uint(a.pos_over_neg);
+  if (xq < a.qpr) {
+    const int x4 = xq * 4;
+    const float cz = ctrz[a.z_global0 + zl];
+    float zt[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) zt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cz * a.m[4 * q + 2] + a.m[4 * q + 3] : a.m[4 * q + 2] * cz;
+    const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;
+    const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
+
+    // ---- stage A: transform + certified projection (project_quad_allin), then every load of the row ----------------
+    auto issue = [&](const int r, PipeRow &R) {
+      const f4 ytv = s_yt[ty + r * a.TY];
+      asm volatile("" ::: "memory");  // (the centres are re-read each row: neither they nor their products live across the loop)
+      int pix[4];
+      project_quad_allin<ORDER>(a, a.m, cam, s_cx[tid], ytv, zt, pix, R.gz);
+      const unsigned soff = (unsigned)r * row_step;
+      const bool d_read = !(r < 64 && (quiet >> r & 1ull));  // wave-uniform (see k_integrate: implied distances)
+      // [phase: voxel loads]
+      if (d_read)
+        R.d4 = bload128(rsD, voff, soff);
+      else
+        asm volatile("" : "=v"(R.d4));  // (no value: rebuilt from the counts where a distance can move, never looked at otherwise)
+      R.k4 = bload32(rsK, voff >> 2, soff >> 2);
+      // [phase: frame gather]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R.z[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, 0, TSDF_GATHER_AUX);
+      if (COUNT) rdb += (d_read ? 16u : 0u) + 4u;
+    };
+
+    // ---- stage B: hpp:152-198 + addObservation on what stage A requested -------------------------------------------
+    auto consume = [&](const int r, const PipeRow &R) {
+      const unsigned soff = (unsigned)r * row_step;
+      const bool d_read = !(r < 64 && (quiet >> r & 1ull));
+      // [phase: hinge / normalise (hpp:159-198)]
+      float raw[4];
+      bool act[4];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        raw[j] = __uint_as_float(R.z[j]) - R.gz[j];  // hpp:159
+        act[j] = raw[j] >= -a.neg;                   // hpp:152 (a NaN depth is a NaN raw) and :193-196 in one compare
+        any |= act[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;  // nothing of this wave's row is observed
+      bool any_div = false;  // an observed voxel inside the truncation band (k_integrate: TSDF_LEAN_BAND)
+      if (__builtin_fminf(__builtin_fminf(raw[0], raw[1]), __builtin_fminf(raw[2], raw[3])) <= a.pos) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) any_div |= act[j] && !(raw[j] > a.pos);
+      }
+      const uint32_t k4 = R.k4;
+      uint32_t d0u[4] = {R.d4.x, R.d4.y, R.d4.z, R.d4.w};
+      // [phase: band / implied-distance flags, hinge rest test]
+      // free space rests: a wave none of whose observed quads holds an in-band voxel or a voxel off the hinge value p sees
+      // (p*w + p)/(w + 1) == p (a.hinge_fixed, host-checked for every weight): the counts are all there is to update
+      bool off_hinge = any_div;
+      if (d_read) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off_hinge |= d0u[j] != pbits;
+      } else {  // distances not read: off the hinge value <=> never observed <=> count 0: is one of the four bytes zero?
+        off_hinge |= ((k4 - 0x01010101u) & ~k4 & 0x80808080u) != 0u;
+      }
+      const bool d_moves = __builtin_amdgcn_ballot_w64(any && off_hinge) != 0ull;  // wave-uniform
+      // [phase: select / change detection / store]
+      // the four counts in one word (k_integrate: TSDF_SWAR_K): k' = k + (observed && k < kmax) per byte
+      const uint32_t km2 = a.kmax * 0x00010001u;
+      const uint32_t te = ((k4 & 0x00ff00ffu) | 0x01000100u) - km2, to = (((k4 >> 8) & 0x00ff00ffu) | 0x01000100u) - km2;
+      const uint32_t lt = ((~te >> 8) & 0x00010001u) | (((~to >> 8) & 0x00010001u) << 8);  // 0x01 in byte j: k_j < kmax
+      const uint32_t actb = (act[0] ? 0x00000001u : 0u) | (act[1] ? 0x00000100u : 0u) | (act[2] ? 0x00010000u : 0u) | (act[3] ? 0x01000000u : 0u);
+      const uint32_t k4n = k4 + (lt & actb);
+      if (d_moves) {  // (a tenth of the observed wave-rows: surfaces, first observations)
+        // [phase: normalise: raw / neg ladder (rows with an in-band voxel)]
+        float dn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dn[j] = a.pos_over_neg;  // hpp:189-192
+        if (any_div) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
+        }
+        // [phase: decode count / weight (PACKED)]
+        float d0[4], w0[4], dv[4];
+        uint32_t kw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          kw[j] = k4 << (24 - 8 * j);
+          w0[j] = (float)(kw[j] >> 24);  // tsdf_decode_w: max_weight is an integer equal to kmax here (ALLIN), so min() is the identity
+          if (!d_read) d0u[j] = kw[j] < 0x01000000u ? 0xbf800000u : pbits;  // never observed: the reset value; else the hinge value
+          d0[j] = __uint_as_float(d0u[j]);
+        }
+        // [phase: d update (octree.cpp:152-163)]
+        if (any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+        bool safe = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Rcp32 rs;
+          rs.nb = -(w0[j] + 1.f);
+          rs.y = s_rcp[kw[j] >> 24].x;
+          dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs);
+          // the guard on the RESULT (k_integrate: TSDF_GUARD_ON_RESULT): a normal quotient is the correctly rounded one
+          safe &= !act[j] || __builtin_amdgcn_classf(dv[j], 0x108);
+        }
+        // [phase: IEEE fallback (rare)]
+        if (!safe) {
+          asm volatile("");  // rare: keep the IEEE divisions out of the hot path's schedule
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float wv = w0[j];
+            uint32_t cv = 0u;
+            dv[j] = d0[j];
+            add_observation_ieee<false>(dv[j], wv, cv, dn[j], 0u, a.wmax);
+          }
+        }
+        uint32_t diff_d = 0u, dn_u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
+          diff_d |= dn_u[j] ^ d0u[j];
+          if (COUNT) chg += dn_u[j] != d0u[j] ? 4u : 0u;
+        }
+        if (diff_d) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
+      }
+      if (COUNT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cnt += act[j] ? 1u : 0u;
+          imp += act[j] && !d_read ? 1u : 0u;
+        }
+        const uint32_t x = k4n ^ k4;
+        chg += (unsigned)__popc((x | (x >> 1) | (x >> 2) | (x >> 3) | (x >> 4) | (x >> 5) | (x >> 6) | (x >> 7)) & 0x01010101u);
+      }
+      if (k4n != k4) bstore32(rsK, voff >> 2, soff >> 2, k4n);
+    };
+
+    PipeRow A, B;
+    const int nr = a.rpb;
+    issue(0, A);
+    int r = 0;
+    for (; r + 2 < nr; r += 2) {  // steady state: every trip issues two rows and consumes two
+      issue(r + 1, B);
+      consume(r, A);
+      issue(r + 2, A);
+      consume(r + 1, B);
+    }
+    if (r + 1 < nr) {
+      issue(r + 1, B);
+      consume(r, A);
+      consume(r + 1, B);
+    } else {
+      consume(r, A);
+    }
+  }
+  if (band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
+    __syncthreads();
+    const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
+    const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
+    const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
+    const int n_fl = (yg1 - yg0 + 1) << lf;
+    for (int i = (int)tid; i < n_fl; i += 256) {
+      const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
+      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+    }
+  }
+  if (COUNT) {  // the same four striped counters as k_integrate
+    __shared__ unsigned s_cnt, s_chg, s_imp, s_rdb;
+    if (tid == 0) s_cnt = s_chg = s_imp = s_rdb = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    if (chg) atomicAdd(&s_chg, chg);
+    if (imp) atomicAdd(&s_imp, imp);
+    if (rdb) atomicAdd(&s_rdb, rdb);
+    __syncthreads();
+    if (tid == 0 && (s_cnt || s_rdb)) {
       const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
       if (s_cnt) atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
       if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
@@ -2436,7 +2774,26 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     else                 \
       L4(ORDER, COLOR, false); \
   } while (0)
-    if (p.xform_order == TSDF_XFORM_PCL_SSE) {
+    // the software-pipelined instance (k_integrate_p): ALLIN, PACKED, no colour, every block's rows present, resting hinge
+    const bool pipe = tsdf_tuning().pipe && fastproj && allin && !live && h->packed && !color && a.hinge_fixed && a.neg_in_window &&
+                      a.ny % (a.rpb * a.TY) == 0;
+    if (pipe) {
+      h->last_launch[0] |= 0x100;  // bit 8: the pipelined row loop
+#define LAUNCH_P(ORDER, COUNT) \
+  hipLaunchKernelGGL((k_integrate_p<ORDER, COUNT>), grid, block, 0, h->stream, a, D, K8, d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, band_arg)
+      if (p.xform_order == TSDF_XFORM_PCL_SSE) {
+        if (count)
+          LAUNCH_P(TSDF_XFORM_PCL_SSE, true);
+        else
+          LAUNCH_P(TSDF_XFORM_PCL_SSE, false);
+      } else {
+        if (count)
+          LAUNCH_P(TSDF_XFORM_LEFT_TO_RIGHT, true);
+        else
+          LAUNCH_P(TSDF_XFORM_LEFT_TO_RIGHT, false);
+      }
+#undef LAUNCH_P
+    } else if (p.xform_order == TSDF_XFORM_PCL_SSE) {
       if (color)
         L2(TSDF_XFORM_PCL_SSE, true);
       else
@@ -2453,6 +2810,24 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
 #undef L6
 #undef LAUNCH
     TSDF_HIP_TRY(hipGetLastError());
+#if TSDF_PHASE_TIMER
+    if (const char *pf = getenv("TSDF_HIP_PHASE_FILE")) {  // diagnostic build: the phase accumulators of THIS launch
+      TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
+      static unsigned long long host_ph[1024 * TSDF_NPHASE];
+      TSDF_HIP_TRY(hipMemcpyFromSymbol(host_ph, HIP_SYMBOL(g_phase), sizeof host_ph));
+      unsigned long long sum[TSDF_NPHASE] = {0};
+      for (int i = 0; i < 1024; ++i)
+        for (int k = 0; k < TSDF_NPHASE; ++k) sum[k] += host_ph[i * TSDF_NPHASE + k];
+      memset(host_ph, 0, sizeof host_ph);
+      TSDF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), host_ph, sizeof host_ph));
+      if (FILE *f = fopen(pf, "a")) {
+        fprintf(f, "{\"color\": %d, \"count\": %d, \"allin\": %d, \"live\": %d, \"packed\": %d, \"blocks\": %d, \"phase\": [", (int)color, (int)count,
+                (int)(fastproj && allin && !live), (int)(live != nullptr), (int)h->packed, h->last_launch[3]);
+        for (int k = 0; k < TSDF_NPHASE; ++k) fprintf(f, "%llu%s", sum[k], k + 1 < TSDF_NPHASE ? ", " : "]}\n");
+        fclose(f);
+      }
+    }
+#endif
   }
   h->count_slots = count ? 4096 : 0;  // slots 1024.. hold the bytes of voxel words whose value changed, 2048.. the observed
                                       // voxels whose distance word was not read, 3072.. the plane bytes requested

@@ -473,7 +473,8 @@ int tsdf_hip_centers(tsdf_handle h, int axis, float *out);
 /* Report: the last integrate launch on this handle (slab 0 of a set) -- out[0] = the kernel: 0 k_integrate's general
  * instance, 1 its ALLIN instance (the host proved from the slab's eight corner voxels that EVERY voxel is inside the sensor
  * range and projects inside the image with a pixel to spare -- the camera-outside-the-volume case -- so the per-voxel range /
- * image-bounds tests are compiled out), 2 k_integrate2 (two frames in one sweep); out[1] = 1 with the certified fp32
+ * image-bounds tests are compiled out), 2 k_integrate2 (two frames in one sweep) -- in the low byte; bit 8 (0x100) is set
+ * when the ALLIN launch ran the software-pipelined row loop (k_integrate_p: PACKED layout without colour); out[1] = 1 with the certified fp32
  * projection; out[2] = 0 no row intervals, 1 row intervals + block flags (the frame sees part of the slab), 2 the same with
  * the reference's frustum cull carried in the intervals; out[3] = blocks launched (0: nothing could be observed). */
 int tsdf_hip_last_launch_info(tsdf_handle h, int32_t out[4]);

@@ -244,7 +244,7 @@ def test_2048_cubed_whole_volume_is_the_same_through_every_kernel_path(gpu, colo
     def info(vol):
         out = (C.c_int32 * 4)()
         capi.check(lib.tsdf_hip_last_launch_info(vol._need(), out), "info")
-        return list(out)
+        return [int(out[0]) & 0xff] + [int(v) for v in out[1:]]  # (bit 8 of out[0]: the pipelined row loop)
 
     vol, sc = make()
     frames_ = []

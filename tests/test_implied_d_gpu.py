@@ -30,7 +30,7 @@ def read_detail(vol):
 def launch_info(vol):
     out = (C.c_int32 * 4)()
     capi.check(capi.load().tsdf_hip_last_launch_info(vol._need(), out), "last_launch_info")
-    return list(out)
+    return [int(out[0]) & 0xff, int(out[1]), int(out[2]), int(out[3]), bool(int(out[0]) & 0x100)]  # [4]: the pipelined row loop (k_integrate_p)
 
 
 def compare(vol, ov):

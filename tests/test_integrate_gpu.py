@@ -474,7 +474,7 @@ def launch_info(vol):
     import ctypes as C
     out = (C.c_int32 * 4)()
     capi.check(capi.load().tsdf_hip_last_launch_info(vol._need(), out), "last_launch_info")
-    return list(out)
+    return [int(out[0]) & 0xff, int(out[1]), int(out[2]), int(out[3]), bool(int(out[0]) & 0x100)]  # [4]: the pipelined row loop (k_integrate_p)
 
 
 @pytest.mark.parametrize("color,layout,wmax", [(True, capi.LAYOUT_AUTO, 100.0), (False, capi.LAYOUT_AUTO, 4.0),
@@ -713,6 +713,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                                 continue  # the ALLIN instances exist only with the certified projection
                             capi.set_tuning("fast_projection", fp)
                             capi.set_tuning("allin", 0 if kind == "general" else 1)
+                            capi.set_tuning("pipe", 0)  # k_integrate's own instances here; k_integrate_p has its block below
                             vol, sc = make_volume(res, W, H, color=color, order=order, max_weight=100.0)
                             if kind == "cull":  # whole grid in view, principal point 60 % off centre: the reference's cull cuts the grid
                                 sc.cx += 0.6 * W / 2
@@ -739,14 +740,33 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                                 assert got is True or got == want, (order, color, layout, fp, kind, i, got, want)
                                 info = launch_info(vol)
                                 expect = {"general": (0, 0), "allin": (1, 0), "rows": (0, None), "cull": (0, 2)}[kind]
-                                ok = info[0] == expect[0] and (expect[1] is None or info[2] == expect[1]) and info[1] == fp
+                                ok = info[0] == expect[0] and (expect[1] is None or info[2] == expect[1]) and info[1] == fp and not info[4]
                                 assert ok and (kind != "rows" or info[2] in (1, 2)), (order, color, layout, fp, kind, info)
                                 hit.add((order, color, layout, fp, count, kind))
                             compare(vol, ov)
                             vol.close()
-        # k_integrate2: transform order x colour x counting (PACKED, certified projection, both poses ALLIN)
+        # k_integrate_p (the software-pipelined row loop: ALLIN, PACKED, no colour): transform order x counting
         capi.set_tuning("fast_projection", 1)
         capi.set_tuning("allin", 1)
+        capi.set_tuning("pipe", 1)
+        for order in (0, 1):
+            vol, sc = make_volume(res, W, H, color=False, order=order, max_weight=100.0)
+            vol.reset()
+            ov = OracleVolume(vol._p)
+            for i in range(4):
+                tr = synth.turntable_pose(i, 9, sc.size)
+                dep = sc.depth(tr, noise_seed=40 + i)
+                dep[(i * 5) % 30::31, ::3] = np.nan
+                count = i % 2 == 0
+                want = ov.integrate_culled(dep, None, tr, synth.cam_from_vol_f32(tr))
+                got = vol.integrateCloud(dep, None, tr, count=count)
+                assert got is True or got == want, (order, i, got, want)
+                info = launch_info(vol)
+                assert info[0] == 1 and info[1] == 1 and info[2] == 0 and info[4], info
+                hit.add((order, "kp", count))
+            compare(vol, ov)
+            vol.close()
+        # k_integrate2: transform order x colour x counting (PACKED, certified projection, both poses ALLIN)
         for order in (0, 1):
             for color in (False, True):
                 vol, sc = make_volume(res, W, H, color=color, order=order)
@@ -775,9 +795,58 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
     finally:
         capi.set_tuning("fast_projection", -1)
         capi.set_tuning("allin", 1)
+        capi.set_tuning("pipe", 1)
     # 8 x {certified: general, ALLIN, row intervals (camera inside), row intervals (cull); exact projection: the same without
-    # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 8 of k_integrate2
-    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 3) + 8, len(hit)
+    # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 4 of k_integrate_p + the 8 of
+    # k_integrate2
+    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 3) + 4 + 8, len(hit)
+
+
+@pytest.mark.parametrize("rows_per_block", [8, 16, 24, 32, 48, 96])
+def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_per_block):
+    """k_integrate_p (round 6: two rows in flight per wave, stage A = projection + every load of a row, stage B = update +
+    stores) on a 96^3 grid without colour, whose blocks walk 1, 2, 3, 4, 6 or 12 row steps (TY = 8 rows per step): the tail of
+    one row, of a pair, the odd tail behind the steady-state loop and the loop itself -- noisy depth with NaN holes, frames
+    past the weight limit (max_weight 4), counting on alternate frames -- against the oracle voxel for voxel, against
+    k_integrate's own instance (knob pipe = 0) plane for plane, observed-voxel counts included; and the row count the
+    pipelined kernel needs (ny a multiple of the block's rows) falls back by itself when it does not hold."""
+    outs = []
+    try:
+        capi.set_tuning("rows_per_block", rows_per_block)
+        for pipe in (1, 0):
+            capi.set_tuning("pipe", pipe)
+            vol, sc = make_volume(96, color=False, max_weight=4.0)
+            vol.reset()
+            ov = OracleVolume(vol._p)
+            counts = []
+            for i, tr, dep, col in frames(sc, 7, 9, noise=True):
+                dep = dep.copy()
+                dep[(i * 7) % 50::53, ::3] = np.nan
+                n_gpu = vol.integrateCloud(dep, None, tr, count=(i % 2 == 0))
+                info = launch_info(vol)
+                assert info[0] == 1 and info[4] == bool(pipe), (pipe, info)
+                n_cpu = ov.integrate(dep, None, synth.cam_from_vol_f32(tr))
+                assert n_gpu is True or n_gpu == n_cpu, (pipe, i, n_gpu, n_cpu)
+                counts.append(n_gpu)
+            compare(vol, ov)
+            outs.append((vol.download(), counts))
+            vol.close()
+        assert_same_f32(outs[0][0][0], outs[1][0][0], "d: pipelined vs plain row loop")
+        assert np.array_equal(outs[0][0][1], outs[1][0][1]) and outs[0][1] == outs[1][1]
+        # 100 rows are no multiple of the block's rows: the launch takes k_integrate's instance by itself
+        capi.set_tuning("pipe", 1)
+        vol, sc = make_volume(96, color=False, res3=(96, 100, 96))
+        vol.reset()
+        ov = OracleVolume(vol._p)
+        tr = synth.turntable_pose(1, 8, sc.size)
+        dep = sc.depth(tr)
+        assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate(dep, None, synth.cam_from_vol_f32(tr))
+        assert launch_info(vol)[0] == 1 and not launch_info(vol)[4], launch_info(vol)
+        compare(vol, ov)
+        vol.close()
+    finally:
+        capi.set_tuning("rows_per_block", 32)
+        capi.set_tuning("pipe", 1)
 
 
 def test_planes_fastest_block_order_changes_nothing(gpu):

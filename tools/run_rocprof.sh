@@ -23,7 +23,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 cd /tmp
-BENCH="python $ROOT/bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 --host-path 0 $EXTRA"
+BENCH="python $ROOT/bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 --host-path 0 --keys 0 $EXTRA"
 [ -n "$LITE" ] && BENCH="$BENCH --extras 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
   $BENCH --steps $STEPS > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
