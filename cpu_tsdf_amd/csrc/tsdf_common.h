@@ -301,7 +301,7 @@ struct TsdfTuning {
   int zfast;           // integrate launches hand out blocks planes-fastest: 1 always (default: 16.26 against 16.60 ms at 2048^3 + colour, 15.5 against 16.9 ms on a 4096 x 4096 x 512 slab with 1280x960 frames), 0 never, -1 only when the frame outgrows an XCD's L2
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
   int implied_d;       // PACKED integrate launches do not read distance words the "band seen" flags and the counts determine (1)
-  int pipe;            // ALLIN PACKED launches without colour run the software-pipelined row loop k_integrate_p (1)
+  int pipe;            // ALLIN PACKED launches run the software-pipelined row loop: bit 0 without colour (k_integrate_p), bit 1 with (k_integrate_pc); 3
 };
 const TsdfTuning &tsdf_tuning();
 // Edge of the voxel blocks save / load stream through host memory: TSDF_HIP_VOL_CHUNK, read at EVERY call (an I/O path: a

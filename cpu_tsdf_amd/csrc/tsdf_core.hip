@@ -52,13 +52,13 @@ static int env_int(const char *name, int dflt) {
 }
 
 static TsdfTuning &tuning_storage() {
-  static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 32)),
+  static TsdfTuning t = {std::max(1, env_int("TSDF_HIP_ROWS_PER_BLOCK", 64)),
                          std::max(1, env_int("TSDF_HIP_BLOCKS_PER_CU", 8)),
                          env_int("TSDF_HIP_FAST_PROJECTION", -1), env_int("TSDF_HIP_MC_FLUSH_AT", 512), env_int("TSDF_HIP_MC_SKIP", 1),
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
                          env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1), env_int("TSDF_HIP_IMPLIED_D", 1),
-                         env_int("TSDF_HIP_PIPE", 1)};
+                         env_int("TSDF_HIP_PIPE", 3)};
   return t;
 }
 

@@ -466,6 +466,32 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
 #ifndef TSDF_NO_BAND
 #define TSDF_NO_BAND 0  // A/B: compile the "band seen" flag store out of k_integrate
 #endif
+#ifndef TSDF_BAND_PER_WAVE
+#define TSDF_BAND_PER_WAVE 1  // the block's "band seen" flags are collected per WAVE (four private LDS sets) and each wave writes its own
+                              // out when it is done: no barrier at the block's end.  The row loop timing itself (profiles/r06_phase_c0.txt)
+                              // showed a wave spending 12-17 % of its life in that barrier, waiting for the block's slowest wave with a
+                              // wave slot in hand -- an eighth of the occupancy the register budget buys.  Every writer stores the same
+                              // 1, so sets that overlap (narrow grids: a cell's four rows belong to two waves) need no merging.
+#endif
+// TSDF_BAND_DECL declares the flag set(s) and clears them (`tid` in scope); TSDF_BAND(i) is flag cell i of the set this thread's wave
+// writes (the set's address is worked out at each -- rare -- use: nothing lives in a register across the row loop for it)
+#if TSDF_BAND_PER_WAVE
+#define TSDF_BAND_DECL                                                                                     \
+  __shared__ __attribute__((aligned(16))) uint8_t s_band_sets[4][1024];                                    \
+  reinterpret_cast<u4 *>(&s_band_sets[0][0])[tid] = (u4){0u, 0u, 0u, 0u} /* 256 threads x 16 B: all four sets; the prologue's barrier follows */
+#define TSDF_BAND(i) s_band_sets[threadIdx.x >> 6][i]
+#define TSDF_BAND_SYNC() ((void)0)
+#define TSDF_BAND_FIRST ((int)(tid & 63u))
+#define TSDF_BAND_STEP 64
+#else
+#define TSDF_BAND_DECL                                                          \
+  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];            \
+  reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0
+#define TSDF_BAND(i) s_band[i]
+#define TSDF_BAND_SYNC() __syncthreads()
+#define TSDF_BAND_FIRST ((int)tid)
+#define TSDF_BAND_STEP 256
+#endif
 #ifndef TSDF_RECOMPUTE_PX
 #define TSDF_RECOMPUTE_PX 1  // 72 instead of 80 VGPRs: 7 waves per SIMD (A/B on the GPU: 17.3-17.5 against 17.8-17.9 ms)
 #endif
@@ -602,8 +628,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   // "band seen" flags of this block's flag cells (64 x 4 x 1 voxels: <= 64 row groups x TX / 16 cells), collected in
   // LDS by the waves that take the in-band path anyway and written out once when the block is done: the free-space
   // hot path pays nothing for them (a global byte store per in-band row cost 3-5 % of the kernel, measured)
-  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
-  if (!TSDF_NO_BAND) reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+  TSDF_BAND_DECL;
 #if TSDF_KTAB
   if (PACKED) s_tab[tid] = tsdf_ktab_entry(a, tid);
 #else
@@ -1061,7 +1086,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           // a voxel of this quad was observed inside the truncation band: its distance may turn negative, which is what
           // marching cubes looks for (see s_band)
           // (the host only passes `band` when every block's first row is a multiple of 4: local row groups == global ones)
-          if (!TSDF_NO_BAND && any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+          if (!TSDF_NO_BAND && any_div) TSDF_BAND(((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)) = 1;
 #pragma unroll
           for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
 #if TSDF_GUARD_ON_RESULT
@@ -1079,7 +1104,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
       // [phase: IEEE fallback (rare)]
       if (!safe) {
         d_touched = true;
-        if (!TSDF_NO_BAND && any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+        if (!TSDF_NO_BAND && any_div) TSDF_BAND(((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)) = 1;
         asm volatile("");  // rare: keep the 16 IEEE divisions out of the hot path's schedule
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1142,14 +1167,14 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
   }
   PT_MARK_OUT(10);  // what is left of the loop (rows that left early are in 0-3), exit
   if (!TSDF_NO_BAND && band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
-    __syncthreads();
+    TSDF_BAND_SYNC();  // (per-wave sets: none -- a wave reads back what it wrote itself)
     const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
     const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
     const int n_fl = (yg1 - yg0 + 1) << lf;
-    for (int i = (int)tid; i < n_fl; i += 256) {
+    for (int i = TSDF_BAND_FIRST; i < n_fl; i += TSDF_BAND_STEP) {
       const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
-      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+      if (TSDF_BAND(i) && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
   PT_MARK_OUT(12);  // epilogue: barrier + flag write-out
@@ -1200,8 +1225,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 // launches it instead of that instance when, additionally, every block's rows exist (ny a multiple of the block's rows),
 // the hinge value rests (hinge_fixed) and max_dist_neg lies in the scale-free divider's window -- else the old instance.
 #ifndef TSDF_WPE_PIPE
-#define TSDF_WPE_PIPE 7  // the SCALAR budget of seven waves (LLVM grants 8 waves 80 SGPRs, 7 waves 96+: at 8 the row loop carried 118
-                         // v_readlane / v_writelane scalar spills, at 7 it carries 5) ...
+#define TSDF_WPE_PIPE 8  // 63 VGPRs, no scratch.  (LLVM grants 8 waves 80 SGPRs, 7 waves 96+: at 8 the loop's rare blocks carry scalar spills
+                         // in VGPR lanes, at 7 -- 65 VGPRs, seven waves -- hardly any; measured by alternation, 2048^3 without colour:
+                         // 7.61 ms at 8 against 7.81 at 7, 8.98 for k_integrate's own row loop: profiles/r06_ab_pipe_c0_call02.txt)
 #endif
 struct PipeRow {      // what stage A hands to stage B
   float gz[4];        // g.z of the quad's four voxels
@@ -1220,9 +1246,8 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
   __shared__ f2 s_rcp[256];  // s_rcp[k] = {Rcp32(k + 1).y, unused here}
   __shared__ f4 s_yt[256];   // the rows' part of pcl::transformPoint (see k_integrate)
   __shared__ f4 s_cx[256];   // every thread's own four x centres
-  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
   __shared__ uint8_t s_bin[1024];
-  reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+  TSDF_BAND_DECL;
   {
     const KEntry e = tsdf_ktab_entry(a, tid);
     s_rcp[tid] = (f2){e.y, e.hy};
@@ -1342,7 +1367,7 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
           d0[j] = __uint_as_float(d0u[j]);
         }
         // [phase: d update (octree.cpp:152-163)]
-        if (any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+        if (any_div) TSDF_BAND(((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)) = 1;
         bool safe = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1404,17 +1429,285 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
     }
   }
   if (band) {  // the block's flags -> the volume's flag array (every writer stores the same 1: no atomics)
-    __syncthreads();
+    TSDF_BAND_SYNC();  // (per-wave sets: none -- a wave reads back what it wrote itself)
     const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
     const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
     const int n_fl = (yg1 - yg0 + 1) << lf;
-    for (int i = (int)tid; i < n_fl; i += 256) {
+    for (int i = TSDF_BAND_FIRST; i < n_fl; i += TSDF_BAND_STEP) {
       const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
-      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+      if (TSDF_BAND(i) && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
   if (COUNT) {  // the same four striped counters as k_integrate
+    __shared__ unsigned s_cnt, s_chg, s_imp, s_rdb;
+    if (tid == 0) s_cnt = s_chg = s_imp = s_rdb = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    if (chg) atomicAdd(&s_chg, chg);
+    if (imp) atomicAdd(&s_imp, imp);
+    if (rdb) atomicAdd(&s_rdb, rdb);
+    __syncthreads();
+    if (tid == 0 && (s_cnt || s_rdb)) {
+      const unsigned b = bc.bx + bc.by * bc.gdx + bc.bz * bc.gdx * bc.gdy;
+      if (s_cnt) atomicAdd(n_obs + (b & 1023u), (unsigned long long)s_cnt);
+      if (s_chg) atomicAdd(n_obs + 1024u + (b & 1023u), (unsigned long long)s_chg);
+      if (s_imp) atomicAdd(n_obs + 2048u + (b & 1023u), (unsigned long long)s_imp);
+      if (s_rdb) atomicAdd(n_obs + 3072u + (b & 1023u), (unsigned long long)s_rdb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_integrate_pc (round 6): the HEADLINE instance -- ALLIN, PACKED, integrate_color -- on k_integrate_p's two-stage pipeline.
+// A row in flight holds more here (four colour gathers and the colour|count words besides the depths: 20 registers per row,
+// two rows), so this kernel runs FEWER waves per SIMD than k_integrate's 64-register instance; what it buys is that a wave
+// never sits in the frame gather's s_waitcnt with nothing else to issue (k_integrate: ~80 % VALU-active at eight waves).
+// The voxel words are requested in stage A by the quads PREDICTED to be observed -- the quad's own outcome in the last row
+// whose stage B has run, i.e. two rows back -- through an exec-free device: an unpredicted quad's byte offset is poisoned
+// (all ones: beyond every descriptor's range, the hardware returns zero and fetches nothing), so stage A always issues the
+// same TEN loads and the compiler can count them behind the row that waits.  An observed quad the predictor missed asks in
+// stage B and waits there (in order: also for the next row's gathers -- rare: where a surface begins along y).
+// Arithmetic: k_integrate<ORDER, true, true, COUNT, true, true, false>'s, operation for operation.
+#ifndef TSDF_WPE_PIPEC
+#define TSDF_WPE_PIPEC 5  // 91 VGPRs, no scratch (six waves: 80 VGPRs + ten spill operations in the row loop, whose waits undo the pipeline)
+#endif
+struct PipeRowC {
+  float gz[4];
+  uint32_t z[4];   // gathered depths (in flight)
+  uint32_t cs[4];  // gathered bgra (in flight)
+  u4 c4;           // the quad's colour|count words (in flight; zero where not asked)
+  u4 d4;           // its distance words (in flight)
+};
+
+template <int ORDER, bool COUNT>
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TSDF_WPE_PIPEC < TSDF_WPE_MAX ? TSDF_WPE_PIPEC : TSDF_WPE_MAX, TSDF_WPE_MAX)))
+k_integrate_pc(const IntegrateArgs a, float *__restrict__ D, uint32_t *__restrict__ RGB, const float *__restrict__ depth,
+               const double *__restrict__ cam, const float *__restrict__ ctrx, const float *__restrict__ ctry,
+               const float *__restrict__ ctrz, unsigned long long *__restrict__ n_obs, uint8_t *__restrict__ band) {
+  const BlockCoords bc = tsdf_block_coords(a.zfast);
+  const unsigned tid = threadIdx.x;
+  __shared__ f2 s_rcp[256];  // s_rcp[k] = {Rcp32(k + 1).y, the colour average's rounding offset for that divisor}
+  __shared__ f4 s_yt[256];
+  __shared__ f4 s_cx[256];
+  __shared__ uint8_t s_bin[1024];
+  TSDF_BAND_DECL;
+  {
+    const KEntry e = tsdf_ktab_entry(a, tid);
+    s_rcp[tid] = (f2){e.y, e.hy};
+    const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
+    const float cy_ = ctry[yy < a.ny ? yy : a.ny - 1], cz_ = ctrz[a.z_global0 + (int)bc.bz];
+    f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      t[q] = ORDER == TSDF_XFORM_PCL_SSE ? cy_ * a.m[4 * q + 1] + (cz_ * a.m[4 * q + 2] + a.m[4 * q + 3]) : a.m[4 * q + 1] * cy_;
+    s_yt[tid] = t;
+    const int xq_ = (int)bc.bx * a.TX + (int)(tid & (unsigned)(a.TX - 1));
+    if (xq_ < a.qpr) s_cx[tid] = *reinterpret_cast<const f4 *>(ctrx + xq_ * 4);
+  }
+  if (a.implied_d) tsdf_flags_before(a, bc, band, s_bin, tid);
+  __syncthreads();
+  const uint64_t quiet = a.implied_d ? tsdf_quiet_passes(a, s_bin, tid) : 0ull;
+  const int tx = (int)(tid & (unsigned)(a.TX - 1));
+  const int ty = (int)(tid >> a.log2TX);
+  const int xq = (int)bc.bx * a.TX + tx;
+  const int zl = (int)bc.bz;
+  const Rcp32 rneg = rcp32_prepare(a.neg);
+  unsigned cnt = 0, chg = 0, imp = 0, rdb = 0;
+  const int row0 = (int)bc.by * a.rpb * a.TY;
+  const int rows = min(a.rpb * a.TY, a.ny - row0);  // == rpb * TY (the host checked)
+  const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
+  const unsigned span = (unsigned)rows * (unsigned)a.pitch;
+  const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
+  const rsrc_t rsC = make_rsrc(RGB + e0, span * 4u);
+  const i4_rsrc rsFi = make_rsrc_2d(depth, 4u, 0xffffffffu);
+  const uint32_t pbits = __float_as_uint(a.pos_over_neg);
+  if (xq < a.qpr) {
+    const int x4 = xq * 4;
+    const float cz = ctrz[a.z_global0 + zl];
+    float zt[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) zt[q] = ORDER == TSDF_XFORM_PCL_SSE ? cz * a.m[4 * q + 2] + a.m[4 * q + 3] : a.m[4 * q + 2] * cz;
+    const unsigned voff = (unsigned)(ty * (int)a.pitch + x4) * 4u;
+    const unsigned row_step = (unsigned)a.TY * (unsigned)a.pitch * 4u;
+    bool obs_a = true, obs_b = true;  // this quad's outcome in the last even / odd row whose stage B has run (the predictor)
+
+    // ---- stage A ----------------------------------------------------------------------------------------------------
+    auto issue = [&](const int r, PipeRowC &R, const bool pred) {
+      const f4 ytv = s_yt[ty + r * a.TY];
+      asm volatile("" ::: "memory");
+      int pix[4];
+      project_quad_allin<ORDER>(a, a.m, cam, s_cx[tid], ytv, zt, pix, R.gz);
+      const unsigned soff = (unsigned)r * row_step;
+      const bool d_read = !(r < 64 && (quiet >> r & 1ull));  // wave-uniform (implied distances, see k_integrate)
+      // [phase: voxel loads]
+      const unsigned offp = pred ? voff : 0x7ffffff0u;  // an unpredicted quad asks for nothing: its offset lies beyond the descriptor
+      R.d4 = bload128(rsD, d_read ? offp : 0x7ffffff0u, soff);
+      R.c4 = bload128(rsC, offp, soff);
+      // [phase: frame gather]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        R.z[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, 0, TSDF_GATHER_AUX);
+        R.cs[j] = tsdf_struct_buffer_load_u32(rsFi, pix[j], 0, (int)a.bgra_off, TSDF_GATHER_AUX);
+      }
+      if (COUNT) rdb += pred ? (d_read ? 32u : 16u) : 0u;
+    };
+
+    // ---- stage B ----------------------------------------------------------------------------------------------------
+    auto consume = [&](const int r, PipeRowC &R, const bool pred, bool &obs_out) {
+      const unsigned soff = (unsigned)r * row_step;
+      const bool d_read = !(r < 64 && (quiet >> r & 1ull));
+      // [phase: hinge / normalise (hpp:159-198)]
+      float raw[4];
+      bool act[4];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        raw[j] = __uint_as_float(R.z[j]) - R.gz[j];  // hpp:159
+        act[j] = raw[j] >= -a.neg;                   // hpp:152 and :193-196 in one compare (see k_integrate)
+        any |= act[j];
+      }
+      obs_out = any;
+      if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;  // nothing of this wave's row is observed
+      // [phase: leave the row if nothing is observed; late voxel loads]
+      if (any && !pred) {  // an observed quad the predictor missed: its words are requested now, and retired here
+        if (d_read) R.d4 = bload128(rsD, voff, soff);
+        R.c4 = bload128(rsC, voff, soff);
+        if (COUNT) rdb += d_read ? 32u : 16u;
+        asm volatile("" ::"v"(R.d4), "v"(R.c4));
+      }
+      bool any_div = false;
+      if (__builtin_fminf(__builtin_fminf(raw[0], raw[1]), __builtin_fminf(raw[2], raw[3])) <= a.pos) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) any_div |= act[j] && !(raw[j] > a.pos);
+      }
+      // [phase: decode count / weight (PACKED)]
+      const uint32_t c0[4] = {R.c4.x, R.c4.y, R.c4.z, R.c4.w};
+      uint32_t d0u[4] = {R.d4.x, R.d4.y, R.d4.z, R.d4.w};
+      // [phase: band / implied-distance flags, hinge rest test]
+      bool off_hinge = any_div;
+      if (d_read) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off_hinge |= d0u[j] != pbits;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off_hinge |= c0[j] < 0x01000000u;
+      }
+      const bool d_moves = __builtin_amdgcn_ballot_w64(any && off_hinge) != 0ull;  // wave-uniform
+      // [phase: colour update (octree.cpp:328-337)]
+      // (voxel by voxel, nothing kept: the rare distance block below works its operands out again -- registers are what
+      // this kernel is short of)
+      uint32_t cv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // colour and count: every observed voxel
+        float w = (float)(c0[j] >> 24);  // tsdf_decode_w: max_weight is an integer equal to kmax here (ALLIN)
+        asm volatile("" : "+v"(w));      // (keeps LLVM from turning the colour sums into integer multiplies: k_integrate, TSDF_LEAN_K)
+        const uint32_t k1 = min(c0[j], a.kcap | 0xffffffu) + a.kinc;  // min(k + 1, kmax) << 24 | old rgb (v_cvt_pk_u8 rewrites bytes 0-2)
+        const f2 yh = s_rcp[c0[j] >> 24];
+        Rcp32 rs;
+        rs.nb = -(w + 1.f);
+        rs.y = yh.x;
+        const float hy = yh.y;
+        float dd = 0.f;
+        cv[j] = c0[j];
+        add_observation_fast<true, false>(dd, w, cv[j], 0.f, R.cs[j], a.wmax, rs, k1, &hy);
+      }
+      // [phase: d update (octree.cpp:152-163)]
+      if (d_moves) {  // (a tenth of the observed wave-rows: surfaces, first observations)
+        float d0[4], dn[4], dv[4], w0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!d_read) d0u[j] = c0[j] < 0x01000000u ? 0xbf800000u : pbits;  // never observed: the reset value; else the hinge value
+          d0[j] = __uint_as_float(d0u[j]);
+          dn[j] = a.pos_over_neg;  // hpp:189-192
+          w0[j] = (float)(c0[j] >> 24);
+        }
+        if (any_div) {
+          TSDF_BAND(((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)) = 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dn[j] = raw[j] > a.pos ? a.pos_over_neg : div32_fast(raw[j], rneg);  // hpp:198
+        }
+        bool safe = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Rcp32 rs;
+          rs.nb = -(w0[j] + 1.f);
+          rs.y = s_rcp[c0[j] >> 24].x;
+          dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs);
+          safe &= !act[j] || __builtin_amdgcn_classf(dv[j], 0x108);  // the guard on the RESULT (k_integrate)
+        }
+        // [phase: IEEE fallback (rare)]
+        if (!safe) {
+          asm volatile("");
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float wv = w0[j];
+            dv[j] = d0[j];
+            cv[j] = c0[j] & 0xffffffu;
+            add_observation_ieee<true>(dv[j], wv, cv[j], dn[j], R.cs[j], a.wmax);
+            cv[j] |= (min(c0[j], a.kcap | 0xffffffu) + a.kinc) & 0xff000000u;
+          }
+        }
+        uint32_t diff_d = 0u, dn_u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dn_u[j] = act[j] ? __float_as_uint(dv[j]) : d0u[j];
+          diff_d |= dn_u[j] ^ d0u[j];
+          if (COUNT) chg += dn_u[j] != d0u[j] ? 4u : 0u;
+        }
+        if (diff_d) bstore128(rsD, voff, soff, (u4){dn_u[0], dn_u[1], dn_u[2], dn_u[3]});
+      }
+      // [phase: select / change detection / store]
+      uint32_t diff_c = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cv[j] = act[j] ? cv[j] : c0[j];
+        diff_c |= cv[j] ^ c0[j];
+        if (COUNT) {
+          cnt += act[j] ? 1u : 0u;
+          imp += act[j] && !d_read ? 1u : 0u;
+          chg += cv[j] != c0[j] ? 4u : 0u;
+        }
+      }
+      if (diff_c) bstore128(rsC, voff, soff, (u4){cv[0], cv[1], cv[2], cv[3]});
+    };
+
+    PipeRowC A, B;
+    const int nr = a.rpb;
+    issue(0, A, true);
+    int r = 0;
+    for (; r + 2 < nr; r += 2) {  // steady state: every trip issues two rows and consumes two
+      const bool pb = obs_b;      // row r + 1 asks by the outcome of row r - 1
+      issue(r + 1, B, pb);
+      const bool pa = obs_a;      // what row r asked by: row r - 2's outcome (the first two rows ask)
+      consume(r, A, pa, obs_a);
+      const bool pa2 = obs_a;     // row r + 2 asks by the outcome of row r
+      issue(r + 2, A, pa2);
+      consume(r + 1, B, pb, obs_b);
+    }
+    if (r + 1 < nr) {
+      const bool pb = obs_b;
+      issue(r + 1, B, pb);
+      const bool pa = obs_a;
+      consume(r, A, pa, obs_a);
+      consume(r + 1, B, pb, obs_b);
+    } else {
+      const bool pa = obs_a;
+      consume(r, A, pa, obs_a);
+    }
+  }
+  if (band) {
+    TSDF_BAND_SYNC();
+    const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
+    const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
+    const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
+    const int n_fl = (yg1 - yg0 + 1) << lf;
+    for (int i = TSDF_BAND_FIRST; i < n_fl; i += TSDF_BAND_STEP) {
+      const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
+      if (TSDF_BAND(i) && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+    }
+  }
+  if (COUNT) {
     __shared__ unsigned s_cnt, s_chg, s_imp, s_rdb;
     if (tid == 0) s_cnt = s_chg = s_imp = s_rdb = 0;
     __syncthreads();
@@ -1467,8 +1760,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
   __shared__ KEntry s_tab[256];        // per count k: decoded weight, Rcp32(k + 1).y, colour rounding offset, next count (k_integrate)
   __shared__ f4 s_ytA[256], s_ytB[256];  // per row of the block: the row's part of each frame's transform (k_integrate's s_yt)
   __shared__ f4 s_cx[256];             // every thread's own four x centres, re-read each row
-  __shared__ __attribute__((aligned(16))) uint8_t s_band[1024 + 64];
-  reinterpret_cast<uint32_t *>(s_band)[tid] = 0u, s_band[1024 + (tid & 63u)] = 0;
+  TSDF_BAND_DECL;
   s_tab[tid] = tsdf_ktab_entry(a, tid);
   {
     const int yy = (int)bc.by * a.rpb * a.TY + (int)tid;
@@ -1626,7 +1918,7 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
           }
           if (d_moves) {
             d_touched = true;
-            if (any_div) s_band[((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)] = 1;
+            if (any_div) TSDF_BAND(((ty + r * a.TY) >> 2) * max(1, a.TX >> 4) + (tx >> 4)) = 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) dv[j] = div32_fast(d0[j] * w0[j] + dn[j], rs[j]);
 #pragma unroll
@@ -1693,14 +1985,14 @@ k_integrate2(const IntegrateArgs a, const Frame2 fb, float *__restrict__ D, uint
 #endif
   }
   if (band) {
-    __syncthreads();
+    TSDF_BAND_SYNC();  // (per-wave sets: none -- a wave reads back what it wrote itself)
     const int lf = max(0, a.log2TX - 4), fxb = 1 << lf;
     const int yg0 = (a.y_abs0 + row0) >> 2, yg1 = (a.y_abs0 + row0 + max(rows, 1) - 1) >> 2;
     const int xc0 = (a.x_abs0 + (int)bc.bx * a.TX * 4) >> 6;
     const int n_fl = (yg1 - yg0 + 1) << lf;
-    for (int i = (int)tid; i < n_fl; i += 256) {
+    for (int i = TSDF_BAND_FIRST; i < n_fl; i += TSDF_BAND_STEP) {
       const int yg = yg0 + (i >> lf), xc = xc0 + (i & (fxb - 1));
-      if (s_band[i] && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
+      if (TSDF_BAND(i) && yg < a.band_fy && xc < a.band_fx) band[((int64_t)(a.zl0 + zl) * a.band_fy + yg) * a.band_fx + xc] = 1;
     }
   }
   if (COUNT) {
@@ -2633,7 +2925,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       a.TX = 1 << ltx, a.log2TX = ltx, a.TY = 256 >> ltx;
       // (twice the rows of a full-width block: 128 voxels x 64 rows, eight passes -- Scene B at 2048^3: 0.43 / 0.36 / 0.34 /
       // 0.36 ms per frame with 16 / 32 / 64 / 128 rows)
-      a.rpb = std::max(1, std::min(2 * tsdf_tuning().rows_per_block, 256) / a.TY);
+      a.rpb = std::max(1, std::min(2 * tsdf_tuning().rows_per_block, 64) / a.TY);  // (64 rows: the default knob's own value since round 6)
       gx = (unsigned)((a.qpr + a.TX - 1) / a.TX);
       gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY));
     }
@@ -2775,12 +3067,20 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
       L4(ORDER, COLOR, false); \
   } while (0)
     // the software-pipelined instance (k_integrate_p): ALLIN, PACKED, no colour, every block's rows present, resting hinge
-    const bool pipe = tsdf_tuning().pipe && fastproj && allin && !live && h->packed && !color && a.hinge_fixed && a.neg_in_window &&
+    // (knob pipe: bit 0 = without colour, k_integrate_p; bit 1 = with colour, k_integrate_pc)
+    const bool pipe = (tsdf_tuning().pipe & (color ? 2 : 1)) && fastproj && allin && !live && h->packed && a.hinge_fixed && a.neg_in_window &&
                       a.ny % (a.rpb * a.TY) == 0;
     if (pipe) {
       h->last_launch[0] |= 0x100;  // bit 8: the pipelined row loop
-#define LAUNCH_P(ORDER, COUNT) \
-  hipLaunchKernelGGL((k_integrate_p<ORDER, COUNT>), grid, block, 0, h->stream, a, D, K8, d_depth, h->cam64, ctrx, ctry, h->ctr[2], h->counter, band_arg)
+#define LAUNCH_P(ORDER, COUNT)                                                                                                           \
+  do {                                                                                                                                   \
+    if (color)                                                                                                                           \
+      hipLaunchKernelGGL((k_integrate_pc<ORDER, COUNT>), grid, block, 0, h->stream, a, D, RGB, d_depth, h->cam64, ctrx, ctry, h->ctr[2], \
+                         h->counter, band_arg);                                                                                          \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((k_integrate_p<ORDER, COUNT>), grid, block, 0, h->stream, a, D, K8, d_depth, h->cam64, ctrx, ctry, h->ctr[2],   \
+                         h->counter, band_arg);                                                                                          \
+  } while (0)
       if (p.xform_order == TSDF_XFORM_PCL_SSE) {
         if (count)
           LAUNCH_P(TSDF_XFORM_PCL_SSE, true);

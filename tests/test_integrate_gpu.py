@@ -748,22 +748,24 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
         # k_integrate_p (the software-pipelined row loop: ALLIN, PACKED, no colour): transform order x counting
         capi.set_tuning("fast_projection", 1)
         capi.set_tuning("allin", 1)
-        capi.set_tuning("pipe", 1)
+        capi.set_tuning("pipe", 3)
         for order in (0, 1):
-            vol, sc = make_volume(res, W, H, color=False, order=order, max_weight=100.0)
+          for color in (False, True):  # k_integrate_p / k_integrate_pc
+            vol, sc = make_volume(res, W, H, color=color, order=order, max_weight=100.0)
             vol.reset()
             ov = OracleVolume(vol._p)
             for i in range(4):
                 tr = synth.turntable_pose(i, 9, sc.size)
                 dep = sc.depth(tr, noise_seed=40 + i)
                 dep[(i * 5) % 30::31, ::3] = np.nan
+                col = sc.bgra(i) if color else None
                 count = i % 2 == 0
-                want = ov.integrate_culled(dep, None, tr, synth.cam_from_vol_f32(tr))
-                got = vol.integrateCloud(dep, None, tr, count=count)
-                assert got is True or got == want, (order, i, got, want)
+                want = ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr))
+                got = vol.integrateCloud(dep, col, tr, count=count)
+                assert got is True or got == want, (order, color, i, got, want)
                 info = launch_info(vol)
                 assert info[0] == 1 and info[1] == 1 and info[2] == 0 and info[4], info
-                hit.add((order, "kp", count))
+                hit.add((order, color, "kp", count))
             compare(vol, ov)
             vol.close()
         # k_integrate2: transform order x colour x counting (PACKED, certified projection, both poses ALLIN)
@@ -795,17 +797,19 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
     finally:
         capi.set_tuning("fast_projection", -1)
         capi.set_tuning("allin", 1)
-        capi.set_tuning("pipe", 1)
+        capi.set_tuning("pipe", 3)
     # 8 x {certified: general, ALLIN, row intervals (camera inside), row intervals (cull); exact projection: the same without
-    # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 4 of k_integrate_p + the 8 of
-    # k_integrate2
-    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 3) + 4 + 8, len(hit)
+    # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 4 + 4 of k_integrate_p /
+    # k_integrate_pc + the 8 of k_integrate2
+    assert len(hit) == 2 * 2 * 2 * 2 * (4 + 3) + 8 + 8, len(hit)
 
 
+@pytest.mark.parametrize("color", [False, True], ids=["k_integrate_p", "k_integrate_pc"])
 @pytest.mark.parametrize("rows_per_block", [8, 16, 24, 32, 48, 96])
-def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_per_block):
-    """k_integrate_p (round 6: two rows in flight per wave, stage A = projection + every load of a row, stage B = update +
-    stores) on a 96^3 grid without colour, whose blocks walk 1, 2, 3, 4, 6 or 12 row steps (TY = 8 rows per step): the tail of
+def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_per_block, color):
+    """k_integrate_p / k_integrate_pc (round 6: two rows in flight per wave, stage A = projection + every load of a row, stage
+    B = update + stores; with colour the voxel words are asked by a predictor two rows back, an observed quad it missed asks
+    late) on a 96^3 grid, whose blocks walk 1, 2, 3, 4, 6 or 12 row steps (TY = 8 rows per step): the tail of
     one row, of a pair, the odd tail behind the steady-state loop and the loop itself -- noisy depth with NaN holes, frames
     past the weight limit (max_weight 4), counting on alternate frames -- against the oracle voxel for voxel, against
     k_integrate's own instance (knob pipe = 0) plane for plane, observed-voxel counts included; and the row count the
@@ -813,19 +817,20 @@ def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_p
     outs = []
     try:
         capi.set_tuning("rows_per_block", rows_per_block)
-        for pipe in (1, 0):
+        for pipe in (3, 0):
             capi.set_tuning("pipe", pipe)
-            vol, sc = make_volume(96, color=False, max_weight=4.0)
+            vol, sc = make_volume(96, color=color, max_weight=4.0)
             vol.reset()
             ov = OracleVolume(vol._p)
             counts = []
             for i, tr, dep, col in frames(sc, 7, 9, noise=True):
                 dep = dep.copy()
                 dep[(i * 7) % 50::53, ::3] = np.nan
-                n_gpu = vol.integrateCloud(dep, None, tr, count=(i % 2 == 0))
+                c = col if color else None
+                n_gpu = vol.integrateCloud(dep, c, tr, count=(i % 2 == 0))
                 info = launch_info(vol)
                 assert info[0] == 1 and info[4] == bool(pipe), (pipe, info)
-                n_cpu = ov.integrate(dep, None, synth.cam_from_vol_f32(tr))
+                n_cpu = ov.integrate(dep, c, synth.cam_from_vol_f32(tr))
                 assert n_gpu is True or n_gpu == n_cpu, (pipe, i, n_gpu, n_cpu)
                 counts.append(n_gpu)
             compare(vol, ov)
@@ -833,20 +838,21 @@ def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_p
             vol.close()
         assert_same_f32(outs[0][0][0], outs[1][0][0], "d: pipelined vs plain row loop")
         assert np.array_equal(outs[0][0][1], outs[1][0][1]) and outs[0][1] == outs[1][1]
+        assert (outs[0][0][2] is None and outs[1][0][2] is None) or np.array_equal(outs[0][0][2], outs[1][0][2])
         # 100 rows are no multiple of the block's rows: the launch takes k_integrate's instance by itself
-        capi.set_tuning("pipe", 1)
-        vol, sc = make_volume(96, color=False, res3=(96, 100, 96))
+        capi.set_tuning("pipe", 3)
+        vol, sc = make_volume(96, color=color, res3=(96, 100, 96))
         vol.reset()
         ov = OracleVolume(vol._p)
         tr = synth.turntable_pose(1, 8, sc.size)
-        dep = sc.depth(tr)
-        assert vol.integrateCloud(dep, None, tr, count=True) == ov.integrate(dep, None, synth.cam_from_vol_f32(tr))
+        dep, c = sc.depth(tr), (sc.bgra(1) if color else None)
+        assert vol.integrateCloud(dep, c, tr, count=True) == ov.integrate(dep, c, synth.cam_from_vol_f32(tr))
         assert launch_info(vol)[0] == 1 and not launch_info(vol)[4], launch_info(vol)
         compare(vol, ov)
         vol.close()
     finally:
-        capi.set_tuning("rows_per_block", 32)
-        capi.set_tuning("pipe", 1)
+        capi.set_tuning("rows_per_block", 64)
+        capi.set_tuning("pipe", 3)
 
 
 def test_planes_fastest_block_order_changes_nothing(gpu):

@@ -228,7 +228,7 @@ def test_marching_cubes_wave_list_flush_paths(gpu):
         _mesh_vs_oracle(vol, ov, 2.0, 0)
     finally:
         capi.set_tuning("mc_flush_at", 512)
-        capi.set_tuning("rows_per_block", 32)
+        capi.set_tuning("rows_per_block", 64)
 
 
 def test_marching_cubes_empty_and_global_transform(gpu):

@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 BUDGET = {
     "_ZL11k_integrateILi0ELb1ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED colour (headline)", 64, 16, 8),
     "_ZL11k_integrateILi0ELb0ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED no colour", 64, 16, 8),
+    "_ZL13k_integrate_pILi0ELb0EE": ("k_integrate_p (software-pipelined rows, no colour)", 64, 16, 8),
+    "_ZL14k_integrate_pcILi0ELb0EE": ("k_integrate_pc (software-pipelined rows, colour: the headline)", 96, 0, 5),
     "_ZL12k_integrate2ILi0ELb1ELb0E": ("k_integrate2 colour", 96, 0, 5),
     "_ZL12k_integrate2ILi0ELb0ELb0E": ("k_integrate2 no colour", 96, 0, 5),
 }
@@ -66,6 +68,14 @@ def inspect(lines, prefix):
     if heads and stores:
         head = max(h for h in heads if h < stores[0])
         tail = next((h for h in heads if h > stores[-1]), len(body))
+        # the loop's own extent where the compiler's block comments give it: the last block marked "in Loop: Header=<this loop>"
+        # (a reload BEHIND the loop -- a value parked across it for the epilogue -- is no vector-memory operation of the row path)
+        m = re.match(r"\.(LBB\d+_\d+):", body[head])
+        if m:
+            inside = [i for i in range(head, tail) if ("Header=" + m.group(1)[1:] + " ") in body[i]]
+            if inside:
+                nxt = next((i for i in range(max(inside) + 1, tail) if re.match(r"\.LBB\d+_\d+:", body[i]) or body[i].startswith("; %bb.")), tail)
+                tail = min(tail, nxt)
         for i in range(head, tail):
             if "scratch_load" in body[i]:
                 # a reload under a wave-uniform rare branch is harmless; one on the path every row takes is not.  Heuristic: the
