@@ -87,6 +87,13 @@ def parse():
     ap.add_argument("--keys", type=int, default=1, help="N=1 with --extras: also time the secondary integrate keys in this run -- the "
                     "headline grid in the SATURATED regime (w == max_weight), the colourless 2048^3 grid, one configs[4] slab "
                     "(4096x4096x512, 1280x960) -- each with kernel_ms, bytes moved, frac and its PMC quote (extras.keys)")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="with --of N, on ONE GPU: integrate the Z-slab rank r of an N-rank strong-scaling "
+                    "run would own ([r * planes / N, (r + 1) * planes / N) of the full grid) with the real turntable frames -- per-slab kernel "
+                    "time and observed voxels for a PREDICTED scaling table (tools/predict_scaling.py); no number from it is a scaling measurement")
+    ap.add_argument("--of", type=int, default=0, help="see --emulate-rank")
+    ap.add_argument("--pairing", type=int, default=0, help="1: the timed frames go two per call (tsdf_hip_integrate_device2 -> k_integrate2: one "
+                    "sweep of the slab per PAIR where both poses see all of it) and, at N > 1, two per collective (ONE broadcast of [A | B]); "
+                    "a step is still one frame, --steps must be even.  The headline stays the single-frame path (default 0)")
     ap.add_argument("--presaturate", type=int, default=0, help="launches BEFORE the warm-up (cycling through the timed frames): the "
                     "timed region then runs in the saturated regime w == max_weight (>= 100 for the default max_weight): how "
                     "tools/run_rocprof.sh profiles that key")
@@ -483,6 +490,40 @@ def host_path_leg(vol, sc, poses, color, first, last):
     return out
 
 
+def cpp_dropin_leg(sc, poses, res, W, H, color, n_frames=40, distinct=8):
+    """Report-only: what a C++ user of the drop-in waits for -- cpu_tsdf::TSDFVolumeOctree::integrateCloud
+    on pcl::PointCloud<pcl::PointXYZRGBA> clouds in host memory (AoS strip into the pinned slot + upload + kernel), through
+    the product's own timing program cpu_tsdf_amd/bin/dropin_rate (csrc/prog/dropin_rate.cpp), a process of its own with its
+    own res^3 volume, frame pairing off and on, `distinct` of this run's Scene-A frames cycled through `n_frames` calls."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "cpu_tsdf_amd", "bin", "dropin_rate")
+    if not os.path.exists(exe):
+        return {"error": "cpu_tsdf_amd/bin/dropin_rate is not built (python __graft_entry__.py)"}
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            path = os.path.join(td, "frames.bin")
+            with open(path, "wb") as f:
+                for i in range(min(distinct, len(poses))):
+                    f.write(np.ascontiguousarray(poses[i], dtype=np.float64).tobytes())
+                    f.write(np.ascontiguousarray(sc.depth(poses[i]), dtype=np.float32).tobytes())
+                    f.write(np.ascontiguousarray(sc.bgra(i), dtype=np.uint8).tobytes())
+            for pairing in (0, 1):
+                p = subprocess.run([exe, str(res), str(W), str(H), str(int(bool(color))), str(pairing), str(n_frames), path],
+                                   capture_output=True, text=True, timeout=180)
+                if p.returncode:
+                    out["pairing_on" if pairing else "pairing_off"] = {"error": f"exit {p.returncode}: {p.stderr.strip()[-300:]}"}
+                else:
+                    out["pairing_on" if pairing else "pairing_off"] = json.loads(p.stdout.strip().splitlines()[-1])
+        out["note"] = ("TSDFVolumeOctree::integrateCloud(PointCloud<PointXYZRGBA>) called back to back from C++ on host clouds: the "
+                       "in-call time is what the caller's thread pays (strip + queue), the sustained rate includes a final call that "
+                       "waits for the device; setSynchronous off")
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
+
+
 def pmc_traffic(key, sha):
     """HBM bytes per timed k_integrate launch from the committed PMC profile of this very command -- only if the
     profile was taken on the kernel sources that are running now."""
@@ -571,6 +612,17 @@ def main():
         res3 = (res, res, planes)
         per = planes // world
         z_begin, z_end = rank * per, (rank + 1) * per if rank < world - 1 else planes
+    emulated = None
+    if args.of and args.emulate_rank >= 0:
+        if world != 1 or args.scaling != "strong" or not 0 <= args.emulate_rank < args.of:
+            raise SystemExit("--emulate-rank r --of N: one process, strong scaling, 0 <= r < N")
+        per = planes // args.of
+        z_begin, z_end = args.emulate_rank * per, ((args.emulate_rank + 1) * per if args.emulate_rank < args.of - 1 else planes)
+        emulated = {"rank": args.emulate_rank, "of": args.of, "z_begin": z_begin, "z_end": z_end,
+                    "note": "ONE GPU integrating the slab this rank of an N-rank run would own: input to a PREDICTED scaling table, not a scaling measurement"}
+        args.extras = 0
+        args.host_path = 0
+        args.cpu_baseline = 0
     size3 = tuple(r * voxel for r in res3)
     S = size3[0]
     W, H = args.width, args.height
@@ -623,6 +675,8 @@ def main():
                                                 "span_bytes": span.value, "dwords_read": words.value})
 
     # ---- synthetic frames, resident in HBM before the timed region ---------------------------------
+    if args.pairing and (args.steps % 2 or args.warmup % 2):
+        raise SystemExit("--pairing 1: --steps and --warmup must be even (frames go two per call; warm-up frames go singly)")
     n_total = args.warmup + args.steps
     n_distinct = args.frames or n_total
     radius = 2.2 * max(size3) / S
@@ -647,7 +701,7 @@ def main():
             if args.color:
                 frames_dev[i, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(sc.bgra(i)))
     # two receive slots: the broadcast of frame i+1 fills one while k_integrate reads frame i from the other
-    recv = torch.empty((2, fplanes, H, W), dtype=torch.float32, device=dev) if use_dist else None
+    recv = torch.empty((4 if args.pairing else 2, fplanes, H, W), dtype=torch.float32, device=dev) if use_dist else None
     pairs = []  # HIP event pairs around each timed launch, on the stream the kernel runs on
     ev_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     host_t = {"launch": 0.0, "broadcast": 0.0, "events": 0.0, "steps": 0}  # host seconds spent ENQUEUEING, timed steps only
@@ -665,7 +719,31 @@ def main():
         return b
 
     def frame_buf(i):
-        return frames_dev[i] if rank == 0 else recv[i & 1]
+        return frames_dev[i] if rank == 0 else recv[i & (3 if args.pairing else 1)]
+
+    def pair_buf(i):  # frames i, i + 1 back to back (warm-up even, so i is): what ONE broadcast carries with --pairing
+        if rank == 0:
+            return frames_dev[i:i + 2]
+        k = i & 3
+        return recv[k:k + 2]
+
+    integ2 = lib.tsdf_hip_integrate_device2
+    fused_pairs = [0, 0]  # pairs launched, pairs every slab swept once
+
+    def launch_pair(i, timed=False):
+        (pa, da, ca, ta), (pb, db, cb, tb) = bound_args(i), bound_args(i + 1)
+        if timed:
+            pairs.append(ev_pool[len(pairs)])
+            pairs[-1][0].record(stream)
+        f = C.c_int32(0)
+        rc = integ2(h, da, ca, ta, pa, db, cb, tb, pb, None, C.byref(f))
+        if timed:
+            pairs[-1][1].record(stream)
+            host_t["steps"] += 2
+        if rc:
+            capi.check(rc, "integrate_device2")
+        fused_pairs[0] += 1
+        fused_pairs[1] += int(f.value)
 
     def bcast(i, async_op):
         # the frame arrives on rank 0; one RCCL broadcast (depth + colour, 2.4 MB) to every slab owner.  RCCL's
@@ -695,6 +773,17 @@ def main():
     def run(first, last, counting=False, timed=False):
         """Frames [first, last): broadcast + integrate, the next frame's broadcast in flight under each kernel.
         counting: through the counting instance of the kernel (synchronous), results appended to `counted`."""
+        if args.pairing and timed and not counting:  # two frames per call and per collective
+            pend = dist.broadcast(pair_buf(first), src=0, async_op=True) if (use_dist and args.overlap and first + 1 < last) else None
+            for i in range(first, last - 1, 2):
+                if use_dist:
+                    if args.overlap:
+                        pend.wait()
+                        pend = dist.broadcast(pair_buf(i + 2), src=0, async_op=True) if i + 3 < last else None
+                    else:
+                        dist.broadcast(pair_buf(i), src=0)
+                launch_pair(i, timed)
+            return
         pending = bcast(first, True) if (use_dist and args.overlap and first < last) else None
         detail, rdet = (C.c_uint64 * 2)(), (C.c_uint64 * 3)()
         for i in range(first, last):
@@ -948,6 +1037,13 @@ def main():
             "note": "rank 0's host time spent ENQUEUEING one timed step (two ctypes calls with pre-bound arguments: cull planes + "
                     "integrate; two event records; the frame broadcast's wait() + next issue at N > 1) -- the GPU runs behind it" +
                     ("; backend gloo stages device tensors through the host inside broadcast(): its share is not RCCL's" if use_dist and backend != "nccl" else "")}
+        if args.pairing:
+            out["pairing"] = {"frames_per_call": 2, "pairs_launched": fused_pairs[0], "pairs_swept_once_by_every_slab": fused_pairs[1],
+                              "note": "tsdf_hip_integrate_device2 per pair (k_integrate2 where both poses see the whole slab); at N > 1 one "
+                                      "broadcast carries both frames.  roofline.kernel_ms = event time of the pairs / steps (per FRAME); the "
+                                      "byte counts are the single-frame kernel's (counted frame by frame) and do not describe k_integrate2"}
+        if emulated:
+            out["emulated_slab"] = emulated
         if args.dry_run_ranks:
             out["dry_run"] = f"{world} ranks on ONE GPU over gloo: control flow only, no number here is a scaling number"
         if use_dist:
@@ -976,6 +1072,12 @@ def main():
                 out["extras"]["scene_b"] = scene_b_leg(res, args.color, 8.0 if args.cpu_baseline else 0.0)
         if world == 1 and not use_dist and args.host_path:
             out["host_path"] = host_path_leg(vol, sc, poses, bool(args.color), args.warmup, n_total)
+            if res3[0] == res3[1] == res3[2]:
+                cd = cpp_dropin_leg(sc, poses, res3[0], W, H, bool(args.color))
+                out["host_path"]["cpp_dropin"] = cd
+                for k in ("pairing_off", "pairing_on"):
+                    if isinstance(cd.get(k), dict) and "sustained_frames_per_s" in cd[k]:
+                        out["host_path"]["cpp_dropin_frames_per_s" + ("_frame_pairing" if k == "pairing_on" else "")] = cd[k]["sustained_frames_per_s"]
         if world == 1 and not use_dist and args.extras == 1 and args.keys:
             # every integrate key in the driver-run line; the headline volume is freed first
             keys = {}

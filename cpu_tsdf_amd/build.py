@@ -129,11 +129,12 @@ def build_shell(force=False, verbose=False):
 
 
 def build_programs(force=False, verbose=False):
-    """cpu_tsdf_amd/bin/{integrate,tsdf2mesh}: the reference's two programs (src/prog/) on the MI355X path."""
+    """cpu_tsdf_amd/bin/{integrate,tsdf2mesh}: the reference's two programs (src/prog/) on the MI355X path; dropin_rate: the
+    timing program of the C++ drop-in's integrateCloud (bench.py host_path.cpp_dropin, tools/cpp_path_timing.py)."""
     build_shell(force=False, verbose=verbose)
     os.makedirs(BINDIR, exist_ok=True)
     outs = []
-    for name in ("integrate", "tsdf2mesh"):
+    for name in ("integrate", "tsdf2mesh", "dropin_rate"):
         src, exe = os.path.join(PROG, name + ".cpp"), os.path.join(BINDIR, name)
         deps = [src, SHELL_LIB] + glob.glob(os.path.join(PROG, "*.h")) + glob.glob(os.path.join(ROOT, "compat", "*.h")) + \
             glob.glob(os.path.join(ROOT, "include", "cpu_tsdf", "*.h"))

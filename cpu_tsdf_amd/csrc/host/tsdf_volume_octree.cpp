@@ -162,7 +162,7 @@ void TSDFVolumeOctree::reset() {
     rc = tsdf_hip_set_weighting(h_, weight_by_depth_, weight_by_variance_);
     if (rc) tsdf_hip_destroy(h_);
   }
-  if (!rc && frame_pairing_ && devices_.empty()) rc = tsdf_hip_set_frame_pairing(h_, 1);
+  if (!rc && frame_pairing_) rc = tsdf_hip_set_frame_pairing(h_, 1);  // (a setDevices set pairs too since round 6)
   if (rc) {
     h_ = nullptr;
     report("reset", rc);

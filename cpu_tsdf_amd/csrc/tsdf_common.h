@@ -141,6 +141,11 @@ int tsdf_multi_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *
 int tsdf_multi_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
 int tsdf_multi_march_stats(tsdf_handle h, uint64_t out[4]);
 tsdf_handle tsdf_multi_first(tsdf_handle h);
+// frame pairing on a set (round 6): the slabs pair the frames of their own rings; tsdf_multi_flush lets them launch what they hold
+int tsdf_multi_flush(tsdf_handle h);
+int tsdf_multi_set_frame_pairing(tsdf_handle h, int on);
+int tsdf_multi_integrate_device2(tsdf_handle h, const float *da, const uint32_t *ca, const float TA[12], const float *planes_a, const float *db,
+                                 const uint32_t *cb, const float TB[12], const float *planes_b, uint64_t *n_observed, int32_t *fused);
 #define TSDF_NOT_ON_MULTI(h, what)                                                                          \
   do {                                                                                                      \
     if ((h) && (h)->multi) {                                                                                \
@@ -301,7 +306,7 @@ struct TsdfTuning {
   int zfast;           // integrate launches hand out blocks planes-fastest: 1 always (default: 16.26 against 16.60 ms at 2048^3 + colour, 15.5 against 16.9 ms on a 4096 x 4096 x 512 slab with 1280x960 frames), 0 never, -1 only when the frame outgrows an XCD's L2
   int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
   int implied_d;       // PACKED integrate launches do not read distance words the "band seen" flags and the counts determine (1)
-  int pipe;            // ALLIN PACKED launches run the software-pipelined row loop: bit 0 without colour (k_integrate_p), bit 1 with (k_integrate_pc); 3
+  int pipe;            // ALLIN PACKED launches run the software-pipelined row loop: bit 0 without colour (k_integrate_p: on), bit 1 with (k_integrate_pc: measured no faster than k_integrate's own loop, off); 1
 };
 const TsdfTuning &tsdf_tuning();
 // Edge of the voxel blocks save / load stream through host memory: TSDF_HIP_VOL_CHUNK, read at EVERY call (an I/O path: a

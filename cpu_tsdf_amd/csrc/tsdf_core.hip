@@ -58,7 +58,7 @@ static TsdfTuning &tuning_storage() {
                          env_int("TSDF_HIP_CULL", 1), std::max(1, env_int("TSDF_HIP_VOL_CHUNK", 256)),
                          env_int("TSDF_HIP_PLAIN_KERNEL", 0), env_int("TSDF_HIP_ALLOC_TRIES", 3), env_int("TSDF_HIP_ALLIN", 1),
                          env_int("TSDF_HIP_REFCULL_PLAIN", 0), env_int("TSDF_HIP_LIVE_LOG2TX", 5), env_int("TSDF_HIP_ZFAST", 1), env_int("TSDF_HIP_FUSE2", 1), env_int("TSDF_HIP_IMPLIED_D", 1),
-                         env_int("TSDF_HIP_PIPE", 3)};
+                         env_int("TSDF_HIP_PIPE", 1)};
   return t;
 }
 

@@ -1469,6 +1469,11 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
 // same TEN loads and the compiler can count them behind the row that waits.  An observed quad the predictor missed asks in
 // stage B and waits there (in order: also for the next row's gathers -- rare: where a surface begins along y).
 // Arithmetic: k_integrate<ORDER, true, true, COUNT, true, true, false>'s, operation for operation.
+// MEASURED (profiles/r06_ab_pipec_call04.txt, five alternations, 2048^3 + colour): 12.80 ms at five waves (91 VGPRs), 12.78-13.46 at
+// four, against 12.59-12.64 for k_integrate's own row loop at eight waves -- no gain, nor on a configs[4] slab (12.21 against
+// 12.14): with colour the row moves 58.6 GB per launch, 4.6 TB/s = 82 % of what this box's plain read-modify-write sweep
+// reaches, while the VALU is 80 % busy -- two limiters at once, neither of which the pipeline touches.  OFF by default (knob
+// pipe, bit 1); kept, oracle-gated like every instance (tests/test_integrate_gpu.py), for hardware where the balance differs.
 #ifndef TSDF_WPE_PIPEC
 #define TSDF_WPE_PIPEC 5  // 91 VGPRs, no scratch (six waves: 80 VGPRs + ten spill operations in the row loop, whose waits undo the pipeline)
 #endif
@@ -2302,6 +2307,7 @@ static IntegrateHost make_args(tsdf_handle h, const float T[12]) {
   a.TX = 1 << l2;
   a.TY = 256 / a.TX;
   a.rpb = std::max(1, std::min(tsdf_tuning().rows_per_block, 256) / a.TY);  // rpb * TY <= 256: the block's row centres sit in LDS
+  a.rpb = std::max(1, std::min(a.rpb, (a.ny + a.TY - 1) / a.TY));           // (... and no taller than the grid)
   a.pitch = h->pitch;
   a.expf_fused_r = h->expf_fused_r;
   a.ref_cull = h->ref_cull ? 1 : 0;
@@ -3309,13 +3315,9 @@ extern "C" int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a,
                                           const float cam_from_vol_b[12], const float *planes_b, uint64_t *n_observed, int32_t *fused) {
   if (!h || !d_depth_a || !d_depth_b || !cam_from_vol_a || !cam_from_vol_b) return TSDF_HIP_E_INVALID;
   if (fused) *fused = 0;
-  if (h->multi) {  // a multi-GPU set: frame by frame (every slab integrates its own planes; no pairing yet)
-    int rc = tsdf_hip_set_reference_cull(h, planes_a);
-    if (!rc) rc = tsdf_multi_integrate_device(h, d_depth_a, d_bgra_a, cam_from_vol_a, n_observed);
-    if (!rc) rc = tsdf_hip_set_reference_cull(h, planes_b);
-    if (!rc) rc = tsdf_multi_integrate_device(h, d_depth_b, d_bgra_b, cam_from_vol_b, n_observed ? n_observed + 1 : nullptr);
-    return rc;
-  }
+  if (h->multi)  // a multi-GPU set: every slab takes both frames and sweeps ONCE where both poses see all of it (round 6)
+    return tsdf_multi_integrate_device2(h, d_depth_a, d_bgra_a, cam_from_vol_a, planes_a, d_depth_b, d_bgra_b, cam_from_vol_b, planes_b,
+                                        n_observed, fused);
   TSDF_ENTER(h);
   bool f = false;
   const int rc = tsdf_integrate_launch2(h, d_depth_a, d_bgra_a, cam_from_vol_a, planes_a, d_depth_b, d_bgra_b, cam_from_vol_b, planes_b,
@@ -3578,7 +3580,7 @@ int tsdf_pipeline_flush(tsdf_hip_volume *h) {
 
 extern "C" int tsdf_hip_set_frame_pairing(tsdf_handle h, int on) {
   if (!h) return TSDF_HIP_E_INVALID;
-  if (h->multi) return on ? TSDF_HIP_E_UNSUPPORTED : TSDF_HIP_OK;  // (a multi-GPU set integrates frame by frame)
+  if (h->multi) return tsdf_multi_set_frame_pairing(h, on);
   TSDF_ENTER(h);  // (switching it off launches what was waiting)
   const int rc = pipeline_ready(h);
   if (rc) return rc;
@@ -3602,21 +3604,12 @@ extern "C" int tsdf_hip_frame_begin(tsdf_handle h, float **depth, uint8_t **bgra
   return TSDF_HIP_OK;
 }
 
-extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]) {
-  if (!h || !cam_from_vol) return TSDF_HIP_E_INVALID;
-  if (h->multi) return tsdf_multi_frame_commit(h, cam_from_vol);
-  if (!h->pipe) {
-    tsdf_set_error("tsdf_hip_frame_commit without tsdf_hip_frame_begin");
-    return TSDF_HIP_E_INVALID;
-  }
-  TSDF_ON_DEVICE(h->device);
+// The ring's second half, once frame `slot` is on its way into p->device[slot] and the handle's stream waits for it: launch
+// it, or -- frame pairing -- hold it back for a partner / launch it together with the frame that was waiting.
+static int pipeline_commit_uploaded(tsdf_handle h, int slot, const float cam_from_vol[12]) {
   tsdf_hip_pipeline *p = h->pipe;
   const bool color = h->p.integrate_color != 0;
-  const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
-  const int slot = (int)(p->frames % tsdf_hip_pipeline::SLOTS);
-  TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], p->pinned[slot], bytes, hipMemcpyHostToDevice, p->copy_stream));
-  TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
-  TSDF_HIP_TRY(hipStreamWaitEvent(h->stream, p->copied[slot], 0));
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
   auto bgra_of = [&](int s) { return color ? reinterpret_cast<const uint32_t *>(p->device[s] + npx) : nullptr; };
   if (h->pair_pending) {  // the partner has arrived: one sweep for both where the poses allow it, two launches otherwise
     h->pair_pending = false;
@@ -3647,6 +3640,81 @@ extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]
   }
   p->frames++;
   return TSDF_HIP_OK;
+}
+
+extern "C" int tsdf_hip_frame_commit(tsdf_handle h, const float cam_from_vol[12]) {
+  if (!h || !cam_from_vol) return TSDF_HIP_E_INVALID;
+  if (h->multi) return tsdf_multi_frame_commit(h, cam_from_vol);
+  if (!h->pipe) {
+    tsdf_set_error("tsdf_hip_frame_commit without tsdf_hip_frame_begin");
+    return TSDF_HIP_E_INVALID;
+  }
+  TSDF_ON_DEVICE(h->device);
+  tsdf_hip_pipeline *p = h->pipe;
+  const bool color = h->p.integrate_color != 0;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
+  const int slot = (int)(p->frames % tsdf_hip_pipeline::SLOTS);
+  TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], p->pinned[slot], bytes, hipMemcpyHostToDevice, p->copy_stream));
+  TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
+  TSDF_HIP_TRY(hipStreamWaitEvent(h->stream, p->copied[slot], 0));
+  return pipeline_commit_uploaded(h, slot, cam_from_vol);
+}
+
+// A SLAB of a multi-GPU set takes a frame through its own ring (tsdf_multi.hip, frame pairing on a set): the frame already
+// sits in `src` -- the set's pinned host slot (src_dev < 0: one upload over this GPU's own PCIe link) or a device buffer on
+// GPU src_dev (a peer copy, or the pinned relay where the driver refuses peer access: `copy`) -- and goes into the slab's next
+// ring slot on the slab's copy stream; then exactly what tsdf_hip_frame_commit does.  *uploaded, when given, is recorded on
+// the copy stream behind the copy (the set waits for it before it reuses its pinned slot).
+int tsdf_pipeline_commit_from(tsdf_handle s, const void *src, int src_dev, const float T[12], bool pairing, hipEvent_t uploaded,
+                              int (*copy)(void *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st), void *ctx) {
+  TSDF_ON_DEVICE(s->device);
+  int rc = pipeline_ready(s);
+  if (rc) return rc;
+  tsdf_hip_pipeline *p = s->pipe;
+  if (p->pairing != pairing) {
+    if (s->pair_pending && (rc = tsdf_pipeline_flush(s))) return rc;
+    p->pairing = pairing;
+  }
+  const bool color = s->p.integrate_color != 0;
+  const size_t npx = (size_t)s->p.image_width * s->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
+  const int slot = (int)(p->frames % tsdf_hip_pipeline::SLOTS);
+  if (p->frames >= (unsigned)tsdf_hip_pipeline::SLOTS) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot]));
+  if (src_dev < 0) {
+    TSDF_HIP_TRY(hipMemcpyAsync(p->device[slot], src, bytes, hipMemcpyHostToDevice, p->copy_stream));
+  } else if ((rc = copy(ctx, p->device[slot], s->device, src, src_dev, bytes, p->copy_stream))) {
+    return rc;
+  }
+  TSDF_HIP_TRY(hipEventRecord(p->copied[slot], p->copy_stream));
+  if (uploaded) TSDF_HIP_TRY(hipEventRecord(uploaded, p->copy_stream));
+  TSDF_HIP_TRY(hipStreamWaitEvent(s->stream, p->copied[slot], 0));
+  return pipeline_commit_uploaded(s, slot, T);
+}
+
+// ... and two device frames at once (tsdf_hip_integrate_device2 on a set): both into ring slots, one tsdf_integrate_launch2.
+int tsdf_pipeline_pair_from(tsdf_handle s, const void *src_a, const void *src_b, int src_dev, const float TA[12], const float *planes_a,
+                            const float TB[12], const float *planes_b, bool count, bool *fused,
+                            int (*copy)(void *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st), void *ctx) {
+  TSDF_ENTER(s);  // (a frame this slab was holding back goes first)
+  int rc = pipeline_ready(s);
+  if (rc) return rc;
+  tsdf_hip_pipeline *p = s->pipe;
+  const bool color = s->p.integrate_color != 0;
+  const size_t npx = (size_t)s->p.image_width * s->p.image_height, bytes = npx * 4 * (color ? 2 : 1);
+  int slot[2];
+  const void *src[2] = {src_a, src_b};
+  for (int k = 0; k < 2; ++k) {
+    slot[k] = (int)((p->frames + k) % tsdf_hip_pipeline::SLOTS);
+    if (p->frames + k >= (unsigned)tsdf_hip_pipeline::SLOTS) TSDF_HIP_TRY(hipEventSynchronize(p->consumed[slot[k]]));
+    if ((rc = copy(ctx, p->device[slot[k]], s->device, src[k], src_dev, bytes, p->copy_stream))) return rc;
+    TSDF_HIP_TRY(hipEventRecord(p->copied[slot[k]], p->copy_stream));
+    TSDF_HIP_TRY(hipStreamWaitEvent(s->stream, p->copied[slot[k]], 0));
+  }
+  auto bgra_of = [&](int q) { return color ? reinterpret_cast<const uint32_t *>(p->device[q] + npx) : nullptr; };
+  rc = tsdf_integrate_launch2(s, p->device[slot[0]], bgra_of(slot[0]), TA, planes_a, p->device[slot[1]], bgra_of(slot[1]), TB, planes_b, count, fused);
+  (void)hipEventRecord(p->consumed[slot[0]], s->stream);
+  (void)hipEventRecord(p->consumed[slot[1]], s->stream);
+  p->frames += 2;
+  return rc;
 }
 
 extern "C" int tsdf_hip_integrate_async(tsdf_handle h, const float *depth, const uint8_t *bgra,

@@ -35,6 +35,7 @@ struct tsdf_hip_multi {
   float *pinned[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> uploaded[2];  // per slot, per slab: the slab's H2D copy out of the slot has finished
   unsigned long long frames = 0;
+  bool pairing = false;                 // tsdf_hip_set_frame_pairing on the set: every slab pairs the frames of its own ring
   std::vector<hipEvent_t> ev, ev2;      // per slab: general cross-device ordering (two, so a wait may follow a wait)
   bool halo1_fresh = false, halo_all_fresh = false;  // plane z_end of every slab / the whole halo is current
   int frame_staged = 0;
@@ -284,6 +285,7 @@ extern "C" int tsdf_hip_slab_info(tsdf_handle h, int k, int32_t *device, int32_t
 }
 
 int tsdf_multi_reset(tsdf_handle h) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   for (tsdf_handle s : m->slab) {
     const int rc = tsdf_hip_reset(s);
@@ -292,6 +294,37 @@ int tsdf_multi_reset(tsdf_handle h) {
   m->halo1_fresh = m->halo_all_fresh = true;  // every plane, halo included, is (d = -1, w = 0)
   m->frame_staged = 0;
   return TSDF_HIP_OK;
+}
+
+// ---- frame pairing on a set (round 6) -------------------------------------------------------------
+// Every slab has the ring of a single handle (tsdf_hip_pipeline, tsdf_integrate.hip) and pairs the frames that pass through
+// it by itself: a committed frame is copied into the slab's next ring slot at once -- from the set's pinned slot over the
+// slab's own PCIe link, or from a device buffer over xGMI -- and its kernel waits for the partner; with both at hand the slab
+// runs k_integrate2 where BOTH poses see all of THAT slab (two launches in order otherwise: slabs decide independently).
+// tsdf_multi_flush: every entry point of the set that reads or writes voxels first lets the slabs launch what they hold.
+int tsdf_pipeline_commit_from(tsdf_handle s, const void *src, int src_dev, const float T[12], bool pairing, hipEvent_t uploaded,
+                              int (*copy)(void *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st), void *ctx);
+int tsdf_pipeline_pair_from(tsdf_handle s, const void *src_a, const void *src_b, int src_dev, const float TA[12], const float *planes_a,
+                            const float TB[12], const float *planes_b, bool count, bool *fused,
+                            int (*copy)(void *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st), void *ctx);
+static int tsdf_multi_copy(tsdf_hip_multi *m, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream, bool cross_slab);
+static int copy_thunk(void *ctx, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st) {
+  return tsdf_multi_copy(static_cast<tsdf_hip_multi *>(ctx), dst, dst_dev, src, src_dev, bytes, st, true);
+}
+
+int tsdf_multi_flush(tsdf_handle h) {
+  for (tsdf_handle s : h->multi->slab)
+    if (s->pair_pending) {
+      TSDF_ON_DEVICE(s->device);
+      const int rc = tsdf_pipeline_flush(s);
+      if (rc) return rc;
+    }
+  return TSDF_HIP_OK;
+}
+
+int tsdf_multi_set_frame_pairing(tsdf_handle h, int on) {
+  h->multi->pairing = on != 0;
+  return on ? TSDF_HIP_OK : tsdf_multi_flush(h);  // (switching it off launches what was waiting)
 }
 
 int tsdf_multi_synchronize(tsdf_handle h) {
@@ -429,12 +462,82 @@ static int upload_slot(tsdf_handle h) {
 }
 
 int tsdf_multi_frame_commit(tsdf_handle h, const float T[12]) {
-  const int rc = upload_slot(h);
+  tsdf_hip_multi *m = h->multi;
+  if (m->pairing) {  // through every slab's own ring: the slab holds the frame back for a partner, or sweeps once for both
+    const int slot = (int)(m->frames & 1ull);
+    if (!m->pinned[slot]) {
+      tsdf_set_error("tsdf_hip_frame_commit without tsdf_hip_frame_begin");
+      return TSDF_HIP_E_INVALID;
+    }
+    m->halo1_fresh = m->halo_all_fresh = false;
+    for (size_t k = 0; k < m->slab.size(); ++k) {
+      const int rc = tsdf_pipeline_commit_from(m->slab[k], m->pinned[slot], -1, T, true, m->uploaded[slot][k], copy_thunk, m);
+      if (rc) return rc;
+    }
+    m->frames++;
+    return TSDF_HIP_OK;
+  }
+  int rc = tsdf_multi_flush(h);
+  if (!rc) rc = upload_slot(h);
   return rc ? rc : integrate_all(h, T, nullptr);
+}
+
+// tsdf_hip_integrate_device2 on a set: both device frames go to every slab's ring, every slab sweeps once where both poses
+// see all of it.  *fused = 1 when EVERY slab did; n_observed[0..1] = the two frames' observed voxels over all slabs.
+int tsdf_multi_integrate_device2(tsdf_handle h, const float *da, const uint32_t *ca, const float TA[12], const float *planes_a, const float *db,
+                                 const uint32_t *cb, const float TB[12], const float *planes_b, uint64_t *n_observed, int32_t *fused) {
+  tsdf_hip_multi *m = h->multi;
+  const bool color = h->p.integrate_color != 0;
+  const size_t npx = (size_t)h->p.image_width * h->p.image_height;
+  if (color && (!ca || !cb)) {
+    tsdf_set_error("integrate_color is set but no colour image was given");
+    return TSDF_HIP_E_INVALID;
+  }
+  // the ring slots hold [depth | bgra] back to back, like the frames bench.py and zslab.py hand over; anything else goes
+  // frame by frame through the staging path
+  const bool packed_frames = !color || (reinterpret_cast<const float *>(ca) == da + npx && reinterpret_cast<const float *>(cb) == db + npx);
+  hipPointerAttribute_t attr;
+  int src_dev = -1;
+  if (hipPointerGetAttributes(&attr, da) == hipSuccess)
+    src_dev = attr.device;
+  else
+    (void)hipGetLastError();
+  if (!packed_frames || src_dev < 0) {
+    int rc = tsdf_multi_flush(h);
+    if (!rc) rc = tsdf_multi_set_reference_cull(h, planes_a);  // (nullptr switches the cull off, as on a single handle)
+    if (!rc) rc = tsdf_multi_integrate_device(h, da, ca, TA, n_observed);
+    if (!rc) rc = tsdf_multi_set_reference_cull(h, planes_b);
+    if (!rc) rc = tsdf_multi_integrate_device(h, db, cb, TB, n_observed ? n_observed + 1 : nullptr);
+    return rc;
+  }
+  m->halo1_fresh = m->halo_all_fresh = false;
+  bool all_fused = true;
+  for (tsdf_handle s : m->slab) {
+    bool f = false;
+    const int rc = tsdf_pipeline_pair_from(s, da, db, src_dev, TA, planes_a, TB, planes_b, n_observed != nullptr, &f, copy_thunk, m);
+    if (rc) return rc;
+    all_fused = all_fused && f;
+  }
+  if (fused) *fused = all_fused ? 1 : 0;
+  if (n_observed) {
+    n_observed[0] = n_observed[1] = 0;
+    unsigned long long observed = 0, changed = 0, implied = 0, read_bytes = 0;
+    for (tsdf_handle s : m->slab) {
+      TSDF_ON_DEVICE(s->device);
+      uint64_t n2[2] = {0, 0};
+      const int rc = tsdf_integrate_collect2(s, n2);
+      if (rc) return rc;
+      n_observed[0] += n2[0], n_observed[1] += n2[1];
+      observed += s->last_observed, changed += s->last_changed_bytes, implied += s->last_implied, read_bytes += s->last_read_bytes;
+    }
+    h->last_observed = observed, h->last_changed_bytes = changed, h->last_implied = implied, h->last_read_bytes = read_bytes;
+  }
+  return TSDF_HIP_OK;
 }
 
 int tsdf_multi_integrate(tsdf_handle h, const float *depth, const uint8_t *bgra, const float T[12], uint64_t *n_observed,
                          bool asynchronous) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   if (h->p.integrate_color && !bgra) {
     tsdf_set_error("integrate_color is set but no colour image was given");
     return TSDF_HIP_E_INVALID;
@@ -588,6 +691,7 @@ static int fan_out_device(tsdf_handle h, const float *d_depth, const uint32_t *d
 
 int tsdf_multi_integrate_device(tsdf_handle h, const float *d_depth, const uint32_t *d_bgra, const float T[12],
                                 uint64_t *n_observed) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   int rc = fan_out_device(h, d_depth, d_bgra, -1);
   if (rc) return rc;
   return integrate_all(h, T, n_observed);
@@ -604,6 +708,7 @@ int tsdf_multi_organize(tsdf_handle h, const float *xyz, size_t xyz_stride, cons
 }
 
 int tsdf_multi_integrate_staged(tsdf_handle h, const float T[12], uint64_t *n_observed) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   if (!m->frame_staged) {
     tsdf_set_error("no staged frame: call tsdf_hip_organize first");
@@ -700,6 +805,7 @@ static int exchange_halo(tsdf_handle h, int planes, bool both) {
 
 // ---- raw voxel blocks --------------------------------------------------------------------------------------------------
 int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *d, float *w, uint8_t *rgb) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   if (nx <= 0 || ny <= 0 || nz <= 0 || z0 < 0 || z0 + nz > h->nz) {
     tsdf_set_error("block outside the grid");
@@ -722,6 +828,7 @@ int tsdf_multi_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, i
 }
 
 int tsdf_multi_variance_block(tsdf_handle h, bool down, int x0, int y0, int z0, int nx, int ny, int nz, float *M, int32_t *ns) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   if (nx <= 0 || ny <= 0 || nz <= 0 || z0 < 0 || z0 + nz > h->nz) {
     tsdf_set_error("block outside the grid");
@@ -742,6 +849,7 @@ int tsdf_multi_variance_block(tsdf_handle h, bool down, int x0, int y0, int z0, 
 
 // ---- getFxn / getGradient / getHessian, renderColoredView's lookup -------------------------------------------------------
 int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, float *grad, float *hess, uint8_t *ok) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   int rc = exchange_halo(h, 1, false);
   if (rc) return rc;
@@ -766,6 +874,7 @@ int tsdf_multi_sample(tsdf_handle h, const float *xyz, size_t n, float *val, flo
 }
 
 int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rgb, uint8_t *found) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   std::vector<uint8_t> c(3 * n), f(n);
   memset(rgb, 0, 3 * n);
@@ -791,6 +900,7 @@ int tsdf_multi_lookup_rgb(tsdf_handle h, const float *xyz, size_t n, uint8_t *rg
 // first slab (36 B each), where k_ray_deliver writes them into the image and applies :422.  No image-sized buffer
 // crosses a link and no stream is synchronised inside a round.
 int tsdf_multi_raycast(tsdf_handle h, const float rot[9], const float origin[3], int downsample, const double *inv, float *out) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   const int n_slab = (int)m->slab.size();
   if (downsample < 1) return TSDF_HIP_E_INVALID;
@@ -943,6 +1053,7 @@ static inline uint64_t morton_of_cell(uint64_t c) {  // cell = x<<42 | y<<21 | z
 }
 
 int tsdf_multi_march(tsdf_handle h, float w_min, int color_mode, uint64_t *n_tri) {
+  if (const int rc_flush = tsdf_multi_flush(h)) return rc_flush;  // (frame pairing: slabs launch what they hold first)
   tsdf_hip_multi *m = h->multi;
   const int n = (int)m->slab.size();
   if (n_tri) *n_tri = 0;

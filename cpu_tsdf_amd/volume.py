@@ -169,7 +169,7 @@ class TSDFVolumeOctree:
             capi.check(lib.tsdf_hip_set_weighting(h, *weighting), "set_weighting")
         if self._stream is not None and not getattr(self, "_devices", None):  # (a stream belongs to one device)
             capi.check(lib.tsdf_hip_set_stream(self._h, C.c_void_p(self._stream)), "set_stream")
-        if getattr(self, "_frame_pairing", False) and not devs:
+        if getattr(self, "_frame_pairing", False):  # (a multi-GPU set pairs too since round 6: every slab its own ring)
             capi.check(lib.tsdf_hip_set_frame_pairing(self._h, 1), "set_frame_pairing")
         self._is_empty = True
 

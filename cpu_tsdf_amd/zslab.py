@@ -115,6 +115,21 @@ class HipSlab:
     def integrate_tensor(self, depth, bgra, trans):
         self.vol.integrateCloudDevice(depth.data_ptr(), bgra.data_ptr() if bgra is not None else 0, trans)
 
+    def pair_buffers(self):
+        """Two frames, each [depth | bgra], in ONE allocation: ZSlabVolume's frame pairing parks frame A in the first half,
+        frame B in the second, and sends both in one broadcast."""
+        W, H = self.vol.getImageSize()
+        buf = torch.empty((2, 2 if self.color else 1, H, W), dtype=torch.float32, device=self.device)
+        views = [(buf[i, 0], buf[i, 1].view(torch.uint8).view(H, W, 4) if self.color else None) for i in range(2)]
+        return buf, views
+
+    def integrate_pair(self, views, trans_a, trans_b):
+        """Both frames of a pair in one call: tsdf_hip_integrate_device2 -- ONE sweep of this slab where both poses see all of
+        it (k_integrate2), two launches in order otherwise; the same voxels either way."""
+        (da, ca), (db, cb) = views
+        self.vol.integrateCloudDevice2((da.data_ptr(), ca.data_ptr() if ca is not None else 0, trans_a),
+                                       (db.data_ptr(), cb.data_ptr() if cb is not None else 0, trans_b))
+
     def get_planes(self, z0, nz):
         nx, ny, _ = self.res
         d = torch.empty((nz, ny, nx), dtype=torch.float32, device=self.device)
@@ -309,11 +324,76 @@ class ZSlabVolume:
         self._is_empty = True
         self.max_cell_size = (0.5, 0.5, 0.5)  # the reference's default (tsdf_volume_octree.cpp:72-74); only save() uses it
         self._store_failed, self._store_error = 0, ""
+        self._pairing, self._held, self._pair = False, None, None
+
+    # -- frame pairing (not in the reference: two integrateCloud calls, include/cpu_tsdf/impl/tsdf_volume_octree.hpp:48-103) ----
+    def setFramePairing(self, flag):
+        """Collective.  With pairing on, integrateCloud parks every other frame on the ingest rank and sends it TOGETHER with
+        the next one -- one broadcast of [A | B] instead of two -- and every rank integrates the pair in one sweep of its slab
+        where both poses see all of it (tsdf_hip_integrate_device2 -> k_integrate2; two launches otherwise).  The voxels are
+        those of the two calls in order, bit for bit.  A parked frame is integrated on its own by the next call of any other
+        method (every one of them is collective, so the ranks agree), or by switching pairing off."""
+        if not flag:
+            self._flush_pair()
+        self._pairing = bool(flag)
+
+    def _pair_buffers(self):
+        if self._pair is None:
+            if hasattr(self.slab, "pair_buffers"):
+                self._pair = self.slab.pair_buffers()
+            else:  # a backend without one allocation for two frames (tests/fake_slab.py): two plain frame buffers
+                a, b = self.slab.frame_buffers(), self.slab.frame_buffers()
+                self._pair = (None, [a, b])
+        return self._pair
+
+    def _integrate_pair(self, views, ta, tb):
+        if hasattr(self.slab, "integrate_pair"):
+            self.slab.integrate_pair(views, ta, tb)
+        else:
+            self.slab.integrate_tensor(views[0][0], views[0][1], ta)
+            self.slab.integrate_tensor(views[1][0], views[1][1], tb)
+
+    def _flush_pair(self):
+        """A frame parked for pairing is sent and integrated on its own (collective: every rank holds the same record)."""
+        if self._held is None:
+            return
+        ta, sa = self._held
+        self._held = None
+        _, views = self._pair_buffers()
+        fd, fc = views[0]
+        if self.world > 1:
+            dist.broadcast(fd, src=sa, group=self.group)
+            if fc is not None:
+                dist.broadcast(fc, src=sa, group=self.group)
+        self.slab.integrate_tensor(fd, fc, ta)
 
     # -- integrateCloud -------------------------------------------------------------------------------
     def integrateCloud(self, depth, bgra, trans, src=0):
         """`depth`/`bgra` are only read on rank `src` (numpy arrays or tensors); everyone gets the frame by
         one broadcast each, then integrates its own slab."""
+        if self._pairing:
+            buf, views = self._pair_buffers()
+            fd, fc = views[0 if self._held is None else 1]
+            if self.rank == src:
+                fd.copy_(torch.as_tensor(depth).reshape(fd.shape))
+                if fc is not None:
+                    fc.copy_(torch.as_tensor(bgra).reshape(fc.shape))
+            self._is_empty = False
+            if self._held is None:  # frame A waits on the ingest rank for its partner
+                self._held = (np.array(trans, dtype=np.float64), src)
+                return True
+            ta, sa = self._held
+            self._held = None
+            if self.world > 1:
+                if buf is not None and sa == src:
+                    dist.broadcast(buf, src=src, group=self.group)  # both frames, depth + colour, in ONE collective
+                else:
+                    for (d_, c_), s_ in ((views[0], sa), (views[1], src)):
+                        dist.broadcast(d_, src=s_, group=self.group)
+                        if c_ is not None:
+                            dist.broadcast(c_, src=s_, group=self.group)
+            self._integrate_pair(views, ta, np.asarray(trans, dtype=np.float64))
+            return True
         fd, fc = self._frame
         if self.rank == src:
             fd.copy_(torch.as_tensor(depth).reshape(fd.shape))
@@ -336,6 +416,7 @@ class ZSlabVolume:
         """Every rank fills the `planes` halo planes above its slab (and, with `both`, below it) with the planes their
         owners hold -- point-to-point, one batch.  The owner is usually the adjacent rank; slabs thinner than
         `planes` make the halo span several ranks, each of which sends what it owns of it."""
+        self._flush_pair()
         if self.world == 1:
             return
         planes = min(int(planes), self.halo)
@@ -591,6 +672,7 @@ class ZSlabVolume:
         is responsible for; after each round a suspended record travels point-to-point to the owner of its next
         voxel (traffic ~ rays crossing a slab boundary), and the finished rays' outputs are summed once at the end.
         Default: "allreduce" for two ranks, "p2p" beyond (the all-reduce moves the whole image up to world + 1 times)."""
+        self._flush_pair()
         if self.world == 1:
             return self.slab.render(trans, downsampleBy)
         if exchange is None:
@@ -789,6 +871,7 @@ class ZSlabVolume:
     def save(self, filename, dst=0):
         """Write the whole grid as one .vol file on rank `dst` (collective).  The file equals the one a single
         handle holding the whole grid would write."""
+        self._flush_pair()
         lib = capi.load()
         p = self.slab.params()
         m = capi.TsdfVolMeta()
@@ -871,6 +954,7 @@ class ZSlabVolume:
         return self.slab.image_size()
 
     def download_local(self):
+        self._flush_pair()
         return self.slab.vol.download()
 
     def close(self):

@@ -126,10 +126,10 @@ class TSDFVolumeOctree : public TSDFInterface {
   // Not in the reference: integrateCloud calls are integrated two per sweep of the volume where both camera poses see
   // the whole grid (tsdf_hip_set_frame_pairing: a cloud's kernel waits for the next integrateCloud -- or for any other
   // method of this class, which launches it on its own first).  The same voxels, bit for bit; ~1.15x the frames per
-  // second on a stream of clouds.  Takes effect at once and survives reset(); single-GPU volumes only.
+  // second on a stream of clouds.  Takes effect at once and survives reset(); on a setDevices set every slab pairs by itself.
   void setFramePairing(bool flag) {
     frame_pairing_ = flag;
-    if (h_ && devices_.empty()) (void)tsdf_hip_set_frame_pairing(h_, flag ? 1 : 0);
+    if (h_) (void)tsdf_hip_set_frame_pairing(h_, flag ? 1 : 0);
   }
   bool getFramePairing() const { return frame_pairing_; }
   // integrateCloud returns as soon as the cloud is staged and its upload + kernel are queued (the reference returns after

@@ -127,3 +127,20 @@ def test_bench_dry_run_ranks_reports_the_host_cost_of_a_step(gpu):
     hu = j["host_us_per_step"]
     assert hu["integrate_calls"] > 0 and hu["event_records"] > 0 and hu["broadcast_calls"] > 0 and hu["total"] < 1e5
     assert single["host_us_per_step"]["broadcast_calls"] is None and 0 < single["host_us_per_step"]["total"] < 2000
+
+
+def test_bench_pairing_one_rank_and_two_ranks(gpu):
+    """`bench.py --pairing 1`: the timed frames go two per call (tsdf_hip_integrate_device2) and, with
+    ranks, two per collective; the JSON contract holds, every pair was swept once on the turntable, and the observed-voxel
+    counts (counted frame by frame, outside the timed region) equal the unpaired run's."""
+    single = run([sys.executable, "bench.py"] + COMMON, {})
+    j = run([sys.executable, "bench.py", "--pairing", "1"] + COMMON, {})
+    check_contract(j, 1)
+    assert j["pairing"]["pairs_launched"] == 2 and j["pairing"]["pairs_swept_once_by_every_slab"] == 2
+    assert j["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]
+    j2 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", free_port(), "bench.py", "--gpus", "2", "--pairing", "1"] + COMMON,
+             {"TSDF_BENCH_ONE_DEVICE": "1", "TSDF_BENCH_BACKEND": "gloo"})
+    check_contract(j2, 2)
+    assert j2["pairing"]["pairs_launched"] == 2
+    assert j2["config"]["observed_voxels_per_frame"] == single["config"]["observed_voxels_per_frame"]

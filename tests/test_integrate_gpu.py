@@ -797,7 +797,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
     finally:
         capi.set_tuning("fast_projection", -1)
         capi.set_tuning("allin", 1)
-        capi.set_tuning("pipe", 3)
+        capi.set_tuning("pipe", 1)
     # 8 x {certified: general, ALLIN, row intervals (camera inside), row intervals (cull); exact projection: the same without
     # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 4 + 4 of k_integrate_p /
     # k_integrate_pc + the 8 of k_integrate2
@@ -852,7 +852,7 @@ def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_p
         vol.close()
     finally:
         capi.set_tuning("rows_per_block", 64)
-        capi.set_tuning("pipe", 3)
+        capi.set_tuning("pipe", 1)
 
 
 def test_planes_fastest_block_order_changes_nothing(gpu):

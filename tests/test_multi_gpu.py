@@ -363,3 +363,57 @@ def test_slabs_without_peer_access_go_through_the_host_relay(gpu, monkeypatch):
     assert_same_f32(a[1][a[0]], b[1][b[0]], "getFxn")
     multi.close()
     one.close()
+
+
+@pytest.mark.parametrize("color", [True, False])
+def test_frame_pairing_on_a_multi_handle_equals_frame_by_frame(gpu, color):
+    """tsdf_hip_set_frame_pairing and tsdf_hip_integrate_device2 on a multi-GPU set.  Every slab takes
+    the frames through its own ring and sweeps ONCE for a pair where both poses see all of that slab; a frame waiting for its
+    partner is launched by any other call on the set.  Host frames (pipelined, pairing on: pair, parked + getFxn, parked +
+    download), device pairs (integrateCloudDevice2, counts included) and single frames in between -- against one handle
+    going frame by frame and the oracle, voxel for voxel."""
+    for devices in ([0, 0, 0], [0, 0]):
+        multi, sc = make(devices, color=color)
+        one, _ = make(None, color=color)
+        ov = OracleVolume(multi._p)
+        multi.setFramePairing(True)
+        poses = [synth.turntable_pose(i, 12, sc.size, tilt=0.05 * i) for i in range(9)]
+        deps = [sc.depth(tr, noise_seed=500 + i) for i, tr in enumerate(poses)]
+        cols = [sc.bgra(i) if color else None for i in range(9)]
+
+        def truth(i):
+            one.integrateCloud(deps[i], cols[i], poses[i])
+            return ov.integrate(deps[i], cols[i], synth.cam_from_vol_f32(poses[i]))
+        pts = np.random.RandomState(4).uniform(-0.1, 0.1, (64, 3)).astype(np.float32)
+        for i in (0, 1, 2):   # a pair, then a frame that waits ...
+            multi.integrateCloud(deps[i], cols[i], poses[i], pipelined=True)
+            truth(i)
+        ok_m, val_m = multi.getFxn(pts)   # ... until getFxn launches it
+        ok_o, val_o, _, _ = ov.sample(pts)
+        assert np.array_equal(ok_m.astype(bool), ok_o) and np.array_equal(val_m[ok_o], val_o[ok_o])
+        multi.integrateCloud(deps[3], cols[3], poses[3], pipelined=True)   # parked again; the device pair below goes AFTER it
+        truth(3)
+        fr = torch.empty((2, 2, H, W), dtype=torch.float32, device="cuda:0")
+        for k, i in enumerate((4, 5)):
+            fr[k, 0].copy_(torch.from_numpy(deps[i]))
+            if color:
+                fr[k, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(cols[i]))
+        torch.cuda.synchronize()
+        fused, counts = multi.integrateCloudDevice2((fr[0, 0].data_ptr(), fr[0, 1].data_ptr() if color else 0, poses[4]),
+                                                    (fr[1, 0].data_ptr(), fr[1, 1].data_ptr() if color else 0, poses[5]), count=True)
+        assert counts == [truth(4), truth(5)], counts
+        assert fused  # the turntable sees every slab whole: every slab swept once for the pair
+        got = multi.integrateCloud(deps[6], cols[6], poses[6], count=True)   # a synchronous counted frame in between
+        assert got == truth(6)
+        multi.integrateCloud(deps[7], cols[7], poses[7], pipelined=True)
+        truth(7)
+        multi.setFramePairing(False)      # switching it off launches the frame that was waiting
+        multi.integrateCloud(deps[8], cols[8], poses[8], pipelined=True)
+        truth(8)
+        a, b = multi.download(), one.download()
+        assert_same_f32(a[0], ov.d, f"d vs oracle, devices {devices}")
+        assert np.array_equal(a[1], ov.w) and (not color or np.array_equal(a[2], ov.rgb))
+        assert_same_f32(a[0], b[0], "d vs one handle")
+        assert np.array_equal(a[1], b[1])
+        multi.close()
+        one.close()

@@ -317,3 +317,65 @@ def test_load_of_fractional_weights_falls_back_to_float_weights_on_every_rank(tm
     got = np.load(out)
     assert (got["layouts"] == capi.LAYOUT_F32W).all()
     assert np.array_equal(got["d"], d) and np.array_equal(got["w"], w)
+
+
+def _pair_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.fake_slab import OracleSlab
+    sc = synth.scene_a(RES, W, H)
+    src = world - 1
+    vol = ZSlabVolume(configure, RES, slab_factory=OracleSlab)
+    vol.setFramePairing(True)
+    n_sent = 0
+
+    def frame(i):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        vol.integrateCloud(sc.depth(tr) if rank == src else None, sc.bgra(i) if rank == src else None, tr, src=src)
+    frame(0)
+    assert vol._held is not None            # parked: nothing integrated, nothing sent yet
+    assert not vol.slab.ov.w[vol.z_begin:vol.z_end].any()
+    frame(1)                                # the partner: both travel and are integrated, in order
+    assert vol._held is None and vol.slab.ov.w[vol.z_begin:vol.z_end].max() == 2.0
+    frame(2)                                # parked again ...
+    pts = np.random.RandomState(2).uniform(-0.06, 0.06, (50, 3)).astype(np.float32)
+    samp = vol.sample(pts)                  # ... and flushed by the next collective call of another kind
+    assert vol._held is None and vol.slab.ov.w[vol.z_begin:vol.z_end].max() == 3.0
+    frame(3)
+    vol.setFramePairing(False)              # switching it off integrates what was waiting
+    assert vol._held is None and vol.slab.ov.w[vol.z_begin:vol.z_end].max() == 4.0
+    frame(4)                                # unpaired again: at once
+    assert vol.slab.ov.w[vol.z_begin:vol.z_end].max() == 5.0
+    zb, ze = vol.z_begin, vol.z_end
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((zb, ze, vol.slab.ov.d[zb:ze].copy(), vol.slab.ov.w[zb:ze].copy(), vol.slab.ov.rgb[zb:ze].copy()), gathered, dst=0)
+    if rank == 0:
+        np.savez(out_path, d=np.concatenate([g[2] for g in gathered]), w=np.concatenate([g[3] for g in gathered]),
+                 rgb=np.concatenate([g[4] for g in gathered]), ok=samp[0], val=samp[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_pairing_across_ranks_equals_frame_by_frame(world, tmp_path):
+    """ZSlabVolume.setFramePairing: every other frame waits on the ingest rank and travels with its
+    partner in one exchange; a parked frame is integrated on its own by the next collective call of another kind and by
+    switching pairing off.  Five frames that way -- pair, parked + getFxn, parked + switch-off, single -- equal five
+    integrateCloud calls on one unpartitioned volume, voxel for voxel, and getFxn saw exactly three frames."""
+    out = str(tmp_path / "pair.npz")
+    mp.spawn(_pair_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    from oracle.oracle import OracleVolume
+    from tests.fake_slab import _Cfg
+    cfg = _Cfg()
+    configure(cfg)
+    ov = OracleVolume(cfg._p)
+    sc = synth.scene_a(RES, W, H)
+    pts = np.random.RandomState(2).uniform(-0.06, 0.06, (50, 3)).astype(np.float32)
+    for i in range(5):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        ov.integrate(sc.depth(tr), sc.bgra(i), synth.cam_from_vol_f32(tr))
+        if i == 2:
+            ok, val, _, _ = ov.sample(pts)
+    assert np.array_equal(got["d"], ov.d) and np.array_equal(got["w"], ov.w) and np.array_equal(got["rgb"], ov.rgb)
+    assert np.array_equal(got["ok"], ok) and np.array_equal(got["val"][ok], val[ok])

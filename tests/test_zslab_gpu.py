@@ -324,3 +324,20 @@ def test_zslab_volume_world1_end_to_end(gpu, tmp_path):
     finally:
         capi.set_tuning("vol_chunk", 256)
     vol.close()
+
+
+def test_zslab_volume_frame_pairing_on_a_hip_slab(gpu):
+    """ZSlabVolume.setFramePairing on a real HIP slab (world 1: HipSlab.pair_buffers + integrate_pair ->
+    tsdf_hip_integrate_device2): NF frames, the odd one flushed by download_local, equal the oracle voxel for voxel."""
+    ov, sc = truth()
+    vol = ZSlabVolume(configure, RES)
+    vol.setFramePairing(True)
+    for i in range(NF):
+        tr = synth.turntable_pose(i, 8, sc.size)
+        vol.integrateCloud(sc.depth(tr), sc.bgra(i), tr)
+    assert (vol._held is not None) == bool(NF % 2)
+    d, w, rgb = vol.download_local()
+    assert vol._held is None
+    assert_same_f32(d, ov.d, "d")
+    assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+    vol.close()

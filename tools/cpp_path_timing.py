@@ -1,49 +1,63 @@
 #!/usr/bin/env python3
-"""ms per TSDFVolumeOctree::integrateCloud call through the C++ drop-in (templated integrateCloud on a
-pcl::PointCloud<PointXYZRGBA>: strip into the pinned slot + upload + k_integrate, pipelined) at 1024^3 and 2048^3,
-Scene-A frames, colour on.  Reports the time inside the call (what the caller's thread pays) and the sustained
-rate (wall clock over all frames incl. a final download that drains the queue).  One JSON line."""
+"""End-to-end rate of the C++ drop-in: cpu_tsdf::TSDFVolumeOctree::integrateCloud on
+pcl::PointCloud<PointXYZRGBA> clouds in host memory -- AoS strip into the pinned slot + upload + kernel -- through the
+product's timing program cpu_tsdf_amd/bin/dropin_rate (csrc/prog/dropin_rate.cpp), frame pairing off and on, beside the
+resident-frame rate of the same kernel (bench.py, frames already in HBM: single frames and k_integrate2 pairs).
+
+usage: cpp_path_timing.py [N_FRAMES [RES ...]]      -> one JSON object on stdout (profiles/r06_cpp_path_timing.json)"""
 import json
 import os
+import subprocess
 import sys
-import time
+import tempfile
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from cpu_tsdf_amd import synth  # noqa: E402
-from oracle import refbind  # noqa: E402  (only its ctypes wrapper of the C driver; the library under test is the drop-in)
 
 
 def main():
-    lib = refbind.DROPIN_LIB if os.path.exists(refbind.DROPIN_LIB) else refbind.build_dropin()
-    out = {}
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    for res in (1024, 2048):
-        W, H = 640, 480
+    sizes = [int(a) for a in sys.argv[2:]] or [2048]
+    exe = os.path.join(ROOT, "cpu_tsdf_amd", "bin", "dropin_rate")
+    out = {"program": "cpu_tsdf_amd/bin/dropin_rate", "host_cores": os.cpu_count()}
+    W, H = 640, 480
+    for res in sizes:
         sc = synth.scene_a(res, W, H)
-        dv = refbind.RefVolume(res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size, color=True, lib_path=lib)
-        frames = [(synth.turntable_pose(i, 16, sc.size),) for i in range(16)]
-        frames = [(tr, sc.depth(tr), sc.bgra(i)) for i, (tr,) in enumerate(frames)]
-        for tr, dep, col in frames[:4]:  # warm-up (pinned ring, first launches)
-            dv.integrate(dep, col, tr)
-        dv.L.ct_voxel_center  # (keep the library alive)
-        in_call = []
-        t0 = time.perf_counter()
-        for i in range(n_frames):
-            tr, dep, col = frames[i % 16]
-            in_call.append(dv.integrate(dep, col, tr))
-        # drain: a tiny readback is ordered after every queued frame
-        pts = np.zeros((1, 3), np.float32)
-        dv.sample(pts)
-        wall = time.perf_counter() - t0
-        out[f"{res}^3"] = {"frames": n_frames, "ms_in_integrateCloud_call_median": float(np.median(in_call)) * 1e3,
-                           "ms_in_integrateCloud_call_mean": float(np.mean(in_call)) * 1e3,
-                           "sustained_ms_per_frame_incl_cloud_build": wall / n_frames * 1e3,
-                           "note": "the sustained figure includes the C driver building the 9.8 MB PointXYZRGBA cloud per frame "
-                                   "(single-threaded, outside the timed call) -- the caller's own work"}
-        dv.close()
-    print(json.dumps(out))
+        e = {}
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            path = os.path.join(td, "frames.bin")
+            with open(path, "wb") as f:
+                for i in range(8):
+                    tr = synth.turntable_pose(i, 24, sc.size)
+                    f.write(np.ascontiguousarray(tr, dtype=np.float64).tobytes())
+                    f.write(np.ascontiguousarray(sc.depth(tr), dtype=np.float32).tobytes())
+                    f.write(np.ascontiguousarray(sc.bgra(i), dtype=np.uint8).tobytes())
+            for color in (1, 0):
+                for pairing in (0, 1):
+                    p = subprocess.run([exe, str(res), str(W), str(H), str(color), str(pairing), str(n_frames), path], capture_output=True, text=True, timeout=300)
+                    key = f"color{color}_pairing{pairing}"
+                    e[key] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": p.stderr.strip()[-300:]}
+        # the resident-frame rate of the same kernels on this box: bench.py with frames in HBM
+        for color in (1, 0):
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--res", str(res), "--color", str(color), "--steps", "20", "--warmup", "3",
+                                "--cpu-baseline", "0", "--host-path", "0", "--scene-b", "0", "--keys", "0", "--extras", "2"], capture_output=True, text=True, timeout=300)
+            try:
+                d = json.loads(p.stdout.strip().splitlines()[-1])
+                e[f"color{color}_resident"] = {"frames_per_s": d["frames_per_s"], "kernel_ms": d["roofline"]["kernel_ms"],
+                                                "fused2_frames_per_s": (d.get("extras", {}).get("fused2") or {}).get("frames_per_s")}
+            except Exception as ex:  # noqa: BLE001
+                e[f"color{color}_resident"] = {"error": repr(ex), "stderr": p.stderr.strip()[-300:]}
+        for color in (1, 0):
+            r = e.get(f"color{color}_resident", {})
+            for pairing, ref in ((0, r.get("frames_per_s")), (1, r.get("fused2_frames_per_s"))):
+                c = e.get(f"color{color}_pairing{pairing}", {})
+                if ref and "sustained_frames_per_s" in c:
+                    c["fraction_of_resident_rate"] = c["sustained_frames_per_s"] / ref
+        out[f"{res}^3"] = e
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

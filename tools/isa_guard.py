@@ -23,7 +23,7 @@ BUDGET = {
     "_ZL11k_integrateILi0ELb1ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED colour (headline)", 64, 16, 8),
     "_ZL11k_integrateILi0ELb0ELb1ELb0ELb1ELb1ELb0E": ("k_integrate ALLIN PACKED no colour", 64, 16, 8),
     "_ZL13k_integrate_pILi0ELb0EE": ("k_integrate_p (software-pipelined rows, no colour)", 64, 16, 8),
-    "_ZL14k_integrate_pcILi0ELb0EE": ("k_integrate_pc (software-pipelined rows, colour: the headline)", 96, 0, 5),
+    "_ZL14k_integrate_pcILi0ELb0EE": ("k_integrate_pc (software-pipelined rows, colour: opt-in)", 96, 0, 5),
     "_ZL12k_integrate2ILi0ELb1ELb0E": ("k_integrate2 colour", 96, 0, 5),
     "_ZL12k_integrate2ILi0ELb0ELb0E": ("k_integrate2 no colour", 96, 0, 5),
 }
