@@ -813,8 +813,9 @@ def main():
     # Warm-up launches go through the COUNTING template instance of k_integrate (they integrate exactly the same
     # way), so that in a `rocprofv3 --kernel-trace --stats` / --pmc table of this command the non-counting instance
     # holds the K timed launches and nothing else: its averages there are directly comparable with roofline.*.
+    _c = C.c_uint64(0)
     for k in range(args.presaturate):  # the saturated regime: every observed voxel at w == max_weight before anything is timed
-        launch(args.warmup + k % args.steps)
+        launch(args.warmup + k % args.steps, C.byref(_c))  # (through the COUNTING instance, like the warm-up: a profile's non-counting instance stays the timed launches)
     run(0, args.warmup, counting=True)
     barrier()
     t0 = time.perf_counter()
@@ -976,6 +977,7 @@ def main():
                             (f", Z-slab {z_end - z_begin} planes/GPU, one RCCL frame broadcast per step"
                              + (" overlapped with the previous kernel" if args.overlap else "") if use_dist else ""),
                 "principal_offset": args.principal_offset or None,
+                "presaturate_launches": args.presaturate or None,   # the saturated regime (w == max_weight) when set
                 "last_launch": last_info,
                 "grid": list(res3), "image": [W, H], "color": bool(args.color),
                 "layout": "packed" if packed else "f32w",

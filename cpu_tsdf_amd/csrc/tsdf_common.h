@@ -304,7 +304,7 @@ struct TsdfTuning {
   int refcull_plain;   // reference-cull replication through the plain per-voxel kernel instead of the row intervals (tests: 0)
   int live_log2tx;     // LIVE launches of a partly visible slab: log2 of the quads per block row (5: 128 voxels x 8 rows per block pass; Scene B at 2048^3: 0.37 ms against 0.60 at 6)
   int zfast;           // integrate launches hand out blocks planes-fastest: 1 always (default: 16.26 against 16.60 ms at 2048^3 + colour, 15.5 against 16.9 ms on a 4096 x 4096 x 512 slab with 1280x960 frames), 0 never, -1 only when the frame outgrows an XCD's L2
-  int fuse2;           // tsdf_hip_integrate_device2 / integrate_async2 may use the two-frames-per-sweep kernel (1)
+  int fuse2;           // tsdf_hip_integrate_device2 / frame pairing: 1 = one sweep per pair where that is the faster way (with colour; without, where k_integrate_p does not apply), 2 = wherever both poses qualify, 0 = never
   int implied_d;       // PACKED integrate launches do not read distance words the "band seen" flags and the counts determine (1)
   int pipe;            // ALLIN PACKED launches run the software-pipelined row loop: bit 0 without colour (k_integrate_p: on), bit 1 with (k_integrate_pc: measured no faster than k_integrate's own loop, off); 1
 };

@@ -3214,7 +3214,12 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   for (int i = 0; i < 12; ++i) fb.m[i] = TB[i];
   const unsigned gx = (unsigned)((a.qpr + a.TX - 1) / a.TX), gy = (unsigned)((a.ny + a.rpb * a.TY - 1) / (a.rpb * a.TY)),
                  gz = (unsigned)hh.planes;
-  const bool ok = tsdf_tuning().fuse2 && tsdf_tuning().cull == 1 && tsdf_tuning().allin && h->packed && !h->cn[0] && !h->weight_by_depth &&
+  // Without colour two frames through the pipelined single-frame kernel beat one shared sweep since round 6 (k_integrate_p 7.1 ms per
+  // frame against k_integrate2's 7.6 at 2048^3: profiles/r06_cpp_path_timing.json), so knob fuse2 = 1 (the default) pairs only where
+  // the sweep wins: with colour, or where k_integrate_p does not apply; fuse2 = 2 always shares the sweep (the tests' k_integrate2
+  // coverage), 0 never.
+  const bool pipe_wins = !color && (tsdf_tuning().pipe & 1) && tsdf_tuning().fuse2 == 1 && a.hinge_fixed && a.neg_in_window && a.ny % (a.rpb * a.TY) == 0;
+  const bool ok = tsdf_tuning().fuse2 && !pipe_wins && tsdf_tuning().cull == 1 && tsdf_tuning().allin && h->packed && !h->cn[0] && !h->weight_by_depth &&
                   !h->weight_by_variance && !tsdf_tuning().plain_kernel && (h->nx & 3) == 0 && a.wmax_is_int && (float)h->kmax == p.max_weight &&
                   gy <= 65535u && gz <= 65535u && gz > 0 && bgra_offset(dA, cA, &a.bgra_off) && bgra_offset(dB, cB, &fb.bgra_off) &&
                   fusable_pose(h, hh, TA, planesA) && fusable_pose(h, hh, TB, planesB);

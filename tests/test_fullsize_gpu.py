@@ -264,6 +264,8 @@ def test_2048_cubed_whole_volume_is_the_same_through_every_kernel_path(gpu, colo
     def run(name, knob=None, pairs=False, loose_planes=False):
         if knob:
             capi.set_tuning(*knob)
+        if pairs:
+            capi.set_tuning("fuse2", 2)  # the shared sweep also without colour (default: two pipelined launches there)
         try:
             vol, _ = make()
             seen = set()
@@ -290,6 +292,7 @@ def test_2048_cubed_whole_volume_is_the_same_through_every_kernel_path(gpu, colo
             c = checksum(vol)
             return vol, c, seen
         finally:
+            capi.set_tuning("fuse2", 1)
             if knob:
                 capi.set_tuning(knob[0], {"allin": 1, "zfast": 1}[knob[0]])
 

@@ -27,6 +27,15 @@ def device_frame(dep, col):
     return t
 
 
+@pytest.fixture(autouse=True)
+def _always_share_the_sweep(gpu):
+    """These tests are about k_integrate2 itself: knob fuse2 = 2 shares the sweep wherever both poses qualify.  (The default,
+    1, leaves COLOURLESS pairs to two launches of the pipelined single-frame kernel, which is faster there since round 6.)"""
+    capi.set_tuning("fuse2", 2)
+    yield
+    capi.set_tuning("fuse2", 1)
+
+
 def launch_info(vol):
     import ctypes as C
     out = (C.c_int32 * 4)()
@@ -106,7 +115,7 @@ def test_pairs_that_do_not_qualify_take_two_launches_with_the_same_result(gpu):
     vol, sc = make_volume(64, color=False, res3=(66, 64, 64))
     cases.append(("nx % 4", vol, sc, None, None, [False, False]))
     vol, sc = make_volume(64, color=True)
-    cases.append(("knob off", vol, sc, None, ("fuse2", 0), [False, False]))
+    cases.append(("knob off", vol, sc, None, ("fuse2", 0), [False, False]))  # (restored to 2 below: this module runs on fuse2 = 2)
     for name, vol, sc, poses, knob, expect in cases:
         try:
             if knob:
@@ -131,7 +140,7 @@ def test_pairs_that_do_not_qualify_take_two_launches_with_the_same_result(gpu):
             vol.close()
         finally:
             if knob:
-                capi.set_tuning(knob[0], 1)
+                capi.set_tuning(knob[0], 2)
 
 
 def test_fused_sweep_on_a_z_slab_and_a_wide_grid(gpu):
@@ -237,3 +246,31 @@ def test_frame_pairing_when_the_reference_cull_decides_voxels(gpu):
         compare(v, ov)
         v.close()
     assert not np.array_equal(ov.w, plain.w)
+
+
+def test_colourless_pairs_take_the_pipelined_kernel_by_default(gpu):
+    """Knob fuse2 = 1 (the default): without colour a pair is TWO launches of the software-pipelined single-frame kernel
+    (k_integrate_p: faster per frame than the shared sweep since round 6), with colour ONE sweep; the voxels and the counts are
+    the oracle's either way, and fuse2 = 2 (this module's setting) shares the sweep without colour too."""
+    for color in (False, True):
+        for knob, expect in ((1, color), (2, True)):
+            capi.set_tuning("fuse2", knob)
+            vol, sc = make_volume(96, color=color)
+            vol.reset()
+            ov = OracleVolume(vol._p)
+            keep = []
+            for k in range(2):
+                pair, want = [], []
+                for i in (2 * k, 2 * k + 1):
+                    tr = synth.turntable_pose(i, 8, sc.size)
+                    dep, col = sc.depth(tr, noise_seed=9 + i), sc.bgra(i) if color else None
+                    t = device_frame(dep, col)
+                    keep.append(t)
+                    pair.append((t[0].data_ptr(), t[1].data_ptr() if color else 0, tr))
+                    want.append(ov.integrate_culled(dep, col, tr, synth.cam_from_vol_f32(tr)))
+                fused, counts = vol.integrateCloudDevice2(pair[0], pair[1], count=True)
+                assert fused == expect and counts == want, (color, knob, fused, counts, want)
+                info = launch_info(vol)
+                assert info[0] == (2 if expect else 1) and (expect or info[4]), info  # else: the pipelined single-frame kernel
+            compare(vol, ov)
+            vol.close()

@@ -199,6 +199,7 @@ def test_two_frames_per_sweep_with_implied_distances(gpu, color):
     keeping the flags and the host's record, so the single frames around it go on skipping."""
     outs = []
     try:
+        capi.set_tuning("fuse2", 2)  # k_integrate2 also without colour (the default leaves those pairs to the pipelined kernel)
         for on in (1, 0):
             capi.set_tuning("implied_d", on)
             vol, sc = make_volume(96, color=color, max_weight=6.0)
@@ -237,6 +238,7 @@ def test_two_frames_per_sweep_with_implied_distances(gpu, color):
             outs.append(compare(vol, ov))
             vol.close()
     finally:
+        capi.set_tuning("fuse2", 1)
         capi.set_tuning("implied_d", 1)
     assert_same_f32(outs[0][0], outs[1][0], "d: implied vs read")
     assert np.array_equal(outs[0][1], outs[1][1])

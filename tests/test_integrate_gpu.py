@@ -768,7 +768,9 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
                 hit.add((order, color, "kp", count))
             compare(vol, ov)
             vol.close()
-        # k_integrate2: transform order x colour x counting (PACKED, certified projection, both poses ALLIN)
+        # k_integrate2: transform order x colour x counting (PACKED, certified projection, both poses ALLIN; knob fuse2 = 2: without
+        # colour the default leaves pairs to the pipelined single-frame kernel)
+        capi.set_tuning("fuse2", 2)
         for order in (0, 1):
             for color in (False, True):
                 vol, sc = make_volume(res, W, H, color=color, order=order)
@@ -798,6 +800,7 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
         capi.set_tuning("fast_projection", -1)
         capi.set_tuning("allin", 1)
         capi.set_tuning("pipe", 1)
+        capi.set_tuning("fuse2", 1)
     # 8 x {certified: general, ALLIN, row intervals (camera inside), row intervals (cull); exact projection: the same without
     # ALLIN} x counting or not: all 80 k_integrate instances (the row-interval one twice) + the 4 + 4 of k_integrate_p /
     # k_integrate_pc + the 8 of k_integrate2

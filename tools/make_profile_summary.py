@@ -24,11 +24,18 @@ def last_json_line(path):
 
 
 def timed_instance(summary):
-    """The non-counting template instance of k_integrate (4th template argument false) = bench.py's timed launches."""
+    """The non-counting template instance of the integrate kernel = bench.py's timed launches: k_integrate<..., COUNT = false (4th
+    argument), ...>, or -- round 6 -- the software-pipelined kernels k_integrate_p / k_integrate_pc<ORDER, COUNT = false>.  A key's
+    timed launches all go through ONE of them; its counting twin holds the warm-up and the byte-counting pass."""
+    found = []
     for k in summary:
         if k.startswith("k_integrate<") and k.rstrip(">").split("<")[1].split(",")[3] == "false":
-            return k
-    raise RuntimeError("no non-counting k_integrate instance in " + ", ".join(summary))
+            found.append(k)
+        if (k.startswith("k_integrate_p<") or k.startswith("k_integrate_pc<")) and k.rstrip(">").split("<")[1].split(",")[1] == "false":
+            found.append(k)
+    if not found:
+        raise RuntimeError("no non-counting integrate instance in " + ", ".join(summary))
+    return max(found, key=lambda k: summary[k].get("dispatches", 0))
 
 
 def main():
@@ -65,7 +72,7 @@ def main():
     wr = write[inst]["WRITE_SIZE"] * 1024 * round(cal_w)
     cfg = bf["config"]
     planes = bf.get("multi_gpu", {}).get("planes_per_gpu", cfg["grid"][2])
-    key = f"{cfg['grid'][0]}x{cfg['grid'][1]}x{planes}_c{int(cfg['color'])}_{cfg['layout']}"
+    key = f"{cfg['grid'][0]}x{cfg['grid'][1]}x{planes}_c{int(cfg['color'])}_{cfg['layout']}" + ("_saturated" if cfg.get("presaturate_launches") else "")
     try:
         head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:

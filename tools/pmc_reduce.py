@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEYS = ("k_integrate_rgbn", "k_integrate_plain", "k_integrate2", "k_integrate", "k_calib_rmw", "k_calib_read", "k_fill_u32", "k_raycast", "k_ray_begin",
+KEYS = ("k_integrate_rgbn", "k_integrate_plain", "k_integrate2", "k_integrate_pc", "k_integrate_p", "k_integrate", "k_calib_rmw", "k_calib_read", "k_fill_u32", "k_raycast", "k_ray_begin",
         "k_mc_classify", "k_mc_emit", "k_mc_counts", "k_sample", "k_block", "k_planes", "k_cull", "k_ingest")
 
 
@@ -24,7 +24,7 @@ def names(name):
     for key in KEYS:
         if key in name:
             m = re.search(re.escape(key) + r"<([^>]*)>", name)
-            if m and key in ("k_integrate", "k_integrate2", "k_mc_classify", "k_raycast", "k_calib_read"):
+            if m and key in ("k_integrate", "k_integrate2", "k_integrate_p", "k_integrate_pc", "k_mc_classify", "k_raycast", "k_calib_read"):
                 return [key, key + "<" + m.group(1).replace(" ", "") + ">"]
             return [key]
     return [name[:48]]
