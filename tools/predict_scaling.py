@@ -25,16 +25,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def bench(extra, env=None):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--warmup", "3", "--cpu-baseline", "0", "--host-path", "0", "--extras", "0"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, **(env or {})))
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     try:
-        return json.loads(p.stdout.strip().splitlines()[-1])
+        return json.loads(lines[-1])
     except Exception:  # noqa: BLE001
-        return {"error": p.stderr.strip()[-400:]}
+        return {"error": f"exit {p.returncode}: " + p.stderr.strip()[-1500:]}
+
+
+def rccl_leg(color, steps):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    d = bench(["--color", str(color), "--steps", str(steps)],
+              env={"TSDF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    mg = d.get("multi_gpu") or {}
+    return {"frame_broadcast_ms_isolated": mg.get("frame_broadcast_ms_isolated"), "rccl_version": mg.get("rccl_version"),
+            "kernel_ms_with_collectives_in_the_loop": (d.get("roofline") or {}).get("kernel_ms"),
+            "ms_per_step": d.get("ms_per_step"), "error": d.get("error")}
 
 
 def main():
     a = sys.argv[1:]
     color = int(a[a.index("--color") + 1]) if "--color" in a else 1
     steps = int(a[a.index("--steps") + 1]) if "--steps" in a else 20
+    if "--rccl-only" in a:  # (re-)measure the world-1 RCCL leg alone and merge it into an existing table: --rccl-only FILE
+        path = a[a.index("--rccl-only") + 1]
+        out = json.load(open(path))
+        out["rccl_world1"] = rccl_leg(color, steps)
+        json.dump(out, open(path, "w"), indent=1)
+        print(json.dumps(out["rccl_world1"]))
+        return
     out = {"what": "PREDICTED strong scaling of integrateCloud at 2048^3, 640x480, from per-slab kernel times measured on ONE GPU; "
                    "not a scaling measurement", "color": bool(color), "steps": steps, "per_N": {}}
     t1 = None
@@ -62,11 +83,7 @@ def main():
                 e["predicted_speedup"] = t1 / worst["kernel_ms"]
                 e["predicted_efficiency"] = t1 / worst["kernel_ms"] / n
         out["per_N"][str(n)] = e
-    d = bench(["--color", str(color), "--steps", str(steps)], env={"TSDF_BENCH_FORCE_DIST": "1"})
-    mg = d.get("multi_gpu") or {}
-    out["rccl_world1"] = {"frame_broadcast_ms_isolated": mg.get("frame_broadcast_ms_isolated"), "rccl_version": mg.get("rccl_version"),
-                          "kernel_ms_with_collectives_in_the_loop": (d.get("roofline") or {}).get("kernel_ms"),
-                          "ms_per_step": d.get("ms_per_step"), "error": d.get("error")}
+    out["rccl_world1"] = rccl_leg(color, steps)
     print(json.dumps(out, indent=1))
     print("# N  max kernel ms  slowest rank  imbalance  predicted frames/s  predicted efficiency", file=sys.stderr)
     for n, e in out["per_N"].items():

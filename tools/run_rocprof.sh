@@ -11,7 +11,8 @@
 # (every rocprofv3 command runs under `timeout 400`: a counter pass that aborts inside the tool can otherwise sit until gpurun's limit)
 # usage: tools/run_rocprof.sh TAG [STEPS [PMC_STEPS [EXTRA_BENCH_ARGS [lite]]]]
 #   EXTRA_BENCH_ARGS  e.g. "--layout f32w", "--color 0", "--res 4096 --planes 512 --width 1280 --height 960": another
-#                     pmc_traffic.json key (bench.py quotes roofline.traffic per key);  lite = trace + FETCH + WRITE only
+#                     pmc_traffic.json key (bench.py quotes roofline.traffic per key);  lite = trace + FETCH + WRITE only, no extras legs;
+#                     noextras = all passes, no extras legs (a key whose fused2 leg runs the SAME kernel as the timed launches: no colour)
 set -u
 TAG=${1:-r03}
 STEPS=${2:-20}
@@ -24,14 +25,14 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 cd /tmp
 BENCH="python $ROOT/bench.py --warmup 2 --cpu-baseline 0 --scene-b 0 --host-path 0 --keys 0 $EXTRA"
-[ -n "$LITE" ] && BENCH="$BENCH --extras 0"
+[ -n "$LITE" ] && BENCH="$BENCH --extras 0"   # lite: trace + FETCH + WRITE only; noextras: the SQ passes too, without the extras legs
 timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace -o bench --output-format csv -- \
   $BENCH --steps $STEPS > $ROOT/$OUT/bench_under_rocprof.json 2> $ROOT/$OUT/bench_under_rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$C -o pmc --output-format csv -- \
     $BENCH --steps $PMC_STEPS --calib 2 > $ROOT/$OUT/bench_pmc_$C.json 2> $ROOT/$OUT/bench_pmc_$C.err
 done
-if [ -z "$LITE" ]; then
+if [ -z "$LITE" ] || [ "$LITE" = noextras ]; then
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
   -d $ROOT/$OUT/pmc_SQ -o pmc --output-format csv -- \
   $BENCH --steps $PMC_STEPS > $ROOT/$OUT/bench_pmc_SQ.json 2> $ROOT/$OUT/bench_pmc_SQ.err
