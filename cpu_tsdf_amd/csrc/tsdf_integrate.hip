@@ -1221,6 +1221,9 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 // loads here -- the count bytes are requested for every quad (1 B per voxel: unobserved quads cost 2 % more traffic) and
 // the distance words per WAVE and pass (the implied-distance decision of k_integrate, a scalar branch whose two paths
 // differ by one load: the wait is conservative by that one load at most).
+// (Tried on top, round 6: stage A requesting the PLANE words BEFORE it projects -- they come from HBM, the gathers from L2, and
+// depend on nothing the projection works out.  No effect, here or in k_integrate_pc: 7.47 against 7.47 ms, 13.16 against 13.20
+// (profiles/r06_ab_planefirst_call10.txt): the stage the pipeline gives every load already covers them.  Not kept.)
 // Same arithmetic as k_integrate<ORDER, false, true, COUNT, true, true, false>, operation for operation; the host
 // launches it instead of that instance when, additionally, every block's rows exist (ny a multiple of the block's rows),
 // the hinge value rests (hinge_fixed) and max_dist_neg lies in the scale-free divider's window -- else the old instance.

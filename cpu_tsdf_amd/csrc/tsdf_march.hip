@@ -6,8 +6,8 @@
 //                  signs and |d| < 1 of the 8 corner values (getValidNeighborList1D :145-177 / getGridValue
 //                  :91-106) as bit masks, case index, triangle count; candidate cells collect in wave-private LDS
 //                  lists, their corner weights are tested when a list is flushed (all lanes busy), survivors become
-//                  (Morton key, packed cell) pairs
-//   rocprim sort   by key: the reference emits triangles in octree pre-order with child index
+//                  one word each: (Morton key << 4) | triangle count
+//   rocprim sort   of those words by key: the reference emits triangles in octree pre-order with child index
 //                  4*(x>cx) + 2*(y>cy) + (z>cz) (octree.cpp:119,257-264) = Morton order, x the high bit
 //   rocprim scan   triangle offsets
 //   k_mc_emit      one thread per active cell: edge interpolation + triangle/colour output
@@ -59,6 +59,25 @@ static __device__ __forceinline__ uint64_t spread3(uint64_t v) {  // 21 bits -> 
   v = (v | v << 4) & 0x10c30c30c30c30c3ull;
   v = (v | v << 2) & 0x1249249249249249ull;
   return v;
+}
+
+static __device__ __forceinline__ uint32_t compact3(uint64_t v) {  // every third bit -> 21 bits (spread3's inverse)
+  v &= 0x1249249249249249ull;
+  v = (v | v >> 2) & 0x10c30c30c30c30c3ull;
+  v = (v | v >> 4) & 0x100f00f00f00f00full;
+  v = (v | v >> 8) & 0x1f0000ff0000ffull;
+  v = (v | v >> 16) & 0x1f00000000ffffull;
+  v = (v | v >> 32) & 0x1fffffull;
+  return (uint32_t)v;
+}
+// An active cell is ONE 64-bit word since round 6: (Morton key << MC_KEY_SHIFT) | triangle count.  The key IS the cell's
+// coordinates (x the high bit of every triple: octree.cpp:119,257-264), so the (key, packed cell) PAIRS of rounds 1-5 carried them
+// twice; sorting words instead of pairs halves what the radix sort moves (the count's bits take no part in it).  mc_unpack
+// gives the packed form the rest of the file reads: x | y << 20 | z << 40 | count << 60.
+#define MC_KEY_SHIFT 4
+static __device__ __forceinline__ uint64_t mc_unpack(uint64_t word) {
+  const uint64_t key = word >> MC_KEY_SHIFT;
+  return (uint64_t)compact3(key >> 2) | ((uint64_t)compact3(key >> 1) << 20) | ((uint64_t)compact3(key) << 40) | ((word & 15ull) << 60);
 }
 
 static __device__ __forceinline__ int cube_index(const float leaf[8]) {
@@ -188,7 +207,7 @@ static __device__ __forceinline__ float mc_load_w(const PlaneView &pv, int64_t i
 
 template <int WL>
 static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, uint64_t capacity,
+k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t capacity,
               unsigned long long *__restrict__ counters) {
   __shared__ unsigned char s_ntri[256];
   __shared__ uint32_t s_buf[4][MC_WAVE_BUF];
@@ -307,9 +326,7 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict_
           tri_sum += e >> 15;
           if (slot < capacity) {
             const unsigned xr = e & 255u, row = wave * MC_R + ((e >> 8) & 3u), zr = (e >> 10) & 31u;
-            keys[slot] = xkey_hi | (uint64_t)s_xkey[xr] | s_ykey[row] | s_zkey[zr];
-            vals[slot] = (uint64_t)(bx * 256u + xr) | ((uint64_t)(yw + (int)((e >> 8) & 3u)) << 20) |
-                         ((uint64_t)(zs + (int)zr) << 40) | ((uint64_t)(e >> 15) << 60);
+            keys[slot] = ((xkey_hi | (uint64_t)s_xkey[xr] | s_ykey[row] | s_zkey[zr]) << MC_KEY_SHIFT) | (uint64_t)(e >> 15);
           }
         }
       }
@@ -461,7 +478,7 @@ static __global__ void __launch_bounds__(256)
 k_mc_cell_index(const McArgs a, const uint64_t *__restrict__ vals, uint64_t n, int64_t *__restrict__ idx) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t v = vals[i];
+  const uint64_t v = mc_unpack(vals[i]);
   const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
   idx[i] = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
 }
@@ -469,7 +486,7 @@ k_mc_cell_index(const McArgs a, const uint64_t *__restrict__ vals, uint64_t n, i
 static __global__ void __launch_bounds__(256)
 k_mc_counts(const uint64_t *__restrict__ vals, uint32_t *__restrict__ counts, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) counts[i] = (uint32_t)(vals[i] >> 60);
+  if (i < n) counts[i] = (uint32_t)(vals[i] & 15ull);  // (vals: the sorted cell words)
 }
 
 // Emit: one thread per active cell (they are all valid: classify tested the eight corner weights).  The eight corner
@@ -489,7 +506,7 @@ k_mc_emit(const McArgs a, const uint64_t *__restrict__ vals, const uint32_t *__r
   __syncthreads();
   const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= n_cells) return;
-  const uint64_t v = vals[ci];
+  const uint64_t v = mc_unpack(vals[ci]);
   const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
   // getGridValue (:91-106) of a valid corner: d * max_dist_neg, corners in pcl::MarchingCubes order
   const int64_t sy = a.pitch, sz = (int64_t)a.ny * a.pitch;
@@ -696,21 +713,19 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
       TSDF_HIP_TRY(hipGetLastError());
     }
     if (!h->packed)
-      hipLaunchKernelGGL(k_mc_classify<0>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+      hipLaunchKernelGGL(k_mc_classify<0>, grid, block, 0, h->stream, a, h->mc_keys, (uint64_t)cap, h->counter);
     else if (h->rgb)
-      hipLaunchKernelGGL(k_mc_classify<1>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+      hipLaunchKernelGGL(k_mc_classify<1>, grid, block, 0, h->stream, a, h->mc_keys, (uint64_t)cap, h->counter);
     else
-      hipLaunchKernelGGL(k_mc_classify<2>, grid, block, 0, h->stream, a, h->mc_keys, h->mc_vals, (uint64_t)cap, h->counter);
+      hipLaunchKernelGGL(k_mc_classify<2>, grid, block, 0, h->stream, a, h->mc_keys, (uint64_t)cap, h->counter);
     TSDF_HIP_TRY(hipGetLastError());
     TSDF_HIP_TRY(hipEventRecord(h->mc_ev[1], h->stream));
     TSDF_HIP_TRY(hipMemcpyAsync(counts, h->counter, sizeof counts, hipMemcpyDeviceToHost, h->stream));
     TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
     if (counts[0] <= cap) break;
     const size_t need = (size_t)counts[0] + (size_t)counts[0] / 8 + 1024;
-    size_t c1 = h->mc_cells_cap, c2 = h->mc_cells_cap;
-    int rc = ensure_buf(&h->mc_keys, &c1, need, h->stream);
-    if (rc) return rc;
-    rc = ensure_buf(&h->mc_vals, &c2, need, h->stream);
+    size_t c1 = h->mc_cells_cap;
+    const int rc = ensure_buf(&h->mc_keys, &c1, need, h->stream);
     if (rc) return rc;
     h->mc_cells_cap = need;
   }
@@ -742,32 +757,32 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     return TSDF_HIP_E_UNSUPPORTED;
   }
 
-  // sort (key, val) by Morton key -> reference triangle order; only the bits a coordinate can set take part
+  // sort the cell words by their Morton key -> reference triangle order; only the bits a coordinate can set take part (the
+  // triangle count below MC_KEY_SHIFT rides along)
   int coord_bits = 1;
   while ((1 << coord_bits) < std::max(a.nx, std::max(a.ny, a.nz))) ++coord_bits;
   const unsigned key_bits = 3u * (unsigned)coord_bits;
-  uint64_t *keys_out = nullptr, *vals_out = nullptr;
+  uint64_t *vals_out = nullptr;
   uint32_t *cnt = nullptr, *off = nullptr;
   size_t tmp_bytes_sort = 0, tmp_bytes_scan = 0;
-  TSDF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
-                                         (size_t)n_cells, 0, key_bits, h->stream));
+  TSDF_HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes_sort, h->mc_keys, vals_out, (size_t)n_cells, MC_KEY_SHIFT,
+                                        MC_KEY_SHIFT + key_bits, h->stream));
   TSDF_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
                                        rocprim::plus<uint32_t>(), h->stream));
   const size_t al = 256;
   auto up = [&](size_t v) { return (v + al - 1) / al * al; };
   const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4), b_trgb = color_mode ? up(ntri * 4) : 0;
-  const size_t total = 2 * b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan)) + b_trgb;
+  const size_t total = b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan)) + b_trgb;
   int rc = tsdf_ensure_scratch(h, total);
   if (rc) return rc;
   char *sp = (char *)h->scratch;
-  keys_out = (uint64_t *)sp;
-  vals_out = (uint64_t *)(sp + b_keys);
-  cnt = (uint32_t *)(sp + 2 * b_keys);
-  off = (uint32_t *)(sp + 2 * b_keys + b_cnt);
-  void *tmp = sp + 2 * b_keys + 2 * b_cnt;
+  vals_out = (uint64_t *)sp;  // the sorted cell words
+  cnt = (uint32_t *)(sp + b_keys);
+  off = (uint32_t *)(sp + b_keys + b_cnt);
+  void *tmp = sp + b_keys + 2 * b_cnt;
   uint32_t *tri_rgb = color_mode ? (uint32_t *)(sp + total - b_trgb) : nullptr;
-  TSDF_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes_sort, h->mc_keys, keys_out, h->mc_vals, vals_out,
-                                         (size_t)n_cells, 0, key_bits, h->stream));
+  TSDF_HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes_sort, h->mc_keys, vals_out, (size_t)n_cells, MC_KEY_SHIFT,
+                                        MC_KEY_SHIFT + key_bits, h->stream));
   const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
   hipLaunchKernelGGL(k_mc_counts, dim3(cell_blocks), dim3(256), 0, h->stream, vals_out, cnt, n_cells);
   TSDF_HIP_TRY(hipGetLastError());

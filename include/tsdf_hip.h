@@ -340,7 +340,8 @@ int tsdf_hip_set_reference_cull(tsdf_handle h, const float planes[24]);
  * tsdf_hip_set_reference_cull (NULL = none); the handle keeps frame B's.  n_observed (nullable, 2 values): per frame, as
  * the single call reports; tsdf_hip_last_count_detail then describes the pair.  *fused (nullable): 1 if one sweep did
  * it.  Each frame's colour image must lie behind its depth image in one allocation (as tsdf_hip_integrate_device
- * prefers); device pointers, asynchronous unless n_observed. */
+ * prefers); device pointers, asynchronous unless n_observed.  On a multi-GPU set both frames go to every slab's ring
+ * and every slab decides for itself; *fused = 1 when every slab swept once, n_observed = the slabs' sums. */
 int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a, const uint32_t *d_bgra_a, const float cam_from_vol_a[12],
                                const float *planes_a, const float *d_depth_b, const uint32_t *d_bgra_b,
                                const float cam_from_vol_b[12], const float *planes_b, uint64_t *n_observed, int32_t *fused);
@@ -351,8 +352,11 @@ int tsdf_hip_integrate_device2(tsdf_handle h, const float *d_depth_a, const uint
  * the handle and both poses allow it, else two launches, frame order kept either way); any other entry point that reads
  * or writes the volume (synchronize, integrate, download, march, raycast, sample, save, reset, ...) first launches a
  * waiting frame on its own.  Results are identical to pairing off; what changes is when the kernels run (a stream of
- * frames: ~14 instead of ~16 ms per frame at 2048^3 + colour).  Each frame keeps the cull planes that
- * were in force (tsdf_hip_set_reference_cull) when IT was committed.  Single-GPU handles only; off by default. */
+ * frames: 11.2 instead of 12.7 ms per frame at 2048^3 + colour; without colour a pair is two launches of
+ * the pipelined single-frame kernel, which is the faster way there since round 6).  Each frame keeps the cull planes that
+ * were in force (tsdf_hip_set_reference_cull) when IT was committed.  Off by default.  On a multi-GPU set
+ * (tsdf_hip_create_multi, round 6) every slab pairs the frames of its own ring: one sweep of a slab per pair where both
+ * poses see all of THAT slab. */
 int tsdf_hip_set_frame_pairing(tsdf_handle h, int on);
 
 /* Host only: those six planes from the forward pose `trans` (row-major 4x4 doubles, camera -> volume, what
