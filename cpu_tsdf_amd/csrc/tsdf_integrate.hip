@@ -315,6 +315,30 @@ static __device__ __forceinline__ void add_observation_fast(float &d, float &w, 
   if (w > wmax) w = wmax;
 }
 
+// The colour half of add_observation_fast for a PAIR of voxels on float pairs -- (0, 1), then (2, 3), one channel at a time:
+// the same two fmas per channel and voxel (N = fma(w, c_old, c_new), t = fma(N, y, hy): v_pk_fma_f32 rounds each half like
+// v_fma_f32, as in project_quad_allin), in half the instructions -- 12 packed fmas instead of 24 (round 6).  y / hy: Rcp32(k + 1).y
+// and the rounding offset of each voxel's divisor (s_rcp); base: the word v_cvt_pk_u8_f32 packs into (byte 3 = the new count).
+// MEASURED and left OFF (profiles/r06_ab_color_f2_call14.txt, five alternations at 2048^3 + colour): the pairs do not fit the 64
+// registers of the eight-wave instance (spills on the row path: 18.7 ms); at seven waves (72 VGPRs, -12 vector instructions per
+// wave-row, no scalar spills) 13.09 against 13.20 ms without it and 13.03 for the shipped eight-wave instance, 12.88 against 12.37 on a
+// configs[4] slab -- a twelfth fewer vector instructions buy nothing: with colour this kernel is gated by its 58.6 GB per launch.
+#ifndef TSDF_COLOR_F2
+#define TSDF_COLOR_F2 0
+#endif
+static __device__ __forceinline__ void colour_pair_pk(const f2 w, const uint32_t c0a, const uint32_t c0b, const uint32_t csa, const uint32_t csb,
+                                                      const f2 y, const f2 hy, const uint32_t base_a, const uint32_t base_b, uint32_t &cva, uint32_t &cvb) {
+  f2 t[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const f2 o = {(float)((c0a >> (8 * ch)) & 255u), (float)((c0b >> (8 * ch)) & 255u)};
+    const f2 n = {(float)((csa >> (16 - 8 * ch)) & 255u), (float)((csb >> (16 - 8 * ch)) & 255u)};  // PCL b,g,r,a -> r,g,b
+    t[ch] = __builtin_elementwise_fma(__builtin_elementwise_fma(w, o, n), y, hy);
+  }
+  cva = __builtin_amdgcn_cvt_pk_u8_f32(t[0].x, 0u, __builtin_amdgcn_cvt_pk_u8_f32(t[1].x, 1u, __builtin_amdgcn_cvt_pk_u8_f32(t[2].x, 2u, base_a)));
+  cvb = __builtin_amdgcn_cvt_pk_u8_f32(t[0].y, 0u, __builtin_amdgcn_cvt_pk_u8_f32(t[1].y, 1u, __builtin_amdgcn_cvt_pk_u8_f32(t[2].y, 2u, base_b)));
+}
+
 static __device__ __forceinline__ bool update_is_safe(float d, float w, float dn) {
   const bool w_ok = fabsf(w - 512.f) <= 512.f && __builtin_amdgcn_fractf(w) == 0.f;  // integer in [0, 1024]
   return w_ok && numerator_ok(d * w + dn);
@@ -1064,6 +1088,17 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
         for (int j = 0; j < 4; ++j) dv[j] = d0[j], wv[j] = w0[j], cv[j] = c0[j];
         // PACKED without colour: the reciprocal of k + 1 is only wanted where a distance moves (wave-uniform: d_moves is a ballot);
         // in resting free space the count bytes are all there is to update
+        constexpr bool QUAD_COLOR = TSDF_COLOR_F2 && COLOR && PACKED && TSDF_COLOR_PK == 2 && !TSDF_KTAB;  // colour_quad_pk
+        if constexpr (QUAD_COLOR) {
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {  // voxels (0, 1), then (2, 3)
+            const f2 yh0 = s_rcp[kw[j] >> 24], yh1 = s_rcp[kw[j + 1] >> 24];  // w0 + 1 == k + 1 here (w0 is an integer)
+            rs[j].nb = -(w0[j] + 1.f), rs[j + 1].nb = -(w0[j + 1] + 1.f);
+            rs[j].y = yh0.x, rs[j + 1].y = yh1.x;
+            colour_pair_pk((f2){w0[j], w0[j + 1]}, c0[j], c0[j + 1], cs[j], cs[j + 1], (f2){yh0.x, yh1.x}, (f2){yh0.y, yh1.y}, k1[j], k1[j + 1],
+                           cv[j], cv[j + 1]);
+          }
+        } else
         if (COLOR || !PACKED || d_moves)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // colour and weight: every observed voxel
@@ -1225,7 +1260,7 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
 // depend on nothing the projection works out.  No effect, here or in k_integrate_pc: 7.47 against 7.47 ms, 13.16 against 13.20
 // (profiles/r06_ab_planefirst_call10.txt): the stage the pipeline gives every load already covers them.  Not kept.)
 // Same arithmetic as k_integrate<ORDER, false, true, COUNT, true, true, false>, operation for operation; the host
-// launches it instead of that instance when, additionally, every block's rows exist (ny a multiple of the block's rows),
+// launches it instead of that instance when, additionally, every row step of a block is whole (ny a multiple of TY),
 // the hinge value rests (hinge_fixed) and max_dist_neg lies in the scale-free divider's window -- else the old instance.
 #ifndef TSDF_WPE_PIPE
 #define TSDF_WPE_PIPE 8  // 63 VGPRs, no scratch.  (LLVM grants 8 waves 80 SGPRs, 7 waves 96+: at 8 the loop's rare blocks carry scalar spills
@@ -1274,7 +1309,7 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0, chg = 0, imp = 0, rdb = 0;
   const int row0 = (int)bc.by * a.rpb * a.TY;
-  const int rows = min(a.rpb * a.TY, a.ny - row0);  // == rpb * TY (the host checked)
+  const int rows = min(a.rpb * a.TY, a.ny - row0);  // a multiple of TY (the host checked)
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
   const unsigned span = (unsigned)rows * (unsigned)a.pitch;
   const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
@@ -1414,7 +1449,7 @@ k_integrate_p(const IntegrateArgs a, float *__restrict__ D, uint8_t *__restrict_
     };
 
     PipeRow A, B;
-    const int nr = a.rpb;
+    const int nr = rows / a.TY;  // (the grid's last block may be shorter: the host checked that ny is a multiple of TY)
     issue(0, A);
     int r = 0;
     for (; r + 2 < nr; r += 2) {  // steady state: every trip issues two rows and consumes two
@@ -1523,7 +1558,7 @@ k_integrate_pc(const IntegrateArgs a, float *__restrict__ D, uint32_t *__restric
   const Rcp32 rneg = rcp32_prepare(a.neg);
   unsigned cnt = 0, chg = 0, imp = 0, rdb = 0;
   const int row0 = (int)bc.by * a.rpb * a.TY;
-  const int rows = min(a.rpb * a.TY, a.ny - row0);  // == rpb * TY (the host checked)
+  const int rows = min(a.rpb * a.TY, a.ny - row0);  // a multiple of TY (the host checked)
   const int64_t e0 = ((int64_t)(a.zl0 + zl) * a.plane_rows + row0) * a.pitch;
   const unsigned span = (unsigned)rows * (unsigned)a.pitch;
   const rsrc_t rsD = make_rsrc(D + e0, span * 4u);
@@ -1681,7 +1716,7 @@ k_integrate_pc(const IntegrateArgs a, float *__restrict__ D, uint32_t *__restric
     };
 
     PipeRowC A, B;
-    const int nr = a.rpb;
+    const int nr = rows / a.TY;  // (the grid's last block may be shorter: the host checked that ny is a multiple of TY)
     issue(0, A, true);
     int r = 0;
     for (; r + 2 < nr; r += 2) {  // steady state: every trip issues two rows and consumes two
@@ -3078,7 +3113,7 @@ int tsdf_integrate_launch(tsdf_handle h, const float *d_depth, const uint32_t *d
     // the software-pipelined instance (k_integrate_p): ALLIN, PACKED, no colour, every block's rows present, resting hinge
     // (knob pipe: bit 0 = without colour, k_integrate_p; bit 1 = with colour, k_integrate_pc)
     const bool pipe = (tsdf_tuning().pipe & (color ? 2 : 1)) && fastproj && allin && !live && h->packed && a.hinge_fixed && a.neg_in_window &&
-                      a.ny % (a.rpb * a.TY) == 0;
+                      a.ny % a.TY == 0;
     if (pipe) {
       h->last_launch[0] |= 0x100;  // bit 8: the pipelined row loop
 #define LAUNCH_P(ORDER, COUNT)                                                                                                           \
@@ -3221,7 +3256,7 @@ int tsdf_integrate_launch2(tsdf_handle h, const float *dA, const uint32_t *cA, c
   // frame against k_integrate2's 7.6 at 2048^3: profiles/r06_cpp_path_timing.json), so knob fuse2 = 1 (the default) pairs only where
   // the sweep wins: with colour, or where k_integrate_p does not apply; fuse2 = 2 always shares the sweep (the tests' k_integrate2
   // coverage), 0 never.
-  const bool pipe_wins = !color && (tsdf_tuning().pipe & 1) && tsdf_tuning().fuse2 == 1 && a.hinge_fixed && a.neg_in_window && a.ny % (a.rpb * a.TY) == 0;
+  const bool pipe_wins = !color && (tsdf_tuning().pipe & 1) && tsdf_tuning().fuse2 == 1 && a.hinge_fixed && a.neg_in_window && a.ny % a.TY == 0;
   const bool ok = tsdf_tuning().fuse2 && !pipe_wins && tsdf_tuning().cull == 1 && tsdf_tuning().allin && h->packed && !h->cn[0] && !h->weight_by_depth &&
                   !h->weight_by_variance && !tsdf_tuning().plain_kernel && (h->nx & 3) == 0 && a.wmax_is_int && (float)h->kmax == p.max_weight &&
                   gy <= 65535u && gz <= 65535u && gz > 0 && bgra_offset(dA, cA, &a.bgra_off) && bgra_offset(dB, cB, &fb.bgra_off) &&

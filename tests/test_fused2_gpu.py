@@ -263,7 +263,7 @@ def test_colourless_pairs_take_the_pipelined_kernel_by_default(gpu):
                 pair, want = [], []
                 for i in (2 * k, 2 * k + 1):
                     tr = synth.turntable_pose(i, 8, sc.size)
-                    dep, col = sc.depth(tr, noise_seed=9 + i), sc.bgra(i) if color else None
+                    dep, col = sc.depth(tr, noise_seed=9 + i), sc.bgra(i) if color else None  # (96 rows: the last 64-row block is short)
                     t = device_frame(dep, col)
                     keep.append(t)
                     pair.append((t[0].data_ptr(), t[1].data_ptr() if color else 0, tr))

@@ -808,15 +808,16 @@ def test_every_reachable_k_integrate_instance_equals_the_oracle(gpu):
 
 
 @pytest.mark.parametrize("color", [False, True], ids=["k_integrate_p", "k_integrate_pc"])
-@pytest.mark.parametrize("rows_per_block", [8, 16, 24, 32, 48, 96])
+@pytest.mark.parametrize("rows_per_block", [8, 16, 24, 32, 40, 48, 64, 96])
 def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_per_block, color):
     """k_integrate_p / k_integrate_pc (round 6: two rows in flight per wave, stage A = projection + every load of a row, stage
     B = update + stores; with colour the voxel words are asked by a predictor two rows back, an observed quad it missed asks
-    late) on a 96^3 grid, whose blocks walk 1, 2, 3, 4, 6 or 12 row steps (TY = 8 rows per step): the tail of
+    late) on a 96^3 grid, whose blocks walk 1, 2, 3, 4, 5, 6, 8 or 12 row steps (TY = 8 rows per step; with 5 and 8 the grid's last
+    block is SHORTER than the others: 16 of 40 rows, 32 of 64): the tail of
     one row, of a pair, the odd tail behind the steady-state loop and the loop itself -- noisy depth with NaN holes, frames
     past the weight limit (max_weight 4), counting on alternate frames -- against the oracle voxel for voxel, against
     k_integrate's own instance (knob pipe = 0) plane for plane, observed-voxel counts included; and the row count the
-    pipelined kernel needs (ny a multiple of the block's rows) falls back by itself when it does not hold."""
+    pipelined kernel needs (ny a multiple of TY, the rows of one step) falls back by itself when it does not hold."""
     outs = []
     try:
         capi.set_tuning("rows_per_block", rows_per_block)
@@ -842,7 +843,7 @@ def test_pipelined_row_loop_equals_the_oracle_and_the_plain_row_loop(gpu, rows_p
         assert_same_f32(outs[0][0][0], outs[1][0][0], "d: pipelined vs plain row loop")
         assert np.array_equal(outs[0][0][1], outs[1][0][1]) and outs[0][1] == outs[1][1]
         assert (outs[0][0][2] is None and outs[1][0][2] is None) or np.array_equal(outs[0][0][2], outs[1][0][2])
-        # 100 rows are no multiple of the block's rows: the launch takes k_integrate's instance by itself
+        # 100 rows are no multiple of the 8 rows of a step: the launch takes k_integrate's instance by itself
         capi.set_tuning("pipe", 3)
         vol, sc = make_volume(96, color=color, res3=(96, 100, 96))
         vol.reset()
