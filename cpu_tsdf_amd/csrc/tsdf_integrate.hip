@@ -481,11 +481,6 @@ static __device__ __forceinline__ KEntry tsdf_ktab_entry(const IntegrateArgs &a,
 #if !TSDF_GUARD_ON_RESULT && TSDF_EARLY_VOXEL_LOADS
 #error "TSDF_GUARD_ON_RESULT=0 tests the numerator d0 * w0 + dn BEFORE unread distance words are rebuilt from the counts, and with TSDF_EARLY_VOXEL_LOADS those words have no initial value: build that A/B with -DTSDF_EARLY_VOXEL_LOADS=0"
 #endif
-#ifndef TSDF_SETPRIO
-#define TSDF_SETPRIO 0  // A/B (round 6): N > 0: s_setprio N from a row's first instruction until its loads are issued, 0 behind them; N < 0: the
-                        // other way round.  Both LOSE against the hardware's own oldest-first arbitration, five alternations at 2048^3 +
-                        // colour: 13.26 (N = 2) against 12.83 ms, 12.89 (N = -2) against 12.66 (profiles/r06_ab_setprio_call17_18.txt).  OFF
-#endif
 #ifndef TSDF_GATHER_AUX
 #define TSDF_GATHER_AUX 0  // cache policy of the ALLIN instance's frame gather (A/B: the default keeps the frame in L2)
 #endif
@@ -745,9 +740,6 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
     for (int r = 0; r < a.rpb; ++r) {
       const int y = row0 + ty + r * a.TY;
       if (y >= a.ny) break;
-#if TSDF_SETPRIO
-      __builtin_amdgcn_s_setprio(TSDF_SETPRIO > 0 ? TSDF_SETPRIO : 0);  // > 0: the projection that leads to the row's loads goes first ...
-#endif
       unsigned iv_lo = 0u, iv_len = 0u;
       if (LIVE && strad) {  // the row's interval: a quad that misses it has nothing to do (a wave all of whose quads miss skips the row)
         const uint32_t iv = s_iv[ty + r * a.TY];
@@ -894,9 +886,6 @@ k_integrate(const IntegrateArgs a, float *__restrict__ D, float *__restrict__ Wt
           if (COLOR) cs[j] = bload32(rsF, (unsigned)pix[j] << 2, a.bgra_off);
         }
       }
-#if TSDF_SETPRIO
-      __builtin_amdgcn_s_setprio(TSDF_SETPRIO < 0 ? -TSDF_SETPRIO : 0);  // ... the update behind the loads yields (< 0: the other way round)
-#endif
       PT_MARK(1);  // early voxel loads + frame gather ISSUED
       PT_DEP4(zs[0], zs[1], zs[2], zs[3]);
       PT_MARK(2);  // ... and the gathered depths HAVE ARRIVED (the wait also covers the early voxel words: in-order return)
