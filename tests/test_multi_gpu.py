@@ -418,3 +418,37 @@ def test_frame_pairing_on_a_multi_handle_equals_frame_by_frame(gpu, color):
         assert np.array_equal(a[1], b[1])
         multi.close()
         one.close()
+
+
+def test_frame_pairs_through_the_host_relay(gpu, monkeypatch):
+    """Frame pairing where no slab may read another's memory (TSDF_HIP_NO_PEER=1): the two frames of a device pair and of a
+    host pair reach every slab through the pinned relay (tsdf_multi_copy) before that slab's single sweep -- same voxels as
+    the oracle, and the relay carried both frames to every slab."""
+    import ctypes as C
+    monkeypatch.setenv("TSDF_HIP_NO_PEER", "1")
+    multi, sc = make([0, 0, 0], color=True)
+    monkeypatch.delenv("TSDF_HIP_NO_PEER")
+    ov = OracleVolume(multi._p)
+    multi.setFramePairing(True)
+    poses = [synth.turntable_pose(i, 12, sc.size) for i in range(4)]
+    deps = [sc.depth(tr, noise_seed=900 + i) for i, tr in enumerate(poses)]
+    cols = [sc.bgra(i) for i in range(4)]
+    fr = torch.empty((2, 2, H, W), dtype=torch.float32, device="cuda:0")
+    for k in range(2):
+        fr[k, 0].copy_(torch.from_numpy(deps[k]))
+        fr[k, 1].view(torch.uint8).view(H, W, 4).copy_(torch.from_numpy(cols[k]))
+    torch.cuda.synchronize()
+    fused, counts = multi.integrateCloudDevice2((fr[0, 0].data_ptr(), fr[0, 1].data_ptr(), poses[0]),
+                                                (fr[1, 0].data_ptr(), fr[1, 1].data_ptr(), poses[1]), count=True)
+    want = [ov.integrate(deps[k], cols[k], synth.cam_from_vol_f32(poses[k])) for k in range(2)]
+    assert fused and counts == want
+    stats = (C.c_uint64 * 3)()
+    capi.check(capi.load().tsdf_hip_multi_link_stats(multi._need(), stats), "link_stats")
+    assert stats[1] == 1 and stats[2] >= 2 * 3 * 2 * W * H * 4  # both frames, to every slab, depth + colour
+    for k in (2, 3):   # a host pair: pinned slot -> each slab, no relay needed, same single sweep
+        multi.integrateCloud(deps[k], cols[k], poses[k], pipelined=True)
+        ov.integrate(deps[k], cols[k], synth.cam_from_vol_f32(poses[k]))
+    d, w, rgb = multi.download()
+    assert_same_f32(d, ov.d, "d vs oracle")
+    assert np.array_equal(w, ov.w) and np.array_equal(rgb, ov.rgb)
+    multi.close()
