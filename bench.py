@@ -205,12 +205,14 @@ def extras(vol, pose, W, H):
             #  classify and through the sort.
             st = (C.c_uint64 * 4)()
             lib.tsdf_hip_march_stats(vol._need(), st)
-            classify_bytes = float(st[2]) + (32.0 + 16.0) * cells.value
+            elided = bool(st[3] & 2)  # no count of a listed cell's corners could fail the weight test: not gathered
+            classify_bytes = float(st[2]) + ((0.0 if elided else 32.0) + 16.0) * cells.value
             emit_bytes = 64.0 * cells.value + (36.0 + (9.0 if color else 0.0) + 8.0) * n.value
             out["reconstruct_classify_bytes"] = classify_bytes
             out["reconstruct_classify_d_bytes_requested"] = int(st[2])
             out["reconstruct_classify_d_plane_bytes"] = 4.0 * vox
-            out["reconstruct_classify_skips_unobserved_space"] = bool(st[3])
+            out["reconstruct_classify_skips_unobserved_space"] = bool(st[3] & 1)
+            out["reconstruct_classify_weight_test_elided"] = elided
             out["reconstruct_classify_GBps"] = classify_bytes / (ms[0] * 1e-3) / 1e9 if ms[0] > 0 else None
             out["reconstruct_classify_frac_of_hbm_peak"] = (classify_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else None
             out["reconstruct_emit_GBps"] = emit_bytes / (ms[2] * 1e-3) / 1e9 if ms[2] > 0 else None

@@ -75,6 +75,7 @@ static __device__ __forceinline__ uint32_t compact3(uint64_t v) {  // every thir
 // twice; sorting words instead of pairs halves what the radix sort moves (the count's bits take no part in it).  mc_unpack
 // gives the packed form the rest of the file reads: x | y << 20 | z << 40 | count << 60.
 #define MC_KEY_SHIFT 4
+#define MC_STAT_COUNTS_PASS (1ull << 63)  // in tsdf_hip_volume::mc_d_bytes, see tsdf_hip_march
 static __device__ __forceinline__ uint64_t mc_unpack(uint64_t word) {
   const uint64_t key = word >> MC_KEY_SHIFT;
   return (uint64_t)compact3(key >> 2) | ((uint64_t)compact3(key >> 1) << 20) | ((uint64_t)compact3(key) << 40) | ((word & 15ull) << 60);
@@ -650,6 +651,13 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
 
   a.qpr = (a.nx + 3) / 4;
   a.check_w = !(h->packed && !(w_min > 0.f));  // a PACKED weight is min(k, max_weight) >= 0: never below w_min <= 0
+  // Nor can it be below w_min <= min(1, max_weight) at a corner of a listed cell, while every owned plane holds only what
+  // this handle's own integrate launches wrote since the reset (band_exact) and no halo plane is among the corners: a
+  // listed cell has all eight |d| < 1 (:98), a distance leaves the reset value -1 only with an observation, and every
+  // observation counts (octree.cpp:157-159: w + 1) -- so all eight counts are >= 1.  The 8 gathers per listed cell go.
+  const bool counts_pass = h->packed && h->band_exact && tsdf_tuning().mc_skip && a.z_hi < h->z_end &&
+                           w_min <= 1.f && w_min <= a.pv.wmax;
+  if (counts_pass) a.check_w = 0;
   a.flush_at = std::min(MC_WAVE_BUF, std::max(0, tsdf_tuning().mc_flush_at));
   const int cell_rows = a.ny - 2;
   // a block = 4 waves = 4 * MC_R consecutive cell rows of one 256-voxel x-chunk, marching zb planes; the weight test
@@ -749,7 +757,10 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     }
     need_bytes = per_plane * (uint64_t)((a.z_hi - a.z_lo) + (int)grid.z);
   }
-  h->mc_d_bytes = need_bytes;
+  // (bit 63 carries "the weight test could not fail and was not evaluated" to tsdf_hip_march_stats: the handle struct lives
+  //  in tsdf_common.h, one of the sources whose hash stamps the committed k_integrate profiles -- bench.py kernel_sha16 --
+  //  and a report-only flag is not worth invalidating them)
+  h->mc_d_bytes = need_bytes | (counts_pass ? MC_STAT_COUNTS_PASS : 0ull);
   h->mc_skipped = a.need != nullptr;
   if (n_cells == 0) return TSDF_HIP_OK;
   if (n_cells > 0xffffffffull || ntri > 0xffffffffull) {
@@ -860,8 +871,8 @@ extern "C" int tsdf_hip_march_stats(tsdf_handle h, uint64_t out[4]) {
   if (h->multi) return tsdf_multi_march_stats(h, out);
   out[0] = h->mc_ncells;
   out[1] = h->mc_ntri;
-  out[2] = h->mc_d_bytes;
-  out[3] = h->mc_skipped ? 1u : 0u;
+  out[2] = h->mc_d_bytes & ~MC_STAT_COUNTS_PASS;
+  out[3] = (h->mc_skipped ? 1u : 0u) | ((h->mc_d_bytes & MC_STAT_COUNTS_PASS) ? 2u : 0u);
   return TSDF_HIP_OK;
 }
 

@@ -393,8 +393,11 @@ int tsdf_hip_march_fetch(tsdf_handle h, float *verts, uint8_t *rgb, uint64_t *ce
 int tsdf_hip_march_timing(tsdf_handle h, float ms[3], uint64_t *n_cells);
 /* Report-only: out[0] active cells, out[1] triangles, out[2] bytes of the distance plane the classify pass of the last
  * tsdf_hip_march REQUESTED (with the band flags of integrateCloud deciding, it reads only the quads an in-band
- * observation is near: src/lib/marching_cubes_tsdf_octree.cpp:179-236 visits every leaf), out[3] 1 if the flags were
- * in use (0: every plane was read -- after an upload / load the flags say nothing until reset). */
+ * observation is near: src/lib/marching_cubes_tsdf_octree.cpp:179-236 visits every leaf), out[3] bit 0: the flags were
+ * in use (0: every plane was read -- after an upload / load the flags say nothing until reset); out[3] bit 1: the
+ * weight test (marching_cubes_tsdf_octree.cpp:98, w < w_min) was not evaluated because it could not fail -- PACKED counts,
+ * planes written only by integrateCloud since the reset, no halo plane, w_min <= min(1, max_weight): a corner with
+ * |d| < 1 has been observed, and an observation counts. */
 int tsdf_hip_march_stats(tsdf_handle h, uint64_t out[4]);
 /* The same copies into DEVICE buffers of the caller, asynchronous on the handle's stream (multi-GPU mesh merge:
  * the buffers go straight to RCCL). */

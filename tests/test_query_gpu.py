@@ -475,6 +475,65 @@ def test_marching_cubes_skips_what_no_band_observation_is_near(gpu, res3, trunc,
     vol.close()
 
 
+@pytest.mark.parametrize("color", [True, False])
+def test_weight_test_is_elided_only_where_no_count_can_fail_it(gpu, color):
+    """marching_cubes_tsdf_octree.cpp:98 drops a cell with a corner of w < w_min.  In the PACKED layout, while the planes
+    hold only what integrateCloud wrote since the reset, a corner inside the band has been observed at least once, so the
+    test cannot fail for w_min <= min(1, max_weight) and the 8 gathers per listed cell are not made (tsdf_hip_march_stats
+    out[3] bit 1).  The mesh equals the oracle's -- which evaluates the test on every corner -- with the elision on
+    (w_min 0.5, 1), where it must stay off (w_min 1.5, 2: first-seen voxels at the rim of every view DO fail), with the
+    flags knob off, after an upload that plants in-band distances with zero weight, and with max_weight below w_min."""
+    lib = capi.load()
+
+    def stats(v):
+        st = (C.c_uint64 * 4)()
+        capi.check(lib.tsdf_hip_march_stats(v._need(), st), "march_stats")
+        return [int(x) for x in st]
+    vol, sc = make_volume(64, color=color)
+    vol.reset()
+    assert vol.getLayout() == capi.LAYOUT_PACKED
+    ov = OracleVolume(vol._p)
+    for i, tr, dep, col in frames(sc, 4, 8, noise=True):
+        vol.integrateCloud(dep, col if color else None, tr)
+        ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+    mode = 1 if color else 0
+    n = {}
+    for wmin, elided in ((0.5, True), (1.0, True), (1.5, False), (2.0, False)):
+        n[wmin] = _mesh_vs_oracle(vol, ov, wmin, mode)
+        assert bool(stats(vol)[3] & 2) == elided, (wmin, stats(vol))
+    assert n[0.5] == n[1.0] > n[2.0] > 1000   # the weight test does bite on this volume where it is evaluated
+    try:
+        capi.set_tuning("mc_skip", 0)
+        assert _mesh_vs_oracle(vol, ov, 1.0, mode) == n[1.0] and stats(vol)[3] == 0
+    finally:
+        capi.set_tuning("mc_skip", 1)
+    # in-band distances nobody observed (weight 0) arrive from outside: the counts prove nothing any more
+    d, w, rgb = vol.download()
+    z, y, x = np.mgrid[0:64, 0:64, 0:64]
+    blob = (np.sqrt((x - 12.0) ** 2 + (y - 50.0) ** 2 + (z - 9.0) ** 2) - 4.0) / 8.0
+    region = np.abs(blob) < 0.9
+    d2, w2 = d.copy(), w.copy()
+    d2[region] = blob[region].astype(np.float32)
+    w2[region] = 0.0
+    vol.upload(d2, w2, rgb)
+    ov2 = OracleVolume(vol._p, adopt=(d2, w2, rgb))
+    n_up = _mesh_vs_oracle(vol, ov2, 1.0, mode)   # the sphere's cells fail the test, in the product as in the oracle
+    assert stats(vol)[3] == 0
+    assert _mesh_vs_oracle(vol, ov2, 0.0, mode) > n_up + 100   # ... and are there without it
+    vol.close()
+    # max_weight 0.5: every observed weight is 0.5 -- below w_min 1 (test evaluated, nothing left), not below 0.5 (elided)
+    vol, sc = make_volume(64, color=color, max_weight=0.5)
+    vol.reset()
+    if vol.getLayout() == capi.LAYOUT_PACKED:
+        ov = OracleVolume(vol._p)
+        for i, tr, dep, col in frames(sc, 3, 8):
+            vol.integrateCloud(dep, col if color else None, tr)
+            ov.integrate(dep, col if color else None, synth.cam_from_vol_f32(tr))
+        assert _mesh_vs_oracle(vol, ov, 1.0, mode) == 0 and not stats(vol)[3] & 2
+        assert _mesh_vs_oracle(vol, ov, 0.5, mode) > 1000 and stats(vol)[3] & 2
+    vol.close()
+
+
 def test_band_flags_are_dropped_when_voxels_arrive_from_outside(gpu):
     """An upload can put a surface where nothing was ever observed: the flags stop describing the planes and marching
     cubes must read everything again (until the next reset)."""
