@@ -56,8 +56,9 @@ def main():
         devices = [0] * int(rng.choice([1, 1, 2, 3]))
         kw = dict(trunc=(pos, neg), max_weight=wmax, color=color)
         cull_active = not capi.load().tsdf_hip_reference_cull_is_noop(C.byref(p))
+        pairing = bool(rng.rand() < 0.4)   # round 6: TSDFVolumeOctree::setFramePairing on the drop-in side only (same voxels)
         gv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, lib_path=dropin,
-                               devices=devices if len(devices) > 1 else None, **kw)
+                               devices=devices if len(devices) > 1 else None, frame_pairing=pairing, **kw)
         rv = refbind.RefVolume(res, size, W, H, fx, fy, cx, cy, zmin, zmax, **kw)
         sc = synth.Scene(size, W, H, sphere=float(rng.uniform(0.15, 0.35)), box=float(rng.uniform(0.35, 0.49)))
         sc.fx, sc.fy, sc.cx, sc.cy = fx, fy, cx, cy
@@ -121,7 +122,7 @@ def main():
             v.close()
         print(f"case {case:4d}: res {res:3d} slabs {len(devices)} size {size:5.3f} {W}x{H} f {fx:6.1f} c ({cx - (W / 2 - 0.5):+5.1f},{cy - (H / 2 - 0.5):+5.1f}) "
               f"z [{zmin:.3f},{zmax:.2f}] trunc {pos / size:.2f}/{neg / size:.2f} wmax {wmax} colour {int(color)} "
-              f"{'refcull ' if cull_active else ''}observed {int((rw > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
+              f"{'refcull ' if cull_active else ''}{'paired ' if pairing else ''}observed {int((rw > 0).sum()):7d}  {'DIFF ' + ','.join(what) if what else 'ok'}", flush=True)
         if what:
             bad.append((case, what))
     print(f"{a.cases} cases, seed {a.seed}: {len(bad)} with differences {bad[:20]}")

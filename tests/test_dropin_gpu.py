@@ -315,6 +315,41 @@ def test_drop_in_default_path_equals_the_reference_with_an_off_centre_camera(gpu
         v.close()
 
 
+@pytest.mark.parametrize("color", [True, False])
+def test_dropin_frame_pairing_equals_the_reference_frame_by_frame(dropin, color):
+    """TSDFVolumeOctree::setFramePairing on the C++ drop-in (round 6: also on a set of devices): integrateCloud calls on
+    pcl clouds are queued in the pinned ring and swept two per launch where both poses see the whole slab, a frame waiting
+    for its partner is launched by the next query.  Against the COMPILED REFERENCE fed the same clouds one by one: an odd
+    number of frames, a query in the middle (getFxn while a frame is parked), one and three slab handles."""
+    res, W, H = 64, 160, 120
+    sc = synth.scene_a(res, W, H)
+    args = (res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size)
+    ref = refbind.RefVolume(*args, color=color)
+    drops = [refbind.RefVolume(*args, color=color, lib_path=dropin, frame_pairing=True, devices=dev) for dev in (None, [0, 0, 0])]
+    pts = np.random.RandomState(2).uniform(-0.12, 0.12, (200, 3)).astype(np.float32)
+    for i in range(7):
+        tr = synth.turntable_pose(i, 9, sc.size, tilt=0.04 * i)
+        dep, col = sc.depth(tr, noise_seed=70 + i), sc.bgra(i)
+        for v in [ref] + drops:
+            v.integrate(dep, col, tr)
+        if i == 2:   # frame 2 is waiting for frame 3 in the drop-ins
+            rok, rval, _, _ = ref.sample(pts)
+            for v in drops:
+                ok, val, _, _ = v.sample(pts)
+                assert np.array_equal(ok, rok)
+                m = (rok & 1).astype(bool)
+                assert m.sum() > 50
+                assert_same_f32(val[m], rval[m], "getFxn with a frame parked")
+    d, w, rgb, _, _ = ref.dump_dense()
+    assert (w > 0).sum() > 100000
+    for v in drops:
+        gd, gw, grgb = v.download()
+        assert_same_f32(gd, d, "d")
+        assert np.array_equal(gw, w) and (not color or np.array_equal(grgb, rgb))
+    for v in [ref] + drops:
+        v.close()
+
+
 def test_dropin_refuses_the_queries_on_a_non_cubic_grid_size(dropin, capfd):
     """VERDICT r04 missing #3: under a non-cubic setGridSize the reference looks per-axis voxel indices
     (src/lib/tsdf_volume_octree.cpp:553-574) up in an octree that is a cube of edge size_x (src/lib/octree.cpp:244-266) -- a
