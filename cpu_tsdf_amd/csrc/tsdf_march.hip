@@ -10,7 +10,7 @@
 //   rocprim sort   of those words by key: the reference emits triangles in octree pre-order with child index
 //                  4*(x>cx) + 2*(y>cy) + (z>cz) (octree.cpp:119,257-264) = Morton order, x the high bit
 //   rocprim scan   triangle offsets
-//   k_mc_emit      one thread per active cell: edge interpolation + triangle/colour output
+//   k_mc_emit      256 active cells per block, output loop over the block's vertices: edge interpolation + triangle/colour output
 // Case tables live in LDS.  Streaming stencil read of d (w only at the surface): HBM-bound, no MFMA.
 #include <string.h>
 
@@ -490,108 +490,120 @@ k_mc_counts(const uint64_t *__restrict__ vals, uint32_t *__restrict__ counts, ui
   if (i < n) counts[i] = (uint32_t)(vals[i] & 15ull);  // (vals: the sorted cell words)
 }
 
-// Emit: one thread per active cell (they are all valid: classify tested the eight corner weights).  The eight corner
-// values sit in LDS so that the triangle table can index them dynamically (in registers that costs a select chain per
-// access); every triangle vertex is interpolated on its own edge when it is needed -- a cell uses 3 to 15 of them, the
-// old version computed all twelve edges with twelve IEEE divisions and staged 144 B per thread -- and a triangle
-// leaves as three 12-byte stores + its packed colour + its cell key.  k_mc_expand_rgb turns the per-triangle colours
-// into the r,g,b-per-vertex bytes of the output with coalesced dword stores.  (Staging a wave's contiguous output run
-// in LDS and copying it out with coalesced dwords was measured SLOWER: 3.1 vs 2.4 ms for 60 M triangles -- the LDS
-// round trip and the lost occupancy cost more than the scattered 12-byte stores.)
+// Emit: a block takes 256 active cells (they are all valid: classify tested the eight corner weights) and its OUTPUT loop
+// runs over the block's vertices, not over each thread's own triangles.  Phase 1 (one thread per cell): the eight corner
+// values go to LDS (the triangle table indexes them dynamically; in registers that costs a select chain per access), with
+// the case index, the colour and the cell key, and the thread notes for each of its 1-5 triangles which cell they belong
+// to (s_map).  Phase 2 walks the block's 3 * (triangles of the block) vertices with consecutive threads on consecutive
+// vertices -- every vertex interpolated on its own edge (interpolateEdge), a cell uses 3 to 15 of the twelve -- so every
+// store instruction of a wave covers 768 CONTIGUOUS bytes of `verts`; the cell keys leave as contiguous 8-byte words,
+// and the per-vertex colour bytes are composed right here: whole dwords over the block's byte range, byte stores for
+// the at most three bytes on either end that a neighbouring block shares.
+// (Rounds 1-5 ran the output loop per cell: 36-byte pieces at a stride of the neighbours' triangle counts in up to five
+// divergent rounds, a per-triangle colour array and a second kernel to expand it -- 1.6 ms for 40 M triangles where this
+// one takes 1.0, profiles/r06_mc_emit_ab_call28.txt.  Staging a wave's output run in LDS and copying it out was
+// measured SLOWER than that in round 2, 3.1 vs 2.4 ms: the LDS round trip of the OUTPUT is what cost, not the inputs.)
 static __global__ void __launch_bounds__(256)
 k_mc_emit(const McArgs a, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ offsets, uint64_t n_cells,
-          float *__restrict__ verts, uint32_t *__restrict__ tri_rgb, uint64_t *__restrict__ cell_out) {
+            float *__restrict__ verts, uint8_t *__restrict__ rgb_out, uint64_t *__restrict__ cell_out) {
   __shared__ signed char s_tri[256 * 16];
-  __shared__ float s_leaf[256 * 9];  // 8 corner values per thread, stride 9: lanes fall on different banks
+  __shared__ float s_leaf[256 * 9];   // 8 corner values per cell, stride 9
+  __shared__ uint64_t s_key[256];     // x << 42 | y << 21 | z of the cell's base voxel
+  __shared__ uint32_t s_col[256];     // r | g << 8 | b << 16
+  __shared__ uint32_t s_first[256];   // the cell's first triangle, relative to the block's
+  __shared__ uint8_t s_cube[256];
+  __shared__ uint8_t s_map[256 * 5];  // triangle of the block -> cell of the block
+  __shared__ uint32_t s_ntri;
   for (int i = threadIdx.x; i < 256 * 16; i += blockDim.x) s_tri[i] = mc_tri_table[i >> 4][i & 15];
-  __syncthreads();
-  const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ci >= n_cells) return;
-  const uint64_t v = mc_unpack(vals[ci]);
-  const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
-  // getGridValue (:91-106) of a valid corner: d * max_dist_neg, corners in pcl::MarchingCubes order
+  const uint64_t c0 = (uint64_t)blockIdx.x * blockDim.x, ci = c0 + threadIdx.x;
+  const uint32_t T0 = offsets[c0];  // (block-uniform; c0 < n_cells by the grid's size)
   const int64_t sy = a.pitch, sz = (int64_t)a.ny * a.pitch;
-  const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
-  const int64_t off[8] = {0, 1, 1 + sz, sz, sy, 1 + sy, 1 + sy + sz, sy + sz};
-  float leaf[8];
+  if (ci < n_cells) {
+    const uint64_t word = vals[ci];
+    const uint64_t v = mc_unpack(word);
+    const int x = (int)(v & 0xfffff), y = (int)((v >> 20) & 0xfffff), z = (int)((v >> 40) & 0xfffff);
+    // getGridValue (:91-106) of a valid corner: d * max_dist_neg, corners in pcl::MarchingCubes order
+    const int64_t vi = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
+    const int64_t off[8] = {0, 1, 1 + sz, sz, sy, 1 + sy, 1 + sy + sz, sy + sz};
+    float leaf[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) leaf[k] = a.d[vi + off[k]] * a.neg;
-  const int cubeindex = cube_index(leaf);
-  float *mine = s_leaf + threadIdx.x * 9;
+    for (int k = 0; k < 8; ++k) leaf[k] = a.d[vi + off[k]] * a.neg;
+    float *mine = s_leaf + threadIdx.x * 9;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) mine[k] = leaf[k];
-  // createSurface [PCL-recall]: centre = lower_boundary_ + size_voxel_ * index; corner k adds size_voxel_
-  // in y if k&4, in z if k&2, in x if (k&1)^((k>>1)&1)
-  const int idx[3] = {x, y, z};
-  float center[3], far_[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    center[k] = a.lower[k] + a.size_voxel[k] * (float)idx[k];
-    far_[k] = center[k] + a.size_voxel[k];
+    for (int k = 0; k < 8; ++k) mine[k] = leaf[k];
+    s_cube[threadIdx.x] = (uint8_t)cube_index(leaf);
+    uint32_t col = 0u;
+    if (a.color_mode == 2) {  // :217-224 colour by confidence, evaluated in double like the reference
+      const float std_dev = (float)((100. - (double)tsdf_load_w(a.pv, vi)) / 100.);
+      const double r = (double)(1 - std_dev) * 255., b = (double)std_dev * 255.;
+      const double rmin = (255. < r) ? 255. : r, bmin = (255. < b) ? 255. : b;  // std::min(x, 255.)
+      col = (uint32_t)(unsigned char)((0. < rmin) ? rmin : 0.) |                 // std::max(0., x)
+            ((uint32_t)(unsigned char)((0. < bmin) ? bmin : 0.) << 16);
+    } else if (a.color_mode == 1 && a.pv.rgb) {  // :226-231
+      col = tsdf_load_rgb(a.pv, vi);
+    }
+    s_col[threadIdx.x] = col;
+    s_key[threadIdx.x] = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+    const uint32_t first = offsets[ci] - T0, cnt = (uint32_t)(word & 15ull);  // 1 .. 5 triangles
+    s_first[threadIdx.x] = first;
+    for (uint32_t k = 0; k < cnt; ++k) s_map[first + k] = (uint8_t)threadIdx.x;
+    if (ci + 1 == n_cells || threadIdx.x == blockDim.x - 1) s_ntri = first + cnt;
   }
-  uint32_t col = 0u;  // r | g << 8 | b << 16
-  if (a.color_mode == 2) {  // :217-224 colour by confidence, evaluated in double like the reference
-    const float std_dev = (float)((100. - (double)tsdf_load_w(a.pv, vi)) / 100.);
-    const double r = (double)(1 - std_dev) * 255., b = (double)std_dev * 255.;
-    const double rmin = (255. < r) ? 255. : r, bmin = (255. < b) ? 255. : b;  // std::min(x, 255.)
-    col = (uint32_t)(unsigned char)((0. < rmin) ? rmin : 0.) |                 // std::max(0., x)
-          ((uint32_t)(unsigned char)((0. < bmin) ? bmin : 0.) << 16);
-  } else if (a.color_mode == 1 && a.pv.rgb) {  // :226-231
-    col = tsdf_load_rgb(a.pv, vi);
-  }
-  uint64_t t = offsets[ci];
-  const signed char *tri = s_tri + cubeindex * 16;
-  const uint64_t key = ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z;
+  __syncthreads();
+  const uint32_t n_t = s_ntri, n_v = 3u * n_t;
+  // edge e joins corners ea[e], eb[e]: {0,1,2,3,4,5,6,7,0,1,2,3} / {1,2,3,0,5,6,7,4,4,5,6,7}, packed 4 bits each
+  const uint64_t EA = 0x321076543210ull, EB = 0x765447650321ull;
   struct __attribute__((packed, aligned(4))) F3 {
     float x, y, z;
   };
-  // edge e joins corners ea[e], eb[e]: {0,1,2,3,4,5,6,7,0,1,2,3} / {1,2,3,0,5,6,7,4,4,5,6,7}, packed 4 bits each
-  const uint64_t EA = 0x321076543210ull, EB = 0x765447650321ull;
-  for (int i = 0; tri[i] != -1; i += 3, ++t) {
+  F3 *vout = reinterpret_cast<F3 *>(verts) + 3ull * T0;
+  for (uint32_t j = threadIdx.x; j < n_v; j += blockDim.x) {
+    const uint32_t t = j / 3u, vtx = j - 3u * t;
+    const uint32_t c = s_map[t];
+    const uint64_t key = s_key[c];
+    const int e = (int)s_tri[(uint32_t)s_cube[c] * 16u + 3u * (t - s_first[c]) + vtx];
+    const int ka = (int)((EA >> (4 * e)) & 15u), kb = (int)((EB >> (4 * e)) & 15u);
+    const float va = s_leaf[c * 9u + (uint32_t)ka], vb = s_leaf[c * 9u + (uint32_t)kb];
+    // createSurface [PCL-recall]: centre = lower_boundary_ + size_voxel_ * index; corner k adds size_voxel_
+    // in y if k&4, in z if k&2, in x if (k&1)^((k>>1)&1)
+    const int idx[3] = {(int)(key >> 42), (int)((key >> 21) & 0x1fffff), (int)(key & 0x1fffff)};
+    float center[3], far_[3];
 #pragma unroll
-    for (int vtx = 0; vtx < 3; ++vtx) {
-      const int e = (int)tri[i + vtx];
-      const int ka = (int)((EA >> (4 * e)) & 15u), kb = (int)((EB >> (4 * e)) & 15u);
-      const float va = mine[ka], vb = mine[kb];
-      // interpolateEdge: mu = (iso - v1) / (v2 - v1); out = p1 + mu * (p2 - p1)
-      const float mu = (0.f - va) / (vb - va);
-      F3 p;
-      {
-        const float pa = ((ka & 1) ^ ((ka >> 1) & 1)) ? far_[0] : center[0], pb = ((kb & 1) ^ ((kb >> 1) & 1)) ? far_[0] : center[0];
-        p.x = pa + mu * (pb - pa);
-      }
-      {
-        const float pa = (ka & 4) ? far_[1] : center[1], pb = (kb & 4) ? far_[1] : center[1];
-        p.y = pa + mu * (pb - pa);
-      }
-      {
-        const float pa = (ka & 2) ? far_[2] : center[2], pb = (kb & 2) ? far_[2] : center[2];
-        p.z = pa + mu * (pb - pa);
-      }
-      *reinterpret_cast<F3 *>(verts + 9 * t + 3 * vtx) = p;
+    for (int k = 0; k < 3; ++k) {
+      center[k] = a.lower[k] + a.size_voxel[k] * (float)idx[k];
+      far_[k] = center[k] + a.size_voxel[k];
     }
-    if (tri_rgb) tri_rgb[t] = col;
-    if (cell_out) cell_out[t] = key;
-  }
-}
-
-// rgb_out[9 t + 3 v + c] = channel c of triangle t's colour (all three vertices of a triangle take the base voxel's
-// colour, :208-233): one thread per output dword.
-static __global__ void __launch_bounds__(256)
-k_mc_expand_rgb(const uint32_t *__restrict__ tri_rgb, uint32_t *__restrict__ rgb_out, uint64_t n_bytes) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (4 * w >= n_bytes) return;
-  uint32_t out = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint64_t b = 4 * w + k;
-    if (b < n_bytes) {
-      const uint64_t t = b / 9u;
-      const unsigned c = (unsigned)(b - 9u * t) % 3u;
-      out |= ((tri_rgb[t] >> (8u * c)) & 255u) << (8 * k);
+    // interpolateEdge: mu = (iso - v1) / (v2 - v1); out = p1 + mu * (p2 - p1)
+    const float mu = (0.f - va) / (vb - va);
+    F3 p;
+    {
+      const float pa = ((ka & 1) ^ ((ka >> 1) & 1)) ? far_[0] : center[0], pb = ((kb & 1) ^ ((kb >> 1) & 1)) ? far_[0] : center[0];
+      p.x = pa + mu * (pb - pa);
     }
+    {
+      const float pa = (ka & 4) ? far_[1] : center[1], pb = (kb & 4) ? far_[1] : center[1];
+      p.y = pa + mu * (pb - pa);
+    }
+    {
+      const float pa = (ka & 2) ? far_[2] : center[2], pb = (kb & 2) ? far_[2] : center[2];
+      p.z = pa + mu * (pb - pa);
+    }
+    vout[j] = p;
   }
-  rgb_out[w] = out;
+  if (cell_out)
+    for (uint32_t t = threadIdx.x; t < n_t; t += blockDim.x) cell_out[(uint64_t)T0 + t] = s_key[s_map[t]];
+  if (rgb_out) {  // bytes [9 T0, 9 (T0 + n_t)): byte b = channel (b % 9) % 3 of triangle b / 9 (:208-233)
+    const uint64_t b0 = 9ull * T0, b1 = b0 + 9ull * n_t;
+    auto byte_at = [&](uint64_t b) -> uint32_t {
+      const uint32_t r = (uint32_t)(b - b0), t = r / 9u, ch = (r - 9u * t) % 3u;
+      return (s_col[s_map[t]] >> (8u * ch)) & 255u;
+    };
+    const uint64_t up = (b0 + 3ull) & ~3ull, a0 = up < b1 ? up : b1, dn = b1 & ~3ull, a1 = dn > a0 ? dn : a0;  // whole dwords: [a0, a1)
+    for (uint64_t w = a0 + 4ull * threadIdx.x; w < a1; w += 4ull * blockDim.x)
+      *reinterpret_cast<uint32_t *>(rgb_out + w) = byte_at(w) | (byte_at(w + 1) << 8) | (byte_at(w + 2) << 16) | (byte_at(w + 3) << 24);
+    if (threadIdx.x < 3u && b0 + threadIdx.x < a0) rgb_out[b0 + threadIdx.x] = (uint8_t)byte_at(b0 + threadIdx.x);
+    if (threadIdx.x >= 4u && threadIdx.x < 7u && a1 + (threadIdx.x - 4u) < b1) rgb_out[a1 + (threadIdx.x - 4u)] = (uint8_t)byte_at(a1 + (threadIdx.x - 4u));
+  }
 }
 
 static float host_voxel_center(const tsdf_params &p, int a, int i) {  // tsdf_volume_octree.cpp:553-560
@@ -782,8 +794,8 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
                                        rocprim::plus<uint32_t>(), h->stream));
   const size_t al = 256;
   auto up = [&](size_t v) { return (v + al - 1) / al * al; };
-  const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4), b_trgb = color_mode ? up(ntri * 4) : 0;
-  const size_t total = b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan)) + b_trgb;
+  const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4);
+  const size_t total = b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan));
   int rc = tsdf_ensure_scratch(h, total);
   if (rc) return rc;
   char *sp = (char *)h->scratch;
@@ -791,7 +803,6 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   cnt = (uint32_t *)(sp + b_keys);
   off = (uint32_t *)(sp + b_keys + b_cnt);
   void *tmp = sp + b_keys + 2 * b_cnt;
-  uint32_t *tri_rgb = color_mode ? (uint32_t *)(sp + total - b_trgb) : nullptr;
   TSDF_HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes_sort, h->mc_keys, vals_out, (size_t)n_cells, MC_KEY_SHIFT,
                                         MC_KEY_SHIFT + key_bits, h->stream));
   const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
@@ -827,15 +838,9 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     if (rcx) return rcx;
   }
   TSDF_HIP_TRY(hipEventRecord(h->mc_ev[2], h->stream));
-  hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts, tri_rgb,
-                     h->mc_cell);
+  hipLaunchKernelGGL(k_mc_emit, dim3(cell_blocks), dim3(256), 0, h->stream, a, vals_out, off, n_cells, h->mc_verts,
+                     color_mode ? h->mc_rgb : nullptr, h->mc_cell);
   TSDF_HIP_TRY(hipGetLastError());
-  if (color_mode) {
-    const uint64_t n_bytes = 9ull * ntri;  // (the buffer holds mc_cap * 9 >= n_bytes + 3 bytes: whole dwords fit)
-    hipLaunchKernelGGL(k_mc_expand_rgb, dim3((unsigned)((n_bytes / 4 + 256) / 256)), dim3(256), 0, h->stream, tri_rgb,
-                       (uint32_t *)h->mc_rgb, n_bytes);
-    TSDF_HIP_TRY(hipGetLastError());
-  }
   TSDF_HIP_TRY(hipEventRecord(h->mc_ev[3], h->stream));
   TSDF_HIP_TRY(hipStreamSynchronize(h->stream));
   (void)hipEventElapsedTime(&h->mc_ms[1], h->mc_ev[1], h->mc_ev[2]);  // count read-back, sort, scan (+ buffer growth)
