@@ -20,6 +20,7 @@
 // only the device-wide sort and scan are needed (rocprim.hpp also drags in texture iterators)
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "tsdf_common.h"
 #ifdef TSDF_HIP_TEST_HOOKS
@@ -198,6 +199,74 @@ k_mc_need(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ ne
     const int k_hi = min((n.n_planes - 2) / n.zb, zi / n.zb), k_lo = max(0, (zi - 1) / n.zb);
     for (int k = k_lo; k <= k_hi; ++k) need_blk[((int64_t)k * n.by + brow) * n.gx + bx] = 1;
   }
+}
+
+// The same verdicts, one thread per (wave row, plane) for ALL the x-chunks of the row (round 6): the <= 2 x 3 flag rows that
+// matter are read once, 16 bytes at a time, and folded into one bit per flag cell; every x-chunk's six cells are then a
+// shift of that mask.  (k_mc_need above reads 36 single bytes per x-chunk: 0.2 ms at 2048^3 for a 33 MB array.)  For
+// grids whose flag rows are whole 16-byte groups and fit 64 bits (nx a multiple of 1024, at most 4096); the others keep
+// the kernel above.  Same outputs, compared by tests/test_query_gpu.py::test_marching_cubes_skips_*.
+static __global__ void __launch_bounds__(256)
+k_mc_need_rows(const NeedArgs n, uint8_t *__restrict__ need, uint8_t *__restrict__ need_blk,
+               unsigned long long *__restrict__ d_bytes) {
+  const int64_t t_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n.rows * n.n_planes;
+  const bool live = t_raw < total;
+  const int64_t t = live ? t_raw : total - 1;
+  const int wrow = (int)(t % n.rows), zi = (int)(t / n.rows);
+  const int z = n.z_lo + zi;
+  const int yw = 1 + wrow * MC_R;
+  const int fy0 = max(0, (yw - 1) >> 2), fy1 = min(n.fy - 1, (yw + MC_R + 1) >> 2);
+  unsigned long long mask = 0ull;  // bit c: a flag is set in x cell c (over the row groups and the three planes)
+  bool halo_plane = false;
+  if (yw < n.ny && fy0 <= fy1) {
+    for (int zz = z - 1; zz <= z + 1; ++zz) {
+      if (zz < n.z_first || zz >= n.z_first + n.nz_alloc) continue;
+      if (zz < n.z_begin || zz >= n.z_end) {
+        halo_plane = true;
+        continue;
+      }
+      const uint8_t *pl = n.band + (int64_t)(zz - n.z_first) * n.fy * n.fx;
+      for (int fy = fy0; fy <= fy1; ++fy)
+        for (int q = 0; q < n.fx; q += 16) {
+          const u4 v = *reinterpret_cast<const u4 *>(pl + fy * n.fx + q);
+          const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if ((w[k] >> (8 * b)) & 255u) mask |= 1ull << (q + 4 * k + b);
+        }
+    }
+  }
+  unsigned long long bytes = 0ull;
+  const unsigned rows = (unsigned)max(0, min((wrow & 3) == 3 ? MC_R + 1 : MC_R, n.ny - yw));
+  const unsigned times = (zi > 0 && zi < n.n_planes - 1 && zi % n.zb == 0) ? 2u : 1u;
+  const int brow = wrow >> 2;
+  const int k_hi = min((n.n_planes - 2) / n.zb, zi / n.zb), k_lo = max(0, (zi - 1) / n.zb);
+  for (int bx = 0; bx < n.gx; ++bx) {
+    unsigned m6 = halo_plane ? 63u : (unsigned)((bx ? mask >> (4 * bx - 1) : mask << 1) & 63ull);
+    unsigned bits = 0u;
+    if (yw < n.ny) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (bx * 256 + g * 64 < n.nx && ((m6 >> g) & 7u)) bits |= 1u << g;
+      if (bx * 256 + 256 < n.nx && ((m6 >> 4) & 3u)) bits |= 16u;
+    }
+    if (live) {
+      need[t * n.gx + bx] = (uint8_t)bits;
+      bytes += (unsigned long long)(__popc(bits & 15u) * 256u + ((bits >> 4) & 1u) * 4u) * rows * times;
+      if (bits)
+        for (int k = k_lo; k <= k_hi; ++k) need_blk[((int64_t)k * n.by + brow) * n.gx + bx] = 1;
+    }
+  }
+  for (int o = 32; o; o >>= 1) bytes += __shfl_xor(bytes, o);
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0u) s_sum = 0ull;
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0u && bytes) atomicAdd(&s_sum, bytes);
+  __syncthreads();
+  if (threadIdx.x == 0u && s_sum) atomicAdd(d_bytes + (blockIdx.x % MC_NEED_SLOTS), s_sum);
 }
 
 template <int WL>  // 0 = F32W (float plane), 1 = PACKED with colour (count in byte 3), 2 = PACKED count plane
@@ -484,11 +553,11 @@ k_mc_cell_index(const McArgs a, const uint64_t *__restrict__ vals, uint64_t n, i
   idx[i] = ((int64_t)(z - a.z_first) * a.ny + y) * a.pitch + x;
 }
 
-static __global__ void __launch_bounds__(256)
-k_mc_counts(const uint64_t *__restrict__ vals, uint32_t *__restrict__ counts, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) counts[i] = (uint32_t)(vals[i] & 15ull);  // (vals: the sorted cell words)
-}
+// The triangle count rides in the low bits of a cell word: the offsets are a scan straight over the sorted words.
+struct McCountOf {
+  __host__ __device__ uint32_t operator()(uint64_t word) const { return (uint32_t)(word & 15ull); }
+};
+using McCountIt = rocprim::transform_iterator<const uint64_t *, McCountOf, uint32_t>;
 
 // Emit: a block takes 256 active cells (they are all valid: classify tested the eight corner weights) and its OUTPUT loop
 // runs over the block's vertices, not over each thread's own triangles.  Phase 1 (one thread per cell): the eight corner
@@ -728,6 +797,11 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
     TSDF_HIP_TRY(hipEventRecord(h->mc_ev[0], h->stream));
     if (a.need && attempt == 0) {  // (inside the classify phase's timing)
       TSDF_HIP_TRY(hipMemsetAsync(const_cast<uint8_t *>(a.need_blk), 0, need_blocks, h->stream));
+      if ((need_args.fx & 15) == 0 && need_args.fx <= 64) {
+        const size_t row_planes = need_elems / (size_t)need_args.gx;
+        hipLaunchKernelGGL(k_mc_need_rows, dim3((unsigned)((row_planes + 255) / 256)), dim3(256), 0, h->stream, need_args,
+                           const_cast<uint8_t *>(a.need), const_cast<uint8_t *>(a.need_blk), h->counter + 2);
+      } else
       hipLaunchKernelGGL(k_mc_need, dim3((unsigned)((need_elems + 255) / 256)), dim3(256), 0, h->stream, need_args,
                          const_cast<uint8_t *>(a.need), const_cast<uint8_t *>(a.need_blk), h->counter + 2);
       TSDF_HIP_TRY(hipGetLastError());
@@ -786,29 +860,26 @@ extern "C" int tsdf_hip_march(tsdf_handle h, float w_min, int color_mode, uint64
   while ((1 << coord_bits) < std::max(a.nx, std::max(a.ny, a.nz))) ++coord_bits;
   const unsigned key_bits = 3u * (unsigned)coord_bits;
   uint64_t *vals_out = nullptr;
-  uint32_t *cnt = nullptr, *off = nullptr;
+  uint32_t *off = nullptr;
   size_t tmp_bytes_sort = 0, tmp_bytes_scan = 0;
   TSDF_HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes_sort, h->mc_keys, vals_out, (size_t)n_cells, MC_KEY_SHIFT,
                                         MC_KEY_SHIFT + key_bits, h->stream));
-  TSDF_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
+  TSDF_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes_scan, McCountIt(vals_out, McCountOf()), off, 0u, (size_t)n_cells,
                                        rocprim::plus<uint32_t>(), h->stream));
   const size_t al = 256;
   auto up = [&](size_t v) { return (v + al - 1) / al * al; };
   const size_t b_keys = up(n_cells * 8), b_cnt = up(n_cells * 4);
-  const size_t total = b_keys + 2 * b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan));
+  const size_t total = b_keys + b_cnt + up(std::max(tmp_bytes_sort, tmp_bytes_scan));
   int rc = tsdf_ensure_scratch(h, total);
   if (rc) return rc;
   char *sp = (char *)h->scratch;
   vals_out = (uint64_t *)sp;  // the sorted cell words
-  cnt = (uint32_t *)(sp + b_keys);
-  off = (uint32_t *)(sp + b_keys + b_cnt);
-  void *tmp = sp + b_keys + 2 * b_cnt;
+  off = (uint32_t *)(sp + b_keys);
+  void *tmp = sp + b_keys + b_cnt;
   TSDF_HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes_sort, h->mc_keys, vals_out, (size_t)n_cells, MC_KEY_SHIFT,
                                         MC_KEY_SHIFT + key_bits, h->stream));
   const unsigned cell_blocks = (unsigned)((n_cells + 255) / 256);
-  hipLaunchKernelGGL(k_mc_counts, dim3(cell_blocks), dim3(256), 0, h->stream, vals_out, cnt, n_cells);
-  TSDF_HIP_TRY(hipGetLastError());
-  TSDF_HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes_scan, cnt, off, 0u, (size_t)n_cells,
+  TSDF_HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes_scan, McCountIt(vals_out, McCountOf()), off, 0u, (size_t)n_cells,
                                        rocprim::plus<uint32_t>(), h->stream));
 
   // output buffers

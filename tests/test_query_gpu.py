@@ -429,13 +429,15 @@ def _same_mesh(a, b, what):
 
 
 @pytest.mark.parametrize("res3,trunc,pose_kind", [((128, 128, 128), (0.03, 0.03), "turntable"), ((200, 72, 150), (0.02, 0.05), "turntable"),
-                                                  ((130, 128, 128), (0.03, 0.03), "inside"), ((320, 96, 64), (0.06, 0.03), "turntable")])
+                                                  ((130, 128, 128), (0.03, 0.03), "inside"), ((320, 96, 64), (0.06, 0.03), "turntable"),
+                                                  ((1024, 44, 48), (0.03, 0.04), "turntable"), ((2048, 24, 20), (0.03, 0.03), "inside")])
 def test_marching_cubes_skips_what_no_band_observation_is_near(gpu, res3, trunc, pose_kind):
     """k_mc_classify reads only what the integrate kernels' "band seen" flags are near (cells of 64 x 4 x 1 voxels, grown
     by one voxel: a triangle needs a negative corner, a negative distance needs an observation inside the truncation
     band).  With the skip on and off the mesh is the same and equals the oracle's: cubic / flat / wide grids (several
     x-chunks, rows that are no multiple of 4 or 64), a hinge value below 1 (pos < neg: free space is INSIDE the band),
-    launches restricted to a sub-box of the grid (camera inside the volume: flag coordinates offset), noise."""
+    launches restricted to a sub-box of the grid (camera inside the volume: flag coordinates offset), noise; rows of 1024
+    and 2048 voxels, whose flag rows are whole 16-byte groups (k_mc_need_rows instead of k_mc_need)."""
     S = max(res3) * 2.0 ** -8
     vol, sc = make_volume(64, color=True, trunc=trunc, size=S, zmax=4 * S, res3=res3, size3=tuple(r * 2.0 ** -8 for r in res3))
     sc.h = np.array([0.47 * r * 2.0 ** -8 for r in res3])
