@@ -33,6 +33,19 @@ TSDFVolumeOctree::TSDFVolumeOctree()
   tsdf_hip_default_params(&p_);
   max_cell_size_[0] = max_cell_size_[1] = max_cell_size_[2] = 0.5f;
   global_transform_ = Eigen::Affine3d::Identity();
+  // The two extensions a program written against the reference cannot name, for a binary that is only RE-LINKED against
+  // this library: CPU_TSDF_HIP_FRAME_PAIRING=1 starts every volume with setFramePairing(true), CPU_TSDF_HIP_DEVICES=0,1,2,3
+  // with setDevices({0, 1, 2, 3}).  The setters override them as usual.
+  if (const char *e = std::getenv("CPU_TSDF_HIP_FRAME_PAIRING")) frame_pairing_ = std::atoi(e) != 0;
+  if (const char *e = std::getenv("CPU_TSDF_HIP_DEVICES")) {
+    for (const char *c = e; *c;) {
+      char *end = nullptr;
+      const long v = std::strtol(c, &end, 10);
+      if (end == c) break;
+      devices_.push_back((int)v);
+      c = *end == ',' ? end + 1 : end;
+    }
+  }
 }
 
 TSDFVolumeOctree::~TSDFVolumeOctree() {

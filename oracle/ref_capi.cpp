@@ -273,6 +273,8 @@ void ct_set_devices(void *h, const int *devices, int n) { V(h)->setDevices(std::
 void ct_set_reference_cull(void *h, int flag) { V(h)->setReferenceCull(flag != 0); }
 // Drop-in build only: integrateCloud calls two per kernel sweep where the poses allow it (same voxels).
 void ct_set_frame_pairing(void *h, int flag) { V(h)->setFramePairing(flag != 0); }
+int ct_get_frame_pairing(void *h) { return V(h)->getFramePairing() ? 1 : 0; }
+int ct_get_num_devices(void *h) { return (int)V(h)->getDevices().size(); }
 #endif
 
 }  // extern "C"

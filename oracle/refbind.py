@@ -102,6 +102,10 @@ def load(path=LIB):
         L.ct_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.ct_set_reference_cull.argtypes = [C.c_void_p, C.c_int]
         L.ct_set_frame_pairing.argtypes = [C.c_void_p, C.c_int]
+        L.ct_get_frame_pairing.restype = C.c_int
+        L.ct_get_frame_pairing.argtypes = [C.c_void_p]
+        L.ct_get_num_devices.restype = C.c_int
+        L.ct_get_num_devices.argtypes = [C.c_void_p]
     _libs[path] = L
     return L
 

@@ -350,6 +350,38 @@ def test_dropin_frame_pairing_equals_the_reference_frame_by_frame(dropin, color)
         v.close()
 
 
+def test_dropin_extensions_through_the_environment(dropin, monkeypatch):
+    """A binary written against the reference and only RE-LINKED against the drop-in cannot call setFramePairing or
+    setDevices: CPU_TSDF_HIP_FRAME_PAIRING / CPU_TSDF_HIP_DEVICES switch them on for every volume it constructs.  Same
+    voxels as the compiled reference; the setters still override."""
+    res, W, H = 32, 80, 60
+    sc = synth.scene_a(res, W, H)
+    args = (res, sc.size, W, H, sc.fx, sc.fy, sc.cx, sc.cy, 0.0, 3 * sc.size)
+    ref = refbind.RefVolume(*args, color=True)
+    plain = refbind.RefVolume(*args, color=True, lib_path=dropin)
+    assert plain.L.ct_get_frame_pairing(plain.h) == 0 and plain.L.ct_get_num_devices(plain.h) == 0
+    monkeypatch.setenv("CPU_TSDF_HIP_FRAME_PAIRING", "1")
+    monkeypatch.setenv("CPU_TSDF_HIP_DEVICES", "0,0,0")
+    env = refbind.RefVolume(*args, color=True, lib_path=dropin)
+    assert env.L.ct_get_frame_pairing(env.h) == 1 and env.L.ct_get_num_devices(env.h) == 3
+    over = refbind.RefVolume(*args, color=True, lib_path=dropin, devices=[0, 0])
+    assert over.L.ct_get_num_devices(over.h) == 2
+    monkeypatch.delenv("CPU_TSDF_HIP_FRAME_PAIRING")
+    monkeypatch.delenv("CPU_TSDF_HIP_DEVICES")
+    for i in range(5):
+        tr = synth.turntable_pose(i, 7, sc.size)
+        dep, col = sc.depth(tr, noise_seed=5 + i), sc.bgra(i)
+        for v in (ref, plain, env, over):
+            v.integrate(dep, col, tr)
+    d, w, rgb, _, _ = ref.dump_dense()
+    for v in (plain, env, over):
+        gd, gw, grgb = v.download()
+        assert_same_f32(gd, d, "d")
+        assert np.array_equal(gw, w) and np.array_equal(grgb, rgb)
+    for v in (ref, plain, env, over):
+        v.close()
+
+
 def test_dropin_refuses_the_queries_on_a_non_cubic_grid_size(dropin, capfd):
     """VERDICT r04 missing #3: under a non-cubic setGridSize the reference looks per-axis voxel indices
     (src/lib/tsdf_volume_octree.cpp:553-574) up in an octree that is a cube of edge size_x (src/lib/octree.cpp:244-266) -- a
