@@ -35,6 +35,26 @@ WEIGHT = {
 }
 
 
+# SIMD cycles per wave64 instruction, measured on MI355X by tools/ubench/valu_cost.hip (profiles/r06_ubench_valu_cost_call36.txt,
+# eight waves per SIMD, 2400 MHz): plain fp32 arithmetic, moves, 32-bit add / sub and two-input logic ~3; packed fp32 ~5.2;
+# fp64 5-6; v_rcp_f32 8.6, v_rcp_f64 17; everything else (conversions, compares, shifts, three-input integer, min / max,
+# selects, lane access) ~4.5.
+def cycles_of(op):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if base.startswith("v_pk_"):
+        return 5.2
+    if base == "v_rcp_f64":
+        return 17.0
+    if base in ("v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_rcp_iflag_f32"):
+        return 8.6
+    if base.endswith("_f64") or base in ("v_mad_u64_u32", "v_lshl_add_u64"):
+        return 5.7
+    if base in ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_legacy_f32", "v_mov_b32",
+                "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32"):
+        return 3.0
+    return 4.5
+
+
 def classify(op):
     if op.startswith("v_pk_"):
         return "VALU"
@@ -79,6 +99,7 @@ def main():
     head = max(h for h in heads if h < stores[0])
     tail = next((h for h in heads if h > stores[-1]), len(body))
     counts = collections.defaultdict(collections.Counter)
+    cyc = collections.Counter()  # VALU cycles by phase (cycles_of)
     cur = 0
     for ln in body[head:tail]:
         m = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", ln)
@@ -95,6 +116,8 @@ def main():
         if not m or ln.strip().startswith((";", ".")):
             continue
         counts[phase_of(cur)][classify(m.group(1))] += 1
+        if classify(m.group(1)) == "VALU":
+            cyc[phase_of(cur)] += cycles_of(m.group(1))
     order = []
     for _, nm in markers:
         if nm not in order and nm in counts:
@@ -104,8 +127,8 @@ def main():
             order.append(nm)
     print(f"# {os.path.basename(__file__)} {' '.join(flags)}: row loop of k_integrate<PCL_SSE, colour, fast projection, PACKED, ALLIN> (the timed instance)")
     print("# static instruction counts of the loop body by phase; `x share` = share of the headline's wave-rows that execute the phase")
-    print(f"{'phase':62s} {'VALU':>5s} {'SALU':>5s} {'VMEM':>5s} {'LDS':>4s} {'wait':>5s}   x share  -> VALU  SALU per wave-row")
-    tv = ts = wv = ws = 0.0
+    print(f"{'phase':62s} {'VALU':>5s} {'SALU':>5s} {'VMEM':>5s} {'LDS':>4s} {'wait':>5s}   x share  -> VALU  SALU per wave-row   VALU cycles per wave-row")
+    tv = ts = wv = ws = wc = 0.0
     for nm in order:
         c = counts[nm]
         w = WEIGHT.get(nm, 1.0)
@@ -113,8 +136,11 @@ def main():
         ts += c["SALU"]
         wv += c["VALU"] * w
         ws += c["SALU"] * w
-        print(f"{nm:62s} {c['VALU']:5d} {c['SALU']:5d} {c['VMEM']:5d} {c['LDS']:4d} {c['wait']:5d}   {w:7.3f}  {c['VALU'] * w:6.1f} {c['SALU'] * w:5.1f}")
-    print(f"{'total':62s} {int(tv):5d} {int(ts):5d}{'':28s}{wv:6.1f} {ws:5.1f}")
+        wc += cyc[nm] * w
+        print(f"{nm:62s} {c['VALU']:5d} {c['SALU']:5d} {c['VMEM']:5d} {c['LDS']:4d} {c['wait']:5d}   {w:7.3f}  {c['VALU'] * w:6.1f} {c['SALU'] * w:5.1f}   {cyc[nm] * w:8.1f}")
+    print(f"{'total':62s} {int(tv):5d} {int(ts):5d}{'':28s}{wv:6.1f} {ws:5.1f}   {wc:8.1f}")
+    print(f"# VALU cycles: the price list of tools/ubench/valu_cost.hip (cycles_of above); {wc:.0f} cycles per wave-row x 32.8 k wave-rows per SIMD "
+          f"= {wc * 32768 / 2.4e9 * 1e3:.2f} ms of vector issue per launch at 2.4 GHz")
     print("# measured (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_SALU over the timed launches / 33.55 M wave-rows): see profiles/r05_summary_pmc_SQ2.json")
 
 
