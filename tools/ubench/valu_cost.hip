@@ -16,7 +16,7 @@ typedef float f2_ __attribute__((ext_vector_type(2)));
     const TYPE A = (TYPE)a, B = (TYPE)b;                                                          \
     (void)A; (void)B;                                                                             \
     for (int it = 0; it < iters; ++it) {                                                          \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(x[i]) : __VA_ARGS__ : "vcc", "s20", "s22", "s23"); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(x[i]) : __VA_ARGS__ : "vcc", "scc", "s20", "s22", "s23", "s24", "s25"); \
     }                                                                                             \
     float s = 0.f;                                                                                \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) s += (float)x[i];                               \
@@ -62,6 +62,13 @@ U32(k_cmp_sgpr_then_cndmask, "v_cmp_gt_u32_e64 s[22:23], %1, %2\n\tv_cndmask_b32
 U32(k_cmp_then_4cndmask, "v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc")
 U32(k_cmp_sgpr_then_4cndmask, "v_cmp_gt_u32_e64 s[22:23], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, s[22:23]\n\tv_cndmask_b32_e64 %0, %0, %2, s[22:23]\n\tv_cndmask_b32_e64 %0, %0, %1, s[22:23]\n\tv_cndmask_b32_e64 %0, %0, %2, s[22:23]")
 U32(k_salu_vcc_then_cndmask, "s_mov_b64 vcc, s[22:23]\n\tv_cndmask_b32 %0, %0, %1, vcc")
+U32(k_cmp_cnd_fma_cnd, "v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_u32 %0, %0, %2\n\tv_cndmask_b32 %0, %0, %2, vcc")
+U32(k_cmp_add_cnd, "v_cmp_gt_u32 vcc, %1, %2\n\tv_add_u32 %0, %0, %2\n\tv_cndmask_b32 %0, %0, %2, vcc")
+U32(k_cmp_2add_cnd, "v_cmp_gt_u32 vcc, %1, %2\n\tv_add_u32 %0, %0, %2\n\tv_add_u32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+U32(k_cmp_sand_cnd, "v_cmp_gt_u32 vcc, %1, %2\n\ts_and_b64 vcc, vcc, s[22:23]\n\tv_cndmask_b32 %0, %0, %2, vcc")
+U32(k_cmp64_sand_cnd64, "v_cmp_gt_u32_e64 s[24:25], %1, %2\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\tv_cndmask_b32_e64 %0, %0, %2, s[24:25]")
+U32(k_cmp_cnd_constsrc, "v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, -1, %0, vcc")
+U32(k_addc_vcc, "v_cmp_gt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %1, vcc")
 U32(k_bfi_b32, "v_bfi_b32 %0, %1, %0, %2")
 U32(k_perm_b32, "v_perm_b32 %0, %0, %1, %2")
 U32(k_or3_b32, "v_or3_b32 %0, %0, %1, %2")
@@ -148,7 +155,10 @@ int main() {
       {"v_writelane_b32", k_writelane}, {"v_cndmask_b32_e64 (sgpr pair mask)", k_cndmask_e64_sgpr}, {"v_cndmask_b32 (dst not a source)", k_cndmask_other_dst},
       {"v_cmp_gt_u32 vcc + v_cndmask vcc (pair)", k_cmp_then_cndmask}, {"v_cmp_e64 sgpr + v_cndmask_e64 (pair)", k_cmp_sgpr_then_cndmask},
       {"v_cmp vcc + 4 x v_cndmask vcc (five instr)", k_cmp_then_4cndmask}, {"v_cmp sgpr + 4 x v_cndmask_e64 (five instr)", k_cmp_sgpr_then_4cndmask},
-      {"s_mov vcc + v_cndmask vcc (pair)", k_salu_vcc_then_cndmask}, {"v_bfi_b32", k_bfi_b32}, {"v_perm_b32", k_perm_b32}, {"v_or3_b32", k_or3_b32}, {"v_and_or_b32", k_and_or_b32}, {"v_lshlrev_b32", k_lshlrev_b32},
+      {"s_mov vcc + v_cndmask vcc (pair)", k_salu_vcc_then_cndmask}, {"v_cmp vcc; cndmask; v_add_u32; cndmask (4 instr)", k_cmp_cnd_fma_cnd}, {"v_cmp vcc; v_add_u32; cndmask (3 instr)", k_cmp_add_cnd},
+      {"v_cmp vcc; 2 x v_add_u32; cndmask (4 instr)", k_cmp_2add_cnd}, {"v_cmp vcc; s_and vcc; cndmask vcc (3 instr)", k_cmp_sand_cnd},
+      {"v_cmp_e64 sgpr; s_and sgpr; cndmask_e64 (3 instr)", k_cmp64_sand_cnd64}, {"v_cmp vcc; cndmask -1, v, vcc (pair)", k_cmp_cnd_constsrc},
+      {"v_cmp vcc; v_addc_co_u32 (pair)", k_addc_vcc}, {"v_bfi_b32", k_bfi_b32}, {"v_perm_b32", k_perm_b32}, {"v_or3_b32", k_or3_b32}, {"v_and_or_b32", k_and_or_b32}, {"v_lshlrev_b32", k_lshlrev_b32},
       {"v_xor_b32", k_xor_b32}, {"v_sub_u32", k_sub_u32}, {"v_add3_u32", k_add3_u32}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_max_f32", k_max_f32},
       {"v_med3_f32", k_med3_f32}, {"v_mul_legacy_f32", k_mul_legacy}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
       {"v_rcp_f64", k_rcp_f64}};
@@ -168,7 +178,7 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     const double cyc = ms * 1e-3 * clock_hz / wave_instr_per_simd;
     if (!base) base = ms;
-    printf("%-42s %8.3f ms  %6.2f cycles per wave instruction  %5.2f x v_fma_f32\n", e.name, ms, cyc, ms / base);
+    printf("%-52s %8.3f ms  %6.2f cycles per wave instruction  %5.2f x v_fma_f32\n", e.name, ms, cyc, ms / base);
   }
   return 0;
 }
