@@ -347,6 +347,11 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t capacity,
   // The deferred weight test + the copy-out.  Every lane takes one listed cell:
   // entry = x - 256 blockIdx.x | row << 8 | (z - zs) << 10 | triangles << 15.
   auto flush = [&]() {
+#if defined(MC_PROBE) && MC_PROBE == 4  // probe: the append loop alone -- lists are built and dropped
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    n_buf = 0;
+    return;
+#endif
     // pass 1 (only if a weight can fail): test the 8 corner weights of every listed cell, 64 cells at a time with every
     // lane busy; a cell that fails loses its triangle count (a listed cell always has one), which marks it dropped
     unsigned total = n_buf;
@@ -394,7 +399,11 @@ k_mc_classify(const McArgs a, uint64_t *__restrict__ keys, uint64_t capacity,
         base += (unsigned long long)__popcll(m);
         if (ok) {
           tri_sum += e >> 15;
+#if defined(MC_PROBE) && MC_PROBE == 5  // probe: everything but the key assembly and its store
+          if (slot == ~0ull) {
+#else
           if (slot < capacity) {
+#endif
             const unsigned xr = e & 255u, row = wave * MC_R + ((e >> 8) & 3u), zr = (e >> 10) & 31u;
             keys[slot] = ((xkey_hi | (uint64_t)s_xkey[xr] | s_ykey[row] | s_zkey[zr]) << MC_KEY_SHIFT) | (uint64_t)(e >> 15);
           }
